@@ -1,0 +1,86 @@
+/*
+ * oracle/mfr_oracle.h -- CPU ORACLE (TEST INFRASTRUCTURE ONLY).
+ *
+ * Plain-C restatement of the pose-solver leg of nianticlabs/map-free-reloc
+ * (reference: lib/models/matching/pose_solver.py).  Nothing under oracle/ is
+ * ever imported, linked or executed by the product package
+ * (map-free-reloc_amd/); only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg use it, and only as the checker / timed CPU baseline.
+ *
+ * Parity status (see DESIGN.md "Oracle"):
+ *   - depth gather / back-projection / scale-RANSAC / validity rules: pinned
+ *     against the reference's own Python executed in the build container
+ *     (oracle/gen_golden.py -> tests/golden/*.npz).
+ *   - PnP-RANSAC, E-matrix RANSAC, recoverPose: the arithmetic lives in
+ *     opencv-python==4.8.0.74 (environment.yml:17), which is NOT available
+ *     offline -> restated from the published algorithms, PARITY UNPINNED
+ *     against OpenCV itself.  Pinned only by known-answer synthetic geometry.
+ *
+ * Floating-point contract shared with the HIP kernels (for bit-exact inlier
+ * sets): IEEE binary64, only + - * / sqrt and comparisons, no FMA contraction
+ * (-ffp-contract=off), reductions in "wave64 order" (64 strided partial sums,
+ * then an xor-butterfly 32,16,8,4,2,1).
+ */
+#ifndef MFR_ORACLE_H
+#define MFR_ORACLE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* per-pair status codes (same values as include/mfr_hip.h) */
+enum {
+    MFR_ST_OK = 0,
+    MFR_ST_TOO_FEW = 1,      /* fewer correspondences than the solver minimum */
+    MFR_ST_BAD_DEPTH = 2,    /* too few correspondences with valid depth      */
+    MFR_ST_NO_MODEL = 3,     /* RANSAC found no model / refinement failed     */
+    MFR_ST_DEGENERATE = 4    /* |t| > 1000 (pose_solver.py:223-225)           */
+};
+
+void mfr_ref_philox4x32_10(const uint32_t ctr[4], uint32_t k0, uint32_t k1, uint32_t out[4]);
+void mfr_ref_sample_distinct(uint64_t seed, uint64_t pair_id, uint32_t iter, int n, int k, int *out);
+double mfr_ref_det_log(double x);
+int mfr_ref_update_num_iters(double p, double ep, int model_points, int max_iters);
+int mfr_ref_poly_real_roots(const double *c, int deg, double *roots);
+
+/* pose_solver.py:6-17 -- xyz[N,3] = depth * (inv(K) @ [u,v,1]); K is the f32
+ * 3x3 pinhole matrix (zero skew), inverse evaluated in f32 (quirk Q5). */
+int mfr_ref_backproject(const int32_t *uv, const float *depth, int n, const float K[9], double *xyz);
+
+float mfr_ref_depth_min(const float *depth, int hw);
+
+/* pose_solver.py:186-206 (PnP input prep): int-truncate pts0, gather depth0,
+ * valid = d > depth_min, compact, back-project with K0.  obs = pts1 (f64). */
+int mfr_ref_pnp_lift(const float *pts0, const float *pts1, int n, const float *depth0, int H, int W,
+                     const float K0[9], double *xyz, double *obs, int32_t *src_idx);
+
+/* cv.solvePnPRansac(P3P) + refit + cv.solvePnPGeneric(ITERATIVE) restatement
+ * (pose_solver.py:209-235).  Returns per-pair status. */
+int mfr_ref_pnp_ransac(const double *xyz, const double *obs, int n, const float K1[9],
+                       int max_iters, double thr, double conf, uint64_t seed, uint64_t pair_id,
+                       double R[9], double t[3], uint8_t *mask, int *n_inl,
+                       int *best_iter, int *iters_run, int32_t *counts /* [max_iters] or NULL */);
+
+/* full PnPSolver.estimate_pose (pose_solver.py:184-235) */
+int mfr_ref_pnp_solve(const float *pts0, const float *pts1, int n, const float *depth0, int H, int W,
+                      const float K0[9], const float K1[9], int max_iters, double thr, double conf,
+                      uint64_t seed, uint64_t pair_id, double R[9], double t[3], int *n_inl);
+
+int mfr_ref_p3p(const double X[9], const double f[9], double Rs[36], double ts[12]);
+
+/* pose_solver.py:137-172 -- depth lift of E-mat inliers + exhaustive 1-D scale RANSAC */
+int mfr_ref_scale_lift(const float *pts0, const float *pts1, const uint8_t *mask, int n,
+                       const float *depth0, const float *depth1, int H, int W,
+                       const float K0[9], const float K1[9], const double R[9], const double t[3],
+                       double *scale /* [n] */);
+int mfr_ref_scale_ransac(const double *scale, int n, double thr, double *best_scale, int *best_idx);
+
+/* LM refinement used by the PnP path (exposed for tests) */
+int mfr_ref_pnp_lm(const double *xyz, const double *obs, const int32_t *idx, int n_idx,
+                   const double Kd[4], int max_iter, double R[9], double t[3]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,173 @@
+"""ctypes binding of the CPU oracle (oracle/mfr_oracle*.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg.  The product package never imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "libmfr_oracle.so")
+
+ST_OK, ST_TOO_FEW, ST_BAD_DEPTH, ST_NO_MODEL, ST_DEGENERATE = range(5)
+
+
+def build(force=False):
+    srcs = [os.path.join(_HERE, f) for f in ("mfr_oracle.c", "mfr_oracle_emat.c", "mfr_oracle.h", "Makefile")]
+    stale = (not os.path.exists(_SO)) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-s", "-C", _HERE], stdout=subprocess.DEVNULL)
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_SO)
+        _lib.mfr_ref_det_log.restype = C.c_double
+        _lib.mfr_ref_det_log.argtypes = [C.c_double]
+        _lib.mfr_ref_depth_min.restype = C.c_float
+        _lib.mfr_ref_update_num_iters.argtypes = [C.c_double, C.c_double, C.c_int, C.c_int]
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def philox(ctr, k0, k1):
+    c = np.asarray(ctr, dtype=np.uint32)
+    out = np.zeros(4, dtype=np.uint32)
+    lib().mfr_ref_philox4x32_10(_p(c), C.c_uint32(k0), C.c_uint32(k1), _p(out))
+    return out
+
+
+def sample_distinct(seed, pair_id, it, n, k):
+    out = np.zeros(k, dtype=np.int32)
+    lib().mfr_ref_sample_distinct(C.c_uint64(seed), C.c_uint64(pair_id), C.c_uint32(it), C.c_int(n), C.c_int(k), _p(out))
+    return out
+
+
+def det_log(x):
+    return lib().mfr_ref_det_log(float(x))
+
+
+def update_num_iters(p, ep, model_points, max_iters):
+    return lib().mfr_ref_update_num_iters(float(p), float(ep), int(model_points), int(max_iters))
+
+
+def poly_real_roots(c):
+    c = _f64(c)
+    out = np.zeros(16, dtype=np.float64)
+    n = lib().mfr_ref_poly_real_roots(_p(c), C.c_int(len(c) - 1), _p(out))
+    return out[:n].copy()
+
+
+def backproject(uv, depth, K):
+    uv = np.ascontiguousarray(uv, dtype=np.int32)
+    depth = _f32(depth)
+    K = _f32(K).reshape(9)
+    xyz = np.zeros((len(uv), 3), dtype=np.float64)
+    rc = lib().mfr_ref_backproject(_p(uv), _p(depth), C.c_int(len(uv)), _p(K), _p(xyz))
+    if rc:
+        raise ValueError("unsupported K")
+    return xyz
+
+
+def pnp_lift(pts0, pts1, depth0, K0):
+    pts0, pts1, depth0 = _f32(pts0), _f32(pts1), _f32(depth0)
+    n = len(pts0)
+    H, W = depth0.shape
+    xyz = np.zeros((max(n, 1), 3)); obs = np.zeros((max(n, 1), 2)); src = np.zeros(max(n, 1), dtype=np.int32)
+    m = lib().mfr_ref_pnp_lift(_p(pts0), _p(pts1), C.c_int(n), _p(depth0), C.c_int(H), C.c_int(W),
+                               _p(_f32(K0).reshape(9)), _p(xyz), _p(obs), _p(src))
+    if m < 0:
+        raise ValueError("unsupported K")
+    return xyz[:m].copy(), obs[:m].copy(), src[:m].copy()
+
+
+def p3p(X, f):
+    X, f = _f64(X), _f64(f)
+    Rs = np.zeros((4, 3, 3)); ts = np.zeros((4, 3))
+    n = lib().mfr_ref_p3p(_p(X), _p(f), _p(Rs), _p(ts))
+    return Rs[:n].copy(), ts[:n].copy()
+
+
+def pnp_ransac(xyz, obs, K1, max_iters=1000, thr=3.0, conf=0.9999, seed=0, pair_id=0, want_counts=False):
+    xyz, obs = _f64(xyz), _f64(obs)
+    n = len(xyz)
+    R = np.zeros((3, 3)); t = np.zeros(3)
+    mask = np.zeros(max(n, 1), dtype=np.uint8)
+    n_inl = C.c_int(0); best_it = C.c_int(0); iters_run = C.c_int(0)
+    counts = np.zeros(max_iters, dtype=np.int32) if want_counts else None
+    st = lib().mfr_ref_pnp_ransac(_p(xyz), _p(obs), C.c_int(n), _p(_f32(K1).reshape(9)),
+                                  C.c_int(max_iters), C.c_double(thr), C.c_double(conf),
+                                  C.c_uint64(seed), C.c_uint64(pair_id), _p(R), _p(t), _p(mask),
+                                  C.byref(n_inl), C.byref(best_it), C.byref(iters_run),
+                                  _p(counts) if want_counts else None)
+    out = dict(status=st, R=R, t=t, mask=mask[:n].copy(), n_inl=n_inl.value, best_iter=best_it.value,
+               iters_run=iters_run.value)
+    if want_counts:
+        out["counts"] = counts
+    return out
+
+
+def pnp_solve(pts0, pts1, depth0, K0, K1, max_iters=1000, thr=3.0, conf=0.9999, seed=0, pair_id=0):
+    pts0, pts1, depth0 = _f32(pts0).reshape(-1, 2), _f32(pts1).reshape(-1, 2), _f32(depth0)
+    H, W = depth0.shape
+    R = np.zeros((3, 3)); t = np.zeros(3); n_inl = C.c_int(0)
+    st = lib().mfr_ref_pnp_solve(_p(pts0), _p(pts1), C.c_int(len(pts0)), _p(depth0), C.c_int(H), C.c_int(W),
+                                 _p(_f32(K0).reshape(9)), _p(_f32(K1).reshape(9)), C.c_int(max_iters),
+                                 C.c_double(thr), C.c_double(conf), C.c_uint64(seed), C.c_uint64(pair_id),
+                                 _p(R), _p(t), C.byref(n_inl))
+    return st, R, t.reshape(3, 1), n_inl.value
+
+
+def pnp_lm(xyz, obs, idx, K1, R, t, max_iter=20):
+    xyz, obs = _f64(xyz), _f64(obs)
+    idx = np.ascontiguousarray(idx, dtype=np.int32)
+    K1 = _f32(K1).reshape(9)
+    Kd = np.array([K1[0], K1[4], K1[2], K1[5]], dtype=np.float64)
+    R = _f64(R).copy(); t = _f64(t).reshape(3).copy()
+    rc = lib().mfr_ref_pnp_lm(_p(xyz), _p(obs), _p(idx), C.c_int(len(idx)), _p(Kd), C.c_int(max_iter), _p(R), _p(t))
+    return rc, R, t
+
+
+def scale_lift(pts0, pts1, mask, depth0, depth1, K0, K1, R, t):
+    pts0, pts1 = _f32(pts0).reshape(-1, 2), _f32(pts1).reshape(-1, 2)
+    depth0, depth1 = _f32(depth0), _f32(depth1)
+    H, W = depth0.shape
+    n = len(pts0)
+    mask_p = None
+    if mask is not None:
+        mask = np.ascontiguousarray(mask, dtype=np.uint8)
+        mask_p = _p(mask)
+    scale = np.zeros(max(n, 1))
+    m = lib().mfr_ref_scale_lift(_p(pts0), _p(pts1), mask_p, C.c_int(n), _p(depth0), _p(depth1),
+                                 C.c_int(H), C.c_int(W), _p(_f32(K0).reshape(9)), _p(_f32(K1).reshape(9)),
+                                 _p(_f64(R).reshape(9)), _p(_f64(t).reshape(3)), _p(scale))
+    if m < 0:
+        raise ValueError("unsupported K")
+    return scale[:m].copy()
+
+
+def scale_ransac(scale, thr):
+    scale = _f64(scale)
+    bs = C.c_double(0); bi = C.c_int(0)
+    n = lib().mfr_ref_scale_ransac(_p(scale), C.c_int(len(scale)), C.c_double(thr), C.byref(bs), C.byref(bi))
+    return n, bs.value, bi.value

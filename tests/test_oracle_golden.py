@@ -1,0 +1,71 @@
+"""Oracle (oracle/mfr_oracle.c) vs fixtures produced by executing the reference's own
+Python (oracle/gen_golden.py; reference lib/models/matching/pose_solver.py,
+feature_matching.py, etc/feature_matching_baselines/utils.py)."""
+import os
+
+import numpy as np
+
+from oracle import oracle_lib as O
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def test_backproject_matches_reference(golden_dir):
+    g = _load(golden_dir, "ref_backproject.npz")
+    for c in range(int(g["n_cases"])):
+        xyz = O.backproject(g[f"c{c}_uv"], g[f"c{c}_d"], g[f"c{c}_K"])
+        ref = g[f"c{c}_xyz"]
+        # f32 inverse of K may differ by 1 ulp(f32) from LAPACK's; products are f64
+        np.testing.assert_allclose(xyz, ref, rtol=3e-7, atol=1e-12)
+
+
+def test_pnp_lift_matches_reference(golden_dir):
+    g = _load(golden_dir, "ref_pnp_lift.npz")
+    for c in range(int(g["n_cases"])):
+        p = f"c{c}_"
+        pts0, pts1 = g[p + "pts0"], g[p + "pts1"]
+        if len(pts0) < 4:
+            assert int(g[p + "called"]) == 0
+            continue
+        xyz, obs, src = O.pnp_lift(pts0, pts1, g[p + "depth0"], g[p + "K0"])
+        if int(g[p + "called"]) == 0:
+            assert len(xyz) < 4        # pose_solver.py:197-198
+            continue
+        ref_xyz, ref_obs = g[p + "xyz"], g[p + "obs"]
+        assert xyz.shape == ref_xyz.shape
+        np.testing.assert_allclose(xyz, ref_xyz, rtol=3e-7, atol=1e-12)
+        np.testing.assert_array_equal(obs, ref_obs)
+        np.testing.assert_array_equal(obs, pts1[src].astype(np.float64))
+
+
+def test_emat_metric_scale_matches_reference(golden_dir):
+    g = _load(golden_dir, "ref_emat_metric.npz")
+    for c in range(int(g["n_cases"])):
+        p = f"c{c}_"
+        R, t = g[p + "R_in"], g[p + "t_in"]
+        scale = O.scale_lift(g[p + "pts0"], g[p + "pts1"], g[p + "mask"], g[p + "depth0"], g[p + "depth1"],
+                             g[p + "K0"], g[p + "K1"], R, t)
+        ref_inl = int(g[p + "inliers"])
+        if len(scale) < 1:
+            assert ref_inl == 0 and np.isnan(g[p + "R_out"]).all()     # pose_solver.py:145-149
+            continue
+        n, best_scale, _ = O.scale_ransac(scale, 0.1)
+        assert n == ref_inl
+        np.testing.assert_allclose(best_scale * t, g[p + "t_out"], rtol=1e-6, atol=1e-9)
+        np.testing.assert_array_equal(R, g[p + "R_out"])
+
+
+def test_wire_format_roundtrip_fixture(golden_dir):
+    g = _load(golden_dir, "ref_wire_format.npz")
+    stack = g["stack"]
+    assert stack.dtype == np.float64 and stack.shape == (6, 33, 4)
+    for i in range(int(g["n_pairs"])):
+        row = stack[i].astype(np.float32)
+        row = row[~np.isnan(row)].reshape(-1, 4)
+        if len(row):
+            np.testing.assert_array_equal(row[:, :2], g[f"p1_{i}"])
+            np.testing.assert_array_equal(row[:, 2:], g[f"p2_{i}"])
+        else:
+            assert g[f"p1_{i}"].shape == (0,)
