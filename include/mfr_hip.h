@@ -1,0 +1,123 @@
+/*
+ * include/mfr_hip.h -- C-ABI of libmfr_hip.so, the MI355X (gfx950) drop-in for the
+ * feature-matching + scale-from-depth relative-pose hot path of
+ * nianticlabs/map-free-reloc.
+ *
+ * Conventions:
+ *   - extern "C", plain pointers and sizes; no torch types.  All data pointers are
+ *     DEVICE pointers unless the parameter name ends in _host.
+ *   - the caller allocates every buffer (including the workspace, whose size is
+ *     returned by the matching *_workspace_bytes query); the library keeps no
+ *     per-call state and is re-entrant per stream.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).
+ *   - return value: 0 = launched OK, <0 = argument / launch error (MFR_E_*).
+ *     Per-pair failures are VALUES, like the reference's NaN-pose convention
+ *     (pose_solver.py:30-33,188-189,197-198,230-233): status[b] != 0 and R,t filled
+ *     with NaN, n_inliers = 0.  A failing pair never aborts the batch.
+ *   - batches: leading dim B = image pairs; correspondences are fixed-stride
+ *     [B, maxN, 2] float32 with a count n_corr[B] (the device-side twin of the
+ *     NaN-padded [Npairs, maxN, 4] npz wire format, utils.py:59-69).
+ *   - images are H x W row-major float32, intrinsics K are 3x3 row-major float32
+ *     with zero skew and bottom row [0,0,1] (lib/datasets/utils.py:117-130).
+ *
+ * Every entry point names the reference interface it replaces (file:line under
+ * the upstream repository).
+ */
+#ifndef MFR_HIP_H
+#define MFR_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MFR_ABI_VERSION 1
+
+/* library-level error codes (negative) */
+#define MFR_E_ARG      (-1)
+#define MFR_E_LAUNCH   (-2)
+#define MFR_E_WORKSPACE (-3)
+
+/* per-pair status values (same as oracle/mfr_oracle.h) */
+#define MFR_ST_OK          0
+#define MFR_ST_TOO_FEW     1   /* fewer correspondences than the solver minimum (Q9) */
+#define MFR_ST_BAD_DEPTH   2   /* too few correspondences with valid depth          */
+#define MFR_ST_NO_MODEL    3   /* RANSAC produced no model / refinement failed      */
+#define MFR_ST_DEGENERATE  4   /* |t| > 1000 (pose_solver.py:223-225)               */
+
+int mfr_abi_version(void);
+/* name of the gfx target the kernels were compiled for ("gfx950") */
+const char *mfr_target_arch(void);
+
+/* ---- numerics self-test hook: out[i] = {a/b, sqrt(a), a*b+c (unfused)} in f64, used by
+ *      tests to prove the host/device IEEE contract the bit-exact parity relies on ---- */
+int mfr_test_f64_ops(const double *a, const double *b, const double *c, int n, double *out3, void *stream);
+/* raw RNG / sampler exposure for parity tests (oracle: mfr_ref_sample_distinct) */
+int mfr_test_sample(uint64_t seed, const int64_t *pair_ids, int B, int iters, int n, int k, int32_t *out, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * PnP path:  PnPSolver.estimate_pose, lib/models/matching/pose_solver.py:184-235
+ *   int-truncate pts0 (:186) -> depth gather (:192-193) -> valid = d > depth.min() (:196, Q6)
+ *   -> backproject_3d with K0 (:206, :6-17) -> cv.solvePnPRansac(P3P, iters, thr, conf) (:209-213)
+ *   -> refit + cv.solvePnPGeneric(ITERATIVE) when >= 6 inliers (:216-220) -> |t| > 1000 reject.
+ * Outputs: R [B,9] f64 row-major, t [B,3] f64, n_inliers [B] i32 (= len(inliers), the
+ * submission confidence, model.py:37), status [B] i32, inlier_mask [B,maxN] u8 indexed by
+ * the ORIGINAL correspondence index (may be NULL).
+ * RNG: Philox4x32-10 keyed by (seed, pair_ids[b], iteration) -- the reference has no seed
+ * knob (OpenCV fixed RNG); results are bit-reproducible for fixed (seed, pair_id).
+ * ------------------------------------------------------------------------------------------ */
+size_t mfr_pnp_workspace_bytes(int B, int maxN, int max_iters);
+int mfr_pnp_solve_batch(const float *pts0, const float *pts1, const int32_t *n_corr, int B, int maxN,
+                        const float *depth0, int H, int W,
+                        const float *K0, const float *K1,
+                        int max_iters, double reproj_thr, double confidence,
+                        uint64_t seed, const int64_t *pair_ids,
+                        void *workspace, size_t workspace_bytes,
+                        double *R, double *t, int32_t *n_inliers, int32_t *status, uint8_t *inlier_mask,
+                        void *stream);
+
+/* stage-level entry points of the PnP path (same arithmetic, exposed for parity tests and
+ * for callers that already hold lifted 3-D points).  xyz [B,maxN,3] f64, obs [B,maxN,2] f64,
+ * src_idx [B,maxN] i32, n_valid [B] i32. */
+int mfr_depth_min(const float *depth, int B, int H, int W, float *partial_min /*[B,16]*/, void *stream);
+int mfr_pnp_lift(const float *pts0, const float *pts1, const int32_t *n_corr, int B, int maxN,
+                 const float *depth0, const float *partial_min, int H, int W, const float *K0,
+                 double *xyz, double *obs, int32_t *src_idx, int32_t *n_valid, void *stream);
+int mfr_pnp_ransac(const double *xyz, const double *obs, const int32_t *n_valid, int B, int maxN,
+                   const float *K1, int max_iters, double reproj_thr, double confidence,
+                   uint64_t seed, const int64_t *pair_ids,
+                   int32_t *counts /*[B,max_iters] workspace*/, int32_t *inl_idx /*[B,maxN] workspace*/,
+                   double *R, double *t, int32_t *n_inliers, int32_t *status,
+                   uint8_t *mask_valid /*[B,maxN] over lifted points, may be NULL*/,
+                   int32_t *best_iter /*[B] may be NULL*/, int32_t *iters_run /*[B] may be NULL*/,
+                   void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Metric scale from depth: EssentialMatrixMetricSolver.estimate_pose, pose_solver.py:137-172
+ *   mask == 1 inliers (:137) -> int-truncate both views (:138-139) -> depth gather (:140-141)
+ *   -> valid = d0 > 0 & d1 > 0 (:144) -> back-project (:150-151) -> xyz0 <- R xyz0 (:154)
+ *   -> scale_i = (xyz1_i - xyz0_i) . t (:157) -> exhaustive 1-D RANSAC, first strict max
+ *   (:160-166, Q2) -> t_metric = best_scale * t (:169).
+ * R [B,9], t [B,3] f64 inputs (unit translation); outputs t_metric [B,3] f64 (NaN on failure),
+ * best_scale [B] f64, n_inliers [B] i32 (scale-consensus count = submission confidence),
+ * status [B] (in_status != 0 is passed through: "inliers == 0 -> return", :131-132;
+ * no valid depth -> MFR_ST_BAD_DEPTH, :145-149).
+ * emat_mask [B,maxN] u8 may be NULL (= all correspondences).
+ * ------------------------------------------------------------------------------------------ */
+size_t mfr_scale_workspace_bytes(int B, int maxN);
+int mfr_scale_from_depth_batch(const float *pts0, const float *pts1, const uint8_t *emat_mask,
+                               const int32_t *n_corr, int B, int maxN,
+                               const float *depth0, const float *depth1, int H, int W,
+                               const float *K0, const float *K1,
+                               const double *R, const double *t,
+                               const int32_t *in_status /* [B] status of the E-mat stage, may be NULL */,
+                               double scale_thr,
+                               void *workspace, size_t workspace_bytes,
+                               double *t_metric, double *best_scale, int32_t *n_inliers, int32_t *status,
+                               void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MFR_HIP_H */

@@ -1,0 +1,81 @@
+"""ctypes loader for csrc/libmfr_hip.so (C-ABI: include/mfr_hip.h).
+
+torch is imported first so that its bundled HIP runtime (libamdhip64.so.7) is the one the
+library binds to -- device pointers and streams handed over from torch tensors then belong to
+the same runtime.  Loading fails loudly; nothing in this package falls back to a CPU path.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "csrc", "libmfr_hip.so")
+
+_lib = None
+
+_vp, _i, _d, _u64, _sz = C.c_void_p, C.c_int, C.c_double, C.c_uint64, C.c_size_t
+
+# name -> (restype, argtypes); mirrors include/mfr_hip.h declaration by declaration
+SIGNATURES = {
+    "mfr_abi_version": (_i, []),
+    "mfr_target_arch": (C.c_char_p, []),
+    "mfr_test_f64_ops": (_i, [_vp, _vp, _vp, _i, _vp, _vp]),
+    "mfr_test_sample": (_i, [_u64, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "mfr_pnp_workspace_bytes": (_sz, [_i, _i, _i]),
+    "mfr_pnp_solve_batch": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _i, _d, _d, _u64, _vp,
+                                 _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mfr_depth_min": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "mfr_pnp_lift": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mfr_pnp_ransac": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _d, _d, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                            _vp, _vp, _vp, _vp]),
+    "mfr_scale_workspace_bytes": (_sz, [_i, _i]),
+    "mfr_scale_from_depth_batch": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp,
+                                        _d, _vp, _sz, _vp, _vp, _vp, _vp, _vp]),
+}
+
+
+class MfrLibraryError(RuntimeError):
+    pass
+
+
+def load(require_gpu=False):
+    """Load libmfr_hip.so and bind every symbol of the C-ABI.  Raises MfrLibraryError if the
+    library (or, with require_gpu, a GPU) is missing -- never falls back."""
+    global _lib
+    if _lib is None:
+        import torch  # noqa: F401  (binds the HIP runtime first)
+        if not os.path.exists(SO_PATH):
+            raise MfrLibraryError(
+                f"{SO_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                f"(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+        lib = C.CDLL(SO_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            try:
+                fn = getattr(lib, name)
+            except AttributeError as e:
+                raise MfrLibraryError(f"libmfr_hip.so does not export {name}") from e
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    if require_gpu:
+        import torch
+        if not torch.cuda.is_available():
+            raise MfrLibraryError("no HIP device visible: the HIP path cannot run (there is no CPU fallback)")
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise MfrLibraryError(f"{what} failed with code {rc} (see include/mfr_hip.h MFR_E_*)")
+
+
+def ptr(t):
+    """device (or host) pointer of a contiguous torch tensor, or None"""
+    if t is None:
+        return None
+    assert t.is_contiguous(), "C-ABI needs contiguous buffers"
+    return t.data_ptr()
+
+
+def stream_ptr():
+    import torch
+    return torch.cuda.current_stream().cuda_stream

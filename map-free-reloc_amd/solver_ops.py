@@ -1,0 +1,174 @@
+"""Batched, device-resident pose-solver ops: thin torch<->C-ABI glue over csrc/pnp.hip,
+csrc/scale.hip, csrc/emat.hip (include/mfr_hip.h).  All tensors live on the GPU; torch only
+provides memory and the stream.
+
+Reference leg being replaced: lib/models/matching/pose_solver.py (PnPSolver :175-235,
+EssentialMatrixSolver :20-61, EssentialMatrixMetricSolver :115-172).
+"""
+import torch
+
+from . import _lib
+
+ST_OK, ST_TOO_FEW, ST_BAD_DEPTH, ST_NO_MODEL, ST_DEGENERATE = range(5)
+NSEG = 16
+
+
+def _chk(t, dtype, name):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda):
+        raise _lib.MfrLibraryError(f"{name} must be a CUDA(HIP) tensor: the HIP path has no CPU fallback")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    return t.contiguous()
+
+
+def _ws(nbytes, device):
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+def depth_min_partials(depth):
+    """[B,H,W] f32 -> [B,16] partial minima (pose_solver.py:196 depth_0.min())."""
+    lib = _lib.load(require_gpu=True)
+    depth = _chk(depth, torch.float32, "depth")
+    B, H, W = depth.shape
+    out = torch.empty(B, NSEG, dtype=torch.float32, device=depth.device)
+    _lib.check(lib.mfr_depth_min(_lib.ptr(depth), B, H, W, _lib.ptr(out), _lib.stream_ptr()), "mfr_depth_min")
+    return out
+
+
+def pnp_lift(pts0, pts1, n_corr, depth0, K0):
+    """pose_solver.py:186-206: returns xyz [B,maxN,3] f64, obs [B,maxN,2] f64, src_idx, n_valid."""
+    lib = _lib.load(require_gpu=True)
+    pts0 = _chk(pts0, torch.float32, "pts0"); pts1 = _chk(pts1, torch.float32, "pts1")
+    n_corr = _chk(n_corr, torch.int32, "n_corr"); depth0 = _chk(depth0, torch.float32, "depth0")
+    K0 = _chk(K0, torch.float32, "K0")
+    B, maxN, _ = pts0.shape
+    _, H, W = depth0.shape
+    dev = pts0.device
+    part = depth_min_partials(depth0)
+    xyz = torch.zeros(B, maxN, 3, dtype=torch.float64, device=dev)
+    obs = torch.zeros(B, maxN, 2, dtype=torch.float64, device=dev)
+    src = torch.zeros(B, maxN, dtype=torch.int32, device=dev)
+    nv = torch.zeros(B, dtype=torch.int32, device=dev)
+    _lib.check(lib.mfr_pnp_lift(_lib.ptr(pts0), _lib.ptr(pts1), _lib.ptr(n_corr), B, maxN, _lib.ptr(depth0),
+                                _lib.ptr(part), H, W, _lib.ptr(K0), _lib.ptr(xyz), _lib.ptr(obs), _lib.ptr(src),
+                                _lib.ptr(nv), _lib.stream_ptr()), "mfr_pnp_lift")
+    return xyz, obs, src, nv
+
+
+def pnp_ransac(xyz, obs, n_valid, K1, pair_ids, max_iters=1000, thr=3.0, conf=0.9999, seed=0):
+    """cv.solvePnPRansac(P3P) + refit + ITERATIVE refinement restatement (pose_solver.py:209-235)
+    on already lifted points.  Returns dict(R, t, n_inliers, status, mask, best_iter, iters_run, counts)."""
+    lib = _lib.load(require_gpu=True)
+    xyz = _chk(xyz, torch.float64, "xyz"); obs = _chk(obs, torch.float64, "obs")
+    n_valid = _chk(n_valid, torch.int32, "n_valid"); K1 = _chk(K1, torch.float32, "K1")
+    pair_ids = _chk(pair_ids, torch.int64, "pair_ids")
+    B, maxN, _ = xyz.shape
+    dev = xyz.device
+    max_iters = max(int(max_iters), 1)
+    counts = torch.empty(B, max_iters, dtype=torch.int32, device=dev)
+    inl = torch.empty(B, maxN, dtype=torch.int32, device=dev)
+    R = torch.empty(B, 3, 3, dtype=torch.float64, device=dev)
+    t = torch.empty(B, 3, dtype=torch.float64, device=dev)
+    ni = torch.empty(B, dtype=torch.int32, device=dev)
+    st = torch.empty(B, dtype=torch.int32, device=dev)
+    mask = torch.empty(B, maxN, dtype=torch.uint8, device=dev)
+    bi = torch.empty(B, dtype=torch.int32, device=dev)
+    ir = torch.empty(B, dtype=torch.int32, device=dev)
+    _lib.check(lib.mfr_pnp_ransac(_lib.ptr(xyz), _lib.ptr(obs), _lib.ptr(n_valid), B, maxN, _lib.ptr(K1), max_iters,
+                                  float(thr), float(conf), int(seed), _lib.ptr(pair_ids), _lib.ptr(counts),
+                                  _lib.ptr(inl), _lib.ptr(R), _lib.ptr(t), _lib.ptr(ni), _lib.ptr(st), _lib.ptr(mask),
+                                  _lib.ptr(bi), _lib.ptr(ir), _lib.stream_ptr()), "mfr_pnp_ransac")
+    return dict(R=R, t=t, n_inliers=ni, status=st, mask=mask, best_iter=bi, iters_run=ir, counts=counts)
+
+
+class PnPBatchSolver:
+    """PnPSolver.estimate_pose (pose_solver.py:184-235) for a batch of pairs, one C-ABI call."""
+
+    def __init__(self, max_iters=1000, reproj_thr=3.0, confidence=0.9999, seed=0):
+        self.max_iters = max(int(max_iters), 1)
+        self.reproj_thr = float(reproj_thr)
+        self.confidence = float(confidence)
+        self.seed = int(seed)
+        self._ws = None
+
+    def __call__(self, pts0, pts1, n_corr, depth0, K0, K1, pair_ids, want_mask=False):
+        lib = _lib.load(require_gpu=True)
+        pts0 = _chk(pts0, torch.float32, "pts0"); pts1 = _chk(pts1, torch.float32, "pts1")
+        n_corr = _chk(n_corr, torch.int32, "n_corr"); depth0 = _chk(depth0, torch.float32, "depth0")
+        K0 = _chk(K0, torch.float32, "K0"); K1 = _chk(K1, torch.float32, "K1")
+        pair_ids = _chk(pair_ids, torch.int64, "pair_ids")
+        B, maxN, _ = pts0.shape
+        _, H, W = depth0.shape
+        dev = pts0.device
+        need = lib.mfr_pnp_workspace_bytes(B, maxN, self.max_iters)
+        if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
+            self._ws = _ws(need, dev)
+        R = torch.empty(B, 3, 3, dtype=torch.float64, device=dev)
+        t = torch.empty(B, 3, dtype=torch.float64, device=dev)
+        ni = torch.empty(B, dtype=torch.int32, device=dev)
+        st = torch.empty(B, dtype=torch.int32, device=dev)
+        mask = torch.empty(B, maxN, dtype=torch.uint8, device=dev) if want_mask else None
+        _lib.check(lib.mfr_pnp_solve_batch(
+            _lib.ptr(pts0), _lib.ptr(pts1), _lib.ptr(n_corr), B, maxN, _lib.ptr(depth0), H, W, _lib.ptr(K0),
+            _lib.ptr(K1), self.max_iters, self.reproj_thr, self.confidence, self.seed, _lib.ptr(pair_ids),
+            _lib.ptr(self._ws), self._ws.numel(), _lib.ptr(R), _lib.ptr(t), _lib.ptr(ni), _lib.ptr(st),
+            _lib.ptr(mask), _lib.stream_ptr()), "mfr_pnp_solve_batch")
+        out = dict(R=R, t=t, n_inliers=ni, status=st)
+        if want_mask:
+            out["mask"] = mask
+        return out
+
+
+class ScaleFromDepthBatch:
+    """EssentialMatrixMetricSolver's own part (pose_solver.py:137-172) for a batch of pairs."""
+
+    def __init__(self, scale_thr=0.1):
+        self.scale_thr = float(scale_thr)
+        self._ws = None
+
+    def __call__(self, pts0, pts1, emat_mask, n_corr, depth0, depth1, K0, K1, R, t, in_status=None):
+        lib = _lib.load(require_gpu=True)
+        pts0 = _chk(pts0, torch.float32, "pts0"); pts1 = _chk(pts1, torch.float32, "pts1")
+        n_corr = _chk(n_corr, torch.int32, "n_corr")
+        depth0 = _chk(depth0, torch.float32, "depth0"); depth1 = _chk(depth1, torch.float32, "depth1")
+        K0 = _chk(K0, torch.float32, "K0"); K1 = _chk(K1, torch.float32, "K1")
+        R = _chk(R, torch.float64, "R"); t = _chk(t, torch.float64, "t")
+        if emat_mask is not None:
+            emat_mask = _chk(emat_mask, torch.uint8, "emat_mask")
+        if in_status is not None:
+            in_status = _chk(in_status, torch.int32, "in_status")
+        B, maxN, _ = pts0.shape
+        _, H, W = depth0.shape
+        dev = pts0.device
+        need = lib.mfr_scale_workspace_bytes(B, maxN)
+        if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
+            self._ws = _ws(need, dev)
+        tm = torch.empty(B, 3, dtype=torch.float64, device=dev)
+        bs = torch.empty(B, dtype=torch.float64, device=dev)
+        ni = torch.empty(B, dtype=torch.int32, device=dev)
+        st = torch.empty(B, dtype=torch.int32, device=dev)
+        _lib.check(lib.mfr_scale_from_depth_batch(
+            _lib.ptr(pts0), _lib.ptr(pts1), _lib.ptr(emat_mask), _lib.ptr(n_corr), B, maxN, _lib.ptr(depth0),
+            _lib.ptr(depth1), H, W, _lib.ptr(K0), _lib.ptr(K1), _lib.ptr(R), _lib.ptr(t), _lib.ptr(in_status),
+            self.scale_thr, _lib.ptr(self._ws), self._ws.numel(), _lib.ptr(tm), _lib.ptr(bs), _lib.ptr(ni),
+            _lib.ptr(st), _lib.stream_ptr()), "mfr_scale_from_depth_batch")
+        return dict(t_metric=tm, best_scale=bs, n_inliers=ni, status=st)
+
+
+def test_f64_ops(a, b, c):
+    lib = _lib.load(require_gpu=True)
+    a = _chk(a, torch.float64, "a"); b = _chk(b, torch.float64, "b"); c = _chk(c, torch.float64, "c")
+    out = torch.empty(a.numel(), 3, dtype=torch.float64, device=a.device)
+    _lib.check(lib.mfr_test_f64_ops(_lib.ptr(a), _lib.ptr(b), _lib.ptr(c), a.numel(), _lib.ptr(out),
+                                    _lib.stream_ptr()), "mfr_test_f64_ops")
+    return out
+
+
+def test_sample(seed, pair_ids, iters, n, k):
+    lib = _lib.load(require_gpu=True)
+    pair_ids = _chk(pair_ids, torch.int64, "pair_ids")
+    B = pair_ids.numel()
+    out = torch.empty(B, iters, k, dtype=torch.int32, device=pair_ids.device)
+    _lib.check(lib.mfr_test_sample(int(seed), _lib.ptr(pair_ids), B, iters, n, k, _lib.ptr(out), _lib.stream_ptr()),
+               "mfr_test_sample")
+    return out
