@@ -117,6 +117,51 @@ int mfr_scale_from_depth_batch(const float *pts0, const float *pts1, const uint8
                                double *t_metric, double *best_scale, int32_t *n_inliers, int32_t *status,
                                void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * SuperPoint post-processing.  Reference call site: SuperGlue_matcher.match,
+ * etc/feature_matching_baselines/matchers.py:93-120 (hyper-parameters :65-71); the network itself
+ * is the un-vendored magicleap submodule (.gitmodules:4-6), restated per SURVEY.md Appendix A.2.
+ *   mfr_sp_scoremap            softmax-65, drop dustbin, 8x8 pixel shuffle: logits [B,65,Hc,Wc]
+ *                              (NCHW) -> scores [B,8Hc,8Wc]
+ *   mfr_sp_nms_candidates      simple_nms(radius 4, 2 rounds) + keypoint threshold + border
+ *                              removal; appends survivors to cand [B,cand_cap] (u64 key = score
+ *                              bits << 32 | ~raster index) and counts them; nms_out [B,H,W] optional
+ *   mfr_sp_select_topk         top-K (K <= 1024) by (score desc, raster index asc); raster order
+ *                              when <= K candidates -> kpts [B,K,2] (x,y), kscores [B,K], n_kpts [B]
+ *   mfr_sp_sample_descriptors  dense descriptors [B,Hc,Wc,256] (NHWC, un-normalised) -> per-cell L2,
+ *                              bilinear grid_sample(align_corners=True), L2 -> desc [B,K,256]
+ * ------------------------------------------------------------------------------------------ */
+int mfr_sp_scoremap(const float *logits, int B, int Hc, int Wc, float *scores, void *stream);
+int mfr_sp_nms_candidates(const float *scores, int B, int H, int W, int nms_radius, float threshold, int border,
+                          float *nms_out, uint64_t *cand, int cand_cap, int32_t *cand_count, void *stream);
+int mfr_sp_select_topk(const uint64_t *cand, int cand_cap, const int32_t *cand_count, int B, int W, int K,
+                       float *kpts, float *kscores, int32_t *n_kpts, void *stream);
+int mfr_sp_sample_descriptors(const float *dense_nhwc, int B, int Hc, int Wc, const float *kpts,
+                              const int32_t *n_kpts, int K, float *desc, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * SuperGlue kernels (same call site; upstream algorithm per SURVEY.md Appendix A.3).
+ *   mfr_sg_attention       softmax(q k^T / 8) v, `heads` heads x 64, exact fp32 on the f32 matrix
+ *                          cores, scores never materialised.  q,k,v [B2,N,ld] (head h = channels
+ *                          [64h, 64h+64) from each base pointer), out [B2,N,ldo]; keys/queries
+ *                          >= n_tok[image] are masked; cross != 0 -> image b reads K/V of image b^1.
+ *   mfr_sg_sinkhorn_match  log_optimal_transport(S, bin_score, iters) without materialising the
+ *                          dustbin-augmented matrix + mutual arg-max + exp(score) > match_thr +
+ *                          ordered compaction (matchers.py:111-116) into pts0/pts1 [B,maxN,2],
+ *                          n_corr [B] -- the layout mfr_pnp_solve_batch consumes.
+ *                          S [B,ldS,ldS] = mdesc0^T mdesc1 / 16, n0/n1 [B] true keypoint counts,
+ *                          kpts0/kpts1 [B,K,2]; also matches0 [B,ldS] (-1 = none), mscores0 [B,ldS].
+ * ------------------------------------------------------------------------------------------ */
+int mfr_sg_attention(const float *q, const float *k, const float *v, int ld, int B2, int N, int heads,
+                     const int32_t *n_tok, int cross, float *out, int ldo, void *stream);
+size_t mfr_sg_match_workspace_bytes(int B, int ldS);
+int mfr_sg_sinkhorn_match(const float *S, int B, int ldS, const int32_t *n0, const int32_t *n1,
+                          float bin_score, int iters, float match_thr,
+                          const float *kpts0, const float *kpts1, int K,
+                          void *workspace, size_t workspace_bytes,
+                          int32_t *matches0, float *mscores0, float *pts0, float *pts1, int maxN, int32_t *n_corr,
+                          void *stream);
+
 #ifdef __cplusplus
 }
 #endif

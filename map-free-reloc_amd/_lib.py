@@ -27,6 +27,14 @@ SIGNATURES = {
     "mfr_pnp_lift": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mfr_pnp_ransac": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _d, _d, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                             _vp, _vp, _vp, _vp]),
+    "mfr_sp_scoremap": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "mfr_sp_nms_candidates": (_i, [_vp, _i, _i, _i, _i, C.c_float, _i, _vp, _vp, _i, _vp, _vp]),
+    "mfr_sp_select_topk": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "mfr_sp_sample_descriptors": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp]),
+    "mfr_sg_attention": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp]),
+    "mfr_sg_match_workspace_bytes": (_sz, [_i, _i]),
+    "mfr_sg_sinkhorn_match": (_i, [_vp, _i, _i, _vp, _vp, C.c_float, _i, C.c_float, _vp, _vp, _i, _vp, _sz,
+                                   _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "mfr_scale_workspace_bytes": (_sz, [_i, _i]),
     "mfr_scale_from_depth_batch": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp,
                                         _d, _vp, _sz, _vp, _vp, _vp, _vp, _vp]),

@@ -1,0 +1,361 @@
+// superpoint_post.hip -- SuperPoint post-processing on gfx950 (everything after the conv heads).
+//
+// Reference call site: SuperGlue_matcher (etc/feature_matching_baselines/matchers.py:62-120,
+// hyper-parameters :65-71) -> upstream SuperPoint.forward (un-vendored submodule; algorithm per
+// SURVEY.md Appendix A.2).  Stages:
+//
+//   sp_scoremap_kernel   softmax over the 65 detector channels, drop the dustbin, 8x8 pixel-shuffle
+//                        [B,65,Hc,Wc] -> [B,8Hc,8Wc]                       (one pass, HBM-bound)
+//   sp_nms_kernel        simple_nms(radius r, 2 suppression rounds) fused in ONE pass: the five
+//                        (2r+1)^2 max-pools run on an LDS tile with a 5r halo; also applies the
+//                        keypoint threshold + border removal and appends survivors to a per-image
+//                        candidate list (key = score bits | ~raster index)
+//   sp_select_kernel     top-K by (score desc, raster index asc) via 64-bit radix select + bitonic
+//                        sort in LDS (or raster order when there are <= K candidates, like upstream's
+//                        nonzero() order) -> keypoints (x,y), scores, count
+//   sp_sample_kernel     descriptor head output (NHWC, un-normalised) -> per-cell L2 normalise,
+//                        bilinear grid_sample(align_corners=True), L2 normalise; one wavefront per
+//                        keypoint, 1 KiB coalesced corner reads
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "../../include/mfr_hip.h"
+
+#define CHECK_LAUNCH() do { if (hipGetLastError() != hipSuccess) return MFR_E_LAUNCH; } while (0)
+
+// ------------------------------------------------------------------------------------------
+// one thread per coarse cell; logits NCHW so lanes (adjacent x) read coalesced per channel
+__global__ void __launch_bounds__(256) sp_scoremap_kernel(const float *__restrict__ logits, int Hc, int Wc,
+                                                          float *__restrict__ out)
+{
+    const int b = blockIdx.y;
+    const int cell = blockIdx.x * 256 + threadIdx.x;
+    if (cell >= Hc * Wc) return;
+    const int y = cell / Wc, x = cell - y * Wc;
+    const float *p = logits + (size_t)b * 65 * Hc * Wc + cell;
+    float v[65];
+    float m = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < 65; ++c) { v[c] = p[(size_t)c * Hc * Wc]; m = fmaxf(m, v[c]); }
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < 65; ++c) { v[c] = expf(v[c] - m); s += v[c]; }
+    const float inv = 1.0f / s;
+    const int W8 = Wc * 8;
+    float *o = out + (size_t)b * Hc * 8 * W8 + (size_t)(y * 8) * W8 + x * 8;
+#pragma unroll
+    for (int dy = 0; dy < 8; ++dy) {
+        float4 a = make_float4(v[dy * 8] * inv, v[dy * 8 + 1] * inv, v[dy * 8 + 2] * inv, v[dy * 8 + 3] * inv);
+        float4 c = make_float4(v[dy * 8 + 4] * inv, v[dy * 8 + 5] * inv, v[dy * 8 + 6] * inv, v[dy * 8 + 7] * inv);
+        *(float4 *)(o + (size_t)dy * W8) = a;
+        *(float4 *)(o + (size_t)dy * W8 + 4) = c;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// fused simple_nms.  Output tile TW x TH, halo 5*R (R = 4 -> 20).
+#define NMS_R 4
+#define NMS_HALO (5 * NMS_R)
+#define NMS_TW 64
+#define NMS_TH 32
+#define NMS_LW (NMS_TW + 2 * NMS_HALO)   // 104
+#define NMS_LH (NMS_TH + 2 * NMS_HALO)   // 72
+#define NMS_N (NMS_LW * NMS_LH)          // 7488
+
+// separable (2R+1)^2 max-pool of `src` into `dst` over the whole LDS tile (edges of the tile are
+// garbage by construction; each pool consumes R of the halo).  tmp is scratch.
+static __device__ __forceinline__ void pool9(const float *src, float *tmp, float *dst)
+{
+    for (int i = threadIdx.x; i < NMS_N; i += 256) {
+        const int y = i / NMS_LW, x = i - y * NMS_LW;
+        float m = -INFINITY;
+#pragma unroll
+        for (int d = -NMS_R; d <= NMS_R; ++d) {
+            const int xx = x + d;
+            if (xx >= 0 && xx < NMS_LW) m = fmaxf(m, src[y * NMS_LW + xx]);
+        }
+        tmp[i] = m;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < NMS_N; i += 256) {
+        const int y = i / NMS_LW, x = i - y * NMS_LW;
+        float m = -INFINITY;
+#pragma unroll
+        for (int d = -NMS_R; d <= NMS_R; ++d) {
+            const int yy = y + d;
+            if (yy >= 0 && yy < NMS_LH) m = fmaxf(m, tmp[yy * NMS_LW + x]);
+        }
+        dst[i] = m;
+    }
+    __syncthreads();
+}
+
+__global__ void __launch_bounds__(256) sp_nms_kernel(const float *__restrict__ scores, int H, int W, float thr,
+                                                     int border, float *__restrict__ nms_out /*may be NULL*/,
+                                                     unsigned long long *__restrict__ cand, int cand_cap,
+                                                     int *__restrict__ cand_count)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *s = (float *)smem;            // scores (-inf outside the image: max_pool2d padding)
+    float *a = s + NMS_N;                // work buffers
+    float *t = a + NMS_N;
+    float *mk = t + NMS_N;               // max_mask as 0/1
+    const int b = blockIdx.z;
+    const int x0 = blockIdx.x * NMS_TW - NMS_HALO, y0 = blockIdx.y * NMS_TH - NMS_HALO;
+    const float *img = scores + (size_t)b * H * W;
+    for (int i = threadIdx.x; i < NMS_N; i += 256) {
+        const int ly = i / NMS_LW, lx = i - ly * NMS_LW;
+        const int gx = x0 + lx, gy = y0 + ly;
+        s[i] = (gx >= 0 && gx < W && gy >= 0 && gy < H) ? img[(size_t)gy * W + gx] : -INFINITY;
+    }
+    __syncthreads();
+    pool9(s, t, a);                                             // a = max_pool(scores)
+    for (int i = threadIdx.x; i < NMS_N; i += 256)                  // max_mask (in-image cells only)
+        mk[i] = (s[i] != -INFINITY && s[i] == a[i]) ? 1.f : 0.f;
+    __syncthreads();
+    for (int round = 0; round < 2; ++round) {
+        pool9(mk, t, a);                                        // a = max_pool(max_mask) (>0 = supp_mask)
+        // a <- supp_scores = supp ? 0 : scores   (keep supp flag in t? t is pool scratch -> recompute)
+        for (int i = threadIdx.x; i < NMS_N; i += 256) {
+            const bool supp = a[i] > 0.f;
+            // out-of-image stays -inf so that it never wins a max (padding semantics)
+            a[i] = (s[i] == -INFINITY) ? -INFINITY : (supp ? 0.f : s[i]);
+            // stash supp in the sign of mk: mk in {0,1} -> encode as mk + 2*supp
+            mk[i] = mk[i] + (supp ? 2.f : 0.f);
+        }
+        __syncthreads();
+        float *pooled = t;                                      // pool9 needs (src, tmp, dst) distinct
+        // use s as tmp is not allowed (still needed) -> pool a into 'pooled' with mk-free scratch:
+        // rows pass into 'pooled', cols pass back into a2 = (we reuse) -> do it manually
+        for (int i = threadIdx.x; i < NMS_N; i += 256) {
+            const int y = i / NMS_LW, x = i - y * NMS_LW;
+            float m = -INFINITY;
+#pragma unroll
+            for (int d = -NMS_R; d <= NMS_R; ++d) {
+                const int xx = x + d;
+                if (xx >= 0 && xx < NMS_LW) m = fmaxf(m, a[y * NMS_LW + xx]);
+            }
+            pooled[i] = m;
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < NMS_N; i += 256) {
+            const int y = i / NMS_LW, x = i - y * NMS_LW;
+            float m = -INFINITY;
+#pragma unroll
+            for (int d = -NMS_R; d <= NMS_R; ++d) {
+                const int yy = y + d;
+                if (yy >= 0 && yy < NMS_LH) m = fmaxf(m, pooled[yy * NMS_LW + x]);
+            }
+            // new_max_mask = supp_scores == max_pool(supp_scores); max_mask |= new & ~supp
+            const float code = mk[i];
+            const bool supp = code >= 2.f;
+            const bool old = (code == 1.f) || (code == 3.f);
+            const bool nw = (a[i] == m);
+            mk[i] = (old || (nw && !supp)) ? 1.f : 0.f;
+        }
+        __syncthreads();
+    }
+    // emit: where(max_mask, scores, 0); candidates above threshold and inside the border
+    for (int i = threadIdx.x; i < NMS_TW * NMS_TH; i += 256) {
+        const int ty = i / NMS_TW, tx = i - ty * NMS_TW;
+        const int gx = blockIdx.x * NMS_TW + tx, gy = blockIdx.y * NMS_TH + ty;
+        if (gx >= W || gy >= H) continue;
+        const int li = (ty + NMS_HALO) * NMS_LW + tx + NMS_HALO;
+        const float v = (mk[li] == 1.f) ? s[li] : 0.f;
+        if (nms_out) nms_out[(size_t)b * H * W + (size_t)gy * W + gx] = v;
+        if (v > thr && gx >= border && gx < W - border && gy >= border && gy < H - border) {
+            const int slot = atomicAdd(&cand_count[b], 1);
+            if (slot < cand_cap) {
+                const unsigned idx = (unsigned)(gy * W + gx);
+                cand[(size_t)b * cand_cap + slot] =
+                    ((unsigned long long)__float_as_uint(v) << 32) | (unsigned long long)(~idx);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// one 1024-thread workgroup per image.  keys are unique (raster index in the low word).
+#define SEL_T 1024
+__global__ void __launch_bounds__(SEL_T) sp_select_kernel(const unsigned long long *__restrict__ cand, int cand_cap,
+                                                          const int *__restrict__ cand_count, int W, int K,
+                                                          float *__restrict__ kpts /*[B,K,2]*/,
+                                                          float *__restrict__ kscores /*[B,K]*/,
+                                                          int *__restrict__ n_kpts /*[B]*/)
+{
+    __shared__ unsigned long long sel[SEL_T];
+    __shared__ int hist[256];
+    __shared__ unsigned long long prefix_s;
+    __shared__ int remaining_s, nsel_s;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    int n = cand_count[b];
+    if (n > cand_cap) n = cand_cap;
+    const unsigned long long *c = cand + (size_t)b * cand_cap;
+    const bool topk = n > K;
+    unsigned long long kth = 0ull;         // smallest selected key when topk
+    if (topk) {
+        // radix select of the K-th largest key, 8 bits per pass from the top
+        unsigned long long prefix = 0ull, pmask = 0ull;
+        int remaining = K;
+        for (int shift = 56; shift >= 0; shift -= 8) {
+            if (tid < 256) hist[tid] = 0;
+            __syncthreads();
+            for (int i = tid; i < n; i += SEL_T) {
+                const unsigned long long k = c[i];
+                if ((k & pmask) == prefix) atomicAdd(&hist[(int)((k >> shift) & 0xff)], 1);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                int acc = 0, d = 255;
+                for (; d >= 0; --d) {
+                    if (acc + hist[d] >= remaining) break;
+                    acc += hist[d];
+                }
+                prefix_s = prefix | ((unsigned long long)d << shift);
+                remaining_s = remaining - acc;
+            }
+            __syncthreads();
+            prefix = prefix_s; remaining = remaining_s;
+            pmask |= 0xffull << shift;
+            __syncthreads();
+        }
+        kth = prefix;
+    }
+    if (tid == 0) nsel_s = 0;
+    sel[tid] = 0ull;
+    __syncthreads();
+    for (int i = tid; i < n; i += SEL_T) {
+        const unsigned long long k = c[i];
+        if (!topk || k >= kth) {
+            const int slot = atomicAdd(&nsel_s, 1);
+            if (slot < SEL_T) sel[slot] = k;
+        }
+    }
+    __syncthreads();
+    const int nsel = min(nsel_s, min(K, SEL_T));
+    // sort key: top-K -> (score desc, index asc) == key desc ; else raster order == low word desc
+    // (low word is ~index).  Unused slots hold 0 and sink to the end.
+    unsigned long long mine = sel[tid];
+    if (!topk && tid < nsel_s) mine = ((mine & 0xffffffffull) << 32) | (mine >> 32);
+    sel[tid] = mine;
+    __syncthreads();
+    for (int k2 = 2; k2 <= SEL_T; k2 <<= 1) {
+        for (int j = k2 >> 1; j > 0; j >>= 1) {
+            const int ixj = tid ^ j;
+            if (ixj > tid) {
+                const unsigned long long x = sel[tid], y = sel[ixj];
+                const bool desc = ((tid & k2) == 0);
+                if ((x < y) == desc) { sel[tid] = y; sel[ixj] = x; }
+            }
+            __syncthreads();
+        }
+    }
+    if (tid < K) {
+        float kx = 0.f, ky = 0.f, sc = 0.f;
+        if (tid < nsel) {
+            unsigned long long k = sel[tid];
+            if (!topk) k = ((k & 0xffffffffull) << 32) | (k >> 32);
+            const unsigned idx = ~(unsigned)(k & 0xffffffffull);
+            sc = __uint_as_float((unsigned)(k >> 32));
+            kx = (float)(idx % (unsigned)W); ky = (float)(idx / (unsigned)W);
+        }
+        kpts[((size_t)b * K + tid) * 2] = kx;
+        kpts[((size_t)b * K + tid) * 2 + 1] = ky;
+        kscores[(size_t)b * K + tid] = sc;
+    }
+    if (tid == 0) n_kpts[b] = nsel;
+}
+
+// ------------------------------------------------------------------------------------------
+// one wavefront per keypoint; dense [B,Hc,Wc,256] NHWC raw descriptors
+__global__ void __launch_bounds__(256) sp_sample_kernel(const float *__restrict__ dense, int Hc, int Wc,
+                                                        const float *__restrict__ kpts, const int *__restrict__ n_kpts,
+                                                        int K, float *__restrict__ desc /*[B,K,256]*/)
+{
+    const int b = blockIdx.y;
+    const int kp = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (kp >= K) return;
+    float4 *o = (float4 *)(desc + ((size_t)b * K + kp) * 256) + lane;
+    if (kp >= n_kpts[b]) { *o = make_float4(0.f, 0.f, 0.f, 0.f); return; }
+    const float s = 8.f;
+    float kx = kpts[((size_t)b * K + kp) * 2], ky = kpts[((size_t)b * K + kp) * 2 + 1];
+    // upstream sample_descriptors: (k - s/2 + 0.5) / (W*s - s/2 - 0.5) * 2 - 1, then
+    // grid_sample align_corners=True: ix = (g + 1) / 2 * (Wc - 1)
+    float gx = (kx - s / 2 + 0.5f) / ((float)Wc * s - s / 2 - 0.5f) * 2.f - 1.f;
+    float gy = (ky - s / 2 + 0.5f) / ((float)Hc * s - s / 2 - 0.5f) * 2.f - 1.f;
+    const float ix = (gx + 1.f) * 0.5f * (float)(Wc - 1), iy = (gy + 1.f) * 0.5f * (float)(Hc - 1);
+    const float fx0 = floorf(ix), fy0 = floorf(iy);
+    const int x0 = (int)fx0, y0 = (int)fy0, x1 = x0 + 1, y1 = y0 + 1;
+    const float wx1 = ix - fx0, wy1 = iy - fy0, wx0 = 1.f - wx1, wy0 = 1.f - wy1;
+    const int xs[4] = { x0, x1, x0, x1 }, ys[4] = { y0, y0, y1, y1 };
+    const float ws[4] = { wx0 * wy0, wx1 * wy0, wx0 * wy1, wx1 * wy1 };
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        if (xs[c] < 0 || xs[c] >= Wc || ys[c] < 0 || ys[c] >= Hc) continue;       // zero padding
+        const float4 v = *((const float4 *)(dense + (((size_t)b * Hc + ys[c]) * Wc + xs[c]) * 256) + lane);
+        float ss = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) ss += __shfl_xor(ss, off, 64);
+        const float inv = ws[c] / fmaxf(sqrtf(ss), 1e-12f);                        // F.normalize eps
+        acc.x += v.x * inv; acc.y += v.y * inv; acc.z += v.z * inv; acc.w += v.w * inv;
+    }
+    float ss = acc.x * acc.x + acc.y * acc.y + acc.z * acc.z + acc.w * acc.w;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) ss += __shfl_xor(ss, off, 64);
+    const float inv = 1.f / fmaxf(sqrtf(ss), 1e-12f);
+    *o = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+}
+
+extern "C" {
+
+int mfr_sp_scoremap(const float *logits, int B, int Hc, int Wc, float *scores, void *stream)
+{
+    if (!logits || !scores || B <= 0 || Hc <= 0 || Wc <= 0) return MFR_E_ARG;
+    hipLaunchKernelGGL(sp_scoremap_kernel, dim3((Hc * Wc + 255) / 256, B), dim3(256), 0, (hipStream_t)stream,
+                       logits, Hc, Wc, scores);
+    CHECK_LAUNCH();
+    return 0;
+}
+
+int mfr_sp_nms_candidates(const float *scores, int B, int H, int W, int nms_radius, float threshold, int border,
+                          float *nms_out, uint64_t *cand, int cand_cap, int32_t *cand_count, void *stream)
+{
+    if (!scores || !cand || !cand_count || B <= 0 || H <= 0 || W <= 0 || cand_cap <= 0) return MFR_E_ARG;
+    if (nms_radius != NMS_R) return MFR_E_ARG;          // compiled for the reference's radius (matchers.py:65)
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(cand_count, 0, sizeof(int32_t) * (size_t)B, s) != hipSuccess) return MFR_E_LAUNCH;
+    dim3 grid((W + NMS_TW - 1) / NMS_TW, (H + NMS_TH - 1) / NMS_TH, B);
+    // 117 KiB of the CU's 160 KiB LDS: above the 64 KiB default dynamic limit
+    if (hipFuncSetAttribute((const void *)sp_nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            4 * NMS_N * sizeof(float)) != hipSuccess) return MFR_E_LAUNCH;
+    hipLaunchKernelGGL(sp_nms_kernel, grid, dim3(256), 4 * NMS_N * sizeof(float), s, scores, H, W, threshold, border,
+                       nms_out, (unsigned long long *)cand, cand_cap, cand_count);
+    CHECK_LAUNCH();
+    return 0;
+}
+
+int mfr_sp_select_topk(const uint64_t *cand, int cand_cap, const int32_t *cand_count, int B, int W, int K,
+                       float *kpts, float *kscores, int32_t *n_kpts, void *stream)
+{
+    if (!cand || !cand_count || !kpts || !kscores || !n_kpts || B <= 0 || K <= 0 || K > SEL_T || W <= 0)
+        return MFR_E_ARG;
+    hipLaunchKernelGGL(sp_select_kernel, dim3(B), dim3(SEL_T), 0, (hipStream_t)stream,
+                       (const unsigned long long *)cand, cand_cap, cand_count, W, K, kpts, kscores, n_kpts);
+    CHECK_LAUNCH();
+    return 0;
+}
+
+int mfr_sp_sample_descriptors(const float *dense_nhwc, int B, int Hc, int Wc, const float *kpts,
+                              const int32_t *n_kpts, int K, float *desc, void *stream)
+{
+    if (!dense_nhwc || !kpts || !n_kpts || !desc || B <= 0 || Hc <= 0 || Wc <= 0 || K <= 0) return MFR_E_ARG;
+    hipLaunchKernelGGL(sp_sample_kernel, dim3((K + 3) / 4, B), dim3(256), 0, (hipStream_t)stream, dense_nhwc, Hc, Wc,
+                       kpts, n_kpts, K, desc);
+    CHECK_LAUNCH();
+    return 0;
+}
+
+}  // extern "C"

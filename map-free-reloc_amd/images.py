@@ -1,0 +1,63 @@
+"""Synthetic 540x720 image pairs (no Map-free data offline): a band-limited random
+texture seen from two views related by a small homography, so that a detector/descriptor finds
+repeatable structure and the matcher has real correspondences to recover.  Values are float32 in
+[0,1] like the reference's read_image (grayscale / 255, matchers.py:101-104)."""
+import numpy as np
+
+
+def _texture(rng, H, W):
+    """sum of bilinearly up-sampled noise octaves + sparse blobs -> [H,W] float32 in [0,1]"""
+    from scipy import ndimage
+    img = np.zeros((H, W), np.float64)
+    for cell, amp in ((64, 0.35), (24, 0.3), (9, 0.25), (4, 0.15)):
+        h, w = H // cell + 2, W // cell + 2
+        n = rng.uniform(0, 1, size=(h, w))
+        img += amp * ndimage.zoom(n, (H / h, W / w), order=1)[:H, :W]
+    img = (img - img.min()) / (img.max() - img.min())
+    return img.astype(np.float32)
+
+
+BAND_SHIFTS = (16, 8, 24)       # pixel disparity of the three horizontal depth bands (multiples of 8)
+
+
+def synthetic_pair(seed, H=720, W=540, f=590.0):
+    """Two views of a scene made of three fronto-parallel depth bands (horizontal strips), the
+    second camera translated along +x by tx: a point at depth Z moves by f*tx/Z pixels, and the
+    band depths are chosen so that the disparities are exactly 16 / 8 / 24 px.  Disparities that
+    are multiples of the networks' 8-px cell make SuperPoint's response exactly translation-
+    equivariant inside each band even with untrained (random) weights, so the matcher has hundreds
+    of true correspondences and the pose has a known answer.
+
+    returns dict(img0, img1 [H,W] f32 in [0,1], depth0, depth1 [H,W] f32 metres (uint16-mm
+    quantised like lib/datasets/utils.py:77-81), K [3,3] f32, R_gt, t_gt)."""
+    rng = np.random.default_rng(seed)
+    pad = 32
+    base = _texture(rng, H, W + 2 * pad)
+    img0 = base[:, pad:pad + W].copy()
+    img1 = np.empty_like(img0)
+    depth = np.empty((H, W), np.float64)
+    Za = 5.0
+    tx = BAND_SHIFTS[0] * Za / f
+    edges = [0, H // 3, 2 * H // 3, H]
+    for k, sft in enumerate(BAND_SHIFTS):
+        y0, y1 = edges[k], edges[k + 1]
+        img1[y0:y1] = base[y0:y1, pad - sft:pad - sft + W]      # x1 = x0 + shift
+        depth[y0:y1] = f * tx / sft
+    depth = (np.round(depth * 1000).astype(np.uint16) / 1000.0).astype(np.float32)
+    K = np.array([[f, 0, W / 2 - 0.5], [0, f, H / 2 - 0.5], [0, 0, 1]], dtype=np.float32)
+    return dict(img0=img0, img1=img1, depth0=depth, depth1=depth.copy(), K=K,
+                R_gt=np.eye(3), t_gt=np.array([tx, 0.0, 0.0]))
+
+
+def synthetic_batch(seeds, H=720, W=540):
+    """dict of stacked arrays: images interleaved [2B,1,H,W] (image 2p = reference view, 2p+1 =
+    query view of pair p), depth0/depth1 [B,H,W], K0/K1 [B,3,3], R_gt, t_gt, pair_ids"""
+    prs = [synthetic_pair(s, H, W) for s in seeds]
+    B = len(prs)
+    images = np.empty((2 * B, 1, H, W), np.float32)
+    for i, p in enumerate(prs):
+        images[2 * i, 0], images[2 * i + 1, 0] = p["img0"], p["img1"]
+    return dict(images=images, depth0=np.stack([p["depth0"] for p in prs]), depth1=np.stack([p["depth1"] for p in prs]),
+                K0=np.stack([p["K"] for p in prs]), K1=np.stack([p["K"] for p in prs]),
+                R_gt=np.stack([p["R_gt"] for p in prs]), t_gt=np.stack([p["t_gt"] for p in prs]),
+                pair_ids=np.asarray(seeds, np.int64))

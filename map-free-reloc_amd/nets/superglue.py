@@ -1,0 +1,114 @@
+"""SuperGlue on MI355X: linear layers through PyTorch-ROCm GEMMs, attention and the
+optimal-transport matching head through csrc/attention.hip and csrc/superglue_match.hip.
+
+Reference call site: SuperGlue_matcher (etc/feature_matching_baselines/matchers.py:62-120; 20
+Sinkhorn iterations, match threshold 0.2 :70-71); network = un-vendored magicleap submodule,
+restated per SURVEY.md Appendix A.3 with upstream parameter names so superglue_{indoor,outdoor}.pth
+load unchanged.  Layout is token-major [2B, K, 256] (image 2p = reference view, 2p+1 = query view
+of pair p); upstream's [dim, head] channel split (channel c = 4 d + h) is re-ordered ONCE at load
+time to head-major (c' = 64 h + d) by permuting the q/k/v output rows and the merge input columns,
+so every head is a contiguous 256-byte slice for the attention kernel.
+"""
+import torch
+import torch.nn.functional as F
+
+from .. import _lib
+
+
+def _fold_bn(w, b, sd, bn):
+    g, beta = sd[bn + ".weight"], sd[bn + ".bias"]
+    mean, var = sd[bn + ".running_mean"], sd[bn + ".running_var"]
+    s = g / torch.sqrt(var + 1e-5)
+    return w * s[:, None], (b - mean) * s + beta
+
+
+class SuperGlueHIP:
+    def __init__(self, state_dict, device="cuda", sinkhorn_iterations=20, match_threshold=0.2, n_layers=18):
+        _lib.load(require_gpu=True)
+        self.device = torch.device(device)
+        self.iters, self.match_thr = int(sinkhorn_iterations), float(match_threshold)
+        sd = {k: v.float() for k, v in state_dict.items()}
+        dev = lambda t: t.to(self.device).contiguous()
+        lin = lambda n: sd[n + ".weight"].squeeze(-1)
+        # keypoint encoder MLP [3,32,64,128,256,256] with BN folded
+        self.kenc = []
+        for i in range(4):
+            w, b = _fold_bn(lin(f"kenc.encoder.{3 * i}"), sd[f"kenc.encoder.{3 * i}.bias"], sd, f"kenc.encoder.{3 * i + 1}")
+            self.kenc.append((dev(w), dev(b)))
+        self.kenc.append((dev(lin("kenc.encoder.12")), dev(sd["kenc.encoder.12.bias"])))
+        perm = torch.tensor([(c % 64) * 4 + c // 64 for c in range(256)])      # head-major <- upstream channel
+        self.layers = []
+        for l in range(n_layers):
+            p = f"gnn.layers.{l}"
+            wq = [lin(f"{p}.attn.proj.{j}")[perm] for j in range(3)]
+            bq = [sd[f"{p}.attn.proj.{j}.bias"][perm] for j in range(3)]
+            wm = lin(f"{p}.attn.merge")[:, perm]
+            w1, b1 = _fold_bn(lin(f"{p}.mlp.0"), sd[f"{p}.mlp.0.bias"], sd, f"{p}.mlp.1")
+            self.layers.append(dict(
+                wqkv=dev(torch.cat(wq, 0)), bqkv=dev(torch.cat(bq, 0)), wm=dev(wm), bm=dev(sd[f"{p}.attn.merge.bias"]),
+                w1=dev(w1), b1=dev(b1), w2=dev(lin(f"{p}.mlp.3")), b2=dev(sd[f"{p}.mlp.3.bias"]),
+                cross=(l % 2 == 1)))
+        self.wf, self.bf = dev(lin("final_proj")), dev(sd["final_proj.bias"])
+        self.bin_score = float(sd["bin_score"])
+        self._ws = None
+
+    def attention(self, qkv, n_tok, cross):
+        """qkv [B2,K,768] (q | k | v, each head-major) -> message [B2,K,256]"""
+        lib = _lib.load()
+        B2, K, _ = qkv.shape
+        out = torch.empty(B2, K, 256, dtype=torch.float32, device=qkv.device)
+        base = qkv.data_ptr()
+        _lib.check(lib.mfr_sg_attention(base, base + 256 * 4, base + 512 * 4, 768, B2, K, 4, _lib.ptr(n_tok),
+                                        1 if cross else 0, _lib.ptr(out), 256, _lib.stream_ptr()), "mfr_sg_attention")
+        return out
+
+    def sinkhorn_match(self, S, n0, n1, kpts0, kpts1, maxN=None):
+        lib = _lib.load()
+        B, ldS, _ = S.shape
+        K = kpts0.shape[1]
+        maxN = maxN or ldS
+        dev = S.device
+        need = lib.mfr_sg_match_workspace_bytes(B, ldS)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        m0 = torch.empty(B, ldS, dtype=torch.int32, device=dev)
+        ms0 = torch.empty(B, ldS, dtype=torch.float32, device=dev)
+        pts0 = torch.zeros(B, maxN, 2, dtype=torch.float32, device=dev)
+        pts1 = torch.zeros(B, maxN, 2, dtype=torch.float32, device=dev)
+        nc = torch.empty(B, dtype=torch.int32, device=dev)
+        _lib.check(lib.mfr_sg_sinkhorn_match(
+            _lib.ptr(S.contiguous()), B, ldS, _lib.ptr(n0), _lib.ptr(n1), self.bin_score, self.iters, self.match_thr,
+            _lib.ptr(kpts0.contiguous()), _lib.ptr(kpts1.contiguous()), K, _lib.ptr(self._ws), self._ws.numel(),
+            _lib.ptr(m0), _lib.ptr(ms0), _lib.ptr(pts0), _lib.ptr(pts1), maxN, _lib.ptr(nc), _lib.stream_ptr()),
+            "mfr_sg_sinkhorn_match")
+        return dict(matches0=m0, matching_scores0=ms0, pts0=pts0, pts1=pts1, n_corr=nc)
+
+    @torch.no_grad()
+    def final_descriptors(self, kpts, scores, desc, n, image_hw):
+        H, W = image_hw
+        B2, K, _ = kpts.shape
+        size = torch.tensor([float(W), float(H)], device=kpts.device)
+        kn = (kpts - size / 2) / (size.max() * 0.7)                                   # normalize_keypoints
+        h = torch.cat([kn, scores.unsqueeze(-1)], -1)
+        for i, (w, b) in enumerate(self.kenc):
+            h = F.linear(h, w, b)
+            if i < len(self.kenc) - 1:
+                h = F.relu_(h)
+        x = desc + h
+        for L in self.layers:
+            qkv = F.linear(x, L["wqkv"], L["bqkv"])
+            msg = self.attention(qkv, n, L["cross"])
+            msg = F.linear(msg, L["wm"], L["bm"])
+            hid = F.relu_(F.linear(torch.cat([x, msg], -1), L["w1"], L["b1"]))
+            x = x + F.linear(hid, L["w2"], L["b2"])
+        return F.linear(x, self.wf, self.bf)
+
+    @torch.no_grad()
+    def __call__(self, sp_out, image_hw, maxN=None):
+        """sp_out: SuperPointHIP output for the interleaved [2B] images -> dict(pts0, pts1 [B,maxN,2],
+        n_corr [B], matches0, matching_scores0)"""
+        kpts, scores, desc, n = sp_out["kpts"], sp_out["scores"], sp_out["desc"], sp_out["n"]
+        md = self.final_descriptors(kpts, scores, desc, n, image_hw)
+        S = torch.bmm(md[0::2], md[1::2].transpose(1, 2)) * (1.0 / 16.0)
+        return self.sinkhorn_match(S, n[0::2].contiguous(), n[1::2].contiguous(),
+                                   kpts[0::2].contiguous(), kpts[1::2].contiguous(), maxN)

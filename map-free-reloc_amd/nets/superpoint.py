@@ -1,0 +1,95 @@
+"""SuperPoint on MI355X: conv stack through PyTorch-ROCm (MIOpen; dense MFMA-bound library work),
+everything after the conv heads through the hand-written HIP kernels of csrc/superpoint_post.hip.
+
+Reference call site: SuperGlue_matcher (etc/feature_matching_baselines/matchers.py:62-120; nms 4,
+threshold 0.005, max 1024 keypoints :65-67); network = un-vendored magicleap submodule, restated
+per SURVEY.md Appendix A.2 with upstream parameter names (conv1a ... convDb) so that
+superpoint_v1.pth loads unchanged.
+"""
+import torch
+import torch.nn.functional as F
+
+from .. import _lib
+
+CAND_CAP = 32768
+
+
+class SuperPointHIP:
+    def __init__(self, state_dict, device="cuda", nms_radius=4, keypoint_threshold=0.005, max_keypoints=1024,
+                 remove_borders=4):
+        _lib.load(require_gpu=True)
+        if max_keypoints <= 0 or max_keypoints > 1024:
+            raise ValueError("max_keypoints must be in [1, 1024] (matchers.py:67 uses 1024)")
+        self.device = torch.device(device)
+        self.nms_radius, self.thr = int(nms_radius), float(keypoint_threshold)
+        self.K, self.border = int(max_keypoints), int(remove_borders)
+        self.w = {k: v.to(self.device, torch.float32).contiguous() for k, v in state_dict.items()}
+        # 1x1 heads as plain matrices
+        self.w["convDb.mat"] = self.w["convDb.weight"].reshape(256, 256).contiguous()
+
+    def _conv(self, x, name, relu=True):
+        x = F.conv2d(x, self.w[name + ".weight"], self.w[name + ".bias"], padding=self.w[name + ".weight"].shape[-1] // 2)
+        return F.relu_(x) if relu else x
+
+    def encode(self, image):
+        x = self._conv(image, "conv1a"); x = self._conv(x, "conv1b"); x = F.max_pool2d(x, 2, 2)
+        x = self._conv(x, "conv2a"); x = self._conv(x, "conv2b"); x = F.max_pool2d(x, 2, 2)
+        x = self._conv(x, "conv3a"); x = self._conv(x, "conv3b"); x = F.max_pool2d(x, 2, 2)
+        x = self._conv(x, "conv4a"); x = self._conv(x, "conv4b")
+        return x
+
+    # -- stage wrappers (each is one C-ABI call; exposed for stage-level parity tests) --
+    def score_map(self, logits):
+        lib = _lib.load()
+        B, C, Hc, Wc = logits.shape
+        assert C == 65
+        logits = logits.contiguous()
+        out = torch.empty(B, Hc * 8, Wc * 8, dtype=torch.float32, device=logits.device)
+        _lib.check(lib.mfr_sp_scoremap(_lib.ptr(logits), B, Hc, Wc, _lib.ptr(out), _lib.stream_ptr()), "mfr_sp_scoremap")
+        return out
+
+    def nms_candidates(self, scores, want_dense=False):
+        lib = _lib.load()
+        B, H, W = scores.shape
+        cand = torch.empty(B, CAND_CAP, dtype=torch.int64, device=scores.device)
+        cnt = torch.empty(B, dtype=torch.int32, device=scores.device)
+        dense = torch.empty_like(scores) if want_dense else None
+        _lib.check(lib.mfr_sp_nms_candidates(_lib.ptr(scores), B, H, W, self.nms_radius, self.thr, self.border,
+                                             _lib.ptr(dense), _lib.ptr(cand), CAND_CAP, _lib.ptr(cnt),
+                                             _lib.stream_ptr()), "mfr_sp_nms_candidates")
+        return cand, cnt, dense
+
+    def select(self, cand, cnt, W):
+        lib = _lib.load()
+        B = cand.shape[0]
+        kpts = torch.empty(B, self.K, 2, dtype=torch.float32, device=cand.device)
+        sc = torch.empty(B, self.K, dtype=torch.float32, device=cand.device)
+        n = torch.empty(B, dtype=torch.int32, device=cand.device)
+        _lib.check(lib.mfr_sp_select_topk(_lib.ptr(cand), CAND_CAP, _lib.ptr(cnt), B, W, self.K, _lib.ptr(kpts),
+                                          _lib.ptr(sc), _lib.ptr(n), _lib.stream_ptr()), "mfr_sp_select_topk")
+        return kpts, sc, n
+
+    def sample(self, dense_nhwc, kpts, n):
+        lib = _lib.load()
+        B, Hc, Wc, C = dense_nhwc.shape
+        assert C == 256
+        desc = torch.empty(B, self.K, 256, dtype=torch.float32, device=kpts.device)
+        _lib.check(lib.mfr_sp_sample_descriptors(_lib.ptr(dense_nhwc.contiguous()), B, Hc, Wc, _lib.ptr(kpts),
+                                                 _lib.ptr(n), self.K, _lib.ptr(desc), _lib.stream_ptr()),
+                   "mfr_sp_sample_descriptors")
+        return desc
+
+    @torch.no_grad()
+    def __call__(self, image):
+        """image [B2,1,H,W] f32 in [0,1] on the GPU -> dict(kpts [B2,K,2] (x,y), scores [B2,K],
+        desc [B2,K,256] token-major, n [B2] i32).  Rows >= n are zero."""
+        x = self.encode(image)
+        logits = self._conv(self._conv(x, "convPa"), "convPb", relu=False)
+        scores = self.score_map(logits)
+        cand, cnt, _ = self.nms_candidates(scores)
+        kpts, sc, n = self.select(cand, cnt, scores.shape[2])
+        cDa = self._conv(x, "convDa")
+        B, C, Hc, Wc = cDa.shape
+        dense = torch.addmm(self.w["convDb.bias"], cDa.permute(0, 2, 3, 1).reshape(-1, C), self.w["convDb.mat"].t())
+        desc = self.sample(dense.view(B, Hc, Wc, 256), kpts, n)
+        return dict(kpts=kpts, scores=sc, desc=desc, n=n)

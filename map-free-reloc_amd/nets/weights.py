@@ -1,0 +1,78 @@
+"""Deterministic synthetic weights with upstream parameter names.
+
+No checkpoints exist offline (superpoint_v1.pth / superglue_{indoor,outdoor}.pth /
+{indoor,outdoor}_ot.ckpt; matchers.py:17,70), so benchmarks and parity tests run on seeded random
+weights of the exact upstream architectures.  The state-dict keys are upstream's, so the real
+checkpoints load through the same path (`load_checkpoint`) when they are available.
+
+Plain i.i.d. weights make SuperGlue's assignment flat (no matches -> the solver stage would be
+idle), so the SuperGlue recipe is "structured random": the GNN updates and the keypoint encoder
+are scaled down (the network stays a mild perturbation of its input descriptors) and the final
+projection is scaled up so that the score matrix is peaky.  Accuracy of such weights is
+meaningless; shapes, arithmetic and control flow are exactly those of the trained network.
+"""
+import torch
+
+
+def _randn(g, shape, std):
+    return torch.randn(shape, generator=g) * std
+
+
+def superpoint_state_dict(seed=1234):
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    chans = [("conv1a", 1, 64, 3), ("conv1b", 64, 64, 3), ("conv2a", 64, 64, 3), ("conv2b", 64, 64, 3),
+             ("conv3a", 64, 128, 3), ("conv3b", 128, 128, 3), ("conv4a", 128, 128, 3), ("conv4b", 128, 128, 3),
+             ("convPa", 128, 256, 3), ("convPb", 256, 65, 1), ("convDa", 128, 256, 3), ("convDb", 256, 256, 1)]
+    for name, ci, co, k in chans:
+        fan_in = ci * k * k
+        w = _randn(g, (co, ci, k, k), 1.0)
+        # zero-sum filters and zero biases: an untrained ReLU stack otherwise responds mostly to
+        # the image's DC level and every descriptor comes out (almost) the same vector
+        w = w - w.mean(dim=(1, 2, 3), keepdim=True)
+        sd[f"{name}.weight"] = w / (w.std(dim=(1, 2, 3), keepdim=True) + 1e-9) * (2.0 / fan_in) ** 0.5
+        sd[f"{name}.bias"] = torch.zeros(co)
+    # a peaky detector head: logits of the zero-bias stack scale with image contrast (~1e-2)
+    sd["convPb.weight"] = sd["convPb.weight"] * 80.0
+    return sd
+
+
+def superglue_state_dict(seed=4321, gnn_gain=0.1, kenc_gain=0.1, proj_gain=12.0, n_layers=18):
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+
+    def conv1d(name, ci, co, gain=1.0, zero_bias=False):
+        sd[f"{name}.weight"] = _randn(g, (co, ci, 1), gain / ci ** 0.5)
+        sd[f"{name}.bias"] = torch.zeros(co) if zero_bias else _randn(g, (co,), 0.02 * gain)
+
+    def bn(name, c):
+        sd[f"{name}.weight"] = 1.0 + _randn(g, (c,), 0.05)
+        sd[f"{name}.bias"] = _randn(g, (c,), 0.05)
+        sd[f"{name}.running_mean"] = _randn(g, (c,), 0.05)
+        sd[f"{name}.running_var"] = 1.0 + 0.1 * torch.rand((c,), generator=g)
+        sd[f"{name}.num_batches_tracked"] = torch.tensor(0)
+    ch = [3, 32, 64, 128, 256, 256]
+    for i in range(1, 6):
+        last = i == 5
+        conv1d(f"kenc.encoder.{3 * (i - 1)}", ch[i - 1], ch[i], gain=kenc_gain if last else 1.4, zero_bias=last)
+        if not last:
+            bn(f"kenc.encoder.{3 * (i - 1) + 1}", ch[i])
+    for l in range(n_layers):
+        p = f"gnn.layers.{l}"
+        for j in range(3):
+            conv1d(f"{p}.attn.proj.{j}", 256, 256, gain=2.0 if j < 2 else 1.0)
+        conv1d(f"{p}.attn.merge", 256, 256)
+        conv1d(f"{p}.mlp.0", 512, 512, gain=1.4)
+        bn(f"{p}.mlp.1", 512)
+        conv1d(f"{p}.mlp.3", 512, 256, gain=gnn_gain, zero_bias=True)
+    conv1d("final_proj", 256, 256, gain=proj_gain)
+    sd["bin_score"] = torch.tensor(1.0)
+    return sd
+
+
+def load_checkpoint(path):
+    """upstream .pth / .ckpt -> flat state dict (Lightning checkpoints keep it under 'state_dict')"""
+    sd = torch.load(path, map_location="cpu")
+    if isinstance(sd, dict) and "state_dict" in sd:
+        sd = sd["state_dict"]
+    return sd
