@@ -62,12 +62,13 @@ __global__ void __launch_bounds__(256) sp_scoremap_kernel(const float *__restric
 #define NMS_LW (NMS_TW + 2 * NMS_HALO)   // 104
 #define NMS_LH (NMS_TH + 2 * NMS_HALO)   // 72
 #define NMS_N (NMS_LW * NMS_LH)          // 7488
+#define NMS_THREADS 1024                 // 16 wavefronts per CU share the one 117 KiB tile (latency hiding)
 
 // separable (2R+1)^2 max-pool of `src` into `dst` over the whole LDS tile (edges of the tile are
 // garbage by construction; each pool consumes R of the halo).  tmp is scratch.
 static __device__ __forceinline__ void pool9(const float *src, float *tmp, float *dst)
 {
-    for (int i = threadIdx.x; i < NMS_N; i += 256) {
+    for (int i = threadIdx.x; i < NMS_N; i += NMS_THREADS) {
         const int y = i / NMS_LW, x = i - y * NMS_LW;
         float m = -INFINITY;
 #pragma unroll
@@ -78,7 +79,7 @@ static __device__ __forceinline__ void pool9(const float *src, float *tmp, float
         tmp[i] = m;
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < NMS_N; i += 256) {
+    for (int i = threadIdx.x; i < NMS_N; i += NMS_THREADS) {
         const int y = i / NMS_LW, x = i - y * NMS_LW;
         float m = -INFINITY;
 #pragma unroll
@@ -91,7 +92,7 @@ static __device__ __forceinline__ void pool9(const float *src, float *tmp, float
     __syncthreads();
 }
 
-__global__ void __launch_bounds__(256) sp_nms_kernel(const float *__restrict__ scores, int H, int W, float thr,
+__global__ void __launch_bounds__(NMS_THREADS) sp_nms_kernel(const float *__restrict__ scores, int H, int W, float thr,
                                                      int border, float *__restrict__ nms_out /*may be NULL*/,
                                                      unsigned long long *__restrict__ cand, int cand_cap,
                                                      int *__restrict__ cand_count)
@@ -104,20 +105,20 @@ __global__ void __launch_bounds__(256) sp_nms_kernel(const float *__restrict__ s
     const int b = blockIdx.z;
     const int x0 = blockIdx.x * NMS_TW - NMS_HALO, y0 = blockIdx.y * NMS_TH - NMS_HALO;
     const float *img = scores + (size_t)b * H * W;
-    for (int i = threadIdx.x; i < NMS_N; i += 256) {
+    for (int i = threadIdx.x; i < NMS_N; i += NMS_THREADS) {
         const int ly = i / NMS_LW, lx = i - ly * NMS_LW;
         const int gx = x0 + lx, gy = y0 + ly;
         s[i] = (gx >= 0 && gx < W && gy >= 0 && gy < H) ? img[(size_t)gy * W + gx] : -INFINITY;
     }
     __syncthreads();
     pool9(s, t, a);                                             // a = max_pool(scores)
-    for (int i = threadIdx.x; i < NMS_N; i += 256)                  // max_mask (in-image cells only)
+    for (int i = threadIdx.x; i < NMS_N; i += NMS_THREADS)                  // max_mask (in-image cells only)
         mk[i] = (s[i] != -INFINITY && s[i] == a[i]) ? 1.f : 0.f;
     __syncthreads();
     for (int round = 0; round < 2; ++round) {
         pool9(mk, t, a);                                        // a = max_pool(max_mask) (>0 = supp_mask)
         // a <- supp_scores = supp ? 0 : scores   (keep supp flag in t? t is pool scratch -> recompute)
-        for (int i = threadIdx.x; i < NMS_N; i += 256) {
+        for (int i = threadIdx.x; i < NMS_N; i += NMS_THREADS) {
             const bool supp = a[i] > 0.f;
             // out-of-image stays -inf so that it never wins a max (padding semantics)
             a[i] = (s[i] == -INFINITY) ? -INFINITY : (supp ? 0.f : s[i]);
@@ -128,7 +129,7 @@ __global__ void __launch_bounds__(256) sp_nms_kernel(const float *__restrict__ s
         float *pooled = t;                                      // pool9 needs (src, tmp, dst) distinct
         // use s as tmp is not allowed (still needed) -> pool a into 'pooled' with mk-free scratch:
         // rows pass into 'pooled', cols pass back into a2 = (we reuse) -> do it manually
-        for (int i = threadIdx.x; i < NMS_N; i += 256) {
+        for (int i = threadIdx.x; i < NMS_N; i += NMS_THREADS) {
             const int y = i / NMS_LW, x = i - y * NMS_LW;
             float m = -INFINITY;
 #pragma unroll
@@ -139,7 +140,7 @@ __global__ void __launch_bounds__(256) sp_nms_kernel(const float *__restrict__ s
             pooled[i] = m;
         }
         __syncthreads();
-        for (int i = threadIdx.x; i < NMS_N; i += 256) {
+        for (int i = threadIdx.x; i < NMS_N; i += NMS_THREADS) {
             const int y = i / NMS_LW, x = i - y * NMS_LW;
             float m = -INFINITY;
 #pragma unroll
@@ -157,7 +158,7 @@ __global__ void __launch_bounds__(256) sp_nms_kernel(const float *__restrict__ s
         __syncthreads();
     }
     // emit: where(max_mask, scores, 0); candidates above threshold and inside the border
-    for (int i = threadIdx.x; i < NMS_TW * NMS_TH; i += 256) {
+    for (int i = threadIdx.x; i < NMS_TW * NMS_TH; i += NMS_THREADS) {
         const int ty = i / NMS_TW, tx = i - ty * NMS_TW;
         const int gx = blockIdx.x * NMS_TW + tx, gy = blockIdx.y * NMS_TH + ty;
         if (gx >= W || gy >= H) continue;
@@ -331,7 +332,7 @@ int mfr_sp_nms_candidates(const float *scores, int B, int H, int W, int nms_radi
     // 117 KiB of the CU's 160 KiB LDS: above the 64 KiB default dynamic limit
     if (hipFuncSetAttribute((const void *)sp_nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                             4 * NMS_N * sizeof(float)) != hipSuccess) return MFR_E_LAUNCH;
-    hipLaunchKernelGGL(sp_nms_kernel, grid, dim3(256), 4 * NMS_N * sizeof(float), s, scores, H, W, threshold, border,
+    hipLaunchKernelGGL(sp_nms_kernel, grid, dim3(NMS_THREADS), 4 * NMS_N * sizeof(float), s, scores, H, W, threshold, border,
                        nms_out, (unsigned long long *)cand, cand_cap, cand_count);
     CHECK_LAUNCH();
     return 0;

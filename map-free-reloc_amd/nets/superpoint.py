@@ -23,18 +23,27 @@ class SuperPointHIP:
         self.device = torch.device(device)
         self.nms_radius, self.thr = int(nms_radius), float(keypoint_threshold)
         self.K, self.border = int(max_keypoints), int(remove_borders)
+        import os
+        self.fused_conv_relu = os.environ.get("MFR_FUSED_CONV_RELU", "0") == "1"
         self.w = {k: v.to(self.device, torch.float32).contiguous() for k, v in state_dict.items()}
         # 1x1 heads as plain matrices
         self.w["convDb.mat"] = self.w["convDb.weight"].reshape(256, 256).contiguous()
 
     def _conv(self, x, name, relu=True):
-        x = F.conv2d(x, self.w[name + ".weight"], self.w[name + ".bias"], padding=self.w[name + ".weight"].shape[-1] // 2)
+        w, b = self.w[name + ".weight"], self.w[name + ".bias"]
+        pad = w.shape[-1] // 2
+        if relu and self.fused_conv_relu:
+            # MIOpen fusion plan conv+bias+ReLU: one pass instead of conv + in-place ReLU
+            return torch.ops.aten.miopen_convolution_relu(x, w, b, [1, 1], [pad, pad], [1, 1], 1)
+        x = F.conv2d(x, w, b, padding=pad)
         return F.relu_(x) if relu else x
 
     def encode(self, image):
-        x = self._conv(image, "conv1a"); x = self._conv(x, "conv1b"); x = F.max_pool2d(x, 2, 2)
-        x = self._conv(x, "conv2a"); x = self._conv(x, "conv2b"); x = F.max_pool2d(x, 2, 2)
-        x = self._conv(x, "conv3a"); x = self._conv(x, "conv3b"); x = F.max_pool2d(x, 2, 2)
+        # relu(max_pool(x)) == max_pool(relu(x)) exactly (both monotone), so the ReLU after the
+        # b-convs runs on the pooled quarter-size tensor instead of the full-resolution one
+        x = self._conv(image, "conv1a"); x = F.relu_(F.max_pool2d(self._conv(x, "conv1b", relu=False), 2, 2))
+        x = self._conv(x, "conv2a"); x = F.relu_(F.max_pool2d(self._conv(x, "conv2b", relu=False), 2, 2))
+        x = self._conv(x, "conv3a"); x = F.relu_(F.max_pool2d(self._conv(x, "conv3b", relu=False), 2, 2))
         x = self._conv(x, "conv4a"); x = self._conv(x, "conv4b")
         return x
 
