@@ -118,6 +118,24 @@ int mfr_scale_from_depth_batch(const float *pts0, const float *pts1, const uint8
                                void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Essential-matrix path: EssentialMatrixSolver.estimate_pose, lib/models/matching/pose_solver.py:29-61
+ *   K-normalise in f32 (:39-40) -> thr = pix_thr / mean(fx0, fy1, fy0, fx1) (:43, Q8)
+ *   -> cv.findEssentialMat(USAC_MAGSAC, prob) (:46-48): 5-point RANSAC, max_iters (OpenCV default
+ *      1000; the reference does not override it), adaptive iteration cap, Sampson inliers
+ *   -> cv.recoverPose per E (:56-60): 4 decompositions, cheirality vote -> LM polish of (R,t).
+ * Outputs: R [B,9], t [B,3] UNIT translation f64 (NaN on failure), n_inliers [B] = number of
+ * cheirality-passing inliers (the `n` recoverPose returns), inlier_mask [B,maxN] u8 = those
+ * inliers (what self.mask aliases after the loop, Q7; feed it to mfr_scale_from_depth_batch),
+ * status [B].  best_iter / iters_run / counts_out [B,max_iters] are optional diagnostics (NULL ok).
+ * ------------------------------------------------------------------------------------------ */
+size_t mfr_emat_workspace_bytes(int B, int maxN, int max_iters);
+int mfr_emat_solve_batch(const float *pts0, const float *pts1, const int32_t *n_corr, int B, int maxN,
+                         const float *K0, const float *K1, double pix_thr, double confidence, int max_iters,
+                         uint64_t seed, const int64_t *pair_ids, void *workspace, size_t workspace_bytes,
+                         double *R, double *t, int32_t *n_inliers, int32_t *status, uint8_t *inlier_mask,
+                         int32_t *best_iter, int32_t *iters_run, int32_t *counts_out, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * SuperPoint post-processing.  Reference call site: SuperGlue_matcher.match,
  * etc/feature_matching_baselines/matchers.py:93-120 (hyper-parameters :65-71); the network itself
  * is the un-vendored magicleap submodule (.gitmodules:4-6), restated per SURVEY.md Appendix A.2.

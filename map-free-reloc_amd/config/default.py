@@ -1,0 +1,62 @@
+"""Config schema: every key the reference declares for the matching path (config/default.py:3-115;
+regression / training keys are kept so that the reference's dataset yamls still merge), plus the
+keys this implementation adds (declared here because unknown keys are rejected on merge):
+
+  FEATURE_MATCHING   additionally accepts 'SuperGlue' (online SuperPoint+SuperGlue on the GPU)
+  RANSAC.SEED        seed of the counter-based RANSAC RNG (the reference has no seed knob)
+  HIP.*              batch size / keypoint budget of the fused device pipeline
+  SUPERGLUE.*        matcher hyper-parameters of record (matchers.py:65-71) and weight paths
+"""
+from .node import CfgNode as CN
+
+
+def get_cfg_defaults():
+    c = CN()
+    c.MODEL = None
+    c.DEBUG = False
+    c.ENCODER = CN(); c.ENCODER.TYPE = None; c.ENCODER.NUM_BLOCKS = None; c.ENCODER.BLOCK_TYPE = None
+    c.ENCODER.NOT_CONCAT = None; c.ENCODER.NUM_OUT_LAYERS = None
+    c.AGGREGATOR = CN()
+    for k, v in dict(TYPE=None, POSITION_ENCODER=None, POSITION_ENCODER_IM1=None, MAX_SCORE_CHANNEL=None,
+                     NORMALISE_DOT=False, RESIDUAL_ATT=False, CV_OUTLAYERS=0, CV_HALF_CHANNELS=False,
+                     UPSAMPLE_POS_ENC=0, DUSTBIN=False).items():
+        c.AGGREGATOR[k] = v
+    c.HEAD = CN()
+    for k, v in dict(TYPE=None, ADD_BASIS=False, NUM_PTS=6, AVG_POOL=False, BATCH_NORM=True, SEPARATE_SCALE=True).items():
+        c.HEAD[k] = v
+    c.BACKPROJECT_ANCHORS = None
+    # feature matching options (config/default.py:39-66)
+    c.FEATURE_MATCHING = None      # 'SIFT' | 'Precomputed' | 'SuperGlue' (new: online, on the GPU)
+    c.POSE_SOLVER = None           # 'EssentialMatrix' | 'EssentialMatrixMetric' | 'Procrustes' | 'PNP'
+    c.SIFT = CN(); c.SIFT.NUM_FEATURES = None; c.SIFT.RATIO_THRESHOLD = None
+    c.MATCHES_FILE_PATH = None
+    c.EMAT_RANSAC = CN(); c.EMAT_RANSAC.PIX_THRESHOLD = None; c.EMAT_RANSAC.SCALE_THRESHOLD = None
+    c.EMAT_RANSAC.CONFIDENCE = None
+    c.PROCRUSTES = CN(); c.PROCRUSTES.MAX_CORR_DIST = None; c.PROCRUSTES.REFINE = False
+    c.PNP = CN(); c.PNP.RANSAC_ITER = None; c.PNP.REPROJECTION_INLIER_THRESHOLD = None; c.PNP.CONFIDENCE = None
+    # dataset (config/default.py:68-92)
+    c.DATASET = CN()
+    for k, v in dict(DATA_SOURCE=None, SCENES=None, DATA_ROOT=None, NPZ_ROOT=None, MIN_OVERLAP_SCORE=None,
+                     MAX_OVERLAP_SCORE=None, AUGMENTATION_TYPE=None, BLACK_WHITE=False, HEIGHT=None, WIDTH=None,
+                     ESTIMATED_DEPTH=None, QUERY_FRAME_COUNT=1).items():
+        c.DATASET[k] = v
+    c.DATASET.PAIRS_TXT = CN(); c.DATASET.PAIRS_TXT.TRAIN = None; c.DATASET.PAIRS_TXT.VAL = None
+    c.DATASET.PAIRS_TXT.TEST = None; c.DATASET.PAIRS_TXT.ONE_NN = False
+    # training (config/default.py:94-112) -- out of scope here, declared so dataset yamls merge
+    c.TRAINING = CN()
+    for k, v in dict(BATCH_SIZE=None, NUM_WORKERS=None, SAMPLER=None, N_SAMPLES_SCENE=None,
+                     SAMPLE_WITH_REPLACEMENT=None, LR=None, LR_STEP_INTERVAL=None, LR_STEP_GAMMA=None,
+                     VAL_INTERVAL=None, VAL_BATCHES=None, LOG_INTERVAL=None, EPOCHS=None, GRAD_CLIP=0.,
+                     ROT_LOSS='rot_frobenius_loss', TRANS_LOSS='trans_l2_loss', LAMBDA=1.0).items():
+        c.TRAINING[k] = v
+    # ---- additions of this implementation ----
+    c.RANSAC = CN(); c.RANSAC.SEED = 0
+    c.HIP = CN(); c.HIP.BATCH_PAIRS = 16; c.HIP.MAX_KEYPOINTS = 1024; c.HIP.MAX_CORRESPONDENCES = 8192
+    c.SUPERGLUE = CN()
+    for k, v in dict(NMS_RADIUS=4, KEYPOINT_THRESHOLD=0.005, MAX_KEYPOINTS=1024, SINKHORN_ITERATIONS=20,
+                     MATCH_THRESHOLD=0.2, SUPERPOINT_WEIGHTS=None, SUPERGLUE_WEIGHTS=None, SYNTHETIC_SEED=1234).items():
+        c.SUPERGLUE[k] = v
+    return c
+
+
+cfg = get_cfg_defaults()

@@ -1,0 +1,489 @@
+// emat.hip -- essential-matrix path of the relative-pose solver on gfx950 (MI355X).
+//
+// Replaces EssentialMatrixSolver.estimate_pose (lib/models/matching/pose_solver.py:29-61) for a
+// BATCH of image pairs:
+//   emat_prep_kernel    K-normalise both views in f32 (:39-40), thr = PIX_THRESHOLD / mean f (:43, Q8)
+//   emat_hyp_kernel     cv.findEssentialMat hypotheses: one LANE per 5-point minimal solve
+//                       (Nister; <= 10 candidate E each)                                  (:46-48)
+//   emat_score_kernel   one WAVEFRONT per hypothesis: lanes stride over the LDS-staged
+//                       correspondences, squared Sampson distance <= thr^2, ballot + popcount
+//   emat_select_kernel  RANSAC replay (adaptive iteration cap) -> best E -> cv.recoverPose
+//                       (4 decompositions, cheirality vote; :56-60) -> LM polish of (R, t) on the
+//                       inliers -> final cheirality-filtered inlier mask (what self.mask holds, Q7)
+// cv.findEssentialMat(USAC_MAGSAC) itself is not reproducible offline (OpenCV absent): MAGSAC++'s
+// sigma-marginalised score is replaced by the inlier count at the same threshold and USAC's local
+// optimisation / polisher by the LM polish (documented in DESIGN.md; parity unpinned vs OpenCV).
+// Compiled with -ffp-contract=off (FP contract in geom_dev.h).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/mfr_hip.h"
+#include "emat_dev.h"
+
+using namespace mfr;
+
+#define EM_HYP_PER_WG 64
+#define EM_TILE 1024
+#define CHECK_LAUNCH() do { if (hipGetLastError() != hipSuccess) return MFR_E_LAUNCH; } while (0)
+
+__global__ void __launch_bounds__(256) emat_prep_kernel(
+    const float *__restrict__ pts0, const float *__restrict__ pts1, const int32_t *__restrict__ n_corr, int maxN,
+    const float *__restrict__ K0, const float *__restrict__ K1, double pix_thr,
+    double *__restrict__ x0, double *__restrict__ x1, double *__restrict__ thr2)
+{
+    const int b = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    const float *k0 = K0 + 9 * b, *k1 = K1 + 9 * b;
+    if (i == 0) {
+        const float m = (((k0[0] + k1[4]) + k0[4]) + k1[0]) / 4.0f;       // np.mean([fx0, fy1, fy0, fx1]) in f32
+        const double thr = pix_thr / (double)m;
+        thr2[b] = thr * thr;
+    }
+    int n = n_corr[b];
+    if (n > maxN) n = maxN;
+    if (i >= n) return;
+    const size_t o = ((size_t)b * maxN + i) * 2;
+    x0[o] = (double)((pts0[o] - k0[2]) / k0[0]); x0[o + 1] = (double)((pts0[o + 1] - k0[5]) / k0[4]);
+    x1[o] = (double)((pts1[o] - k1[2]) / k1[0]); x1[o + 1] = (double)((pts1[o + 1] - k1[5]) / k1[4]);
+}
+
+// grid (ceil(iters/64), B), one lane per hypothesis
+__global__ void __launch_bounds__(64) emat_hyp_kernel(
+    const double *__restrict__ x0, const double *__restrict__ x1, const int32_t *__restrict__ n_corr, int maxN,
+    int max_iters, uint64_t seed, const int64_t *__restrict__ pair_ids, double *__restrict__ Es /*[B,iters,10,9]*/,
+    int32_t *__restrict__ nsol /*[B,iters]*/)
+{
+    const int b = blockIdx.y, it = blockIdx.x * 64 + threadIdx.x;
+    if (it >= max_iters) return;
+    int n = n_corr[b];
+    if (n > maxN) n = maxN;
+    int ns = 0;
+    double E[90];
+    if (n >= 5 && (n > 5 || it == 0)) {
+        int s[5];
+        if (n == 5) { for (int k = 0; k < 5; ++k) s[k] = k; }
+        else sample_distinct<5>(seed, (uint64_t)pair_ids[b], (uint32_t)it, n, s);
+        double a[10], c[10];
+        const double *p0 = x0 + (size_t)b * maxN * 2, *p1 = x1 + (size_t)b * maxN * 2;
+        for (int k = 0; k < 5; ++k) {
+            a[2 * k] = p0[2 * s[k]]; a[2 * k + 1] = p0[2 * s[k] + 1];
+            c[2 * k] = p1[2 * s[k]]; c[2 * k + 1] = p1[2 * s[k] + 1];
+        }
+        ns = fivept(a, c, E);
+    }
+    nsol[(size_t)b * max_iters + it] = ns;
+    double *o = Es + ((size_t)b * max_iters + it) * 90;
+    for (int k = 0; k < ns * 9; ++k) o[k] = E[k];
+}
+
+// grid (ceil(iters/64), B), 4 wavefronts; wavefront w scores hypotheses w, w+4, ... of the block's 64
+__global__ void __launch_bounds__(256) emat_score_kernel(
+    const double *__restrict__ x0, const double *__restrict__ x1, const int32_t *__restrict__ n_corr, int maxN,
+    int max_iters, const double *__restrict__ thr2p, const double *__restrict__ Es, const int32_t *__restrict__ nsol,
+    int32_t *__restrict__ counts /*[B,iters]*/, int32_t *__restrict__ bestm /*[B,iters]*/)
+{
+    __shared__ double ta[EM_TILE], tb[EM_TILE], tc[EM_TILE], td[EM_TILE];
+    __shared__ int cnt[EM_HYP_PER_WG][10];
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    int n = n_corr[b];
+    if (n > maxN) n = maxN;
+    const double thr2 = thr2p[b];
+    const int it0 = blockIdx.x * EM_HYP_PER_WG;
+    for (int i = tid; i < EM_HYP_PER_WG * 10; i += 256) cnt[i / 10][i % 10] = 0;
+    const double *p0 = x0 + (size_t)b * maxN * 2, *p1 = x1 + (size_t)b * maxN * 2;
+    for (int base = 0; base < n; base += EM_TILE) {
+        const int tn = min(EM_TILE, n - base);
+        __syncthreads();
+        for (int i = tid; i < tn; i += 256) {
+            ta[i] = p0[2 * (size_t)(base + i)]; tb[i] = p0[2 * (size_t)(base + i) + 1];
+            tc[i] = p1[2 * (size_t)(base + i)]; td[i] = p1[2 * (size_t)(base + i) + 1];
+        }
+        __syncthreads();
+        for (int h = wid; h < EM_HYP_PER_WG; h += 4) {
+            const int it = it0 + h;
+            if (it >= max_iters) break;
+            const int ns = nsol[(size_t)b * max_iters + it];
+            const double *Eh = Es + ((size_t)b * max_iters + it) * 90;
+            for (int m = 0; m < ns; ++m) {
+                double E[9];
+#pragma unroll
+                for (int k = 0; k < 9; ++k) E[k] = Eh[9 * m + k];
+                int c = 0;
+                for (int i0 = 0; i0 < tn; i0 += 64) {
+                    const int i = i0 + lane;
+                    bool in = false;
+                    if (i < tn) in = sampson2(E, ta[i], tb[i], tc[i], td[i]) <= thr2;
+                    c += __popcll(__ballot(in));
+                }
+                if (lane == 0) cnt[h][m] += c;
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < EM_HYP_PER_WG) {
+        const int it = it0 + tid;
+        if (it < max_iters) {
+            const int ns = nsol[(size_t)b * max_iters + it];
+            int best = 0, bm = -1;
+            for (int m = 0; m < ns; ++m) if (cnt[tid][m] > best) { best = cnt[tid][m]; bm = m; }   // first max
+            counts[(size_t)b * max_iters + it] = best;
+            bestm[(size_t)b * max_iters + it] = bm;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+static __device__ __forceinline__ void quat_right_update(const double *R, const double *dw, double *Rn)
+{
+    const double hx = 0.5 * dw[0], hy = 0.5 * dw[1], hz = 0.5 * dw[2];
+    const double nn = sqrt(((hx * hx + hy * hy) + hz * hz) + 1.0);
+    const double w = 1.0 / nn, x = hx / nn, y = hy / nn, z = hz / nn;
+    double Q[9];
+    Q[0] = 1.0 - 2.0 * (y * y + z * z); Q[1] = 2.0 * (x * y - w * z);       Q[2] = 2.0 * (x * z + w * y);
+    Q[3] = 2.0 * (x * y + w * z);       Q[4] = 1.0 - 2.0 * (x * x + z * z); Q[5] = 2.0 * (y * z - w * x);
+    Q[6] = 2.0 * (x * z - w * y);       Q[7] = 2.0 * (y * z + w * x);       Q[8] = 1.0 - 2.0 * (x * x + y * y);
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            Rn[3 * i + j] = (R[3 * i] * Q[j] + R[3 * i + 1] * Q[3 + j]) + R[3 * i + 2] * Q[6 + j];
+}
+
+static __device__ __forceinline__ int chol_solve6(const double *A, const double *bvec, double *x)
+{
+    double L[36];
+    for (int i = 0; i < 36; ++i) L[i] = 0.0;
+    for (int i = 0; i < 6; ++i)
+        for (int j = 0; j <= i; ++j) {
+            double s = A[6 * i + j];
+            for (int k = 0; k < j; ++k) s = s - L[6 * i + k] * L[6 * j + k];
+            if (i == j) {
+                if (!(s > 0.0)) return -1;
+                L[6 * i + i] = sqrt(s);
+            } else L[6 * i + j] = s / L[6 * j + j];
+        }
+    double y[6];
+    for (int i = 0; i < 6; ++i) {
+        double s = bvec[i];
+        for (int k = 0; k < i; ++k) s = s - L[6 * i + k] * y[k];
+        y[i] = s / L[6 * i + i];
+    }
+    for (int i = 5; i >= 0; --i) {
+        double s = y[i];
+        for (int k = i + 1; k < 6; ++k) s = s - L[6 * k + i] * x[k];
+        x[i] = s / L[6 * i + i];
+    }
+    return 0;
+}
+
+static __device__ __forceinline__ double emat_cost(const double *p0, const double *p1, const int32_t *idx, int n,
+                                                   const double *R, const double *t)
+{
+    double E[9];
+    skew_mul(t, R, E);
+    double acc = 0.0;
+    for (int i = lane_id(); i < n; i += 64) {
+        const int j = idx[i];
+        acc = acc + sampson2(E, p0[2 * (size_t)j], p0[2 * (size_t)j + 1], p1[2 * (size_t)j], p1[2 * (size_t)j + 1]);
+    }
+    return wave_sum(acc);
+}
+
+// LM polish of (R, unit t) on the Sampson cost (wave-parallel, wave64-ordered reductions)
+static __device__ __noinline__ int emat_refine(const double *p0, const double *p1, const int32_t *idx, int n,
+                                               int max_iter, double *R, double *t)
+{
+    double lambda = 1e-3;
+    double cost = emat_cost(p0, p1, idx, n, R, t);
+    if (!(cost == cost)) return -1;
+    for (int it = 0; it < max_iter; ++it) {
+        double E[9];
+        skew_mul(t, R, E);
+        double acc[27];
+#pragma unroll
+        for (int q = 0; q < 27; ++q) acc[q] = 0.0;
+        for (int i = lane_id(); i < n; i += 64) {
+            const int j = idx[i];
+            const double a = p0[2 * (size_t)j], b = p0[2 * (size_t)j + 1], c = p1[2 * (size_t)j], d = p1[2 * (size_t)j + 1];
+            const double Ex0 = (E[0] * a + E[1] * b) + E[2], Ex1 = (E[3] * a + E[4] * b) + E[5], Ex2 = (E[6] * a + E[7] * b) + E[8];
+            const double Et0 = (E[0] * c + E[3] * d) + E[6], Et1 = (E[1] * c + E[4] * d) + E[7];
+            const double num = (c * Ex0 + d * Ex1) + Ex2;
+            const double den = ((Ex0 * Ex0 + Ex1 * Ex1) + Et0 * Et0) + Et1 * Et1;
+            const double wgt = 1.0 / sqrt(den);
+            const double q[3] = { c, d, 1.0 }, p[3] = { a, b, 1.0 };
+            const double txq[3] = { t[1] * q[2] - t[2] * q[1], t[2] * q[0] - t[0] * q[2], t[0] * q[1] - t[1] * q[0] };
+            const double u[3] = { -((R[0] * txq[0] + R[3] * txq[1]) + R[6] * txq[2]),
+                                  -((R[1] * txq[0] + R[4] * txq[1]) + R[7] * txq[2]),
+                                  -((R[2] * txq[0] + R[5] * txq[1]) + R[8] * txq[2]) };
+            const double Rp[3] = { (R[0] * p[0] + R[1] * p[1]) + R[2] * p[2], (R[3] * p[0] + R[4] * p[1]) + R[5] * p[2],
+                                   (R[6] * p[0] + R[7] * p[1]) + R[8] * p[2] };
+            double J[6];
+            J[0] = (p[1] * u[2] - p[2] * u[1]) * wgt; J[1] = (p[2] * u[0] - p[0] * u[2]) * wgt; J[2] = (p[0] * u[1] - p[1] * u[0]) * wgt;
+            J[3] = (Rp[1] * q[2] - Rp[2] * q[1]) * wgt; J[4] = (Rp[2] * q[0] - Rp[0] * q[2]) * wgt; J[5] = (Rp[0] * q[1] - Rp[1] * q[0]) * wgt;
+            const double r = num * wgt;
+            int qq = 0;
+#pragma unroll
+            for (int rr = 0; rr < 6; ++rr)
+#pragma unroll
+                for (int cc = rr; cc < 6; ++cc, ++qq) acc[qq] = acc[qq] + J[rr] * J[cc];
+#pragma unroll
+            for (int rr = 0; rr < 6; ++rr, ++qq) acc[qq] = acc[qq] + J[rr] * r;
+        }
+#pragma unroll
+        for (int q = 0; q < 27; ++q) acc[q] = wave_sum(acc[q]);
+        double H[36], g[6];
+        {
+            int qq = 0;
+            for (int rr = 0; rr < 6; ++rr)
+                for (int cc = rr; cc < 6; ++cc, ++qq) { H[6 * rr + cc] = acc[qq]; H[6 * cc + rr] = acc[qq]; }
+            for (int rr = 0; rr < 6; ++rr, ++qq) g[rr] = -acc[qq];
+        }
+        for (int rr = 0; rr < 6; ++rr) H[6 * rr + rr] = H[6 * rr + rr] + lambda * H[6 * rr + rr];
+        for (int rr = 0; rr < 3; ++rr)
+            for (int cc = 0; cc < 3; ++cc) H[6 * (3 + rr) + 3 + cc] = H[6 * (3 + rr) + 3 + cc] + t[rr] * t[cc];
+        double dl[6];
+        if (chol_solve6(H, g, dl)) {
+            lambda = lambda * 10.0;
+            if (lambda > 1e12) break;
+            continue;
+        }
+        double Rn[9], tn[3];
+        quat_right_update(R, dl, Rn);
+        tn[0] = t[0] + dl[3]; tn[1] = t[1] + dl[4]; tn[2] = t[2] + dl[5];
+        const double nt = sqrt((tn[0] * tn[0] + tn[1] * tn[1]) + tn[2] * tn[2]);
+        if (!(nt > 0.0)) {
+            lambda = lambda * 10.0;
+            if (lambda > 1e12) break;
+            continue;
+        }
+        tn[0] = tn[0] / nt; tn[1] = tn[1] / nt; tn[2] = tn[2] / nt;
+        const double cn = emat_cost(p0, p1, idx, n, Rn, tn);
+        double mx = 0.0;
+        for (int k = 0; k < 6; ++k) { const double v = dl[k] < 0.0 ? -dl[k] : dl[k]; if (v > mx) mx = v; }
+        if (cn < cost) {
+            const double dec = cost - cn;
+            for (int k = 0; k < 9; ++k) R[k] = Rn[k];
+            for (int k = 0; k < 3; ++k) t[k] = tn[k];
+            const bool done = (dec <= 1e-14 * cost);
+            cost = cn;
+            lambda = lambda * 0.1;
+            if (lambda < 1e-12) lambda = 1e-12;
+            if (done) break;
+        } else {
+            lambda = lambda * 10.0;
+            if (lambda > 1e12) break;
+        }
+        if (mx < 1e-13) break;
+    }
+    return 0;
+}
+
+// wave-wide count of a per-point predicate over all n points
+template <typename F>
+static __device__ __forceinline__ int wave_count(int n, F pred)
+{
+    int c = 0;
+    for (int i0 = 0; i0 < n; i0 += 64) {
+        const int i = i0 + lane_id();
+        c += __popcll(__ballot(i < n && pred(i)));
+    }
+    return c;
+}
+
+__global__ void __launch_bounds__(64) emat_select_kernel(
+    const double *__restrict__ x0, const double *__restrict__ x1, const int32_t *__restrict__ n_corr, int maxN,
+    int max_iters, const double *__restrict__ thr2p, double conf, const double *__restrict__ Es,
+    const int32_t *__restrict__ counts, const int32_t *__restrict__ bestm, int32_t *__restrict__ idx_ws /*[B,maxN]*/,
+    uint8_t *__restrict__ rmask_ws /*[B,maxN]*/, double *__restrict__ Rout, double *__restrict__ tout,
+    int32_t *__restrict__ n_inliers, int32_t *__restrict__ status, uint8_t *__restrict__ mask_out,
+    int32_t *__restrict__ best_iter, int32_t *__restrict__ iters_run)
+{
+    const int b = blockIdx.x, lane = threadIdx.x;
+    int n = n_corr[b];
+    if (n > maxN) n = maxN;
+    const double *p0 = x0 + (size_t)b * maxN * 2, *p1 = x1 + (size_t)b * maxN * 2;
+    const double thr2 = thr2p[b];
+    int32_t *idx = idx_ws + (size_t)b * maxN;
+    uint8_t *rm = rmask_ws + (size_t)b * maxN;
+    uint8_t *mo = mask_out ? mask_out + (size_t)b * maxN : nullptr;
+    const double qnan = __longlong_as_double(0x7ff8000000000000LL);
+    if (mo) for (int i = lane; i < maxN; i += 64) mo[i] = 0;
+    int st = (n < 5) ? MFR_ST_TOO_FEW : MFR_ST_OK;
+    int bit = -1, best = 4, run = 0;
+    const int32_t *cnt = counts + (size_t)b * max_iters;
+    if (st == MFR_ST_OK) {
+        if (n == 5) {
+            run = 1;
+            if (cnt[0] > 0) { best = cnt[0]; bit = 0; }
+        } else {
+            int niters = max_iters, carry = 4;
+            bool stop = false;
+            for (int c0 = 0; c0 < max_iters && !stop && c0 < niters; c0 += 64) {
+                const int it = c0 + lane;
+                const int v = (it < max_iters) ? cnt[it] : -1;
+                int incl = v;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const int o = __shfl_up(incl, off, 64);
+                    if (lane >= off && o > incl) incl = o;
+                }
+                int excl = __shfl_up(incl, 1, 64);
+                if (lane == 0 || excl < carry) excl = carry;
+                unsigned long long rec = __ballot(v > excl);
+                while (rec) {
+                    const int l = __ffsll((long long)rec) - 1;
+                    rec &= rec - 1;
+                    const int itr = c0 + l;
+                    if (itr >= niters) { stop = true; break; }
+                    best = __shfl(v, l, 64);
+                    bit = itr;
+                    niters = update_num_iters(conf, (double)(n - best) / (double)n, 5, niters);
+                }
+                const int last = __shfl(incl, 63, 64);
+                if (last > carry) carry = last;
+            }
+            run = (bit + 1 > niters) ? bit + 1 : niters;
+        }
+        if (bit < 0) st = MFR_ST_NO_MODEL;
+    }
+    double R[9], t[3];
+    int m = 0;
+    if (st == MFR_ST_OK) {
+        double Eb[9];
+        const double *src = Es + ((size_t)b * max_iters + bit) * 90 + 9 * bestm[(size_t)b * max_iters + bit];
+        for (int k = 0; k < 9; ++k) Eb[k] = src[k];
+        // RANSAC inlier set of the best model (ascending index order)
+        for (int i0 = 0; i0 < n; i0 += 64) {
+            const int i = i0 + lane;
+            const bool in = (i < n) && (sampson2(Eb, p0[2 * (size_t)i], p0[2 * (size_t)i + 1], p1[2 * (size_t)i], p1[2 * (size_t)i + 1]) <= thr2);
+            const unsigned long long bal = __ballot(in);
+            if (in) idx[m + __popcll(bal & ((1ull << lane) - 1ull))] = i;
+            if (i < n) rm[i] = in ? 1 : 0;
+            m += __popcll(bal);
+        }
+        __threadfence();
+        double Ra[9], Rc[9], tu[3];
+        if (emat_decompose(Eb, Ra, Rc, tu)) st = MFR_ST_NO_MODEL;
+        else {
+            int bestc = -1;
+            for (int c = 0; c < 4; ++c) {
+                const double *Rk = (c < 2) ? Ra : Rc;
+                const double tk[3] = { (c & 1) ? -tu[0] : tu[0], (c & 1) ? -tu[1] : tu[1], (c & 1) ? -tu[2] : tu[2] };
+                const int cc = wave_count(m, [&](int q) {
+                    const int i = idx[q];
+                    return cheirality(Rk, tk, p0[2 * (size_t)i], p0[2 * (size_t)i + 1], p1[2 * (size_t)i], p1[2 * (size_t)i + 1]);
+                });
+                if (cc > bestc) {
+                    bestc = cc;
+                    for (int k = 0; k < 9; ++k) R[k] = Rk[k];
+                    for (int k = 0; k < 3; ++k) t[k] = tk[k];
+                }
+            }
+            if (bestc <= 0) st = MFR_ST_NO_MODEL;
+        }
+        if (st == MFR_ST_OK && n > 5) {
+            double Rr[9], tr[3];
+            for (int k = 0; k < 9; ++k) Rr[k] = R[k];
+            for (int k = 0; k < 3; ++k) tr[k] = t[k];
+            if (emat_refine(p0, p1, idx, m, 20, Rr, tr) == 0) {
+                double Er[9];
+                skew_mul(tr, Rr, Er);
+                const int m2 = wave_count(n, [&](int i) {
+                    return sampson2(Er, p0[2 * (size_t)i], p0[2 * (size_t)i + 1], p1[2 * (size_t)i], p1[2 * (size_t)i + 1]) <= thr2;
+                });
+                if (m2 >= m) {
+                    for (int k = 0; k < 9; ++k) R[k] = Rr[k];
+                    for (int k = 0; k < 3; ++k) t[k] = tr[k];
+                    for (int i = lane; i < n; i += 64)
+                        rm[i] = (sampson2(Er, p0[2 * (size_t)i], p0[2 * (size_t)i + 1], p1[2 * (size_t)i], p1[2 * (size_t)i + 1]) <= thr2) ? 1 : 0;
+                }
+            }
+        }
+    }
+    int cntf = 0;
+    if (st == MFR_ST_OK) {
+        __threadfence();
+        for (int i0 = 0; i0 < n; i0 += 64) {
+            const int i = i0 + lane;
+            bool in = false;
+            if (i < n) in = rm[i] && cheirality(R, t, p0[2 * (size_t)i], p0[2 * (size_t)i + 1], p1[2 * (size_t)i], p1[2 * (size_t)i + 1]);
+            if (mo && i < n) mo[i] = in ? 1 : 0;
+            cntf += __popcll(__ballot(in));
+        }
+        if (cntf <= 0) st = MFR_ST_NO_MODEL;
+    }
+    if (st != MFR_ST_OK && mo) {
+        __threadfence();
+        for (int i = lane; i < maxN; i += 64) mo[i] = 0;
+    }
+    if (lane == 0) {
+        for (int k = 0; k < 9; ++k) Rout[9 * b + k] = (st == MFR_ST_OK) ? R[k] : qnan;
+        for (int k = 0; k < 3; ++k) tout[3 * b + k] = (st == MFR_ST_OK) ? t[k] : qnan;
+        n_inliers[b] = (st == MFR_ST_OK) ? cntf : 0;
+        status[b] = st;
+        if (best_iter) best_iter[b] = bit;
+        if (iters_run) iters_run[b] = run;
+    }
+}
+
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+struct EmWs { size_t x0, x1, thr2, Es, nsol, counts, bestm, idx, rm, total; };
+static EmWs em_ws_layout(int B, int maxN, int iters)
+{
+    EmWs w; size_t o = 0;
+    w.x0 = o;     o = align_up(o + sizeof(double) * 2 * (size_t)B * maxN, 256);
+    w.x1 = o;     o = align_up(o + sizeof(double) * 2 * (size_t)B * maxN, 256);
+    w.thr2 = o;   o = align_up(o + sizeof(double) * (size_t)B, 256);
+    w.Es = o;     o = align_up(o + sizeof(double) * 90 * (size_t)B * iters, 256);
+    w.nsol = o;   o = align_up(o + sizeof(int32_t) * (size_t)B * iters, 256);
+    w.counts = o; o = align_up(o + sizeof(int32_t) * (size_t)B * iters, 256);
+    w.bestm = o;  o = align_up(o + sizeof(int32_t) * (size_t)B * iters, 256);
+    w.idx = o;    o = align_up(o + sizeof(int32_t) * (size_t)B * maxN, 256);
+    w.rm = o;     o = align_up(o + (size_t)B * maxN, 256);
+    w.total = o;
+    return w;
+}
+
+extern "C" {
+
+size_t mfr_emat_workspace_bytes(int B, int maxN, int max_iters)
+{
+    if (B <= 0 || maxN <= 0) return 0;
+    if (max_iters < 1) max_iters = 1;
+    return em_ws_layout(B, maxN, max_iters).total;
+}
+
+int mfr_emat_solve_batch(const float *pts0, const float *pts1, const int32_t *n_corr, int B, int maxN,
+                         const float *K0, const float *K1, double pix_thr, double confidence, int max_iters,
+                         uint64_t seed, const int64_t *pair_ids, void *workspace, size_t workspace_bytes,
+                         double *R, double *t, int32_t *n_inliers, int32_t *status, uint8_t *inlier_mask,
+                         int32_t *best_iter, int32_t *iters_run, int32_t *counts_out, void *stream)
+{
+    if (!pts0 || !pts1 || !n_corr || !K0 || !K1 || !pair_ids || !workspace || !R || !t || !n_inliers || !status ||
+        B <= 0 || maxN <= 0) return MFR_E_ARG;
+    if (max_iters < 1) max_iters = 1;
+    const EmWs w = em_ws_layout(B, maxN, max_iters);
+    if (workspace_bytes < w.total) return MFR_E_WORKSPACE;
+    char *ws = (char *)workspace;
+    hipStream_t s = (hipStream_t)stream;
+    double *x0 = (double *)(ws + w.x0), *x1 = (double *)(ws + w.x1), *thr2 = (double *)(ws + w.thr2);
+    double *Es = (double *)(ws + w.Es);
+    int32_t *nsol = (int32_t *)(ws + w.nsol), *counts = (int32_t *)(ws + w.counts), *bestm = (int32_t *)(ws + w.bestm);
+    int32_t *idx = (int32_t *)(ws + w.idx);
+    uint8_t *rm = (uint8_t *)(ws + w.rm);
+    hipLaunchKernelGGL(emat_prep_kernel, dim3((maxN + 255) / 256, B), dim3(256), 0, s, pts0, pts1, n_corr, maxN, K0, K1,
+                       pix_thr, x0, x1, thr2);
+    CHECK_LAUNCH();
+    const dim3 hgrid((max_iters + 63) / 64, B);
+    hipLaunchKernelGGL(emat_hyp_kernel, hgrid, dim3(64), 0, s, x0, x1, n_corr, maxN, max_iters, seed, pair_ids, Es, nsol);
+    CHECK_LAUNCH();
+    hipLaunchKernelGGL(emat_score_kernel, hgrid, dim3(256), 0, s, x0, x1, n_corr, maxN, max_iters, thr2, Es, nsol,
+                       counts, bestm);
+    CHECK_LAUNCH();
+    hipLaunchKernelGGL(emat_select_kernel, dim3(B), dim3(64), 0, s, x0, x1, n_corr, maxN, max_iters, thr2, confidence, Es,
+                       counts, bestm, idx, rm, R, t, n_inliers, status, inlier_mask, best_iter, iters_run);
+    CHECK_LAUNCH();
+    if (counts_out)
+        if (hipMemcpyAsync(counts_out, counts, sizeof(int32_t) * (size_t)B * max_iters, hipMemcpyDeviceToDevice, s) != hipSuccess)
+            return MFR_E_LAUNCH;
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,80 @@
+"""Correspondence plugins (`cfg.FEATURE_MATCHING`): objects with
+`get_correspondences(data) -> (pts1, pts2)`, each ndarray [N,2] float32 in the dataset-resized
+pixel frame, N may be 0 (np.array([])).  Mirrors lib/models/matching/feature_matching.py.
+
+  PrecomputedMatching  npz lookup by pair_id (feature_matching.py:5-50) -- host IO glue, same
+                       semantics incl. lazy per-scene reload, float32 cast and NaN stripping
+  SuperGlueMatching    NEW: online SuperPoint+SuperGlue on the GPU (the reference only has it
+                       offline, etc/feature_matching_baselines/matchers.py:62-120)
+  SIFTMatching         OpenCV SIFT + FLANN (feature_matching.py:53-118): not available offline and
+                       outside the accelerated path -> raises
+"""
+import numpy as np
+
+from .. import wire
+
+
+class PrecomputedMatching:
+    def __init__(self, cfg):
+        self.correspondences = None
+        self.debug = cfg.DEBUG
+        if '{' in cfg.MATCHES_FILE_PATH:
+            self.matches_file_path = cfg.MATCHES_FILE_PATH
+            self.scene_id = None
+            self.pairs_txt = cfg.DATASET.PAIRS_TXT.TEST
+        else:
+            self.load_correspondences(cfg.MATCHES_FILE_PATH)
+
+    def load_correspondences(self, file_path):
+        self.correspondences = wire.load_correspondences(file_path)
+
+    def get_correspondences(self, data):
+        if hasattr(self, 'scene_id'):
+            if self.scene_id != data['scene_id'][0]:
+                self.scene_id = data['scene_id'][0]
+                scene_root = data['scene_root'][0]
+                self.load_correspondences(self.matches_file_path.format(scene_root=scene_root, pairs_txt=self.pairs_txt))
+        pair_id = int(data['pair_id'].item()) if hasattr(data['pair_id'], 'item') else int(data['pair_id'])
+        return wire.strip_nan(self.correspondences[pair_id])
+
+
+def _to_gray(img):
+    """[3,H,W] or [1,H,W] float tensor in [0,1] -> [H,W] float32 luma (BT.601, what
+    cv2.imread(GRAYSCALE) / COLOR_RGB2GRAY compute)"""
+    if img.shape[0] == 1:
+        return img[0]
+    return 0.299 * img[0] + 0.587 * img[1] + 0.114 * img[2]
+
+
+class SuperGlueMatching:
+    """online matcher: data['image0'], data['image1'] ([1,3,H,W] in [0,1]) -> correspondences"""
+
+    def __init__(self, cfg):
+        import torch
+        from ..nets import weights as WT
+        from ..nets.superpoint import SuperPointHIP
+        from ..nets.superglue import SuperGlueHIP
+        sg = cfg.SUPERGLUE
+        sp_sd = WT.load_checkpoint(sg.SUPERPOINT_WEIGHTS) if sg.SUPERPOINT_WEIGHTS else WT.superpoint_state_dict(sg.SYNTHETIC_SEED)
+        sg_sd = WT.load_checkpoint(sg.SUPERGLUE_WEIGHTS) if sg.SUPERGLUE_WEIGHTS else WT.superglue_state_dict()
+        self.device = torch.device("cuda")
+        self.sp = SuperPointHIP(sp_sd, self.device, sg.NMS_RADIUS, sg.KEYPOINT_THRESHOLD, sg.MAX_KEYPOINTS)
+        self.sg = SuperGlueHIP(sg_sd, self.device, sg.SINKHORN_ITERATIONS, sg.MATCH_THRESHOLD)
+
+    def get_correspondences(self, data):
+        import torch
+        im0, im1 = _to_gray(data['image0'][0]), _to_gray(data['image1'][0])
+        ims = torch.stack([im0, im1])[:, None].to(self.device, torch.float32).contiguous()
+        out = self.sg(self.sp(ims), tuple(ims.shape[-2:]))
+        n = int(out["n_corr"][0])
+        if n == 0:
+            e = np.array([])
+            return e, e
+        return out["pts0"][0, :n].cpu().numpy(), out["pts1"][0, :n].cpu().numpy()
+
+
+class SIFTMatching:
+    def __init__(self, cfg):
+        raise NotImplementedError(
+            "SIFTMatching needs OpenCV SIFT/FLANN (feature_matching.py:53-118), which is outside the "
+            "GPU hot path (SURVEY 8f rank 2); use FEATURE_MATCHING 'Precomputed' or 'SuperGlue'")

@@ -105,18 +105,27 @@ static double poly_eval(const double *c, int deg, double x)
 
 static double refine_root(const double *c, const double *dc, int deg, double lo, double hi, double flo)
 {
-    double x = 0.5 * (lo + hi);
-    for (int it = 0; it < 100; ++it) {
-        double fx = poly_eval(c, deg, x);
+    /* safeguarded Newton (Numerical Recipes rtsafe): bisect whenever the Newton step would leave
+     * the bracket or is not shrinking it at least as fast as bisection would */
+    double x = 0.5 * (lo + hi), dxold = hi - lo, dx = dxold;
+    double fx = poly_eval(c, deg, x), dfx = poly_eval(dc, deg - 1, x);
+    for (int it = 0; it < 200; ++it) {
         if (fx == 0.0) break;
         if ((fx < 0.0) == (flo < 0.0)) lo = x; else hi = x;
-        double dfx = poly_eval(dc, deg - 1, x);
-        double xn = x - fx / dfx;
-        if (!(xn > lo && xn < hi)) xn = 0.5 * (lo + hi);
-        double dx = xn - x; if (dx < 0.0) dx = -dx;
-        double ax = xn < 0.0 ? -xn : xn;
+        double a = (x - hi) * dfx - fx, b = (x - lo) * dfx - fx;
+        double tf = 2.0 * fx; if (tf < 0.0) tf = -tf;
+        double td = dxold * dfx; if (td < 0.0) td = -td;
+        int newton = ((a < 0.0) != (b < 0.0)) && (tf <= td);
+        double xn;
+        dxold = dx;
+        if (newton) { dx = fx / dfx; xn = x - dx; }
+        else { dx = 0.5 * (hi - lo); xn = lo + dx; }
+        if (!(xn > lo && xn < hi)) { dx = 0.5 * (hi - lo); xn = lo + dx; }
+        if (xn == x) break;
+        double adx = dx < 0.0 ? -dx : dx, ax = xn < 0.0 ? -xn : xn;
         x = xn;
-        if (dx <= 4e-16 * ax || dx < 1e-300) break;
+        if (adx <= 2e-16 * ax || adx < 1e-300) break;
+        fx = poly_eval(c, deg, x); dfx = poly_eval(dc, deg - 1, x);
     }
     return x;
 }

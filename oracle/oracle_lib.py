@@ -171,3 +171,47 @@ def scale_ransac(scale, thr):
     bs = C.c_double(0); bi = C.c_int(0)
     n = lib().mfr_ref_scale_ransac(_p(scale), C.c_int(len(scale)), C.c_double(thr), C.byref(bs), C.byref(bi))
     return n, bs.value, bi.value
+
+
+def fivept(x0, x1):
+    x0, x1 = _f64(x0).reshape(5, 2), _f64(x1).reshape(5, 2)
+    Es = np.zeros((10, 3, 3))
+    n = lib().mfr_ref_fivept(_p(x0), _p(x1), _p(Es))
+    return Es[:n].copy()
+
+
+def emat_decompose(E):
+    E = _f64(E)
+    Ra = np.zeros((3, 3)); Rb = np.zeros((3, 3)); t = np.zeros(3)
+    rc = lib().mfr_ref_emat_decompose(_p(E), _p(Ra), _p(Rb), _p(t))
+    return rc, Ra, Rb, t
+
+
+def emat_threshold(pix_thr, K0, K1):
+    lib().mfr_ref_emat_threshold.restype = C.c_double
+    return lib().mfr_ref_emat_threshold(C.c_double(pix_thr), _p(_f32(K0).reshape(9)), _p(_f32(K1).reshape(9)))
+
+
+def normalize_points(pts, K):
+    pts = _f32(pts).reshape(-1, 2)
+    out = np.zeros((len(pts), 2))
+    lib().mfr_ref_normalize_points(_p(pts), C.c_int(len(pts)), _p(_f32(K).reshape(9)), _p(out))
+    return out
+
+
+def emat_solve(pts0, pts1, K0, K1, pix_thr=2.0, conf=0.9999, max_iters=1000, seed=0, pair_id=0, want_counts=False):
+    pts0, pts1 = _f32(pts0).reshape(-1, 2), _f32(pts1).reshape(-1, 2)
+    n = len(pts0)
+    R = np.zeros((3, 3)); t = np.zeros(3)
+    mask = np.zeros(max(n, 1), np.uint8); rmask = np.zeros(max(n, 1), np.uint8)
+    n_inl = C.c_int(0); bi = C.c_int(0); ir = C.c_int(0)
+    counts = np.zeros(max_iters, np.int32) if want_counts else None
+    st = lib().mfr_ref_emat_solve(_p(pts0), _p(pts1), C.c_int(n), _p(_f32(K0).reshape(9)), _p(_f32(K1).reshape(9)),
+                                  C.c_double(pix_thr), C.c_double(conf), C.c_int(max_iters), C.c_uint64(seed),
+                                  C.c_uint64(pair_id), _p(R), _p(t), _p(mask), C.byref(n_inl), C.byref(bi), C.byref(ir),
+                                  _p(counts) if want_counts else None, _p(rmask))
+    out = dict(status=st, R=R, t=t, mask=mask[:n].copy(), ransac_mask=rmask[:n].copy(), n_inl=n_inl.value,
+               best_iter=bi.value, iters_run=ir.value)
+    if want_counts:
+        out["counts"] = counts
+    return out

@@ -1,0 +1,92 @@
+"""-m gpu: the reference's plugin surface on top of the HIP path: config merge,
+build_model, FeatureMatchingModel.forward contract, PrecomputedMatching from an npz on disk,
+per-pair solver classes == batched kernels == oracle, NaN-pose convention."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import mapfree_reloc_amd as mfr
+from mapfree_reloc_amd import synth, wire
+from mapfree_reloc_amd.builder import build_model
+from mapfree_reloc_amd.config import get_cfg_defaults
+from oracle import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _cfg(solver, tmp, matcher="Precomputed"):
+    cfg = get_cfg_defaults()
+    cfg.MODEL = "FeatureMatching"
+    cfg.FEATURE_MATCHING = matcher
+    cfg.POSE_SOLVER = solver
+    cfg.MATCHES_FILE_PATH = "{scene_root}/correspondences_SG.npz"
+    cfg.PNP.RANSAC_ITER, cfg.PNP.REPROJECTION_INLIER_THRESHOLD, cfg.PNP.CONFIDENCE = 1000, 3, 0.9999
+    cfg.EMAT_RANSAC.PIX_THRESHOLD, cfg.EMAT_RANSAC.SCALE_THRESHOLD, cfg.EMAT_RANSAC.CONFIDENCE = 2.0, 0.1, 0.9999
+    return cfg
+
+
+def _scene(tmp_path, n_list, seeds):
+    pairs = [synth.make_pair(s, n, outlier_frac=0.3) if n else synth.make_pair(s, 8) for s, n in zip(seeds, n_list)]
+    rows = [np.concatenate([p["pts0"], p["pts1"]], 1)[:n] if n else np.full((1, 4), np.nan) for p, n in zip(pairs, n_list)]
+    wire.save_correspondences(os.path.join(tmp_path, "correspondences_SG.npz"), rows)
+    datas = []
+    for i, p in enumerate(pairs):
+        datas.append({
+            "depth0": torch.from_numpy(p["depth0"])[None], "depth1": torch.from_numpy(p["depth1"])[None],
+            "K_color0": torch.from_numpy(p["K0"])[None], "K_color1": torch.from_numpy(p["K1"])[None],
+            "pair_id": torch.tensor([i]), "scene_id": ["s00000"], "scene_root": [str(tmp_path)],
+            "pair_names": [["seq0/frame_00000.jpg"], [f"seq1/frame_{i:05d}.jpg"]]})
+    return pairs, datas
+
+
+def test_pnp_model_forward_contract(tmp_path):
+    n_list = [600, 0, 3, 200]
+    pairs, datas = _scene(tmp_path, n_list, [1, 2, 3, 4])
+    model = build_model(_cfg("PNP", tmp_path))
+    for i, (p, data) in enumerate(zip(pairs, datas)):
+        R, t = model(data)
+        assert R.shape == (1, 3, 3) and t.shape == (1, 1, 3) and R.dtype == torch.float32      # model.py:38-39
+        n = n_list[i]
+        st, Rr, tr, ninl = O.pnp_solve(p["pts0"][:n], p["pts1"][:n], p["depth0"], p["K0"], p["K1"], seed=0, pair_id=i)
+        if st != 0:
+            assert torch.isnan(R).all() and torch.isnan(t).all() and data["inliers"] == 0        # NaN convention
+        else:
+            assert data["inliers"] == ninl
+            np.testing.assert_array_equal(R[0].numpy(), Rr.astype(np.float32))
+            np.testing.assert_array_equal(t[0, 0].numpy(), tr.reshape(3).astype(np.float32))
+            assert synth.rot_err_deg(Rr, p["R_gt"]) < 0.3
+
+
+def test_emat_metric_model_forward(tmp_path):
+    n_list = [900, 4, 300]
+    pairs, datas = _scene(tmp_path, n_list, [11, 12, 13])
+    model = build_model(_cfg("EssentialMatrixMetric", tmp_path))
+    for i, (p, data) in enumerate(zip(pairs, datas)):
+        R, t = model(data)
+        n = n_list[i]
+        ref = O.emat_solve(p["pts0"][:n], p["pts1"][:n], p["K0"], p["K1"], 2.0, 0.9999, 1000, 0, i)
+        if ref["status"] != 0:
+            assert torch.isnan(R).all() and data["inliers"] == 0
+            continue
+        sc = O.scale_lift(p["pts0"][:n], p["pts1"][:n], ref["mask"], p["depth0"], p["depth1"], p["K0"], p["K1"], ref["R"], ref["t"])
+        cnt, bs, _ = O.scale_ransac(sc, 0.1)
+        assert data["inliers"] == cnt                                                         # Q2: confidence = scale inliers
+        np.testing.assert_array_equal(t[0, 0].numpy(), (bs * ref["t"]).astype(np.float32))
+        np.testing.assert_array_equal(model.pose_solver.mask.ravel(), ref["mask"])              # Q7
+
+
+def test_emat_up_to_scale_solver_shapes(tmp_path):
+    pairs, datas = _scene(tmp_path, [500], [21])
+    model = build_model(_cfg("EssentialMatrix", tmp_path))
+    R, t = model(datas[0])
+    assert abs(float(t.norm()) - 1.0) < 1e-5 and datas[0]["inliers"] > 100
+
+
+def test_unknown_config_values_raise(tmp_path):
+    with pytest.raises(NotImplementedError):
+        build_model(_cfg("Nope", tmp_path))
+    cfg = _cfg("PNP", tmp_path); cfg.MODEL = "Regression"
+    with pytest.raises(NotImplementedError):
+        build_model(cfg)
