@@ -180,6 +180,30 @@ int mfr_sg_sinkhorn_match(const float *S, int B, int ldS, const int32_t *n0, con
                           int32_t *matches0, float *mscores0, float *pts0, float *pts1, int maxN, int32_t *n_corr,
                           void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * LoFTR kernels.  Reference call site: LoFTR_matcher.match, etc/feature_matching_baselines/
+ * matchers.py:24-59 (LoFTR(default_cfg), *_ot.ckpt strict=False :16-18); network = un-vendored
+ * zju3dv/LoFTR submodule (.gitmodules:1-3), restated per SURVEY.md Appendix A.4.
+ *   mfr_loftr_linear_attention   LinearAttention of the coarse transformer (heads x 32, elu+1 feature
+ *                                map, eps 1e-6): out = phi(Q) (phi(K)^T V/L) / (phi(Q).sum phi(K)) * L.
+ *                                q [B,L,ldq], k,v [B,L,ld], out [B,L,ldo]; head h = channels [32h,32h+32)
+ *   mfr_loftr_coarse_match       CoarseMatching(dual_softmax) + get_coarse_match: S [B,L0,L1] =
+ *                                (f0/sqrt C)(f1/sqrt C)^T; conf = softmax_i(S/T) * softmax_j(S/T);
+ *                                conf > thr, border removal, mutual max -> i_ids, j_ids [B,L0] i32
+ *                                (ascending i), mconf [B,L0], n_match [B]
+ *   mfr_loftr_gather_windows     FinePreprocess unfold(win, stride, pad win/2) restricted to the
+ *                                matched cells: feat [Bimg,Hf,Wf,C] NHWC -> out [M, win*win, C]
+ * ------------------------------------------------------------------------------------------ */
+size_t mfr_loftr_linear_attention_workspace_bytes(int B, int L, int heads);
+int mfr_loftr_linear_attention(const float *q, int ldq, const float *k, const float *v, int ld, int B, int L, int heads,
+                               void *workspace, size_t workspace_bytes, float *out, int ldo, void *stream);
+size_t mfr_loftr_coarse_match_workspace_bytes(int B, int L0, int L1);
+int mfr_loftr_coarse_match(const float *S, int B, int h0, int w0, int h1, int w1, float temperature, float thr, int border,
+                           void *workspace, size_t workspace_bytes, int32_t *i_ids, int32_t *j_ids, float *mconf,
+                           int32_t *n_match, void *stream);
+int mfr_loftr_gather_windows(const float *feat, int Bimg, int Hf, int Wf, int C, const int32_t *img_ids,
+                             const int32_t *cell_ids, int M, int wc, int stride, int win, float *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,362 @@
+// loftr.hip -- LoFTR matcher kernels on gfx950.
+//
+// Reference call site: LoFTR_matcher.match (etc/feature_matching_baselines/matchers.py:24-59) ->
+// upstream LoFTR(default_cfg) (un-vendored submodule, .gitmodules:1-3; algorithm per SURVEY.md
+// Appendix A.4).  Hand-written here:
+//
+//   la_kv_kernel / la_out_kernel   linear attention of the coarse transformer (d_model 256, 8 heads x 32,
+//       phi = elu + 1):  KV = phi(K)^T (V / L) and K-sum reduced over the 6120 tokens on the exact
+//       fp32 matrix cores (v_mfma_f32_32x32x2_f32, 2 tokens per instruction), then
+//       out = phi(Q) KV / (phi(Q).Ksum + eps) * L, again on MFMA.  HBM-bound: Q, K, V are read once,
+//       the message is written once; per-chunk partial KV are summed in a FIXED order (deterministic).
+//   dsm_* kernels   dual-softmax coarse matching: conf = softmax_row(S) * softmax_col(S) with
+//       S = f0 f1^T / (C * temperature) materialised ONCE (by the GEMM) and then only streamed:
+//       row/col (max, sum-exp) statistics, row arg-max / col max of conf, threshold 0.2, border 2,
+//       mutual-max check, ordered compaction -> (i, j, conf) per match.  Upstream materialises sim,
+//       two softmaxes, conf, the mask and two max reductions (>= 6 full 150 MB tensors per pair).
+//   fine_gather_kernel   the 5x5 windows of the 1/2-resolution feature map around every coarse match
+//       (upstream unfolds the WHOLE map: 78 MB per image) gathered straight from NHWC features.
+//
+// Compiled with -ffp-contract=off: conf values are compared for equality across kernels (mutual-max
+// test), so every kernel must evaluate the same expression with the same roundings.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "../../include/mfr_hip.h"
+
+#define CHECK_LAUNCH() do { if (hipGetLastError() != hipSuccess) return MFR_E_LAUNCH; } while (0)
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+static __device__ __forceinline__ float phi(float x) { return x > 0.f ? x + 1.f : expf(x); }   // elu(x) + 1
+
+#define LA_DH 32
+#define LA_CHUNK 256          // tokens per workgroup in the KV pass (64 per wavefront)
+
+// grid (nchunks, H, B), 256 threads.  partial KV [B,H,nchunks,32,32] (d-major), partial Ksum [B,H,nchunks,32]
+__global__ void __launch_bounds__(256) la_kv_kernel(const float *__restrict__ K, const float *__restrict__ V, int ld, int L,
+                                                    float inv_len, float *__restrict__ kv_part, float *__restrict__ ks_part)
+{
+    __shared__ float red[4][32 * 32];
+    __shared__ float redk[4][64];
+    const int c = blockIdx.x, h = blockIdx.y, b = blockIdx.z, nchunks = gridDim.x, H = gridDim.y;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, col = lane & 31, half = lane >> 5;
+    const float *Kb = K + (size_t)b * L * ld + h * LA_DH + col;
+    const float *Vb = V + (size_t)b * L * ld + h * LA_DH + col;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float ks = 0.f;
+    const int t0 = c * LA_CHUNK + wid * 64;
+#pragma unroll 4
+    for (int s = 0; s < 32; ++s) {
+        const int tok = t0 + 2 * s + half;
+        float kk = 0.f, vv = 0.f;
+        if (tok < L) { kk = phi(Kb[(size_t)tok * ld]); vv = Vb[(size_t)tok * ld] * inv_len; }
+        ks += kk;
+        // A[i = d][k = token], B[k = token][j = v]
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(kk, vv, acc, 0, 0, 0);
+    }
+    // C[row = d][col = v]: rows (r&3) + 8 (r>>2) + 4 half
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wid][((r & 3) + 8 * (r >> 2) + 4 * half) * 32 + col] = acc[r];
+    redk[wid][lane] = ks;
+    __syncthreads();
+    float *o = kv_part + (((size_t)b * H + h) * nchunks + c) * 1024;
+    for (int i = tid; i < 1024; i += 256) o[i] = ((red[0][i] + red[1][i]) + red[2][i]) + red[3][i];
+    if (tid < 32) {
+        float s = 0.f;
+        for (int w = 0; w < 4; ++w) s = s + (redk[w][tid] + redk[w][tid + 32]);
+        ks_part[(((size_t)b * H + h) * nchunks + c) * 32 + tid] = s;
+    }
+}
+
+// grid (ceil(L/128), H, B), 256 threads: wavefront = 32 query tokens
+__global__ void __launch_bounds__(256) la_out_kernel(const float *__restrict__ Q, int ldq, int L, int nchunks,
+                                                     const float *__restrict__ kv_part, const float *__restrict__ ks_part,
+                                                     float v_len, float *__restrict__ out, int ldo)
+{
+    const int h = blockIdx.y, b = blockIdx.z, H = gridDim.y;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, col = lane & 31, half = lane >> 5;
+    // B operand: KV[d = 16 half + s][v = col], summed over the chunks in chunk order
+    float kv[16], ksum[16];
+    {
+        const float *p = kv_part + ((size_t)b * H + h) * nchunks * 1024;
+        const float *pk = ks_part + ((size_t)b * H + h) * nchunks * 32;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) { kv[s] = 0.f; ksum[s] = 0.f; }
+        for (int c = 0; c < nchunks; ++c) {
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                kv[s] = kv[s] + p[(size_t)c * 1024 + (16 * half + s) * 32 + col];
+                ksum[s] = ksum[s] + pk[(size_t)c * 32 + 16 * half + s];
+            }
+        }
+    }
+    const int tok = blockIdx.x * 128 + wid * 32 + col;
+    float q[16];
+    {
+        const bool ok = tok < L;
+        const float4 *qp = (const float4 *)(Q + ((size_t)b * L + (ok ? tok : 0)) * ldq + h * LA_DH + 16 * half);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 t = ok ? qp[g] : make_float4(0.f, 0.f, 0.f, 0.f);
+            q[4 * g] = ok ? phi(t.x) : 0.f; q[4 * g + 1] = ok ? phi(t.y) : 0.f;
+            q[4 * g + 2] = ok ? phi(t.z) : 0.f; q[4 * g + 3] = ok ? phi(t.w) : 0.f;
+        }
+    }
+    float dz = 0.f;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) dz = dz + q[s] * ksum[s];
+    dz = dz + __shfl_xor(dz, 32, 64);
+    const float z = 1.0f / (dz + 1e-6f);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(q[s], kv[s], acc, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+        const float zr = __shfl(z, row, 64);
+        const int t = blockIdx.x * 128 + wid * 32 + row;
+        if (t < L) out[((size_t)b * L + t) * ldo + h * LA_DH + col] = (acc[r] * zr) * v_len;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ dual softmax
+struct Lse { float m, s; };
+static __device__ __forceinline__ void lse_add(Lse &a, float x)
+{
+    if (x > a.m) { a.s = a.s * expf(a.m - x) + 1.f; a.m = x; }
+    else a.s = a.s + expf(x - a.m);
+}
+static __device__ __forceinline__ void lse_merge(Lse &a, float m, float s)
+{
+    if (m == -INFINITY) return;
+    if (m > a.m) { a.s = a.s * expf(a.m - m) + s; a.m = m; }
+    else a.s = a.s + s * expf(m - a.m);
+}
+// conf_ij = softmax over rows-dim * softmax over cols-dim; ONE definition used by every kernel
+static __device__ __forceinline__ float conf_val(float s, float rmax, float rsum, float cmax, float csum)
+{
+    return (expf(s - cmax) / csum) * (expf(s - rmax) / rsum);
+}
+
+// row statistics (over j) : one wavefront per row
+__global__ void __launch_bounds__(256) dsm_rowstat_kernel(const float *__restrict__ S, int L0, int L1, float temp,
+                                                          float *__restrict__ rmax, float *__restrict__ rsum)
+{
+    const int b = blockIdx.y, lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= L0) return;
+    const float *row = S + ((size_t)b * L0 + i) * L1;
+    Lse a = { -INFINITY, 0.f };
+    for (int j = lane; j < L1; j += 64) lse_add(a, row[j] / temp);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const float om = __shfl_xor(a.m, off, 64), os = __shfl_xor(a.s, off, 64);
+        lse_merge(a, om, os);
+    }
+    if (lane == 0) { rmax[(size_t)b * L0 + i] = a.m; rsum[(size_t)b * L0 + i] = a.s; }
+}
+
+// column statistics (over i): 64 columns x 16 row groups
+__global__ void __launch_bounds__(1024) dsm_colstat_kernel(const float *__restrict__ S, int L0, int L1, float temp,
+                                                           float *__restrict__ cmax, float *__restrict__ csum)
+{
+    __shared__ float sm[16][64], ss[16][64];
+    const int b = blockIdx.y, lane = threadIdx.x & 63, g = threadIdx.x >> 6, j = blockIdx.x * 64 + lane;
+    Lse a = { -INFINITY, 0.f };
+    if (j < L1) {
+        const float *colp = S + (size_t)b * L0 * L1 + j;
+        for (int i = g; i < L0; i += 16) lse_add(a, colp[(size_t)i * L1] / temp);
+    }
+    sm[g][lane] = a.m; ss[g][lane] = a.s;
+    __syncthreads();
+    if (g == 0 && j < L1) {
+        for (int k = 1; k < 16; ++k) lse_merge(a, sm[k][lane], ss[k][lane]);
+        cmax[(size_t)b * L1 + j] = a.m; csum[(size_t)b * L1 + j] = a.s;
+    }
+}
+
+__global__ void __launch_bounds__(256) dsm_rowbest_kernel(const float *__restrict__ S, int L0, int L1, float temp,
+                                                          const float *__restrict__ rmax, const float *__restrict__ rsum,
+                                                          const float *__restrict__ cmax, const float *__restrict__ csum,
+                                                          float *__restrict__ rbest, int *__restrict__ rarg)
+{
+    const int b = blockIdx.y, lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= L0) return;
+    const float *row = S + ((size_t)b * L0 + i) * L1;
+    const float rm = rmax[(size_t)b * L0 + i], rs = rsum[(size_t)b * L0 + i];
+    float best = -1.f; int bj = 0x7fffffff;
+    for (int j = lane; j < L1; j += 64) {
+        const float c = conf_val(row[j] / temp, rm, rs, cmax[(size_t)b * L1 + j], csum[(size_t)b * L1 + j]);
+        if (c > best) { best = c; bj = j; }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const float ob = __shfl_xor(best, off, 64); const int oj = __shfl_xor(bj, off, 64);
+        if (ob > best || (ob == best && oj < bj)) { best = ob; bj = oj; }
+    }
+    if (lane == 0) { rbest[(size_t)b * L0 + i] = best; rarg[(size_t)b * L0 + i] = bj; }
+}
+
+__global__ void __launch_bounds__(1024) dsm_colbest_kernel(const float *__restrict__ S, int L0, int L1, float temp,
+                                                           const float *__restrict__ rmax, const float *__restrict__ rsum,
+                                                           const float *__restrict__ cmax, const float *__restrict__ csum,
+                                                           float *__restrict__ cbest)
+{
+    __shared__ float sb[16][64];
+    const int b = blockIdx.y, lane = threadIdx.x & 63, g = threadIdx.x >> 6, j = blockIdx.x * 64 + lane;
+    float best = -1.f;
+    if (j < L1) {
+        const float *colp = S + (size_t)b * L0 * L1 + j;
+        const float cm = cmax[(size_t)b * L1 + j], cs = csum[(size_t)b * L1 + j];
+        for (int i = g; i < L0; i += 16) {
+            const float c = conf_val(colp[(size_t)i * L1] / temp, rmax[(size_t)b * L0 + i], rsum[(size_t)b * L0 + i], cm, cs);
+            if (c > best) best = c;
+        }
+    }
+    sb[g][lane] = best;
+    __syncthreads();
+    if (g == 0 && j < L1) {
+        for (int k = 1; k < 16; ++k) if (sb[k][lane] > best) best = sb[k][lane];
+        cbest[(size_t)b * L1 + j] = best;
+    }
+}
+
+// one workgroup per pair: threshold, border, mutual max, ordered compaction (upstream get_coarse_match)
+__global__ void __launch_bounds__(256) dsm_match_kernel(int L0, int L1, int h0, int w0, int h1, int w1, float thr, int border,
+                                                        const float *__restrict__ rbest, const int *__restrict__ rarg,
+                                                        const float *__restrict__ cbest, int *__restrict__ i_ids,
+                                                        int *__restrict__ j_ids, float *__restrict__ mconf,
+                                                        int *__restrict__ n_match)
+{
+    __shared__ int wave_cnt[4];
+    __shared__ int base_s;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    if (tid == 0) base_s = 0;
+    __syncthreads();
+    for (int start = 0; start < L0; start += 256) {
+        const int i = start + tid;
+        bool valid = false; int j = 0; float c = 0.f;
+        if (i < L0) {
+            c = rbest[(size_t)b * L0 + i]; j = rarg[(size_t)b * L0 + i];
+            const int y0 = i / w0, x0 = i - y0 * w0, y1 = j / w1, x1 = j - y1 * w1;
+            const bool inb = y0 >= border && y0 < h0 - border && x0 >= border && x0 < w0 - border &&
+                             y1 >= border && y1 < h1 - border && x1 >= border && x1 < w1 - border;
+            valid = (c > thr) && inb && (c == cbest[(size_t)b * L1 + j]);
+        }
+        const unsigned long long bal = __ballot(valid);
+        const int wpre = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_cnt[wid] = __popcll(bal);
+        __syncthreads();
+        int off = base_s;
+        for (int w = 0; w < wid; ++w) off += wave_cnt[w];
+        if (valid) {
+            const int o = off + wpre;
+            i_ids[(size_t)b * L0 + o] = i; j_ids[(size_t)b * L0 + o] = j; mconf[(size_t)b * L0 + o] = c;
+        }
+        __syncthreads();
+        if (tid == 0) base_s = off + wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+        __syncthreads();
+    }
+    if (tid == 0) n_match[b] = base_s;
+}
+
+// ------------------------------------------------------------------------------------------ fine windows
+// feat [Bimg, Hf, Wf, C] NHWC; one workgroup per match: 25 cells x C channels, zero padding
+__global__ void __launch_bounds__(256) fine_gather_kernel(const float *__restrict__ feat, int Hf, int Wf, int C,
+                                                          const int *__restrict__ img_ids, const int *__restrict__ cell_ids,
+                                                          int wc, int stride, int win, float *__restrict__ out)
+{
+    const int m = blockIdx.x;
+    const int img = img_ids[m], cell = cell_ids[m];
+    const int cy = (cell / wc) * stride - win / 2, cx = (cell % wc) * stride - win / 2;
+    const int total = win * win * C;
+    for (int e = threadIdx.x; e < total; e += 256) {
+        const int k = e / C, ch = e - k * C;
+        const int y = cy + k / win, x = cx + k % win;
+        float v = 0.f;
+        if (y >= 0 && y < Hf && x >= 0 && x < Wf) v = feat[(((size_t)img * Hf + y) * Wf + x) * C + ch];
+        out[(size_t)m * total + e] = v;
+    }
+}
+
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+extern "C" {
+
+size_t mfr_loftr_linear_attention_workspace_bytes(int B, int L, int heads)
+{
+    if (B <= 0 || L <= 0 || heads <= 0) return 0;
+    const size_t nch = (size_t)(L + LA_CHUNK - 1) / LA_CHUNK;
+    return align_up((size_t)B * heads * nch * 1024 * sizeof(float), 256) + align_up((size_t)B * heads * nch * 32 * sizeof(float), 256);
+}
+
+// q [B,L,ldq], k,v [B,L,ld] (head h = channels [32h, 32h+32)); out [B,L,ldo]
+int mfr_loftr_linear_attention(const float *q, int ldq, const float *k, const float *v, int ld, int B, int L, int heads,
+                               void *workspace, size_t workspace_bytes, float *out, int ldo, void *stream)
+{
+    if (!q || !k || !v || !out || !workspace || B <= 0 || L <= 0 || heads <= 0 || (ldq & 3)) return MFR_E_ARG;
+    if (workspace_bytes < mfr_loftr_linear_attention_workspace_bytes(B, L, heads)) return MFR_E_WORKSPACE;
+    const int nch = (L + LA_CHUNK - 1) / LA_CHUNK;
+    float *kvp = (float *)workspace;
+    float *ksp = (float *)((char *)workspace + align_up((size_t)B * heads * nch * 1024 * sizeof(float), 256));
+    hipStream_t s = (hipStream_t)stream;
+    const float vlen = (float)L;
+    hipLaunchKernelGGL(la_kv_kernel, dim3(nch, heads, B), dim3(256), 0, s, k, v, ld, L, 1.0f / vlen, kvp, ksp);
+    CHECK_LAUNCH();
+    hipLaunchKernelGGL(la_out_kernel, dim3((L + 127) / 128, heads, B), dim3(256), 0, s, q, ldq, L, nch, kvp, ksp, vlen, out, ldo);
+    CHECK_LAUNCH();
+    return 0;
+}
+
+size_t mfr_loftr_coarse_match_workspace_bytes(int B, int L0, int L1)
+{
+    if (B <= 0 || L0 <= 0 || L1 <= 0) return 0;
+    return align_up((size_t)B * L0 * 4, 256) * 4 + align_up((size_t)B * L1 * 4, 256) * 3;
+}
+
+// S [B,L0,L1] = (f0/sqrt(C)) (f1/sqrt(C))^T (temperature applied here) -> matches (i ascending)
+int mfr_loftr_coarse_match(const float *S, int B, int h0, int w0, int h1, int w1, float temperature, float thr, int border,
+                           void *workspace, size_t workspace_bytes, int32_t *i_ids, int32_t *j_ids, float *mconf,
+                           int32_t *n_match, void *stream)
+{
+    if (!S || !workspace || !i_ids || !j_ids || !mconf || !n_match || B <= 0 || h0 <= 0 || w0 <= 0 || h1 <= 0 || w1 <= 0)
+        return MFR_E_ARG;
+    const int L0 = h0 * w0, L1 = h1 * w1;
+    if (workspace_bytes < mfr_loftr_coarse_match_workspace_bytes(B, L0, L1)) return MFR_E_WORKSPACE;
+    char *ws = (char *)workspace;
+    const size_t a0 = align_up((size_t)B * L0 * 4, 256), a1 = align_up((size_t)B * L1 * 4, 256);
+    float *rmax = (float *)ws, *rsum = (float *)(ws + a0), *rbest = (float *)(ws + 2 * a0);
+    int *rarg = (int *)(ws + 3 * a0);
+    float *cmax = (float *)(ws + 4 * a0), *csum = (float *)(ws + 4 * a0 + a1), *cbest = (float *)(ws + 4 * a0 + 2 * a1);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(dsm_rowstat_kernel, dim3((L0 + 3) / 4, B), dim3(256), 0, s, S, L0, L1, temperature, rmax, rsum);
+    hipLaunchKernelGGL(dsm_colstat_kernel, dim3((L1 + 63) / 64, B), dim3(1024), 0, s, S, L0, L1, temperature, cmax, csum);
+    CHECK_LAUNCH();
+    hipLaunchKernelGGL(dsm_rowbest_kernel, dim3((L0 + 3) / 4, B), dim3(256), 0, s, S, L0, L1, temperature, rmax, rsum, cmax,
+                       csum, rbest, rarg);
+    hipLaunchKernelGGL(dsm_colbest_kernel, dim3((L1 + 63) / 64, B), dim3(1024), 0, s, S, L0, L1, temperature, rmax, rsum,
+                       cmax, csum, cbest);
+    CHECK_LAUNCH();
+    hipLaunchKernelGGL(dsm_match_kernel, dim3(B), dim3(256), 0, s, L0, L1, h0, w0, h1, w1, thr, border, rbest, rarg, cbest,
+                       i_ids, j_ids, mconf, n_match);
+    CHECK_LAUNCH();
+    return 0;
+}
+
+// feat [Bimg,Hf,Wf,C] NHWC -> out [M, win*win, C] windows centred on coarse cell `cell_ids[m]` of image `img_ids[m]`
+int mfr_loftr_gather_windows(const float *feat, int Bimg, int Hf, int Wf, int C, const int32_t *img_ids,
+                             const int32_t *cell_ids, int M, int wc, int stride, int win, float *out, void *stream)
+{
+    if (!feat || !img_ids || !cell_ids || !out || Bimg <= 0 || Hf <= 0 || Wf <= 0 || C <= 0 || M < 0 || wc <= 0) return MFR_E_ARG;
+    if (M == 0) return 0;
+    hipLaunchKernelGGL(fine_gather_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, feat, Hf, Wf, C, img_ids, cell_ids, wc,
+                       stride, win, out);
+    CHECK_LAUNCH();
+    return 0;
+}
+
+}  // extern "C"

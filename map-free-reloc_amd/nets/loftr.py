@@ -1,0 +1,231 @@
+"""LoFTR on MI355X: ResNet-FPN backbone, linear layers and LayerNorm through PyTorch-ROCm (dense
+library work), the coarse transformer's linear attention, the dual-softmax coarse matching and the
+fine-window gather through csrc/loftr.hip.
+
+Reference call site: LoFTR_matcher (etc/feature_matching_baselines/matchers.py:12-59): LoFTR
+(default_cfg) + `*_ot.ckpt` loaded strict=False; network = un-vendored zju3dv/LoFTR submodule,
+restated per SURVEY.md Appendix A.4 with upstream parameter names (`backbone.*`, `loftr_coarse.*`,
+`fine_preprocess.*`, `loftr_fine.*`) so the real checkpoints load through the same path.
+BatchNorm (eval) is folded into the preceding bias-free convolutions at load time.
+
+The fine-level transformer (2M sequences of 25 tokens, d 128) and the 5x5 expectation are tiny and
+stay on torch ops; everything that touches the 6120-token coarse level is a HIP kernel.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+from .. import _lib
+
+
+def _fold(w, sd, bn):
+    s = sd[bn + ".weight"] / torch.sqrt(sd[bn + ".running_var"] + 1e-5)
+    return w * s[:, None, None, None], sd[bn + ".bias"] - sd[bn + ".running_mean"] * s
+
+
+def position_encoding_sine(d_model, H, W, device):
+    """upstream PositionEncodingSine with TEMP_BUG_FIX False: (-log(1e4)/d_model)//2 == -1.0"""
+    pe = torch.zeros((d_model, H, W))
+    y_position = torch.ones((H, W)).cumsum(0).float().unsqueeze(0)
+    x_position = torch.ones((H, W)).cumsum(1).float().unsqueeze(0)
+    div_term = torch.exp(torch.arange(0, d_model // 2, 2).float() * (-math.log(10000.0) / d_model // 2))[:, None, None]
+    pe[0::4] = torch.sin(x_position * div_term); pe[1::4] = torch.cos(x_position * div_term)
+    pe[2::4] = torch.sin(y_position * div_term); pe[3::4] = torch.cos(y_position * div_term)
+    return pe.to(device)
+
+
+class LoFTRHIP:
+    def __init__(self, state_dict, device="cuda", thr=0.2, border_rm=2, temperature=0.1, window=5):
+        _lib.load(require_gpu=True)
+        self.device = torch.device(device)
+        self.thr, self.border, self.temp, self.W = float(thr), int(border_rm), float(temperature), int(window)
+        sd = {k: v.float() for k, v in state_dict.items()}
+        dev = lambda t: t.to(self.device).contiguous()
+        w = {}
+
+        def convbn(name, conv, bn):
+            cw, cb = _fold(sd[conv + ".weight"], sd, bn)
+            w[name] = (dev(cw), dev(cb))
+
+        def conv(name, key):
+            w[name] = (dev(sd[key + ".weight"]), None)
+        convbn("conv1", "backbone.conv1", "backbone.bn1")
+        for L, stride in (("layer1", 1), ("layer2", 2), ("layer3", 2)):
+            for b in (0, 1):
+                p = f"backbone.{L}.{b}"
+                convbn(f"{L}.{b}.c1", f"{p}.conv1", f"{p}.bn1"); convbn(f"{L}.{b}.c2", f"{p}.conv2", f"{p}.bn2")
+                if b == 0 and stride != 1:
+                    convbn(f"{L}.{b}.ds", f"{p}.downsample.0", f"{p}.downsample.1")
+        conv("l3out", "backbone.layer3_outconv"); conv("l2out", "backbone.layer2_outconv"); conv("l1out", "backbone.layer1_outconv")
+        convbn("l2out2.0", "backbone.layer2_outconv2.0", "backbone.layer2_outconv2.1"); conv("l2out2.3", "backbone.layer2_outconv2.3")
+        convbn("l1out2.0", "backbone.layer1_outconv2.0", "backbone.layer1_outconv2.1"); conv("l1out2.3", "backbone.layer1_outconv2.3")
+        self.w = w
+
+        def encoder(prefix, n):
+            layers = []
+            for l in range(n):
+                p = f"{prefix}.layers.{l}"
+                layers.append(dict(
+                    wq=dev(sd[f"{p}.q_proj.weight"]), wkv=dev(torch.cat([sd[f"{p}.k_proj.weight"], sd[f"{p}.v_proj.weight"]], 0)),
+                    wm=dev(sd[f"{p}.merge.weight"]), w1=dev(sd[f"{p}.mlp.0.weight"]), w2=dev(sd[f"{p}.mlp.2.weight"]),
+                    n1=(dev(sd[f"{p}.norm1.weight"]), dev(sd[f"{p}.norm1.bias"])),
+                    n2=(dev(sd[f"{p}.norm2.weight"]), dev(sd[f"{p}.norm2.bias"]))))
+            return layers
+        self.coarse = encoder("loftr_coarse", 8)
+        self.fine = encoder("loftr_fine", 2)
+        self.down_proj = (dev(sd["fine_preprocess.down_proj.weight"]), dev(sd["fine_preprocess.down_proj.bias"]))
+        self.merge_feat = (dev(sd["fine_preprocess.merge_feat.weight"]), dev(sd["fine_preprocess.merge_feat.bias"]))
+        self._ws_la = self._ws_cm = None
+        self._pe = {}
+
+    # ------------------------------------------------------------------ backbone (torch / MIOpen)
+    def _c(self, x, name, stride=1, act=None):
+        cw, cb = self.w[name]
+        x = F.conv2d(x, cw, cb, stride=stride, padding=cw.shape[-1] // 2)
+        if act == "relu":
+            x = F.relu_(x)
+        elif act == "leaky":
+            x = F.leaky_relu_(x, 0.01)
+        return x
+
+    def _block(self, x, name, stride):
+        y = self._c(x, f"{name}.c1", stride, "relu")
+        y = self._c(y, f"{name}.c2")
+        if stride != 1:
+            x = self._c(x, f"{name}.ds", stride)
+        return F.relu_(x + y)
+
+    def backbone(self, x):
+        x0 = self._c(x, "conv1", 2, "relu")
+        x1 = self._block(self._block(x0, "layer1.0", 1), "layer1.1", 1)
+        x2 = self._block(self._block(x1, "layer2.0", 2), "layer2.1", 1)
+        x3 = self._block(self._block(x2, "layer3.0", 2), "layer3.1", 1)
+        x3_out = self._c(x3, "l3out")
+        x3_2x = F.interpolate(x3_out, scale_factor=2., mode='bilinear', align_corners=True)
+        x2_out = self._c(self._c(self._c(x2, "l2out") + x3_2x, "l2out2.0", 1, "leaky"), "l2out2.3")
+        x2_2x = F.interpolate(x2_out, scale_factor=2., mode='bilinear', align_corners=True)
+        x1_out = self._c(self._c(self._c(x1, "l1out") + x2_2x, "l1out2.0", 1, "leaky"), "l1out2.3")
+        return x3_out, x1_out
+
+    # ------------------------------------------------------------------ HIP stage wrappers
+    def linear_attention(self, q, kv):
+        """q [B,L,256]; kv [B,L,512] (k | v) -> message [B,L,256]  (upstream LinearAttention)"""
+        lib = _lib.load()
+        B, L, D = q.shape
+        heads = D // 32
+        need = lib.mfr_loftr_linear_attention_workspace_bytes(B, L, heads)
+        if self._ws_la is None or self._ws_la.numel() < need:
+            self._ws_la = torch.empty(need, dtype=torch.uint8, device=q.device)
+        out = torch.empty(B, L, D, dtype=torch.float32, device=q.device)
+        base = kv.data_ptr()
+        _lib.check(lib.mfr_loftr_linear_attention(_lib.ptr(q), D, base, base + D * 4, 2 * D, B, L, heads, _lib.ptr(self._ws_la),
+                                                  self._ws_la.numel(), _lib.ptr(out), D, _lib.stream_ptr()),
+                   "mfr_loftr_linear_attention")
+        return out
+
+    def coarse_match(self, S, hw0, hw1):
+        lib = _lib.load()
+        B, L0, L1 = S.shape
+        need = lib.mfr_loftr_coarse_match_workspace_bytes(B, L0, L1)
+        if self._ws_cm is None or self._ws_cm.numel() < need:
+            self._ws_cm = torch.empty(need, dtype=torch.uint8, device=S.device)
+        i_ids = torch.empty(B, L0, dtype=torch.int32, device=S.device); j_ids = torch.empty_like(i_ids)
+        mconf = torch.empty(B, L0, dtype=torch.float32, device=S.device)
+        n = torch.empty(B, dtype=torch.int32, device=S.device)
+        _lib.check(lib.mfr_loftr_coarse_match(_lib.ptr(S.contiguous()), B, hw0[0], hw0[1], hw1[0], hw1[1], self.temp, self.thr,
+                                              self.border, _lib.ptr(self._ws_cm), self._ws_cm.numel(), _lib.ptr(i_ids),
+                                              _lib.ptr(j_ids), _lib.ptr(mconf), _lib.ptr(n), _lib.stream_ptr()),
+                   "mfr_loftr_coarse_match")
+        return i_ids, j_ids, mconf, n
+
+    def gather_windows(self, feat_nhwc, img_ids, cell_ids, wc, stride):
+        lib = _lib.load()
+        Bimg, Hf, Wf, C = feat_nhwc.shape
+        M = img_ids.numel()
+        out = torch.empty(M, self.W * self.W, C, dtype=torch.float32, device=feat_nhwc.device)
+        _lib.check(lib.mfr_loftr_gather_windows(_lib.ptr(feat_nhwc), Bimg, Hf, Wf, C, _lib.ptr(img_ids), _lib.ptr(cell_ids), M,
+                                                wc, stride, self.W, _lib.ptr(out), _lib.stream_ptr()), "mfr_loftr_gather_windows")
+        return out
+
+    # ------------------------------------------------------------------ transformer layers
+    def _layer(self, Lw, x, src, attn):
+        q = F.linear(x, Lw["wq"])
+        kv = F.linear(src, Lw["wkv"])
+        msg = attn(q, kv)
+        msg = F.layer_norm(F.linear(msg, Lw["wm"]), (x.shape[-1],), *Lw["n1"])
+        msg = F.linear(F.relu_(F.linear(torch.cat([x, msg], -1), Lw["w1"])), Lw["w2"])
+        return x + F.layer_norm(msg, (x.shape[-1],), *Lw["n2"])
+
+    @staticmethod
+    def _torch_linear_attention(nhead):
+        def attn(q, kv):
+            B, L, D = q.shape
+            k, v = kv.split(D, -1)
+            Q = F.elu(q.view(B, L, nhead, -1)) + 1
+            K = F.elu(k.reshape(B, L, nhead, -1)) + 1
+            V = v.reshape(B, L, nhead, -1) / L
+            KV = torch.einsum("nshd,nshv->nhdv", K, V)
+            Z = 1 / (torch.einsum("nlhd,nhd->nlh", Q, K.sum(1)) + 1e-6)
+            return (torch.einsum("nlhd,nhdv,nlh->nlhv", Q, KV, Z) * L).reshape(B, L, D)
+        return attn
+
+    def _transformer(self, layers, f0, f1, attn):
+        for l, Lw in enumerate(layers):
+            if l % 2 == 0:      # self: both images independent -> one batched call
+                B = f0.shape[0]
+                x = self._layer(Lw, torch.cat([f0, f1], 0), torch.cat([f0, f1], 0), attn)
+                f0, f1 = x[:B], x[B:]
+            else:               # cross: feat1 attends to the UPDATED feat0 (upstream order)
+                f0 = self._layer(Lw, f0, f1, attn)
+                f1 = self._layer(Lw, f1, f0, attn)
+        return f0, f1
+
+    # ------------------------------------------------------------------ full forward
+    @torch.no_grad()
+    def __call__(self, images):
+        """images [2B,1,H,W] (interleaved pairs; H, W multiples of 8) -> dict(pts0, pts1 [B,L0,2],
+        n_corr [B], mconf [B,L0]) in the matcher's pixel frame (mkpts0_f / mkpts1_f)."""
+        B2, _, H, W = images.shape
+        B = B2 // 2
+        fc, ff = self.backbone(images)
+        hc, wc = fc.shape[2:]
+        key = (hc, wc)
+        if key not in self._pe:
+            self._pe[key] = position_encoding_sine(256, hc, wc, images.device)
+        fc = (fc + self._pe[key][None]).flatten(2).transpose(1, 2).contiguous()        # [2B, L, 256]
+        f0, f1 = fc[0::2].contiguous(), fc[1::2].contiguous()
+        f0, f1 = self._transformer(self.coarse, f0, f1, self.linear_attention)
+        C = f0.shape[-1]
+        S = torch.bmm(f0 / C ** .5, (f1 / C ** .5).transpose(1, 2))
+        i_ids, j_ids, mconf, n = self.coarse_match(S, (hc, wc), (hc, wc))
+        L0 = hc * wc
+        scale = H // hc
+        # coarse keypoints (padded layout)
+        ii, jj = i_ids.long(), j_ids.long()
+        valid = torch.arange(L0, device=images.device)[None] < n[:, None]
+        k0 = torch.stack([ii % wc, ii // wc], -1).float() * scale
+        k1 = torch.stack([jj % wc, jj // wc], -1).float() * scale
+        b_ids, slot = torch.where(valid)                                            # (host sync: match count)
+        M = b_ids.numel()
+        pts1 = k1.clone()
+        if M > 0:
+            mi, mj = ii[b_ids, slot], jj[b_ids, slot]
+            ff_nhwc = ff.permute(0, 2, 3, 1).contiguous()                           # [2B, Hf, Wf, 128]
+            stride = ff.shape[2] // hc
+            w0 = self.gather_windows(ff_nhwc, (2 * b_ids).int(), mi.int(), wc, stride)
+            w1 = self.gather_windows(ff_nhwc, (2 * b_ids + 1).int(), mj.int(), wc, stride)
+            fcw = F.linear(torch.cat([f0[b_ids, mi], f1[b_ids, mj]], 0), *self.down_proj)
+            WW = self.W * self.W
+            fcf = F.linear(torch.cat([torch.cat([w0, w1], 0), fcw[:, None].expand(-1, WW, -1)], -1), *self.merge_feat)
+            g0, g1 = fcf[:M], fcf[M:]
+            g0, g1 = self._transformer(self.fine, g0, g1, self._torch_linear_attention(8))
+            picked = g0[:, WW // 2]
+            heat = torch.softmax(torch.einsum('mc,mrc->mr', picked, g1) / g0.shape[-1] ** .5, dim=1).view(-1, self.W, self.W)
+            lin = torch.linspace(-1, 1, self.W, device=images.device)
+            coords = torch.stack([(heat * lin[None, None, :]).sum((1, 2)), (heat * lin[None, :, None]).sum((1, 2))], 1)
+            scale1 = H // ff.shape[2]
+            pts1[b_ids, slot] = k1[b_ids, slot] + coords * (self.W // 2) * scale1
+        zero = torch.zeros_like(k0)
+        return dict(pts0=torch.where(valid[..., None], k0, zero).contiguous(), pts1=torch.where(valid[..., None], pts1, zero).contiguous(),
+                    n_corr=n, mconf=mconf, i_ids=i_ids, j_ids=j_ids)

@@ -70,6 +70,60 @@ def superglue_state_dict(seed=4321, gnn_gain=0.1, kenc_gain=0.1, proj_gain=12.0,
     return sd
 
 
+def loftr_state_dict(seed=2468, feat_gain=20.0, msg_gain=0.1):
+    """LoFTR (default_cfg architecture) with upstream parameter names (`backbone.*`,
+    `loftr_coarse.layers.N.*`, `fine_preprocess.*`, `loftr_fine.layers.N.*`).  Structured random like
+    the SuperGlue recipe: zero-sum conv filters, identity-like BatchNorm, coarse features scaled so
+    that the dual-softmax is peaky (conf > 0.2 needs a ~9 nat margin over 6120 candidates), and
+    transformer messages scaled down through norm2 so the GNN stays a perturbation."""
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+
+    def conv(name, ci, co, k, gain=1.0):
+        w = _randn(g, (co, ci, k, k), 1.0)
+        w = w - w.mean(dim=(1, 2, 3), keepdim=True)
+        sd[f"{name}.weight"] = w / (w.std(dim=(1, 2, 3), keepdim=True) + 1e-9) * (gain * (2.0 / (ci * k * k)) ** 0.5)
+
+    def bn(name, c):
+        sd[f"{name}.weight"] = torch.ones(c); sd[f"{name}.bias"] = torch.zeros(c)
+        sd[f"{name}.running_mean"] = torch.zeros(c); sd[f"{name}.running_var"] = torch.ones(c)
+        sd[f"{name}.num_batches_tracked"] = torch.tensor(0)
+
+    def block(name, ci, co, stride):
+        conv(f"{name}.conv1", ci, co, 3); conv(f"{name}.conv2", co, co, 3); bn(f"{name}.bn1", co); bn(f"{name}.bn2", co)
+        if stride != 1:
+            conv(f"{name}.downsample.0", ci, co, 1); bn(f"{name}.downsample.1", co)
+    conv("backbone.conv1", 1, 128, 7, gain=8.0); bn("backbone.bn1", 128)
+    dims = [128, 196, 256]
+    block("backbone.layer1.0", 128, 128, 1); block("backbone.layer1.1", 128, 128, 1)
+    block("backbone.layer2.0", 128, 196, 2); block("backbone.layer2.1", 196, 196, 1)
+    block("backbone.layer3.0", 196, 256, 2); block("backbone.layer3.1", 256, 256, 1)
+    conv("backbone.layer3_outconv", 256, 256, 1, gain=feat_gain)
+    conv("backbone.layer2_outconv", 196, 256, 1)
+    conv("backbone.layer2_outconv2.0", 256, 256, 3); bn("backbone.layer2_outconv2.1", 256); conv("backbone.layer2_outconv2.3", 256, 196, 3)
+    conv("backbone.layer1_outconv", 128, 196, 1)
+    conv("backbone.layer1_outconv2.0", 196, 196, 3); bn("backbone.layer1_outconv2.1", 196); conv("backbone.layer1_outconv2.3", 196, 128, 3)
+
+    def lin(name, ci, co, gain=1.0, bias=False):
+        sd[f"{name}.weight"] = _randn(g, (co, ci), gain / ci ** 0.5)
+        if bias:
+            sd[f"{name}.bias"] = torch.zeros(co)
+
+    def encoder(prefix, d, n):
+        for l in range(n):
+            p = f"{prefix}.layers.{l}"
+            for nm in ("q_proj", "k_proj", "v_proj", "merge"):
+                lin(f"{p}.{nm}", d, d)
+            lin(f"{p}.mlp.0", 2 * d, 2 * d, gain=1.4); lin(f"{p}.mlp.2", 2 * d, d)
+            sd[f"{p}.norm1.weight"] = torch.ones(d); sd[f"{p}.norm1.bias"] = torch.zeros(d)
+            sd[f"{p}.norm2.weight"] = torch.full((d,), msg_gain); sd[f"{p}.norm2.bias"] = torch.zeros(d)
+    encoder("loftr_coarse", 256, 8)
+    lin("fine_preprocess.down_proj", 256, 128, gain=0.05, bias=True)
+    lin("fine_preprocess.merge_feat", 256, 128, bias=True)
+    encoder("loftr_fine", 128, 2)
+    return sd
+
+
 def load_checkpoint(path):
     """upstream .pth / .ckpt -> flat state dict (Lightning checkpoints keep it under 'state_dict')"""
     sd = torch.load(path, map_location="cpu")

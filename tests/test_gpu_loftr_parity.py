@@ -1,0 +1,103 @@
+"""-m gpu parity tests of the LoFTR kernels (csrc/loftr.hip) and the LoFTR device module against the
+PyTorch-CPU oracle (oracle/loftr_ref.py)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from mapfree_reloc_amd import images as IM
+from mapfree_reloc_amd.nets import weights as WT
+from mapfree_reloc_amd.nets.loftr import LoFTRHIP
+from oracle import loftr_ref as LR
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def pair():
+    sd = WT.loftr_state_dict()
+    ref = LR.LoFTRRef().eval(); ref.load_state_dict(sd)
+    return ref, LoFTRHIP(sd, DEV)
+
+
+def test_linear_attention_vs_oracle(pair):
+    ref, hip = pair
+    g = torch.Generator().manual_seed(0)
+    B, L = 3, 6120
+    q = torch.randn(B, L, 256, generator=g); k = torch.randn(B, L, 256, generator=g); v = torch.randn(B, L, 256, generator=g)
+    want = LR.linear_attention(q.view(B, L, 8, 32), k.view(B, L, 8, 32), v.view(B, L, 8, 32)).reshape(B, L, 256)
+    got = hip.linear_attention(q.to(DEV), torch.cat([k, v], -1).to(DEV)).cpu()
+    np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=2e-4, atol=2e-5)
+
+
+def test_linear_attention_ragged_length(pair):
+    ref, hip = pair
+    g = torch.Generator().manual_seed(1)
+    B, L = 2, 333
+    q = torch.randn(B, L, 256, generator=g); k = torch.randn(B, L, 256, generator=g); v = torch.randn(B, L, 256, generator=g)
+    want = LR.linear_attention(q.view(B, L, 8, 32), k.view(B, L, 8, 32), v.view(B, L, 8, 32)).reshape(B, L, 256)
+    got = hip.linear_attention(q.to(DEV), torch.cat([k, v], -1).to(DEV)).cpu()
+    np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=2e-4, atol=2e-5)
+
+
+def test_coarse_match_vs_oracle(pair):
+    ref, hip = pair
+    g = torch.Generator().manual_seed(2)
+    h, w = 30, 22
+    L = h * w
+    B = 2
+    f0 = torch.randn(B, L, 256, generator=g) * 2.2
+    perm = torch.stack([torch.randperm(L, generator=g) for _ in range(B)])
+    f1 = torch.gather(f0, 1, perm[..., None].expand(-1, -1, 256)) + 0.3 * torch.randn(B, L, 256, generator=g)
+    cm = LR.coarse_matching(f0, f1, (h, w), (h, w))
+    S = torch.bmm(f0 / 16.0, (f1 / 16.0).transpose(1, 2))
+    i_ids, j_ids, mconf, n = [t.cpu() for t in hip.coarse_match(S.to(DEV), (h, w), (h, w))]
+    conf = cm["conf_matrix"]
+    for b in range(B):
+        sel = cm["b_ids"] == b
+        wi, wj, wc = cm["i_ids"][sel], cm["j_ids"][sel], cm["mconf"][sel]
+        # matches whose confidence is within 1e-3 of the threshold may legitimately differ in fp32
+        safe_w = (wc - 0.2).abs() > 1e-3
+        gi, gj, gc = i_ids[b, :n[b]].long(), j_ids[b, :n[b]].long(), mconf[b, :n[b]]
+        safe_g = (gc - 0.2).abs() > 1e-3
+        assert len(wi) > L // 4
+        np.testing.assert_array_equal(gi[safe_g].numpy(), wi[safe_w].numpy())
+        np.testing.assert_array_equal(gj[safe_g].numpy(), wj[safe_w].numpy())
+        np.testing.assert_allclose(gc[safe_g].numpy(), wc[safe_w].numpy(), rtol=2e-4)
+
+
+def test_fine_window_gather_vs_unfold(pair):
+    ref, hip = pair
+    g = torch.Generator().manual_seed(3)
+    Bimg, C, Hf, Wf, wc, hc = 4, 128, 60, 44, 11, 15
+    feat = torch.randn(Bimg, C, Hf, Wf, generator=g)
+    unf = F.unfold(feat, kernel_size=(5, 5), stride=4, padding=2).view(Bimg, C, 25, -1).permute(0, 3, 2, 1)   # [B, L, 25, C]
+    M = 500
+    img = torch.randint(0, Bimg, (M,), generator=g); cell = torch.randint(0, wc * hc, (M,), generator=g)
+    got = hip.gather_windows(feat.permute(0, 2, 3, 1).contiguous().to(DEV), img.int().to(DEV), cell.int().to(DEV), wc, 4).cpu()
+    np.testing.assert_array_equal(got.numpy(), unf[img, cell].numpy())
+
+
+@pytest.mark.parametrize("hw", [(240, 176), (720, 544)])
+def test_loftr_end_to_end_vs_oracle(pair, hw):
+    """(720, 544) = the reference's padded Map-free input (matchers.py:41-46, quirk Q3)"""
+    ref, hip = pair
+    H, W = hw
+    pr = IM.synthetic_pair(7, H, 540 if W == 544 else W)
+    im0, im1 = torch.from_numpy(pr["img0"])[None, None], torch.from_numpy(pr["img1"])[None, None]
+    torch.set_num_threads(16)
+    want = LR.loftr_match_pair(ref, im0, im1)
+    if W == 544:
+        im0, im1 = F.pad(im0, (0, 4)), F.pad(im1, (0, 4))
+    out = hip(torch.cat([im0, im1], 0).to(DEV))
+    n = int(out["n_corr"][0])
+    got = torch.cat([out["pts0"][0, :n], out["pts1"][0, :n]], 1).cpu().numpy()
+    assert len(want) > 100 and not np.isnan(want).any()
+    # same coarse matches (key = the two coarse cells); fine offsets within 1e-2 px
+    kw = {(int(r[0]), int(r[1])): r for r in want}
+    kg = {(int(r[0]), int(r[1])): r for r in got}
+    common = set(kw) & set(kg)
+    assert len(common) >= 0.97 * max(len(kw), len(kg)), (len(kw), len(kg), len(common))
+    d = np.array([np.abs(kw[k] - kg[k]).max() for k in common])
+    assert np.quantile(d, 0.99) < 2e-2, np.quantile(d, [0.5, 0.9, 0.99, 1.0])
