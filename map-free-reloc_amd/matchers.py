@@ -1,0 +1,88 @@
+"""Offline matcher plugins with the reference's API (etc/feature_matching_baselines/matchers.py):
+class M(resize: (W, H), outdoor: bool) with match(pair_path: (str, str)) -> ndarray [N,4]
+(x0,y0,x1,y1) in the resized pixel frame, or np.full((1,4), nan) when there is no correspondence
+(:59, :120); registered in MATCHERS and driven by compute.py (-ds Mapfree -m SG|LoFTR).
+
+Image reading: the reference uses SuperGlue's read_image (cv2.imread GRAYSCALE, resize to (W,H),
+/255).  cv2 is not available offline, so PIL is used (L mode = the same BT.601
+luma; bilinear resize on the uint8 image rather than cv2's float resize -- sub-grey-level
+differences, documented).
+
+Weights: upstream checkpoints when present (same file names as matchers.py:17,70), else the seeded
+synthetic weights of nets/weights.py with a warning.
+"""
+import os
+import warnings
+
+import numpy as np
+import torch
+
+from .nets import weights as WT
+
+
+def read_image(path, resize):
+    from PIL import Image
+    im = Image.open(path).convert("L").resize((int(resize[0]), int(resize[1])), Image.BILINEAR)
+    return np.asarray(im, dtype=np.float32) / 255.0
+
+
+def _weights(path, synth, what):
+    if path and os.path.exists(path):
+        return WT.load_checkpoint(path)
+    warnings.warn(f"{what}: checkpoint {path!r} not found -> seeded synthetic weights (results are NOT meaningful)")
+    return synth()
+
+
+class SuperGlue_matcher:
+    def __init__(self, resize, outdoor=False, weights_dir="SuperGlue/models/weights"):
+        from .nets.superpoint import SuperPointHIP
+        from .nets.superglue import SuperGlueHIP
+        self.resize = resize
+        self.device = torch.device("cuda")
+        sp = _weights(os.path.join(weights_dir, "superpoint_v1.pth"), WT.superpoint_state_dict, "SuperPoint")
+        sg = _weights(os.path.join(weights_dir, f"superglue_{'outdoor' if outdoor else 'indoor'}.pth"),
+                      WT.superglue_state_dict, "SuperGlue")
+        self.sp = SuperPointHIP(sp, self.device, nms_radius=4, keypoint_threshold=0.005, max_keypoints=1024)   # :65-67
+        self.sg = SuperGlueHIP(sg, self.device, sinkhorn_iterations=20, match_threshold=0.2)                   # :70-71
+
+    def match_tensors(self, im0, im1):
+        ims = torch.from_numpy(np.stack([im0, im1]))[:, None].to(self.device)
+        out = self.sg(self.sp(ims), tuple(ims.shape[-2:]))
+        n = int(out["n_corr"][0])
+        if n > 0:
+            return torch.cat([out["pts0"][0, :n], out["pts1"][0, :n]], 1).cpu().numpy()
+        print("no correspondences")
+        return np.full((1, 4), np.nan)
+
+    def match(self, pair_path):
+        '''return correspondences between images (w/ path pair_path)'''
+        return self.match_tensors(read_image(pair_path[0], self.resize), read_image(pair_path[1], self.resize))
+
+
+class LoFTR_matcher:
+    def __init__(self, resize, outdoor=False, weights_dir="LoFTR/weights"):
+        from .pipeline import LoFTREmatPipeline
+        self.resize = resize
+        sd = _weights(os.path.join(weights_dir, "outdoor_ot.ckpt" if outdoor else "indoor_ot.ckpt"), WT.loftr_state_dict, "LoFTR")
+        sd = {k[len("matcher."):] if k.startswith("matcher.") else k: v for k, v in sd.items()}
+        self._pipe = LoFTREmatPipeline("cuda", loftr_state=sd)
+
+    def match_tensors(self, im0, im1):
+        ims = torch.from_numpy(np.stack([im0, im1]))[:, None].to(self._pipe.device)
+        out = self._pipe.match(ims)
+        n = int(out["n_corr"][0])
+        if n > 0:
+            return torch.cat([out["pts0"][0, :n], out["pts1"][0, :n]], 1).cpu().numpy()
+        print("no correspondences")
+        return np.full((1, 4), np.nan)
+
+    def match(self, pair_path):
+        return self.match_tensors(read_image(pair_path[0], self.resize), read_image(pair_path[1], self.resize))
+
+
+class SIFT_matcher:
+    def __init__(self, resize, outdoor=False):
+        raise NotImplementedError("SIFT_matcher needs OpenCV SIFT/FLANN (matchers.py:123-188); outside the GPU hot path")
+
+
+MATCHERS = {'LoFTR': LoFTR_matcher, 'SG': SuperGlue_matcher, 'SIFT': SIFT_matcher}

@@ -41,3 +41,38 @@ class SuperGluePnPPipeline:
         out["n_corr"] = m["n_corr"]
         out["pts0"], out["pts1"] = m["pts0"], m["pts1"]
         return out
+
+
+class LoFTREmatPipeline:
+    """LoFTR coarse-to-fine matching -> E-matrix RANSAC -> metric scale from depth
+    (config/matching/mapfree/loftr_emat_dptkitti.yaml: PIX_THRESHOLD 2.0, SCALE_THRESHOLD 0.1,
+    CONFIDENCE 0.9999), one device-resident pass over a batch of pairs.  Replaces
+    LoFTR_matcher.match (matchers.py:24-59) + EssentialMatrixMetricSolver (pose_solver.py:115-172)."""
+
+    def __init__(self, device="cuda", loftr_state=None, pix_thr=2.0, scale_thr=0.1, conf=0.9999, seed=0, pad_to=8):
+        from .nets.loftr import LoFTRHIP
+        from .solver_ops import EssentialBatchSolver, ScaleFromDepthBatch
+        _lib.load(require_gpu=True)
+        self.device = torch.device(device)
+        self.loftr = LoFTRHIP(loftr_state or WT.loftr_state_dict(), self.device)
+        self.emat = EssentialBatchSolver(pix_thr, conf, seed)
+        self.scale = ScaleFromDepthBatch(scale_thr)
+        self.pad_to = pad_to
+
+    @torch.no_grad()
+    def match(self, images):
+        H, W = images.shape[-2:]
+        # LoFTR needs multiples of 8; the reference right-pads W 540 -> 544 (matchers.py:41-46, quirk Q3)
+        ph, pw = (-H) % self.pad_to, (-W) % self.pad_to
+        if ph or pw:
+            images = torch.nn.functional.pad(images, (0, pw, 0, ph))
+        return self.loftr(images)
+
+    @torch.no_grad()
+    def __call__(self, images, depth0, depth1, K0, K1, pair_ids):
+        m = self.match(images)
+        e = self.emat(m["pts0"], m["pts1"], m["n_corr"], K0, K1, pair_ids)
+        s = self.scale(m["pts0"], m["pts1"], e["mask"], m["n_corr"], depth0, depth1, K0, K1, e["R"], e["t"], e["status"])
+        return dict(R=torch.where((s["status"] == 0)[:, None, None], e["R"], torch.full_like(e["R"], float("nan"))),
+                    t=s["t_metric"], n_inliers=s["n_inliers"], status=s["status"], n_corr=m["n_corr"],
+                    emat_inliers=e["n_inliers"])
