@@ -33,8 +33,8 @@ FP32_MFMA_PEAK_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md (v
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=16, help="image pairs per GPU per step")
     ap.add_argument("--cpu-pairs", type=int, default=6, help="pairs timed for the CPU baseline (rank 0, N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -120,8 +120,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    use_dist = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl")
     if args.gpus != world and rank == 0 and world > 1:
         print(f"warning: --gpus {args.gpus} != WORLD_SIZE {world}", file=sys.stderr)
@@ -150,10 +152,17 @@ def main():
         d = batches[i & 1]
         return pipe(d["images"], d["depth0"], d["K0"], d["K1"], d["pair_ids"])
 
+    # initialisation, not warm-up: the first calls on a fresh box pay MIOpen's lazy solution selection /
+    # code-object loading and the GPU's clock ramp (measured: the first process on a cold box ran the
+    # same steps 1.5x slower when timed right after 3 calls)
+    for i in range(6):
+        step(i)
+    torch.cuda.synchronize()
+
     for i in range(args.warmup):
         out = step(i)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     timer.enabled = True
@@ -164,18 +173,20 @@ def main():
         out = step(i)
         results.append((batches[i & 1]["pair_ids"], out))
         if args.verbose:
-            print(f"step {i}: host issue {1e3 * (time.perf_counter() - ts):.1f} ms", file=sys.stderr)
+            hi = 1e3 * (time.perf_counter() - ts)
+            torch.cuda.synchronize()
+            print(f"step {i}: host issue {hi:.1f} ms, done {1e3 * (time.perf_counter() - ts):.1f} ms", file=sys.stderr)
     # one gather of the per-pair pose records for the whole run
     all_ids = torch.cat([r[0] for r in results])
     all_out = {k: torch.cat([r[1][k] for r in results]) for k in ("R", "t", "n_inliers", "status")}
-    rec = gather_pose_records(all_ids, all_out, world)
+    rec = gather_pose_records(all_ids, all_out, world if use_dist else 1)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     timer.enabled = False
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -210,7 +221,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline_subprocess(args.cpu_pairs, args.cpu_threads)
         print(json.dumps(line))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

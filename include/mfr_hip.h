@@ -204,6 +204,16 @@ int mfr_loftr_coarse_match(const float *S, int B, int h0, int w0, int h1, int w1
 int mfr_loftr_gather_windows(const float *feat, int Bimg, int Hf, int Wf, int C, const int32_t *img_ids,
                              const int32_t *cell_ids, int M, int wc, int stride, int win, float *out, void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Fused conv epilogues of the SuperPoint encoder (NCHW f32; same call site as above): the MIOpen
+ * convolutions run without bias and these finish the layer in one pass.
+ *   mfr_bias_relu_nchw        x <- relu(x + bias[c]) in place, x [B,C,HW]
+ *   mfr_bias_pool2_relu_nchw  y = relu(max_pool2x2(x) + bias[c]), x [B,C,H,W] -> y [B,C,H/2,W/2]
+ * Bit-identical to conv -> +bias -> ReLU -> max_pool2d(2,2) (monotone rounding).
+ * ------------------------------------------------------------------------------------------ */
+int mfr_bias_relu_nchw(float *x, const float *bias, int B, int C, int HW, void *stream);
+int mfr_bias_pool2_relu_nchw(const float *x, const float *bias, int B, int C, int H, int W, float *y, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -61,33 +61,56 @@ __global__ void __launch_bounds__(256) sp_scoremap_kernel(const float *__restric
 #define NMS_TH 32
 #define NMS_LW (NMS_TW + 2 * NMS_HALO)   // 104
 #define NMS_LH (NMS_TH + 2 * NMS_HALO)   // 72
-#define NMS_N (NMS_LW * NMS_LH)          // 7488
+#define NMS_LS (NMS_LW + 1)               // LDS row stride 105: odd -> lanes walking down a column of strips hit 32 distinct banks
+#define NMS_N (NMS_LS * NMS_LH)          // 7560
 #define NMS_THREADS 1024                 // 16 wavefronts per CU share the one 117 KiB tile (latency hiding)
 
 // separable (2R+1)^2 max-pool of `src` into `dst` over the whole LDS tile (edges of the tile are
 // garbage by construction; each pool consumes R of the halo).  tmp is scratch.
+// Each thread produces a strip of 8 consecutive outputs from 16 inputs held in registers
+// (log-step sliding maximum: 2 LDS reads and ~5 max per output instead of 9 and 9).
+static __device__ __forceinline__ void strip_max9(const float v[16], float o[8])
+{
+    float m2[15], m4[13], m8[9];
+#pragma unroll
+    for (int i = 0; i < 15; ++i) m2[i] = fmaxf(v[i], v[i + 1]);
+#pragma unroll
+    for (int i = 0; i < 13; ++i) m4[i] = fmaxf(m2[i], m2[i + 2]);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) m8[i] = fmaxf(m4[i], m4[i + 4]);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = fmaxf(m8[i], v[i + 8]);      // window [i, i+8] = outputs centred at i+4
+}
+
 static __device__ __forceinline__ void pool9(const float *src, float *tmp, float *dst)
 {
-    for (int i = threadIdx.x; i < NMS_N; i += NMS_THREADS) {
-        const int y = i / NMS_LW, x = i - y * NMS_LW;
-        float m = -INFINITY;
+    // row pass: strip = 8 outputs x0..x0+7 of row y, inputs x0-4..x0+11
+    // (consecutive lanes -> consecutive rows: stride 105 floats = conflict-free)
+    for (int t = threadIdx.x; t < NMS_LH * (NMS_LW / 8); t += NMS_THREADS) {
+        const int st = t / NMS_LH, y = t - st * NMS_LH, x0 = st * 8;
+        float v[16], o[8];
 #pragma unroll
-        for (int d = -NMS_R; d <= NMS_R; ++d) {
-            const int xx = x + d;
-            if (xx >= 0 && xx < NMS_LW) m = fmaxf(m, src[y * NMS_LW + xx]);
+        for (int i = 0; i < 16; ++i) {
+            const int xx = x0 - NMS_R + i;
+            v[i] = (xx >= 0 && xx < NMS_LW) ? src[y * NMS_LS + xx] : -INFINITY;
         }
-        tmp[i] = m;
+        strip_max9(v, o);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) tmp[y * NMS_LS + x0 + i] = o[i];
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < NMS_N; i += NMS_THREADS) {
-        const int y = i / NMS_LW, x = i - y * NMS_LW;
-        float m = -INFINITY;
+    // column pass: strip = 8 outputs y0..y0+7 of column x (consecutive threads -> consecutive x)
+    for (int t = threadIdx.x; t < (NMS_LH / 8) * NMS_LW; t += NMS_THREADS) {
+        const int ys = t / NMS_LW, x = t - ys * NMS_LW, y0 = ys * 8;
+        float v[16], o[8];
 #pragma unroll
-        for (int d = -NMS_R; d <= NMS_R; ++d) {
-            const int yy = y + d;
-            if (yy >= 0 && yy < NMS_LH) m = fmaxf(m, tmp[yy * NMS_LW + x]);
+        for (int i = 0; i < 16; ++i) {
+            const int yy = y0 - NMS_R + i;
+            v[i] = (yy >= 0 && yy < NMS_LH) ? tmp[yy * NMS_LS + x] : -INFINITY;
         }
-        dst[i] = m;
+        strip_max9(v, o);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dst[(y0 + i) * NMS_LS + x] = o[i];
     }
     __syncthreads();
 }
@@ -102,13 +125,14 @@ __global__ void __launch_bounds__(NMS_THREADS) sp_nms_kernel(const float *__rest
     float *a = s + NMS_N;                // work buffers
     float *t = a + NMS_N;
     float *mk = t + NMS_N;               // max_mask as 0/1
+    float *p5 = mk + NMS_N;              // pooled suppressed scores
     const int b = blockIdx.z;
     const int x0 = blockIdx.x * NMS_TW - NMS_HALO, y0 = blockIdx.y * NMS_TH - NMS_HALO;
     const float *img = scores + (size_t)b * H * W;
     for (int i = threadIdx.x; i < NMS_N; i += NMS_THREADS) {
-        const int ly = i / NMS_LW, lx = i - ly * NMS_LW;
+        const int ly = i / NMS_LS, lx = i - ly * NMS_LS;               // lx == NMS_LW is the padding column
         const int gx = x0 + lx, gy = y0 + ly;
-        s[i] = (gx >= 0 && gx < W && gy >= 0 && gy < H) ? img[(size_t)gy * W + gx] : -INFINITY;
+        s[i] = (lx < NMS_LW && gx >= 0 && gx < W && gy >= 0 && gy < H) ? img[(size_t)gy * W + gx] : -INFINITY;
     }
     __syncthreads();
     pool9(s, t, a);                                             // a = max_pool(scores)
@@ -126,28 +150,9 @@ __global__ void __launch_bounds__(NMS_THREADS) sp_nms_kernel(const float *__rest
             mk[i] = mk[i] + (supp ? 2.f : 0.f);
         }
         __syncthreads();
-        float *pooled = t;                                      // pool9 needs (src, tmp, dst) distinct
-        // use s as tmp is not allowed (still needed) -> pool a into 'pooled' with mk-free scratch:
-        // rows pass into 'pooled', cols pass back into a2 = (we reuse) -> do it manually
+        pool9(a, t, p5);                                        // p5 = max_pool(supp_scores)
         for (int i = threadIdx.x; i < NMS_N; i += NMS_THREADS) {
-            const int y = i / NMS_LW, x = i - y * NMS_LW;
-            float m = -INFINITY;
-#pragma unroll
-            for (int d = -NMS_R; d <= NMS_R; ++d) {
-                const int xx = x + d;
-                if (xx >= 0 && xx < NMS_LW) m = fmaxf(m, a[y * NMS_LW + xx]);
-            }
-            pooled[i] = m;
-        }
-        __syncthreads();
-        for (int i = threadIdx.x; i < NMS_N; i += NMS_THREADS) {
-            const int y = i / NMS_LW, x = i - y * NMS_LW;
-            float m = -INFINITY;
-#pragma unroll
-            for (int d = -NMS_R; d <= NMS_R; ++d) {
-                const int yy = y + d;
-                if (yy >= 0 && yy < NMS_LH) m = fmaxf(m, pooled[yy * NMS_LW + x]);
-            }
+            const float m = p5[i];
             // new_max_mask = supp_scores == max_pool(supp_scores); max_mask |= new & ~supp
             const float code = mk[i];
             const bool supp = code >= 2.f;
@@ -157,23 +162,34 @@ __global__ void __launch_bounds__(NMS_THREADS) sp_nms_kernel(const float *__rest
         }
         __syncthreads();
     }
-    // emit: where(max_mask, scores, 0); candidates above threshold and inside the border
+    // emit: where(max_mask, scores, 0); candidates above threshold and inside the border.
+    // Survivors are first compacted in LDS (the pooling scratch is dead by now) and the workgroup
+    // reserves its range of the per-image list with ONE global atomic: per-candidate atomics on the
+    // 32 adjacent per-image counters (one cache line) serialised the whole launch (1.7 ms -> ...).
+    unsigned long long *lkeys = (unsigned long long *)a;          // <= NMS_TW*NMS_TH keys = 16 KB
+    int *lcount = (int *)p5, *lbase = lcount + 1;
+    if (threadIdx.x == 0) *lcount = 0;
+    __syncthreads();
     for (int i = threadIdx.x; i < NMS_TW * NMS_TH; i += NMS_THREADS) {
         const int ty = i / NMS_TW, tx = i - ty * NMS_TW;
         const int gx = blockIdx.x * NMS_TW + tx, gy = blockIdx.y * NMS_TH + ty;
         if (gx >= W || gy >= H) continue;
-        const int li = (ty + NMS_HALO) * NMS_LW + tx + NMS_HALO;
+        const int li = (ty + NMS_HALO) * NMS_LS + tx + NMS_HALO;
         const float v = (mk[li] == 1.f) ? s[li] : 0.f;
         if (nms_out) nms_out[(size_t)b * H * W + (size_t)gy * W + gx] = v;
         if (v > thr && gx >= border && gx < W - border && gy >= border && gy < H - border) {
-            const int slot = atomicAdd(&cand_count[b], 1);
-            if (slot < cand_cap) {
-                const unsigned idx = (unsigned)(gy * W + gx);
-                cand[(size_t)b * cand_cap + slot] =
-                    ((unsigned long long)__float_as_uint(v) << 32) | (unsigned long long)(~idx);
-            }
+            const int slot = atomicAdd(lcount, 1);
+            const unsigned idx = (unsigned)(gy * W + gx);
+            lkeys[slot] = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned long long)(~idx);
         }
     }
+    __syncthreads();
+    const int nloc = *lcount;
+    if (threadIdx.x == 0) *lbase = nloc ? atomicAdd(&cand_count[b], nloc) : 0;
+    __syncthreads();
+    const int base = *lbase;
+    for (int i = threadIdx.x; i < nloc; i += NMS_THREADS)
+        if (base + i < cand_cap) cand[(size_t)b * cand_cap + base + i] = lkeys[i];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -329,10 +345,10 @@ int mfr_sp_nms_candidates(const float *scores, int B, int H, int W, int nms_radi
     hipStream_t s = (hipStream_t)stream;
     if (hipMemsetAsync(cand_count, 0, sizeof(int32_t) * (size_t)B, s) != hipSuccess) return MFR_E_LAUNCH;
     dim3 grid((W + NMS_TW - 1) / NMS_TW, (H + NMS_TH - 1) / NMS_TH, B);
-    // 117 KiB of the CU's 160 KiB LDS: above the 64 KiB default dynamic limit
+    // 148 KiB of the CU's 160 KiB LDS: above the 64 KiB default dynamic limit
     if (hipFuncSetAttribute((const void *)sp_nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            4 * NMS_N * sizeof(float)) != hipSuccess) return MFR_E_LAUNCH;
-    hipLaunchKernelGGL(sp_nms_kernel, grid, dim3(NMS_THREADS), 4 * NMS_N * sizeof(float), s, scores, H, W, threshold, border,
+                            5 * NMS_N * sizeof(float)) != hipSuccess) return MFR_E_LAUNCH;
+    hipLaunchKernelGGL(sp_nms_kernel, grid, dim3(NMS_THREADS), 5 * NMS_N * sizeof(float), s, scores, H, W, threshold, border,
                        nms_out, (unsigned long long *)cand, cand_cap, cand_count);
     CHECK_LAUNCH();
     return 0;

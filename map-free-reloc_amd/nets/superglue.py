@@ -51,6 +51,7 @@ class SuperGlueHIP:
         self.wf, self.bf = dev(lin("final_proj")), dev(sd["final_proj.bias"])
         self.bin_score = float(sd["bin_score"])
         self._ws = None
+        self._size = {}
 
     def attention(self, qkv, n_tok, cross):
         """qkv [B2,K,768] (q | k | v, each head-major) -> message [B2,K,256]"""
@@ -87,8 +88,11 @@ class SuperGlueHIP:
     def final_descriptors(self, kpts, scores, desc, n, image_hw):
         H, W = image_hw
         B2, K, _ = kpts.shape
-        size = torch.tensor([float(W), float(H)], device=kpts.device)
-        kn = (kpts - size / 2) / (size.max() * 0.7)                                   # normalize_keypoints
+        key = (H, W, kpts.device)
+        if key not in self._size:      # cached: an H2D copy is not allowed while a HIP graph is capturing
+            self._size[key] = torch.tensor([float(W), float(H)], device=kpts.device)
+        size = self._size[key]
+        kn = (kpts - size / 2) / (float(max(W, H)) * 0.7)                             # normalize_keypoints
         h = torch.cat([kn, scores.unsqueeze(-1)], -1)
         for i, (w, b) in enumerate(self.kenc):
             h = F.linear(h, w, b)

@@ -29,21 +29,30 @@ class SuperPointHIP:
         # 1x1 heads as plain matrices
         self.w["convDb.mat"] = self.w["convDb.weight"].reshape(256, 256).contiguous()
 
-    def _conv(self, x, name, relu=True):
+    def _conv(self, x, name, relu=True, pool=False):
+        """conv (MIOpen, no bias) + ONE fused HIP epilogue pass: relu(x + b) in place, or
+        relu(max_pool2x2(x) + b) for the b-convolutions (csrc/elementwise.hip)"""
+        lib = _lib.load()
         w, b = self.w[name + ".weight"], self.w[name + ".bias"]
         pad = w.shape[-1] // 2
-        if relu and self.fused_conv_relu:
-            # MIOpen fusion plan conv+bias+ReLU: one pass instead of conv + in-place ReLU
+        if not relu:
+            return F.conv2d(x, w, b, padding=pad)
+        if self.fused_conv_relu and not pool:
             return torch.ops.aten.miopen_convolution_relu(x, w, b, [1, 1], [pad, pad], [1, 1], 1)
-        x = F.conv2d(x, w, b, padding=pad)
-        return F.relu_(x) if relu else x
+        x = F.conv2d(x, w, None, padding=pad).contiguous()
+        B, C, H, W = x.shape
+        if pool:
+            y = torch.empty(B, C, H // 2, W // 2, dtype=x.dtype, device=x.device)
+            _lib.check(lib.mfr_bias_pool2_relu_nchw(_lib.ptr(x), _lib.ptr(b), B, C, H, W, _lib.ptr(y), _lib.stream_ptr()),
+                       "mfr_bias_pool2_relu_nchw")
+            return y
+        _lib.check(lib.mfr_bias_relu_nchw(_lib.ptr(x), _lib.ptr(b), B, C, H * W, _lib.stream_ptr()), "mfr_bias_relu_nchw")
+        return x
 
     def encode(self, image):
-        # relu(max_pool(x)) == max_pool(relu(x)) exactly (both monotone), so the ReLU after the
-        # b-convs runs on the pooled quarter-size tensor instead of the full-resolution one
-        x = self._conv(image, "conv1a"); x = F.relu_(F.max_pool2d(self._conv(x, "conv1b", relu=False), 2, 2))
-        x = self._conv(x, "conv2a"); x = F.relu_(F.max_pool2d(self._conv(x, "conv2b", relu=False), 2, 2))
-        x = self._conv(x, "conv3a"); x = F.relu_(F.max_pool2d(self._conv(x, "conv3b", relu=False), 2, 2))
+        x = self._conv(image, "conv1a"); x = self._conv(x, "conv1b", pool=True)
+        x = self._conv(x, "conv2a"); x = self._conv(x, "conv2b", pool=True)
+        x = self._conv(x, "conv3a"); x = self._conv(x, "conv3b", pool=True)
         x = self._conv(x, "conv4a"); x = self._conv(x, "conv4b")
         return x
 

@@ -77,7 +77,7 @@ def gather_pose_records(pair_ids, out, world=None):
     rec = pose_records(pair_ids, out)
     if world is None:
         world = dist.get_world_size() if dist.is_initialized() else 1
-    if world == 1 or not dist.is_initialized():
+    if not dist.is_initialized():
         return rec
     n = torch.tensor([rec.shape[0]], device=rec.device, dtype=torch.int64)
     ns = [torch.zeros_like(n) for _ in range(world)]

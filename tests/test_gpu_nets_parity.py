@@ -211,3 +211,22 @@ def test_superpoint_superglue_end_to_end_vs_oracle(sp_pair, sg_pair):
     sw = {tuple(r) for r in want.tolist()}
     sg_ = {tuple(r) for r in got.tolist()}
     assert len(sw & sg_) >= 0.95 * max(len(sw), len(sg_)), (len(sw), len(sg_), len(sw & sg_))
+
+
+@pytest.mark.parametrize("shape", [(3, 64, 720, 540), (2, 64, 360, 270), (2, 128, 180, 135), (1, 5, 7, 9)])
+def test_fused_conv_epilogues_bit_exact(shape):
+    """csrc/elementwise.hip == conv-output -> +bias -> ReLU (-> max_pool2d(2,2)), bit for bit"""
+    lib = mfr._lib.load(require_gpu=True)
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(*shape, generator=g).to(DEV)
+    b = torch.randn(shape[1], generator=g).to(DEV)
+    want_relu = F.relu(x + b[None, :, None, None])
+    want_pool = F.max_pool2d(want_relu, 2, 2)
+    B, C, H, W = shape
+    y = torch.empty(B, C, H // 2, W // 2, device=DEV)
+    mfr._lib.check(lib.mfr_bias_pool2_relu_nchw(x.data_ptr(), b.data_ptr(), B, C, H, W, y.data_ptr(), mfr._lib.stream_ptr()), "pool")
+    x2 = x.clone()
+    mfr._lib.check(lib.mfr_bias_relu_nchw(x2.data_ptr(), b.data_ptr(), B, C, H * W, mfr._lib.stream_ptr()), "relu")
+    torch.cuda.synchronize()
+    assert torch.equal(x2, want_relu)
+    assert torch.equal(y, want_pool)
