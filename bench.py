@@ -201,6 +201,17 @@ def main():
         nk = 1024
         flops = 2 * B * 4 * 2 * (2.0 * nk * nk * 64)
         achieved = flops / (att_ms * 1e-3) / 1e12 if att_ms else None
+        # HBM traffic of the dominant kernel: PMC counters cannot be read inside this process, so the
+        # per-launch figure comes from the committed rocprofv3 --pmc passes of this same command
+        # (profiles/r01_pmc_attention.json: 2 x FETCH_SIZE + WRITE_SIZE, guide's gfx950 correction)
+        traffic = None
+        try:
+            pj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_attention.json")))
+            if B == 16:
+                traffic = {"bytes_per_launch": round(pj["hbm_bytes_per_launch"]), "algorithmic_bytes_per_launch": pj["algorithmic_bytes_per_launch"],
+                           "source": "profiles/r01_pmc_attention.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"}
+        except Exception:
+            pass
         line = {
             "metric": "image-pairs/sec @ 540x720 (SuperPoint+SuperGlue + PnP w/ depth)",
             "value": round(value, 3), "unit": "image-pairs/s", "n_gpus": world, "steps": args.steps,
@@ -215,7 +226,7 @@ def main():
             "roofline": {"kernel": "sg_attention_kernel (dominant hand-written kernel)", "bound": "mfma",
                          "achieved": round(achieved, 2) if achieved else None, "peak": FP32_MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4) if achieved else None,
-                         "traffic": None, "avg_launch_ms": round(att_ms, 4) if att_ms else None,
+                         "traffic": traffic, "avg_launch_ms": round(att_ms, 4) if att_ms else None,
                          "launches_timed": len(timer.events)},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -53,8 +53,15 @@ __global__ void __launch_bounds__(256, 2) sg_attention_kernel(
     const int ql = lane & 31, half = lane >> 5;
     const int nq = n_tok[b], nk = n_tok[bk];
     const int q0 = qb * (AT_QW * AT_WAVES);
-    if (q0 >= nq) return;                                   // whole workgroup beyond this image's keypoints
     const int q = q0 + wid * AT_QW + ql;
+    if (q0 >= nq) {                                         // whole workgroup beyond this image's keypoints:
+        if (q < N) {                                        // rows >= n_tok are defined to be zero
+            float4 *op = (float4 *)(O + ((size_t)b * N + q) * ldo + h * AT_D + 32 * half);
+#pragma unroll
+            for (int g = 0; g < 8; ++g) op[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        return;
+    }
 
     // Q^T operand: lane (q, half) keeps Q[q][half*32 + s], s = 0..31, pre-scaled by log2(e)/sqrt(64)
     float qreg[32];
