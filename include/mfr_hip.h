@@ -136,6 +136,22 @@ int mfr_emat_solve_batch(const float *pts0, const float *pts1, const int32_t *n_
                          int32_t *best_iter, int32_t *iters_run, int32_t *counts_out, void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Procrustes path: ProcrustesSolver.estimate_pose, lib/models/matching/pose_solver.py:238-320 with
+ * PROCRUSTES.REFINE False (config/matching/mapfree/sg_procrustes_dptkitti.yaml; ICP refinement is
+ * not built).  int-truncate both views (:248-249) -> depth gather (:256-258) -> valid vs each map's
+ * minimum (:261, Q6) -> back-project both (:273-274) -> o3d registration_ransac_based_on_correspondence
+ * (3-point Kabsch RANSAC, max_corr_dist, confidence 0.999, best = fitness then RMSE, final re-fit)
+ * (:286-287) -> inliers = int(fitness * N) (:288).  max_iters caps Open3D's 100000.
+ * No model found -> identity pose with 0 inliers and status OK (Open3D's default result), as upstream.
+ * ------------------------------------------------------------------------------------------ */
+size_t mfr_procrustes_workspace_bytes(int B, int maxN, int max_iters);
+int mfr_procrustes_solve_batch(const float *pts0, const float *pts1, const int32_t *n_corr, int B, int maxN,
+                               const float *depth0, const float *depth1, int H, int W, const float *K0, const float *K1,
+                               double max_corr_dist, double confidence, int max_iters, uint64_t seed, const int64_t *pair_ids,
+                               void *workspace, size_t workspace_bytes, double *R, double *t, int32_t *n_inliers,
+                               int32_t *status, int32_t *best_iter, int32_t *iters_run, int32_t *counts_out, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * SuperPoint post-processing.  Reference call site: SuperGlue_matcher.match,
  * etc/feature_matching_baselines/matchers.py:93-120 (hyper-parameters :65-71); the network itself
  * is the un-vendored magicleap submodule (.gitmodules:4-6), restated per SURVEY.md Appendix A.2.

@@ -128,8 +128,29 @@ class EssentialMatrixMetricSolver(EssentialMatrixSolver):
         return out["R"][0].cpu().numpy(), sc["t_metric"][0].cpu().numpy().reshape(3, 1), int(sc["n_inliers"][0])
 
 
-class ProcrustesSolver:
+class ProcrustesSolver(_Base):
+    '''Estimate relative pose (metric) using 3D-3D correspondences (pose_solver.py:238-320).
+    PROCRUSTES.REFINE (full-cloud ICP, :291-315) is not built: requesting it raises.'''
+
     def __init__(self, cfg):
-        raise NotImplementedError(
-            "ProcrustesSolver (Open3D correspondence RANSAC + ICP, pose_solver.py:238-320) is a 'next' row "
-            "(SURVEY 8f rank 1) and not built yet")
+        super().__init__(cfg)
+        self.ransac_max_corr_distance = cfg.PROCRUSTES.MAX_CORR_DIST
+        self.refine = cfg.PROCRUSTES.REFINE
+        if self.refine:
+            raise NotImplementedError("PROCRUSTES.REFINE (Open3D ICP, pose_solver.py:291-315) is not built")
+        self._solver = ops.ProcrustesBatchSolver(self.ransac_max_corr_distance, 0.999, self.seed)
+
+    def estimate_pose(self, pts0, pts1, data):
+        if len(pts0) < 3:                                                   # :252-253
+            return _nan_pose()
+        p0, p1, n = self._corr(pts0, pts1)
+        hw = data['depth0'].shape[-2:]
+        depth0 = data['depth0'].reshape(1, *hw).to(torch.float32).cuda()
+        depth1 = data['depth1'].reshape(1, *hw).to(torch.float32).cuda()
+        K0 = data['K_color0'].reshape(1, 3, 3).to(torch.float32).cuda()
+        K1 = data['K_color1'].reshape(1, 3, 3).to(torch.float32).cuda()
+        pid = torch.tensor([_pair_id(data)], dtype=torch.int64).cuda()
+        out = self._solver(p0, p1, n, depth0, depth1, K0, K1, pid)
+        if int(out["status"][0]) != ops.ST_OK:
+            return _nan_pose()
+        return out["R"][0].cpu().numpy(), out["t"][0].cpu().numpy().reshape(3, 1), int(out["n_inliers"][0])

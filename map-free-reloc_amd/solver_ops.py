@@ -158,6 +158,46 @@ class EssentialBatchSolver:
         return out
 
 
+class ProcrustesBatchSolver:
+    """ProcrustesSolver.estimate_pose (pose_solver.py:238-320, REFINE False) for a batch of pairs."""
+
+    def __init__(self, max_corr_dist=0.05, confidence=0.999, seed=0, max_iters=4096):
+        self.max_corr_dist, self.confidence = float(max_corr_dist), float(confidence)
+        self.seed, self.max_iters = int(seed), max(int(max_iters), 1)
+        self._ws = None
+
+    def __call__(self, pts0, pts1, n_corr, depth0, depth1, K0, K1, pair_ids, diagnostics=False):
+        lib = _lib.load(require_gpu=True)
+        pts0 = _chk(pts0, torch.float32, "pts0"); pts1 = _chk(pts1, torch.float32, "pts1")
+        n_corr = _chk(n_corr, torch.int32, "n_corr")
+        depth0 = _chk(depth0, torch.float32, "depth0"); depth1 = _chk(depth1, torch.float32, "depth1")
+        K0 = _chk(K0, torch.float32, "K0"); K1 = _chk(K1, torch.float32, "K1")
+        pair_ids = _chk(pair_ids, torch.int64, "pair_ids")
+        B, maxN, _ = pts0.shape
+        _, H, W = depth0.shape
+        dev = pts0.device
+        need = lib.mfr_procrustes_workspace_bytes(B, maxN, self.max_iters)
+        if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
+            self._ws = _ws(need, dev)
+        R = torch.empty(B, 3, 3, dtype=torch.float64, device=dev)
+        t = torch.empty(B, 3, dtype=torch.float64, device=dev)
+        ni = torch.empty(B, dtype=torch.int32, device=dev)
+        st = torch.empty(B, dtype=torch.int32, device=dev)
+        bi = ir = cnt = None
+        if diagnostics:
+            bi = torch.empty(B, dtype=torch.int32, device=dev); ir = torch.empty(B, dtype=torch.int32, device=dev)
+            cnt = torch.empty(B, self.max_iters, dtype=torch.int32, device=dev)
+        _lib.check(lib.mfr_procrustes_solve_batch(
+            _lib.ptr(pts0), _lib.ptr(pts1), _lib.ptr(n_corr), B, maxN, _lib.ptr(depth0), _lib.ptr(depth1), H, W, _lib.ptr(K0),
+            _lib.ptr(K1), self.max_corr_dist, self.confidence, self.max_iters, self.seed, _lib.ptr(pair_ids),
+            _lib.ptr(self._ws), self._ws.numel(), _lib.ptr(R), _lib.ptr(t), _lib.ptr(ni), _lib.ptr(st), _lib.ptr(bi),
+            _lib.ptr(ir), _lib.ptr(cnt), _lib.stream_ptr()), "mfr_procrustes_solve_batch")
+        out = dict(R=R, t=t, n_inliers=ni, status=st)
+        if diagnostics:
+            out.update(best_iter=bi, iters_run=ir, counts=cnt)
+        return out
+
+
 class ScaleFromDepthBatch:
     """EssentialMatrixMetricSolver's own part (pose_solver.py:137-172) for a batch of pairs."""
 

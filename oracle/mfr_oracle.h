@@ -10,7 +10,7 @@
  * Parity status (see DESIGN.md "Oracle"):
  *   - depth gather / back-projection / scale-RANSAC / validity rules: pinned
  *     against the reference's own Python executed in the build container
- *     (oracle/gen_golden.py -> tests/golden/*.npz).
+ *     (oracle/gen_golden.py -> tests/golden/ ref_*.npz files).
  *   - PnP-RANSAC, E-matrix RANSAC, recoverPose: the arithmetic lives in
  *     opencv-python==4.8.0.74 (environment.yml:17), which is NOT available
  *     offline -> restated from the published algorithms, PARITY UNPINNED

@@ -16,7 +16,7 @@ ST_OK, ST_TOO_FEW, ST_BAD_DEPTH, ST_NO_MODEL, ST_DEGENERATE = range(5)
 
 
 def build(force=False):
-    srcs = [os.path.join(_HERE, f) for f in ("mfr_oracle.c", "mfr_oracle_emat.c", "mfr_oracle.h", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("mfr_oracle.c", "mfr_oracle_emat.c", "mfr_oracle_procrustes.c", "mfr_oracle.h", "Makefile")]
     stale = (not os.path.exists(_SO)) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs)
     if force or stale:
         subprocess.check_call(["make", "-s", "-C", _HERE], stdout=subprocess.DEVNULL)
@@ -215,3 +215,39 @@ def emat_solve(pts0, pts1, K0, K1, pix_thr=2.0, conf=0.9999, max_iters=1000, see
     if want_counts:
         out["counts"] = counts
     return out
+
+
+def procrustes_lift(pts0, pts1, depth0, depth1, K0, K1):
+    pts0, pts1 = _f32(pts0).reshape(-1, 2), _f32(pts1).reshape(-1, 2)
+    depth0, depth1 = _f32(depth0), _f32(depth1)
+    H, W = depth0.shape
+    n = len(pts0)
+    P = np.zeros((max(n, 1), 3)); Q = np.zeros((max(n, 1), 3))
+    m = lib().mfr_ref_procrustes_lift(_p(pts0), _p(pts1), C.c_int(n), _p(depth0), _p(depth1), C.c_int(H), C.c_int(W),
+                                      _p(_f32(K0).reshape(9)), _p(_f32(K1).reshape(9)), _p(P), _p(Q))
+    return P[:m].copy(), Q[:m].copy()
+
+
+def procrustes_ransac(P, Q, max_dist=0.05, conf=0.999, max_iters=4096, seed=0, pair_id=0, want_counts=False):
+    P, Q = _f64(P), _f64(Q)
+    n = len(P)
+    R = np.zeros((3, 3)); t = np.zeros(3); n_inl = C.c_int(0); bi = C.c_int(0); ir = C.c_int(0)
+    counts = np.zeros(max_iters, np.int32) if want_counts else None
+    st = lib().mfr_ref_procrustes_ransac(_p(P), _p(Q), C.c_int(n), C.c_double(max_dist), C.c_double(conf), C.c_int(max_iters),
+                                         C.c_uint64(seed), C.c_uint64(pair_id), _p(R), _p(t), C.byref(n_inl), C.byref(bi),
+                                         C.byref(ir), _p(counts) if want_counts else None)
+    out = dict(status=st, R=R, t=t, n_inl=n_inl.value, best_iter=bi.value, iters_run=ir.value)
+    if want_counts:
+        out["counts"] = counts
+    return out
+
+
+def procrustes_solve(pts0, pts1, depth0, depth1, K0, K1, max_dist=0.05, conf=0.999, max_iters=4096, seed=0, pair_id=0):
+    pts0, pts1 = _f32(pts0).reshape(-1, 2), _f32(pts1).reshape(-1, 2)
+    depth0, depth1 = _f32(depth0), _f32(depth1)
+    H, W = depth0.shape
+    R = np.zeros((3, 3)); t = np.zeros(3); n_inl = C.c_int(0)
+    st = lib().mfr_ref_procrustes_solve(_p(pts0), _p(pts1), C.c_int(len(pts0)), _p(depth0), _p(depth1), C.c_int(H), C.c_int(W),
+                                        _p(_f32(K0).reshape(9)), _p(_f32(K1).reshape(9)), C.c_double(max_dist), C.c_double(conf),
+                                        C.c_int(max_iters), C.c_uint64(seed), C.c_uint64(pair_id), _p(R), _p(t), C.byref(n_inl))
+    return st, R, t.reshape(3, 1), n_inl.value

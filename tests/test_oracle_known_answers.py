@@ -121,3 +121,26 @@ def test_solver_edge_cases():
     assert O.emat_solve(p["pts0"][:4], p["pts1"][:4], p["K0"], p["K1"])["status"] == O.ST_TOO_FEW
     st, R, t, n = O.pnp_solve(np.zeros((0, 2)), np.zeros((0, 2)), p["depth0"], p["K0"], p["K1"])
     assert st == O.ST_TOO_FEW and np.isnan(R).all() and n == 0
+
+
+def test_procrustes_recovers_known_pose_and_kabsch_is_optimal():
+    rng = np.random.default_rng(7)
+    for n, outl in [(300, 0.3), (900, 0.6)]:
+        R = synth.rand_rot(rng, 40); t = rng.normal(size=3)
+        P = rng.uniform(-3, 3, (n, 3)) + np.array([0, 0, 6.0])
+        Q = (R @ P.T).T + t + rng.normal(size=(n, 3)) * 0.01
+        no = int(outl * n); Q[:no] += rng.normal(size=(no, 3)) * 2
+        r = O.procrustes_ransac(P, Q, 0.05)
+        assert r["status"] == 0 and r["n_inl"] >= 0.95 * (n - no)
+        assert synth.rot_err_deg(r["R"], R) < 0.1 and np.linalg.norm(r["t"] - t) < 0.01
+        # the final re-fit is the least-squares optimum on its inliers (compare with numpy SVD Kabsch)
+        d = np.linalg.norm((r["R"] @ P.T).T + r["t"] - Q, axis=1)
+        inl = d < 0.05
+        Pc, Qc = P[inl] - P[inl].mean(0), Q[inl] - Q[inl].mean(0)
+        U, _, Vt = np.linalg.svd(Qc.T @ Pc)
+        Rk = U @ np.diag([1, 1, np.linalg.det(U @ Vt)]) @ Vt
+        assert synth.rot_err_deg(r["R"], Rk) < 1e-3
+    p = synth.make_pair(3, 800, outlier_frac=0.3)
+    st, R, t, n = O.procrustes_solve(p["pts0"], p["pts1"], p["depth0"], p["depth1"], p["K0"], p["K1"])
+    assert st == 0 and n > 300 and synth.rot_err_deg(R, p["R_gt"]) < 0.1 and np.linalg.norm(t.ravel() - p["t_gt"]) < 0.01
+    assert O.procrustes_solve(p["pts0"][:2], p["pts1"][:2], p["depth0"], p["depth1"], p["K0"], p["K1"])[0] == O.ST_TOO_FEW
