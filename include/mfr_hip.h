@@ -226,7 +226,11 @@ int mfr_loftr_gather_windows(const float *feat, int Bimg, int Hf, int Wf, int C,
  *   mfr_bias_relu_nchw        x <- relu(x + bias[c]) in place, x [B,C,HW]
  *   mfr_bias_pool2_relu_nchw  y = relu(max_pool2x2(x) + bias[c]), x [B,C,H,W] -> y [B,C,H/2,W/2]
  * Bit-identical to conv -> +bias -> ReLU -> max_pool2d(2,2) (monotone rounding).
- * ------------------------------------------------------------------------------------------ */
+ *   mfr_conv3x3_c1_relu       SuperPoint conv1a fused: y = relu(conv3x3(x [B,1,H,W], w [64,1,3,3], pad 1) + bias),
+ *                             y [B,64,H,W]; W % 4 == 0 (HBM-write-bound first layer, one pass)
+ */
+int mfr_conv3x3_c1_relu(const float *x, const float *w, const float *bias, int B, int H, int W, int out_channels,
+                        float *y, void *stream);
 int mfr_bias_relu_nchw(float *x, const float *bias, int B, int C, int HW, void *stream);
 int mfr_bias_pool2_relu_nchw(const float *x, const float *bias, int B, int C, int H, int W, float *y, void *stream);
 

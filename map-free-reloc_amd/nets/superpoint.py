@@ -49,8 +49,20 @@ class SuperPointHIP:
         _lib.check(lib.mfr_bias_relu_nchw(_lib.ptr(x), _lib.ptr(b), B, C, H * W, _lib.stream_ptr()), "mfr_bias_relu_nchw")
         return x
 
+    def _conv1a(self, image):
+        """first layer (1 -> 64 channels) as one fused HIP pass (csrc/elementwise.hip)"""
+        lib = _lib.load()
+        B, C, H, W = image.shape
+        w, b = self.w["conv1a.weight"], self.w["conv1a.bias"]
+        if C != 1 or w.shape[0] != 64 or (W & 3):
+            return self._conv(image, "conv1a")
+        y = torch.empty(B, 64, H, W, dtype=torch.float32, device=image.device)
+        _lib.check(lib.mfr_conv3x3_c1_relu(_lib.ptr(image.contiguous()), _lib.ptr(w), _lib.ptr(b), B, H, W, 64, _lib.ptr(y),
+                                           _lib.stream_ptr()), "mfr_conv3x3_c1_relu")
+        return y
+
     def encode(self, image):
-        x = self._conv(image, "conv1a"); x = self._conv(x, "conv1b", pool=True)
+        x = self._conv1a(image); x = self._conv(x, "conv1b", pool=True)
         x = self._conv(x, "conv2a"); x = self._conv(x, "conv2b", pool=True)
         x = self._conv(x, "conv3a"); x = self._conv(x, "conv3b", pool=True)
         x = self._conv(x, "conv4a"); x = self._conv(x, "conv4b")

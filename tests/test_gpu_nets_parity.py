@@ -230,3 +230,21 @@ def test_fused_conv_epilogues_bit_exact(shape):
     torch.cuda.synchronize()
     assert torch.equal(x2, want_relu)
     assert torch.equal(y, want_pool)
+
+
+def test_fused_conv1a_vs_torch_fp64():
+    """csrc/elementwise.hip conv3x3_c1_relu == relu(conv2d(x, w, b, padding=1)) (fp32 9-tap fma chain
+    vs an fp64 reference: <= 2e-6 absolute on O(1) activations)"""
+    lib = mfr._lib.load(require_gpu=True)
+    g = torch.Generator().manual_seed(9)
+    for (B, H, W) in [(3, 720, 540), (2, 37, 44)]:
+        x = torch.rand(B, 1, H, W, generator=g)
+        w = torch.randn(64, 1, 3, 3, generator=g) * 0.5
+        b = torch.randn(64, generator=g) * 0.1
+        want = F.relu(F.conv2d(x.double(), w.double(), b.double(), padding=1)).float()
+        xd, wd, bd = x.to(DEV), w.to(DEV), b.to(DEV)
+        y = torch.empty(B, 64, H, W, device=DEV)
+        mfr._lib.check(lib.mfr_conv3x3_c1_relu(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), B, H, W, 64, y.data_ptr(),
+                                               mfr._lib.stream_ptr()), "conv1a")
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(y.cpu().numpy(), want.numpy(), rtol=0, atol=2e-6)
