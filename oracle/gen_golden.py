@@ -222,6 +222,85 @@ def gen_wire_format(fm, ut, rng, tmpdir="/tmp/mfr_golden_tmp"):
     np.savez_compressed(os.path.join(OUT, "ref_wire_format.npz"), **cases)
 
 
+def gen_metrics(rng):
+    """the reference's benchmark metric code (benchmark/metrics.py, reprojection.py, utils.py,
+    mapfree.py:aggregate_results) executed for real; only the `transforms3d` package (absent offline)
+    is replaced by a self-contained quaternion module written here (Hamilton product, w-first)."""
+    q3 = types.ModuleType("transforms3d.quaternions")
+
+    def qmult(a, b):
+        w1, x1, y1, z1 = a; w2, x2, y2, z2 = b
+        return np.array([w1*w2 - x1*x2 - y1*y2 - z1*z2, w1*x2 + x1*w2 + y1*z2 - z1*y2,
+                         w1*y2 - x1*z2 + y1*w2 + z1*x2, w1*z2 + x1*y2 - y1*x2 + z1*w2])
+
+    def qconj(q):
+        return np.array([q[0], -q[1], -q[2], -q[3]])
+    q3.qmult = qmult
+    q3.qinverse = lambda q: qconj(q) / np.dot(q, q)
+    q3.rotate_vector = lambda v, q: qmult(q, qmult(np.r_[0.0, v], qconj(q)))[1:]
+
+    def quat2mat(q):
+        w, x, y, z = np.asarray(q, float) / np.linalg.norm(q)
+        return np.array([[1 - 2*(y*y + z*z), 2*(x*y - w*z), 2*(x*z + w*y)], [2*(x*y + w*z), 1 - 2*(x*x + z*z), 2*(y*z - w*x)],
+                         [2*(x*z - w*y), 2*(y*z + w*x), 1 - 2*(x*x + y*y)]])
+    q3.quat2mat = quat2mat
+    t3 = types.ModuleType("transforms3d"); t3.quaternions = q3
+    sys.modules["transforms3d"] = t3; sys.modules["transforms3d.quaternions"] = q3
+    import importlib
+    # benchmark/mapfree.py:14 imports the yacs-based config only for its CLI defaults: stub it
+    yc = types.ModuleType("yacs.config")
+
+    class _CN(dict):
+        def __getattr__(self, k):
+            return self.get(k)
+
+        def __setattr__(self, k, v):
+            self[k] = v
+    yc.CfgNode = _CN
+    sys.modules["yacs"] = types.ModuleType("yacs"); sys.modules["yacs.config"] = yc
+    metrics = importlib.import_module("benchmark.metrics")
+    mapfree = importlib.import_module("benchmark.mapfree")
+    butils = importlib.import_module("benchmark.utils")
+    K = np.array([[590.0, 0, 269.5], [0, 590.0, 359.5], [0, 0, 1]], dtype=np.float32)
+    W, H = 540, 720
+    cases = {"K": K, "W": np.int64(W), "H": np.int64(H)}
+    mm = metrics.MetricManager()
+    all_results = {}
+    fi = 0
+    from collections import defaultdict
+    for s in range(3):
+        res = defaultdict(list)
+        for f in range(12):
+            q_gt = rng.normal(size=4); q_gt /= np.linalg.norm(q_gt)
+            t_gt = rng.normal(size=3) * 2
+            ang = np.deg2rad(rng.uniform(0, 12)) * (0.2 if f % 3 else 1.0)
+            ax = rng.normal(size=3); ax /= np.linalg.norm(ax)
+            dq = np.r_[np.cos(ang / 2), np.sin(ang / 2) * ax]
+            q_est = qmult(q_gt, dq) * rng.choice([-1.0, 1.0]) * rng.uniform(0.5, 2.0)
+            t_est = t_gt + rng.normal(size=3) * (0.05 if f % 2 else 0.4)
+            conf = float(rng.integers(0, 40)) if f % 4 else 17.0
+            inp = metrics.Inputs(q_gt=q_gt, t_gt=t_gt, q_est=q_est, t_est=t_est, confidence=conf, K=K, W=W, H=H)
+            before = {k: len(v) for k, v in res.items()}
+            mm(inp, res)
+            p = f"f{fi}_"
+            cases[p + "q_gt"] = q_gt; cases[p + "t_gt"] = t_gt; cases[p + "q_est"] = q_est; cases[p + "t_est"] = t_est
+            cases[p + "conf"] = np.float64(conf); cases[p + "scene"] = np.int64(s)
+            for m in ("trans_err", "rot_err", "reproj_err"):
+                cases[p + m] = np.float64(res[m][-1])
+            fi += 1
+        all_results[f"s{s}"] = res
+    cases["n_frames"] = np.int64(fi)
+    agg = mapfree.aggregate_results(all_results, all_failures=5)
+    for i, (k, v) in enumerate(agg.items()):
+        cases[f"agg{i}_name"] = np.array(k); cases[f"agg{i}_val"] = np.float64(v)
+    cases["n_agg"] = np.int64(len(agg))
+    # world2cam -> cam2world conversion used when reading pose files (benchmark/utils.py:12-15)
+    q = rng.normal(size=4); t = rng.normal(size=3)
+    qi, ti = butils.convert_world2cam_to_cam2world(q, t)
+    cases["w2c_q"] = q; cases["w2c_t"] = t; cases["c2w_q"] = qi; cases["c2w_t"] = ti
+    np.savez_compressed(os.path.join(OUT, "ref_metrics.npz"), **cases)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     cv, ps, fm, ut = _import_reference()
@@ -230,6 +309,7 @@ def main():
     gen_emat_metric(cv, ps, rng)
     gen_pnp_lift(cv, ps, rng)
     gen_wire_format(fm, ut, rng)
+    gen_metrics(rng)
     print("golden fixtures written to", os.path.abspath(OUT))
 
 
