@@ -175,3 +175,38 @@ def test_gather_pose_records_gloo_world2(tmp_path):
                        capture_output=True, text=True, timeout=240, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert r.stdout.count("ok") == 2
+
+
+def test_mapfree_scene_reader_on_synthetic_tree(tmp_path):
+    """directory layout / file formats of README.md:60-120 read back with the reference's conventions"""
+    from PIL import Image
+    from mapfree_reloc_amd.datasets import MapFreeScene, collate_batch1
+    sc = tmp_path / "val" / "s00460"
+    (sc / "seq0").mkdir(parents=True); (sc / "seq1").mkdir()
+    rng = np.random.default_rng(0)
+    lines_p, lines_k = ["# comment"], ["# comment"]
+    names = ["seq0/frame_00000.jpg"] + [f"seq1/frame_{i:05d}.jpg" for i in range(12)]
+    for i, nme in enumerate(names):
+        Image.fromarray(rng.integers(0, 255, (96, 72, 3), dtype=np.uint8)).save(sc / nme, format="PNG")
+        depth = (rng.uniform(0.5, 6.0, (48, 36)) * 1000).astype(np.uint16)
+        Image.fromarray(depth).save(str(sc / nme).replace(".jpg", ".dptkitti.png"))
+        q = np.array([1.0, 0, 0, 0]) if i == 0 else rng.normal(size=4); q /= np.linalg.norm(q)
+        t = np.zeros(3) if i == 0 else rng.normal(size=3)
+        lines_p.append(nme + " " + " ".join(f"{v:.8f}" for v in np.r_[q, t]))
+        lines_k.append(nme + " 100.0 110.0 35.5 47.5 72 96")
+    (sc / "poses.txt").write_text("\n".join(lines_p) + "\n"); (sc / "intrinsics.txt").write_text("\n".join(lines_k) + "\n")
+    ds = MapFreeScene(sc, resize=(36, 48), sample_factor=5, estimated_depth="dptkitti")
+    assert len(ds) == 3 and [p[3] for p in ds.pairs] == [0, 5, 10]                     # every 5th query frame
+    d = ds[1]
+    assert d["pair_id"] == 5 and d["pair_names"] == ("seq0/frame_00000.jpg", "seq1/frame_00005.jpg")
+    assert d["image0"].shape == (3, 48, 36) and d["image0"].dtype == torch.float32 and float(d["image0"].max()) <= 1.0
+    assert d["depth0"].shape == (48, 36) and 0.4 < float(d["depth0"].mean()) < 7.0      # uint16 mm / 1000
+    K = d["K_color0"].numpy()
+    np.testing.assert_allclose(K, [[50.0, 0, 0.5 * 35.5 + 0.25 - 0.5], [0, 55.0, 0.5 * 47.5 + 0.25 - 0.5], [0, 0, 1]])
+    # seq0 pose is the identity -> relative pose == absolute pose of the query (mapfree.py:240-243)
+    from mapfree_reloc_amd import evaluation as E
+    q2 = np.array(list(map(float, lines_p[1 + 1 + 5].split(" ")[1:5]))); t2 = np.array(list(map(float, lines_p[1 + 1 + 5].split(" ")[5:])))
+    np.testing.assert_allclose(d["T_0to1"][:3, :3].numpy(), E.quat2mat(q2), atol=1e-6)
+    np.testing.assert_allclose(d["T_0to1"][:3, 3].numpy(), t2, atol=1e-6)
+    b = collate_batch1(d)
+    assert b["depth0"].shape == (1, 48, 36) and b["scene_id"] == ["s00460"] and b["pair_names"][1] == ["seq1/frame_00005.jpg"]
