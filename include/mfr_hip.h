@@ -234,6 +234,31 @@ int mfr_conv3x3_c1_relu(const float *x, const float *w, const float *bias, int B
 int mfr_bias_relu_nchw(float *x, const float *bias, int B, int C, int HW, void *stream);
 int mfr_bias_pool2_relu_nchw(const float *x, const float *bias, int B, int C, int H, int W, float *y, void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * SIFT-descriptor correspondence leg.  Reference call sites:
+ * SIFTMatching.get_correspondences (lib/models/matching/feature_matching.py:75-118) and
+ * SIFT_matcher.match (etc/feature_matching_baselines/matchers.py:135-188), everything AFTER
+ * cv.SIFT.detectAndCompute (keypoint detection/description stays with the caller):
+ *   mfr_rootsift          root_sift (feature_matching.py:68-74): out = sqrt(desc / (rowsum + 1e-7f)),
+ *                         desc/out [n_rows,128] f32 (out may alias desc), norm2 [n_rows] = |out row|^2.
+ *                         Bit-identical to the reference's numpy (same summation order).
+ *   mfr_desc_ratio_match  replaces cv.FlannBasedMatcher(kd-tree).knnMatch(des0, des1, k=2) + Lowe's
+ *                         ratio loop (:86-101): EXACT 2-NN (squared L2, ties -> lower train index) of
+ *                         every query row, then keep i where sqrt(d1) < ratio * sqrt(d2) (binary64
+ *                         compare, as the Python loop does), in query order.
+ *                         des0 [B,N0,128], des1 [B,N1,128] (rootSIFT), norm0 [B,N0], norm1 [B,N1],
+ *                         kp0 [B,N0,2], kp1 [B,N1,2] pixel (x,y); n0,n1 [B] valid rows per pair.
+ *                         Out: nn_idx [B,N0] i32, nn_d2 [B,N0,2] f32 (best, second), pts0/pts1
+ *                         [B,maxN,2] + n_corr [B] in the layout the solver entry points take.
+ *                         Pairs with n1 < 2 yield no correspondences.
+ * ------------------------------------------------------------------------------------------ */
+int mfr_rootsift(const float *desc, int n_rows, float *out, float *norm2, void *stream);
+int mfr_desc_ratio_match(const float *des0, const float *des1, const float *norm0, const float *norm1,
+                         const float *kp0, const float *kp1, int B, int N0, int N1,
+                         const int32_t *n0, const int32_t *n1, double ratio,
+                         int32_t *nn_idx, float *nn_d2, float *pts0, float *pts1, int maxN, int32_t *n_corr,
+                         void *stream);
+
 #ifdef __cplusplus
 }
 #endif

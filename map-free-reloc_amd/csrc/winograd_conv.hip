@@ -1,0 +1,247 @@
+// winograd_conv.hip -- 3x3 / stride 1 / pad 1 convolution (NCHW f32) of the SuperPoint encoder as a fused
+// Winograd F(2x2, 3x3) kernel on the gfx950 matrix cores, with the layer epilogue (+bias, ReLU, optional
+// 2x2 max-pool) folded into the output transform.
+//
+// Reference call site: SuperGlue_matcher (etc/feature_matching_baselines/matchers.py:62-120) -> upstream
+// SuperPoint encoder conv1b..conv4b, convPa, convDa (un-vendored; restated in SURVEY.md Appendix A.2):
+// 8 of the 12 convolutions, >95 % of the encoder FLOPs (conv1b alone: 0.92 TFLOP per 16-pair step).
+// The library path (MIOpen's fp32 Winograd on the VALU) runs them at ~107 TFLOP/s direct-equivalent and
+// was half of the whole step; F(2,3) needs 2.25x fewer multiplications, and here they run on the fp32
+// MFMA pipe (v_mfma_f32_16x16x4_f32, 157 TFLOP/s dense).
+//
+//   Y = A^T [ (G g G^T) (.) (B^T d B) ] A          d = 4x4 input patch, Y = 2x2 outputs, per (cin, cout)
+//   => 16 independent GEMMs  M_xi[cout, tile] = sum_cin U_xi[cout, cin] V_xi[cin, tile]
+//
+// Mapping to CDNA4:
+//   * workgroup = 4 wavefronts = 4 tile rows x 16 tiles (8 x 32 output pixels) x 32 output channels;
+//     wavefront w owns tile row w: 16 tiles = the N dimension of the 16x16x4 MFMA, 2 M-blocks of 16 couts,
+//     all 16 Winograd positions xi -> 16 x 2 accumulators of 4 VGPRs = 128 accumulator registers.
+//   * the K dimension is cin, 4 per MFMA.  Lane (kq = lane>>4, col = lane&15) loads the 4x4 input patch of
+//     (cin = 4c + kq, tile col), transforms it in registers (32 adds) -- and the 16 results ARE that lane's
+//     B operands for the 16 xi MFMAs: the input transform never touches LDS.
+//   * U (transformed filters) is pre-packed once per weight set in exactly the order the lanes consume it;
+//     an 8 KB slab per (cin chunk, cout block) is staged through LDS (double buffered, one barrier per
+//     chunk) and read back as conflict-free ds_read_b128: one read = A operands of 4 MFMAs.
+//   * all 16 xi of a (tile, cout) end in the same lane, so the output transform, bias, ReLU and the 2x2
+//     max-pool (= exactly one Winograd tile) run in registers; the activation is written once.
+//   * grid: 1-D, remapped so the cout blocks of one spatial block land on the same XCD (shared input in L2).
+// Per cin chunk and wavefront: 16 dword loads, 32 VALU adds, 8 ds_read_b128, 32 MFMAs (1024 MFMA cycles).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/mfr_hip.h"
+
+#define CHECK_LAUNCH() do { if (hipGetLastError() != hipSuccess) return MFR_E_LAUNCH; } while (0)
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define WN_TX 16                 // tiles along x per workgroup
+#define WN_TY 4                  // tile rows per workgroup (= wavefronts)
+#define WN_CO 32                 // output channels per workgroup
+#define WN_SLAB 2048             // floats of packed U per (cin chunk of 4, cout block of 32)
+
+// packed index of U_xi[cout][cin]: [chunk c = cin/4][cout block cb][q = xi/4][blk][lane = (cin%4)*16 + cout%16][e = xi%4]
+__global__ void __launch_bounds__(256) wino_filter_kernel(const float *__restrict__ w, int Cin, int Cout, float *__restrict__ upk)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Cin * Cout) return;
+    const int co = i / Cin, ci = i - co * Cin;
+    const float *g = w + (size_t)i * 9;
+    float t[4][3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const float g0 = g[j], g1 = g[3 + j], g2 = g[6 + j];
+        t[0][j] = g0; t[1][j] = 0.5f * (g0 + g1 + g2); t[2][j] = 0.5f * (g0 - g1 + g2); t[3][j] = g2;
+    }
+    const int ncb = Cout / WN_CO;
+    const int c = ci >> 2, kq = ci & 3, cb = co / WN_CO, blk = (co % WN_CO) >> 4, row = co & 15;
+    float *dst = upk + ((size_t)c * ncb + cb) * WN_SLAB;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float u[4];
+        u[0] = t[r][0]; u[1] = 0.5f * (t[r][0] + t[r][1] + t[r][2]); u[2] = 0.5f * (t[r][0] - t[r][1] + t[r][2]); u[3] = t[r][2];
+        // xi = 4 r + j  ->  q = r, e = j
+        *(float4 *)(dst + (((size_t)r * 2 + blk) * 64 + kq * 16 + row) * 4) = make_float4(u[0], u[1], u[2], u[3]);
+    }
+}
+
+template <bool POOL>
+__global__ void __launch_bounds__(256, 2) wino_conv3x3_kernel(
+    const float *__restrict__ x, const float *__restrict__ upk, const float *__restrict__ bias, float *__restrict__ y,
+    int Cin, int Cout, int H, int W, int nbx, int nby, int S, int ncb, int relu)
+{
+    __shared__ __attribute__((aligned(16))) float Us[2][WN_SLAB];
+    const int id = blockIdx.x;
+    const int xcd = id & 7, jj = id >> 3;
+    const int cb = jj % ncb;
+    const int s = (jj / ncb) * 8 + xcd;
+    if (s >= S) return;
+    const int bx = s % nbx, by = (s / nbx) % nby, b = s / (nbx * nby);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int col = lane & 15, kq = lane >> 4;
+    const int ty = by * WN_TY + w, tx = bx * WN_TX + col;
+    const size_t HW = (size_t)H * W;
+
+    unsigned off[16];                                        // lane offsets inside a 4-channel slab (always in bounds)
+    unsigned vmask = 0;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const int iy = 2 * ty - 1 + a;
+        const bool rv = iy >= 0 && iy < H;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int ix = 2 * tx - 1 + c;
+            const bool ok = rv && ix >= 0 && ix < W;
+            off[a * 4 + c] = (unsigned)(kq * (int)HW + (ok ? iy * W + ix : 0));
+            vmask |= ok ? (1u << (a * 4 + c)) : 0u;
+        }
+    }
+    const float *xb = x + (size_t)b * Cin * HW;
+    const float4 *ub = (const float4 *)(upk + (size_t)cb * WN_SLAB) + tid;
+    const size_t ustride = (size_t)ncb * (WN_SLAB / 4);      // float4 per chunk
+    const int nchunks = Cin >> 2;
+
+    float raw[16];
+    float4 u0, u1;
+    auto gload = [&](int c) {
+        const float *p = xb + (size_t)c * 4 * HW;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) raw[i] = p[off[i]];      // unconditional (clamped address); masked in the transform
+        const float4 *q = ub + (size_t)c * ustride;
+        u0 = q[0]; u1 = q[256];
+    };
+    auto ustore = [&](int st) {
+        ((float4 *)Us[st])[tid] = u0;
+        ((float4 *)Us[st])[256 + tid] = u1;
+    };
+
+    f32x4 acc[16][2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { acc[i][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[i][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+
+    gload(0);
+    ustore(0);
+    __syncthreads();
+
+    for (int c = 0; c < nchunks; ++c) {
+        // input transform B^T d B in registers: v[4 i + j] is this lane's B operand of Winograd position (i, j)
+        float v[16];
+        {
+            float t[16];
+            if (vmask != 0xffffu) {                          // border / out-of-image tiles only: zero padding
+#pragma unroll
+                for (int i = 0; i < 16; ++i) raw[i] = ((vmask >> i) & 1u) ? raw[i] : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                t[j] = raw[j] - raw[8 + j];
+                t[4 + j] = raw[4 + j] + raw[8 + j];
+                t[8 + j] = raw[8 + j] - raw[4 + j];
+                t[12 + j] = raw[4 + j] - raw[12 + j];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                v[4 * i] = t[4 * i] - t[4 * i + 2];
+                v[4 * i + 1] = t[4 * i + 1] + t[4 * i + 2];
+                v[4 * i + 2] = t[4 * i + 2] - t[4 * i + 1];
+                v[4 * i + 3] = t[4 * i + 1] - t[4 * i + 3];
+            }
+        }
+        if (c + 1 < nchunks) gload(c + 1);                   // in flight during the MFMAs below
+        const float4 *us = (const float4 *)Us[c & 1] + lane;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 a0 = us[(q * 2) * 64], a1 = us[(q * 2 + 1) * 64];
+            acc[4 * q][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, v[4 * q], acc[4 * q][0], 0, 0, 0);
+            acc[4 * q][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, v[4 * q], acc[4 * q][1], 0, 0, 0);
+            acc[4 * q + 1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, v[4 * q + 1], acc[4 * q + 1][0], 0, 0, 0);
+            acc[4 * q + 1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, v[4 * q + 1], acc[4 * q + 1][1], 0, 0, 0);
+            acc[4 * q + 2][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, v[4 * q + 2], acc[4 * q + 2][0], 0, 0, 0);
+            acc[4 * q + 2][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, v[4 * q + 2], acc[4 * q + 2][1], 0, 0, 0);
+            acc[4 * q + 3][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, v[4 * q + 3], acc[4 * q + 3][0], 0, 0, 0);
+            acc[4 * q + 3][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, v[4 * q + 3], acc[4 * q + 3][1], 0, 0, 0);
+        }
+        if (c + 1 < nchunks) ustore((c + 1) & 1);
+        __syncthreads();
+    }
+
+    // output transform A^T M A + bias (+ReLU) (+2x2 max-pool) in registers; accumulator register r of
+    // M-block blk = cout cb*32 + blk*16 + 4 kq + r, column = this lane's tile
+    const int Ho = POOL ? (H >> 1) : H, Wo = POOL ? (W >> 1) : W;
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int co = cb * WN_CO + blk * 16 + 4 * kq + r;
+            float a0[4], a1[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                a0[j] = acc[j][blk][r] + acc[4 + j][blk][r] + acc[8 + j][blk][r];
+                a1[j] = acc[4 + j][blk][r] - acc[8 + j][blk][r] - acc[12 + j][blk][r];
+            }
+            const float bv = bias ? bias[co] : 0.f;
+            float y00 = a0[0] + a0[1] + a0[2] + bv, y01 = a0[1] - a0[2] - a0[3] + bv;
+            float y10 = a1[0] + a1[1] + a1[2] + bv, y11 = a1[1] - a1[2] - a1[3] + bv;
+            float *yo = y + ((size_t)b * Cout + co) * ((size_t)Ho * Wo);
+            if (POOL) {
+                float m = fmaxf(fmaxf(y00, y01), fmaxf(y10, y11));
+                if (relu) m = fmaxf(m, 0.f);
+                if (ty < Ho && tx < Wo) yo[(size_t)ty * Wo + tx] = m;
+            } else {
+                if (relu) { y00 = fmaxf(y00, 0.f); y01 = fmaxf(y01, 0.f); y10 = fmaxf(y10, 0.f); y11 = fmaxf(y11, 0.f); }
+                const int oy = 2 * ty, ox = 2 * tx;
+                if (ox + 1 < W) {
+                    if (!(W & 1)) {
+                        if (oy < H) *(float2 *)(yo + (size_t)oy * W + ox) = make_float2(y00, y01);
+                        if (oy + 1 < H) *(float2 *)(yo + (size_t)(oy + 1) * W + ox) = make_float2(y10, y11);
+                    } else {
+                        if (oy < H) { yo[(size_t)oy * W + ox] = y00; yo[(size_t)oy * W + ox + 1] = y01; }
+                        if (oy + 1 < H) { yo[(size_t)(oy + 1) * W + ox] = y10; yo[(size_t)(oy + 1) * W + ox + 1] = y11; }
+                    }
+                } else if (ox < W) {
+                    if (oy < H) yo[(size_t)oy * W + ox] = y00;
+                    if (oy + 1 < H) yo[(size_t)(oy + 1) * W + ox] = y10;
+                }
+            }
+        }
+    }
+}
+
+extern "C" {
+
+size_t mfr_wino_filter_bytes(int Cin, int Cout)
+{
+    if (Cin <= 0 || Cout <= 0 || (Cin & 3) || (Cout % WN_CO)) return 0;
+    return sizeof(float) * 16 * (size_t)Cin * Cout;
+}
+
+int mfr_wino_filter_transform(const float *w, int Cin, int Cout, float *upk, void *stream)
+{
+    if (!w || !upk || Cin <= 0 || Cout <= 0 || (Cin & 3) || (Cout % WN_CO)) return MFR_E_ARG;
+    hipLaunchKernelGGL(wino_filter_kernel, dim3((Cin * Cout + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, Cin, Cout, upk);
+    CHECK_LAUNCH();
+    return 0;
+}
+
+int mfr_conv3x3_wino(const float *x, const float *upk, const float *bias, int B, int Cin, int Cout, int H, int W,
+                     int relu, int pool, float *y, void *stream)
+{
+    if (!x || !upk || !y || B <= 0 || Cin <= 0 || Cout <= 0 || (Cin & 3) || (Cout % WN_CO) || H <= 0 || W <= 0) return MFR_E_ARG;
+    if (pool && (H < 2 || W < 2)) return MFR_E_ARG;
+    if ((size_t)4 * H * W >= 0x7fffffffull) return MFR_E_ARG;
+    const int nbx = ((W + 1) / 2 + WN_TX - 1) / WN_TX, nby = ((H + 1) / 2 + WN_TY - 1) / WN_TY;
+    const int ncb = Cout / WN_CO;
+    const long long S = (long long)nbx * nby * B;
+    const long long grid = (S + 7) / 8 * 8 * ncb;
+    if (grid > 0x7fffffffll) return MFR_E_ARG;
+    if (pool)
+        hipLaunchKernelGGL(wino_conv3x3_kernel<true>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, x, upk, bias, y, Cin, Cout,
+                           H, W, nbx, nby, (int)S, ncb, relu);
+    else
+        hipLaunchKernelGGL(wino_conv3x3_kernel<false>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, x, upk, bias, y, Cin, Cout,
+                           H, W, nbx, nby, (int)S, ncb, relu);
+    CHECK_LAUNCH();
+    return 0;
+}
+
+}  // extern "C"

@@ -81,8 +81,27 @@ class LoFTR_matcher:
 
 
 class SIFT_matcher:
-    def __init__(self, resize, outdoor=False):
-        raise NotImplementedError("SIFT_matcher needs OpenCV SIFT/FLANN (matchers.py:123-188); outside the GPU hot path")
+    """matchers.py:123-188: 2048 SIFT features, rootSIFT, 2-NN, ratio 0.8.  Detection is OpenCV's (or the
+    `detector` callable's); the descriptor leg runs in csrc/descriptor_match.hip."""
+
+    def __init__(self, resize, outdoor=False, detector=None):
+        from .descriptor_ops import DescriptorRatioMatcher
+        from .matching.feature_matching import _cv_sift_detector
+        self.resize = resize
+        self.detector = detector if detector is not None else _cv_sift_detector(2048)     # :146-147
+        self.matcher = DescriptorRatioMatcher(0.8)                                          # :145
+
+    def match_arrays(self, img0, img1):
+        out = self.matcher([self.detector(img0)], [self.detector(img1)])
+        n = int(out["n_corr"][0])
+        if n > 0:
+            return torch.cat([out["pts0"][0, :n], out["pts1"][0, :n]], 1).cpu().numpy()
+        print("no correspondences")
+        return np.full((1, 4), np.nan)
+
+    def match(self, pair_path):
+        g = [np.round(read_image(p, self.resize) * 255.0).astype(np.uint8) for p in pair_path]
+        return self.match_arrays(g[0], g[1])
 
 
 MATCHERS = {'LoFTR': LoFTR_matcher, 'SG': SuperGlue_matcher, 'SIFT': SIFT_matcher}

@@ -6,8 +6,9 @@ pixel frame, N may be 0 (np.array([])).  Mirrors lib/models/matching/feature_mat
                        semantics incl. lazy per-scene reload, float32 cast and NaN stripping
   SuperGlueMatching    NEW: online SuperPoint+SuperGlue on the GPU (the reference only has it
                        offline, etc/feature_matching_baselines/matchers.py:62-120)
-  SIFTMatching         OpenCV SIFT + FLANN (feature_matching.py:53-118): not available offline and
-                       outside the accelerated path -> raises
+  SIFTMatching         feature_matching.py:53-118: detectAndCompute from OpenCV (or a caller-supplied
+                       detector; raises ImportError when neither exists), rootSIFT + exact 2-NN + ratio
+                       test on the GPU (csrc/descriptor_match.hip) instead of FLANN
 """
 import numpy as np
 
@@ -73,8 +74,51 @@ class SuperGlueMatching:
         return out["pts0"][0, :n].cpu().numpy(), out["pts1"][0, :n].cpu().numpy()
 
 
+def _cv_sift_detector(num_features):
+    """detectAndCompute of OpenCV SIFT (feature_matching.py:58,82-83) -- keypoint detection and
+    description are NOT part of the accelerated path; cv2 is used when importable"""
+    try:
+        import cv2 as cv
+    except ImportError as e:
+        raise ImportError(
+            "SIFT detection needs OpenCV (cv.SIFT_create; feature_matching.py:58), which is not installed; pass "
+            "detector=callable(gray_u8 [H,W]) -> (kpts [n,2] f32, desc [n,128] f32) to use another "
+            "SIFT implementation -- everything after detectAndCompute runs on the GPU") from e
+    sift = cv.SIFT_create(num_features)
+
+    def detect(gray):
+        kp, des = sift.detectAndCompute(gray, None)
+        if des is None:
+            return np.zeros((0, 2), np.float32), np.zeros((0, 128), np.float32)
+        return np.float32([k.pt for k in kp]).reshape(-1, 2), np.float32(des)
+    return detect
+
+
 class SIFTMatching:
-    def __init__(self, cfg):
-        raise NotImplementedError(
-            "SIFTMatching needs OpenCV SIFT/FLANN (feature_matching.py:53-118), which is outside the "
-            "GPU hot path (SURVEY 8f rank 2); use FEATURE_MATCHING 'Precomputed' or 'SuperGlue'")
+    """feature_matching.py:53-118.  detectAndCompute stays with the caller-supplied / OpenCV detector
+    (CPU); rootSIFT + 2-NN + ratio test run in csrc/descriptor_match.hip (exact 2-NN instead of FLANN's
+    approximate kd-forest)."""
+
+    def __init__(self, cfg, detector=None):
+        from ..descriptor_ops import DescriptorRatioMatcher
+        self.ratio_threshold = cfg.SIFT.RATIO_THRESHOLD
+        self.detector = detector if detector is not None else _cv_sift_detector(cfg.SIFT.NUM_FEATURES)
+        self.matcher = DescriptorRatioMatcher(self.ratio_threshold)
+        self.debug = cfg.DEBUG
+
+    @staticmethod
+    def transform_grayscale(img):
+        """[3,H,W] float in [0,1] -> u8 gray: (255*img).astype(uint8) then COLOR_RGB2GRAY, which OpenCV
+        evaluates in 14-bit fixed point: (4899 R + 9617 G + 1868 B + 8192) >> 14 (feature_matching.py:61-65)"""
+        a = np.asarray(img.permute(1, 2, 0).cpu().numpy() if hasattr(img, "permute") else img)
+        a = (255 * a).astype(np.uint8).astype(np.int32)
+        return ((4899 * a[..., 0] + 9617 * a[..., 1] + 1868 * a[..., 2] + 8192) >> 14).astype(np.uint8)
+
+    def get_correspondences(self, data):
+        img0 = self.transform_grayscale(data['image0'].squeeze(0))
+        img1 = self.transform_grayscale(data['image1'].squeeze(0))
+        out = self.matcher([self.detector(img0)], [self.detector(img1)])
+        n = int(out["n_corr"][0])
+        pts1 = out["pts0"][0, :n].cpu().numpy().reshape(-1, 2)
+        pts2 = out["pts1"][0, :n].cpu().numpy().reshape(-1, 2)
+        return pts1, pts2

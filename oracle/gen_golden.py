@@ -301,6 +301,80 @@ def gen_metrics(rng):
     np.savez_compressed(os.path.join(OUT, "ref_metrics.npz"), **cases)
 
 
+def _sift_like(rng, n):
+    """integer-valued 128-d descriptors with OpenCV SIFT's statistics (u8-saturated, |d|_2 ~ 512)"""
+    d = rng.gamma(0.6, 1.0, (n, 128))
+    d = np.minimum(d / np.linalg.norm(d, axis=1, keepdims=True), 0.2)
+    d = np.clip(np.rint(512.0 * d / np.linalg.norm(d, axis=1, keepdims=True)), 0, 255)
+    return d.astype(np.float32)
+
+
+def gen_sift(cv, fm, rng):
+    """root_sift (feature_matching.py:68-74) and the whole get_correspondences loop (:75-118) of the
+    reference, executed with a stub cv2 whose SIFT returns prepared (keypoints, descriptors) and whose
+    FlannBasedMatcher is an exact float64 brute-force 2-NN (FLANN itself is unavailable offline)."""
+    cases = {}
+    # (1) root_sift on SIFT-like integer descriptors, on general floats and on an all-zero row
+    a = _sift_like(rng, 257)
+    b = (rng.random((64, 128)) * 37.0).astype(np.float32)
+    b[5] = 0.0
+    for name, d in (("rs_int", a), ("rs_float", b)):
+        cases[name + "_in"] = d
+        cases[name + "_out"] = fm.SIFTMatching.root_sift(None, d.copy())
+
+    # (2) get_correspondences with stubbed detection / 2-NN
+    class KP:
+        def __init__(self, pt):
+            self.pt = (float(pt[0]), float(pt[1]))
+
+    class DM:
+        def __init__(self, q, t, dist):
+            self.queryIdx, self.trainIdx, self.distance = int(q), int(t), float(np.float32(dist))
+
+    class Flann:
+        def __init__(self, *a, **k):
+            pass
+
+        def knnMatch(self, d0, d1, k=2):
+            D = ((d0[:, None, :].astype(np.float64) - d1[None].astype(np.float64)) ** 2).sum(-1)
+            order = np.argsort(D, axis=1, kind="stable")[:, :2]
+            return [(DM(i, order[i, 0], np.sqrt(D[i, order[i, 0]])), DM(i, order[i, 1], np.sqrt(D[i, order[i, 1]])))
+                    for i in range(len(d0))]
+
+    for ci, (n0, n1, n_true) in enumerate(((300, 280, 150), (64, 97, 20), (2048, 2048, 700))):
+        d0 = _sift_like(rng, n0)
+        d1 = _sift_like(rng, n1)
+        perm = rng.permutation(n1)[:n_true]
+        src = rng.permutation(n0)[:n_true]
+        noisy = d0[src] + rng.normal(0, rng.uniform(2.0, 60.0, (n_true, 1)), (n_true, 128))
+        d1[perm] = np.clip(np.rint(noisy), 0, 255).astype(np.float32)
+        kp0 = (rng.random((n0, 2)) * [720, 540]).astype(np.float32)
+        kp1 = (rng.random((n1, 2)) * [720, 540]).astype(np.float32)
+        feats = [([KP(p) for p in kp0], d0.copy()), ([KP(p) for p in kp1], d1.copy())]
+
+        class Sift:
+            def __init__(self):
+                self.i = 0
+
+            def detectAndCompute(self, img, mask):
+                r = feats[self.i]
+                self.i += 1
+                return r
+
+        m = fm.SIFTMatching.__new__(fm.SIFTMatching)
+        m.ratio_threshold = 0.8
+        m.sift = Sift()
+        m.debug = False
+        cv.FlannBasedMatcher = Flann
+        cv.cvtColor = lambda im, code: im[..., 0]
+        img = torch.zeros(1, 3, 8, 8)
+        pts1, pts2 = m.get_correspondences({"image0": img, "image1": img})
+        cases[f"gc{ci}_des0"] = d0.astype(np.uint8); cases[f"gc{ci}_des1"] = d1.astype(np.uint8)   # integer-valued
+        cases[f"gc{ci}_kp0"] = kp0; cases[f"gc{ci}_kp1"] = kp1
+        cases[f"gc{ci}_pts1"] = pts1; cases[f"gc{ci}_pts2"] = pts2
+    np.savez_compressed(os.path.join(OUT, "ref_sift_ratio.npz"), **cases)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     cv, ps, fm, ut = _import_reference()
@@ -310,6 +384,7 @@ def main():
     gen_pnp_lift(cv, ps, rng)
     gen_wire_format(fm, ut, rng)
     gen_metrics(rng)
+    gen_sift(cv, fm, np.random.default_rng(20240808))
     print("golden fixtures written to", os.path.abspath(OUT))
 
 

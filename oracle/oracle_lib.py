@@ -16,7 +16,7 @@ ST_OK, ST_TOO_FEW, ST_BAD_DEPTH, ST_NO_MODEL, ST_DEGENERATE = range(5)
 
 
 def build(force=False):
-    srcs = [os.path.join(_HERE, f) for f in ("mfr_oracle.c", "mfr_oracle_emat.c", "mfr_oracle_procrustes.c", "mfr_oracle.h", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("mfr_oracle.c", "mfr_oracle_emat.c", "mfr_oracle_procrustes.c", "mfr_oracle_desc.c", "mfr_oracle.h", "Makefile")]
     stale = (not os.path.exists(_SO)) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs)
     if force or stale:
         subprocess.check_call(["make", "-s", "-C", _HERE], stdout=subprocess.DEVNULL)
@@ -251,3 +251,35 @@ def procrustes_solve(pts0, pts1, depth0, depth1, K0, K1, max_dist=0.05, conf=0.9
                                         _p(_f32(K0).reshape(9)), _p(_f32(K1).reshape(9)), C.c_double(max_dist), C.c_double(conf),
                                         C.c_int(max_iters), C.c_uint64(seed), C.c_uint64(pair_id), _p(R), _p(t), C.byref(n_inl))
     return st, R, t.reshape(3, 1), n_inl.value
+
+
+def rootsift(desc):
+    """feature_matching.py:68-74 -> (rootSIFT descriptors f32 [n,128], squared norms f32 [n])"""
+    desc = _f32(desc).reshape(-1, 128)
+    out = np.zeros_like(desc); n2 = np.zeros(len(desc), np.float32)
+    lib().mfr_ref_rootsift(_p(desc), C.c_int(len(desc)), _p(out), _p(n2))
+    return out, n2
+
+
+def desc_2nn(des0, des1, nrm0, nrm1):
+    des0, des1 = _f32(des0).reshape(-1, 128), _f32(des1).reshape(-1, 128)
+    n0, n1 = len(des0), len(des1)
+    idx = np.zeros(max(n0, 1), np.int32); d2 = np.zeros((max(n0, 1), 2), np.float32)
+    lib().mfr_ref_desc_2nn(_p(des0), _p(des1), _p(_f32(nrm0)), _p(_f32(nrm1)), C.c_int(n0), C.c_int(n1), _p(idx), _p(d2))
+    return idx[:n0], d2[:n0]
+
+
+def desc_ratio(nn_idx, nn_d2, n1, ratio, kp0, kp1):
+    nn_idx = np.ascontiguousarray(nn_idx, np.int32); nn_d2 = _f32(nn_d2)
+    kp0, kp1 = _f32(kp0).reshape(-1, 2), _f32(kp1).reshape(-1, 2)
+    n0 = len(nn_idx)
+    p0 = np.zeros((max(n0, 1), 2), np.float32); p1 = np.zeros((max(n0, 1), 2), np.float32)
+    m = lib().mfr_ref_desc_ratio(_p(nn_idx), _p(nn_d2), C.c_int(n0), C.c_int(n1), C.c_double(ratio), _p(kp0), _p(kp1), _p(p0), _p(p1))
+    return p0[:m].copy(), p1[:m].copy()
+
+
+def sift_ratio_match(des0_raw, des1_raw, kp0, kp1, ratio=0.8):
+    """whole a-3 leg after detectAndCompute: rootSIFT, exact 2-NN, ratio test -> (pts0, pts1)"""
+    d0, n0 = rootsift(des0_raw); d1, n1 = rootsift(des1_raw)
+    idx, d2 = desc_2nn(d0, d1, n0, n1)
+    return desc_ratio(idx, d2, len(d1), ratio, kp0, kp1)

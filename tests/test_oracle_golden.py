@@ -69,3 +69,39 @@ def test_wire_format_roundtrip_fixture(golden_dir):
             np.testing.assert_array_equal(row[:, 2:], g[f"p2_{i}"])
         else:
             assert g[f"p1_{i}"].shape == (0,)
+
+
+def test_rootsift_matches_reference_bitwise(golden_dir):
+    """root_sift (feature_matching.py:68-74) executed by the reference's own numpy code"""
+    g = _load(golden_dir, "ref_sift_ratio.npz")
+    for name in ("rs_int", "rs_float"):
+        out, n2 = O.rootsift(g[name + "_in"])
+        np.testing.assert_array_equal(out, g[name + "_out"])
+        np.testing.assert_allclose(n2, (out.astype(np.float64) ** 2).sum(1), rtol=2e-6)
+
+
+def test_sift_ratio_loop_matches_reference(golden_dir):
+    """SIFTMatching.get_correspondences (feature_matching.py:75-118) run with stubbed detection and an
+    exact 2-NN in place of FLANN: same kept matches, same order, same coordinates"""
+    g = _load(golden_dir, "ref_sift_ratio.npz")
+    for ci in range(3):
+        p0, p1 = O.sift_ratio_match(g[f"gc{ci}_des0"].astype(np.float32), g[f"gc{ci}_des1"].astype(np.float32),
+                                    g[f"gc{ci}_kp0"], g[f"gc{ci}_kp1"], 0.8)
+        assert len(p0) > 0
+        np.testing.assert_array_equal(p0, g[f"gc{ci}_pts1"])
+        np.testing.assert_array_equal(p1, g[f"gc{ci}_pts2"])
+
+
+def test_sift_ratio_edge_cases():
+    rng = np.random.default_rng(3)
+    d = (rng.random((5, 128)) * 100).astype(np.float32)
+    kp = rng.random((5, 2)).astype(np.float32)
+    # a single train descriptor: knnMatch(k=2) has no second neighbour -> no correspondences
+    p0, p1 = O.sift_ratio_match(d, d[:1], kp, kp[:1])
+    assert p0.shape == (0, 2) and p1.shape == (0, 2)
+    # duplicate train rows: d1 == d2 == 0 -> 0 < 0.8*0 is False -> rejected
+    p0, _ = O.sift_ratio_match(d, np.concatenate([d, d]), kp, np.concatenate([kp, kp]))
+    assert len(p0) == 0
+    # identical sets: best distance 0, second > 0 -> every query kept, identity assignment
+    p0, p1 = O.sift_ratio_match(d, d, kp, kp)
+    np.testing.assert_array_equal(p0, kp); np.testing.assert_array_equal(p1, kp)
