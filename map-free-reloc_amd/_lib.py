@@ -49,6 +49,9 @@ SIGNATURES = {
     "mfr_conv3x3_c1_relu": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "mfr_bias_relu_nchw": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "mfr_bias_pool2_relu_nchw": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "mfr_wino_filter_bytes": (_sz, [_i, _i]),
+    "mfr_wino_filter_transform": (_i, [_vp, _i, _i, _vp, _vp]),
+    "mfr_conv3x3_wino": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "mfr_rootsift": (_i, [_vp, _i, _vp, _vp, _vp]),
     "mfr_desc_ratio_match": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _d, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "mfr_scale_workspace_bytes": (_sz, [_i, _i]),

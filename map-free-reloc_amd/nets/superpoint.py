@@ -1,5 +1,7 @@
-"""SuperPoint on MI355X: conv stack through PyTorch-ROCm (MIOpen; dense MFMA-bound library work),
-everything after the conv heads through the hand-written HIP kernels of csrc/superpoint_post.hip.
+"""SuperPoint on MI355X: the 3x3 convolutions through the fused Winograd/MFMA kernel of
+csrc/winograd_conv.hip (conv1a: csrc/elementwise.hip; MFR_CONV=miopen selects the library convolution +
+epilogue kernels instead), the 1x1 heads as library GEMMs, everything after the conv heads through the
+hand-written HIP kernels of csrc/superpoint_post.hip.
 
 Reference call site: SuperGlue_matcher (etc/feature_matching_baselines/matchers.py:62-120; nms 4,
 threshold 0.005, max 1024 keypoints :65-67); network = un-vendored magicleap submodule, restated
@@ -25,9 +27,22 @@ class SuperPointHIP:
         self.K, self.border = int(max_keypoints), int(remove_borders)
         import os
         self.fused_conv_relu = os.environ.get("MFR_FUSED_CONV_RELU", "0") == "1"
+        self.use_wino = os.environ.get("MFR_CONV", "wino") == "wino"      # "miopen": library conv + epilogue kernels
         self.w = {k: v.to(self.device, torch.float32).contiguous() for k, v in state_dict.items()}
         # 1x1 heads as plain matrices
         self.w["convDb.mat"] = self.w["convDb.weight"].reshape(256, 256).contiguous()
+        # Winograd-transformed 3x3 filters, packed in MFMA operand order (csrc/winograd_conv.hip), once per weight set
+        self.upk = {}
+        lib = _lib.load()
+        for name in ("conv1b", "conv2a", "conv2b", "conv3a", "conv3b", "conv4a", "conv4b", "convPa", "convDa"):
+            w = self.w[name + ".weight"]
+            co, ci = int(w.shape[0]), int(w.shape[1])
+            nbytes = lib.mfr_wino_filter_bytes(ci, co)
+            if tuple(w.shape[2:]) != (3, 3) or nbytes == 0:
+                continue
+            u = torch.empty(nbytes // 4, dtype=torch.float32, device=self.device)
+            _lib.check(lib.mfr_wino_filter_transform(_lib.ptr(w), ci, co, _lib.ptr(u), _lib.stream_ptr()), "mfr_wino_filter_transform")
+            self.upk[name] = u
 
     def _conv(self, x, name, relu=True, pool=False):
         """conv (MIOpen, no bias) + ONE fused HIP epilogue pass: relu(x + b) in place, or
@@ -35,6 +50,14 @@ class SuperPointHIP:
         lib = _lib.load()
         w, b = self.w[name + ".weight"], self.w[name + ".bias"]
         pad = w.shape[-1] // 2
+        if self.use_wino and relu and name in self.upk:
+            x = x.contiguous()
+            B, C, H, W = x.shape
+            co = int(w.shape[0])
+            y = torch.empty((B, co, H // 2, W // 2) if pool else (B, co, H, W), dtype=torch.float32, device=x.device)
+            _lib.check(lib.mfr_conv3x3_wino(_lib.ptr(x), _lib.ptr(self.upk[name]), _lib.ptr(b), B, C, co, H, W, 1, int(pool),
+                                            _lib.ptr(y), _lib.stream_ptr()), "mfr_conv3x3_wino")
+            return y
         if not relu:
             return F.conv2d(x, w, b, padding=pad)
         if self.fused_conv_relu and not pool:
