@@ -28,6 +28,7 @@
 // Per cin chunk and wavefront: 16 dword loads, 32 VALU adds, 8 ds_read_b128, 32 MFMAs (1024 MFMA cycles).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/mfr_hip.h"
 
@@ -65,12 +66,20 @@ __global__ void __launch_bounds__(256) wino_filter_kernel(const float *__restric
     }
 }
 
-template <bool POOL>
+// dword3 of a raw buffer descriptor on gfx9-family CDNA (32-bit data format); out-of-range reads return 0,
+// which is how the zero padding of the convolution is produced: padded taps get an offset beyond the buffer
+#define WN_RSRC_FLAGS 0x00020000
+#define WN_OOB 0x80000000u
+
+// PAIR: W even -> each lane loads its two own columns as one aligned dwordx2 and takes the other two
+// from its neighbours' registers (DPP row shifts inside the 16-lane tile row); only the two edge lanes of a row
+// fetch a halo element.  8 vector-memory instructions per 4x4x(4 cin) patch instead of 16.
+template <bool POOL, bool PAIR, int ABL>
 __global__ void __launch_bounds__(256, 2) wino_conv3x3_kernel(
     const float *__restrict__ x, const float *__restrict__ upk, const float *__restrict__ bias, float *__restrict__ y,
     int Cin, int Cout, int H, int W, int nbx, int nby, int S, int ncb, int relu)
 {
-    __shared__ __attribute__((aligned(16))) float Us[2][WN_SLAB];
+    __shared__ __attribute__((aligned(16))) float Us[2][WN_SLAB];         // double-buffered U slab of one cin chunk
     const int id = blockIdx.x;
     const int xcd = id & 7, jj = id >> 3;
     const int cb = jj % ncb;
@@ -80,75 +89,91 @@ __global__ void __launch_bounds__(256, 2) wino_conv3x3_kernel(
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int col = lane & 15, kq = lane >> 4;
     const int ty = by * WN_TY + w, tx = bx * WN_TX + col;
-    const size_t HW = (size_t)H * W;
+    const int HW = H * W;
 
-    unsigned off[16];                                        // lane offsets inside a 4-channel slab (always in bounds)
-    unsigned vmask = 0;
+    // one buffer per image: [Cin, H, W] f32; lane byte offsets inside a 4-channel slab, chunk advance in soffset
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(x + (size_t)b * Cin * HW), 0, Cin * HW * 4, WN_RSRC_FLAGS);
+    constexpr int NOFF = PAIR ? 8 : 16;
+    constexpr int NRAW = PAIR ? 12 : 16;
+    unsigned off[NOFF];
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
         const int iy = 2 * ty - 1 + a;
         const bool rv = iy >= 0 && iy < H;
+        const unsigned rowb = (unsigned)(kq * HW + iy * W) * 4u;
+        if (PAIR) {
+            off[a] = (rv && 2 * tx < W) ? rowb + 8u * tx : WN_OOB;
+            const int hx = (col == 0) ? 2 * tx - 1 : 2 * tx + 2;
+            off[4 + a] = (rv && (col == 0 || col == 15) && hx >= 0 && hx < W) ? rowb + 4u * hx : WN_OOB;
+        } else {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int ix = 2 * tx - 1 + c;
-            const bool ok = rv && ix >= 0 && ix < W;
-            off[a * 4 + c] = (unsigned)(kq * (int)HW + (ok ? iy * W + ix : 0));
-            vmask |= ok ? (1u << (a * 4 + c)) : 0u;
+            for (int c = 0; c < 4; ++c) {
+                const int ix = 2 * tx - 1 + c;
+                off[a * 4 + c] = (rv && ix >= 0 && ix < W) ? rowb + 4u * ix : WN_OOB;
+            }
         }
     }
-    const float *xb = x + (size_t)b * Cin * HW;
     const float4 *ub = (const float4 *)(upk + (size_t)cb * WN_SLAB) + tid;
     const size_t ustride = (size_t)ncb * (WN_SLAB / 4);      // float4 per chunk
     const int nchunks = Cin >> 2;
+    const unsigned cstep = 16u * HW;                         // bytes per 4-channel chunk
 
-    float raw[16];
-    float4 u0, u1;
-    auto gload = [&](int c) {
-        const float *p = xb + (size_t)c * 4 * HW;
+    auto gload = [&](unsigned (&raw)[NRAW], int c) {
+        const unsigned so = (unsigned)c * cstep;
+        if (ABL & 1) return;
+        if (PAIR) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) raw[i] = p[off[i]];      // unconditional (clamped address); masked in the transform
-        const float4 *q = ub + (size_t)c * ustride;
-        u0 = q[0]; u1 = q[256];
+            for (int a = 0; a < 4; ++a) {
+                const auto pr = __builtin_amdgcn_raw_buffer_load_b64(rs, off[a], so, 0);
+                raw[3 * a] = pr[0]; raw[3 * a + 1] = pr[1];
+                raw[3 * a + 2] = __builtin_amdgcn_raw_buffer_load_b32(rs, off[4 + a], so, 0);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) raw[i] = __builtin_amdgcn_raw_buffer_load_b32(rs, off[i], so, 0);
+        }
     };
-    auto ustore = [&](int st) {
-        ((float4 *)Us[st])[tid] = u0;
-        ((float4 *)Us[st])[256 + tid] = u1;
+    // input transform B^T d B in registers: v[4 i + j] is this lane's B operand of Winograd position (i, j)
+    auto transform = [&](const unsigned (&raw)[NRAW], float (&v)[16]) {
+        float d[16];                                         // 4x4 patch d[4 a + col] of (cin, this lane's tile)
+        if (PAIR) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const int p0 = (int)raw[3 * a], p1 = (int)raw[3 * a + 1], hv = (int)raw[3 * a + 2];
+                // column 2tx-1 = left neighbour's second element, column 2tx+2 = right neighbour's first; the edge
+                // lanes of the 16-lane row have no neighbour and keep `old` = their halo load
+                d[4 * a] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(hv, p1, 0x111 /* row_shr:1 */, 0xf, 0xf, false));
+                d[4 * a + 1] = __builtin_bit_cast(float, p0);
+                d[4 * a + 2] = __builtin_bit_cast(float, p1);
+                d[4 * a + 3] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(hv, p0, 0x101 /* row_shl:1 */, 0xf, 0xf, false));
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) d[i] = __builtin_bit_cast(float, raw[i]);
+        }
+        float t[16];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            t[j] = d[j] - d[8 + j];
+            t[4 + j] = d[4 + j] + d[8 + j];
+            t[8 + j] = d[8 + j] - d[4 + j];
+            t[12 + j] = d[4 + j] - d[12 + j];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[4 * i] = t[4 * i] - t[4 * i + 2];
+            v[4 * i + 1] = t[4 * i + 1] + t[4 * i + 2];
+            v[4 * i + 2] = t[4 * i + 2] - t[4 * i + 1];
+            v[4 * i + 3] = t[4 * i + 1] - t[4 * i + 3];
+        }
     };
 
     f32x4 acc[16][2];
 #pragma unroll
     for (int i = 0; i < 16; ++i) { acc[i][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[i][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 
-    gload(0);
-    ustore(0);
-    __syncthreads();
-
-    for (int c = 0; c < nchunks; ++c) {
-        // input transform B^T d B in registers: v[4 i + j] is this lane's B operand of Winograd position (i, j)
-        float v[16];
-        {
-            float t[16];
-            if (vmask != 0xffffu) {                          // border / out-of-image tiles only: zero padding
-#pragma unroll
-                for (int i = 0; i < 16; ++i) raw[i] = ((vmask >> i) & 1u) ? raw[i] : 0.f;
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                t[j] = raw[j] - raw[8 + j];
-                t[4 + j] = raw[4 + j] + raw[8 + j];
-                t[8 + j] = raw[8 + j] - raw[4 + j];
-                t[12 + j] = raw[4 + j] - raw[12 + j];
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                v[4 * i] = t[4 * i] - t[4 * i + 2];
-                v[4 * i + 1] = t[4 * i + 1] + t[4 * i + 2];
-                v[4 * i + 2] = t[4 * i + 2] - t[4 * i + 1];
-                v[4 * i + 3] = t[4 * i + 1] - t[4 * i + 3];
-            }
-        }
-        if (c + 1 < nchunks) gload(c + 1);                   // in flight during the MFMAs below
-        const float4 *us = (const float4 *)Us[c & 1] + lane;
+    auto mfma_chunk = [&](const float *slab, const float (&v)[16]) {
+        const float4 *us = (const float4 *)slab + lane;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const float4 a0 = us[(q * 2) * 64], a1 = us[(q * 2 + 1) * 64];
@@ -161,9 +186,40 @@ __global__ void __launch_bounds__(256, 2) wino_conv3x3_kernel(
             acc[4 * q + 3][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, v[4 * q + 3], acc[4 * q + 3][0], 0, 0, 0);
             acc[4 * q + 3][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, v[4 * q + 3], acc[4 * q + 3][1], 0, 0, 0);
         }
-        if (c + 1 < nchunks) ustore((c + 1) & 1);
-        __syncthreads();
+    };
+
+    unsigned raw[NRAW];
+    float4 u0, u1;
+    auto uload = [&](int c) {                                // the chunk's 8 KB slab: 2 float4 per thread
+        if (ABL & 2) return;
+        const float4 *q = ub + (size_t)c * ustride;
+        u0 = q[0]; u1 = q[256];
+    };
+    auto ustore = [&](int st) {
+        if (ABL & 2) return;
+        float4 *d0 = (float4 *)Us[st] + tid;
+        d0[0] = u0; d0[256] = u1;
+    };
+    if (ABL & 1) {
+#pragma unroll
+        for (int i = 0; i < NRAW; ++i) raw[i] = off[i % NOFF] ^ (unsigned)i;
     }
+    if (ABL & 2) { u0 = make_float4(0.f, 0.f, 0.f, 0.f); u1 = u0; }
+    gload(raw, 0);
+    uload(0);
+    ustore(0);
+    __syncthreads();
+
+    for (int c = 0; c < nchunks; ++c) {
+        const bool more = c + 1 < nchunks;
+        float v[16];
+        transform(raw, v);
+        if (more) { gload(raw, c + 1); uload(c + 1); }       // in flight during the 32 MFMAs below
+        mfma_chunk(Us[c & 1], v);
+        if (more) ustore((c + 1) & 1);
+        if (!(ABL & 2)) __syncthreads();
+    }
+    if (ABL & 4) { if (acc[0][0][0] != 123.456f) return; }
 
     // output transform A^T M A + bias (+ReLU) (+2x2 max-pool) in registers; accumulator register r of
     // M-block blk = cout cb*32 + blk*16 + 4 kq + r, column = this lane's tile
@@ -228,18 +284,33 @@ int mfr_conv3x3_wino(const float *x, const float *upk, const float *bias, int B,
 {
     if (!x || !upk || !y || B <= 0 || Cin <= 0 || Cout <= 0 || (Cin & 3) || (Cout % WN_CO) || H <= 0 || W <= 0) return MFR_E_ARG;
     if (pool && (H < 2 || W < 2)) return MFR_E_ARG;
-    if ((size_t)4 * H * W >= 0x7fffffffull) return MFR_E_ARG;
+    if ((size_t)4 * Cin * H * W >= 0x7fffffffull) return MFR_E_ARG;    // one image must fit a 2 GB buffer descriptor
     const int nbx = ((W + 1) / 2 + WN_TX - 1) / WN_TX, nby = ((H + 1) / 2 + WN_TY - 1) / WN_TY;
     const int ncb = Cout / WN_CO;
     const long long S = (long long)nbx * nby * B;
     const long long grid = (S + 7) / 8 * 8 * ncb;
     if (grid > 0x7fffffffll) return MFR_E_ARG;
-    if (pool)
-        hipLaunchKernelGGL(wino_conv3x3_kernel<true>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, x, upk, bias, y, Cin, Cout,
-                           H, W, nbx, nby, (int)S, ncb, relu);
-    else
-        hipLaunchKernelGGL(wino_conv3x3_kernel<false>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, x, upk, bias, y, Cin, Cout,
-                           H, W, nbx, nby, (int)S, ncb, relu);
+    const bool pair = !(W & 1) && !((uintptr_t)x & 7);
+#define WN_LAUNCH(P, Q, A) hipLaunchKernelGGL((wino_conv3x3_kernel<P, Q, A>), dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, x, upk, bias, \
+                                              y, Cin, Cout, H, W, nbx, nby, (int)S, ncb, relu)
+    const char *ev = getenv("MFR_WINO_ABL");
+    const int abl = ev ? atoi(ev) : 0;
+    if (abl && pool && pair) {
+        switch (abl) {
+        case 1: WN_LAUNCH(true, true, 1); break;
+        case 2: WN_LAUNCH(true, true, 2); break;
+        case 3: WN_LAUNCH(true, true, 3); break;
+        case 4: WN_LAUNCH(true, true, 4); break;
+        case 7: WN_LAUNCH(true, true, 7); break;
+        case 16: WN_LAUNCH(true, false, 0); break;
+        default: return MFR_E_ARG;
+        }
+        CHECK_LAUNCH();
+        return 0;
+    }
+    if (pool) { if (pair) WN_LAUNCH(true, true, 0); else WN_LAUNCH(true, false, 0); }
+    else { if (pair) WN_LAUNCH(false, true, 0); else WN_LAUNCH(false, false, 0); }
+#undef WN_LAUNCH
     CHECK_LAUNCH();
     return 0;
 }

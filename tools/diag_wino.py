@@ -7,7 +7,7 @@ import time
 import torch
 import torch.nn.functional as F
 
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import mapfree_reloc_amd as m  # noqa: E402
 from mapfree_reloc_amd import _lib  # noqa: E402
 
@@ -44,9 +44,9 @@ def main():
     dev = torch.device("cuda")
     torch.manual_seed(0)
     ok = True
-    for (B, ci, co, H, W, relu, pool, bias) in [(1, 4, 32, 8, 32, 0, 0, 0), (2, 8, 32, 11, 38, 1, 0, 1), (1, 64, 64, 17, 45, 1, 1, 1),
-                                                 (3, 12, 96, 9, 33, 0, 1, 1), (1, 128, 256, 67, 90, 1, 0, 1), (2, 64, 128, 135, 180, 1, 1, 1),
-                                                 (1, 4, 32, 2, 2, 1, 1, 1), (1, 4, 32, 1, 1, 0, 0, 1)]:
+    for (B, ci, co, H, W, relu, pool, bias) in [(1, 8, 32, 8, 32, 0, 0, 0), (2, 8, 32, 11, 38, 1, 0, 1), (1, 64, 64, 17, 45, 1, 1, 1),
+                                                 (3, 24, 96, 9, 33, 0, 1, 1), (1, 128, 256, 67, 90, 1, 0, 1), (2, 64, 128, 135, 180, 1, 1, 1),
+                                                 (1, 8, 32, 2, 2, 1, 1, 1), (1, 8, 32, 1, 1, 0, 0, 1), (1, 16, 32, 12, 31, 1, 1, 1)]:
         x = torch.randn(B, ci, H, W, device=dev)
         w = torch.randn(co, ci, 3, 3, device=dev) * (1.0 / (3.0 * ci ** 0.5))
         b = torch.randn(co, device=dev) if bias else None

@@ -1,6 +1,6 @@
 set -x
 mkdir -p gpurun_out/final
-timeout 420 python -m pytest tests -m gpu -q -x > gpurun_out/final/pytest.log 2>&1; echo "pytest rc=$?" >> gpurun_out/final/pytest.log
+timeout 600 python -m pytest tests -m gpu -q -x > gpurun_out/final/pytest.log 2>&1; echo "pytest rc=$?" >> gpurun_out/final/pytest.log
 timeout 120 python -c "import __graft_entry__ as g; g.smoke(); print('SMOKE OK')" > gpurun_out/final/smoke.log 2>&1
 timeout 300 python bench.py > gpurun_out/final/bench.json 2> gpurun_out/final/bench.err
 cd /tmp && export TMPDIR=/tmp
