@@ -144,9 +144,12 @@ def main():
         sb = IM.synthetic_batch(seeds, H, W)
         batches.append({key: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for key, v in sb.items()})
     pipe = SuperGluePnPPipeline(dev, seed=0)
-    timer = KernelTimer()
+    timer = KernelTimer()               # SuperGlue attention launches (every 9th)
+    conv_timer = KernelTimer(every=1)   # the conv1b launch of the Winograd convolution: the largest single launch
     if not args.no_kernel_timer:
         pipe.sg.attention = timer.wrap(pipe.sg.attention)
+        sp_conv, timed_conv = pipe.sp._conv, conv_timer.wrap(pipe.sp._conv)
+        pipe.sp._conv = lambda x, name, **kw: (timed_conv if name == "conv1b" else sp_conv)(x, name, **kw)
 
     def step(i):
         d = batches[i & 1]
@@ -165,7 +168,7 @@ def main():
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
-    timer.enabled = True
+    timer.enabled = conv_timer.enabled = True
     t0 = time.perf_counter()
     results = []
     for i in range(args.steps):
@@ -185,7 +188,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    timer.enabled = False
+    timer.enabled = conv_timer.enabled = False
     if use_dist:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -196,20 +199,26 @@ def main():
         value = total_pairs / elapsed
         o = results[-1][1]
         n_ok = int((o["status"] == 0).sum())
-        att_ms = timer.mean_ms()
-        # algorithmic flops of one attention launch: 2B images x 4 heads x (QK^T + PV) = 2 * 2*N*N*64 each
+        att_ms, conv_ms = timer.mean_ms(), conv_timer.mean_ms()
+        # attention: 2B images x 4 heads x (QK^T + PV) = 2 * 2*N*N*64 flops each
         nk = 1024
-        flops = 2 * B * 4 * 2 * (2.0 * nk * nk * 64)
-        achieved = flops / (att_ms * 1e-3) / 1e12 if att_ms else None
-        # HBM traffic of the dominant kernel: PMC counters cannot be read inside this process, so the
-        # per-launch figure comes from the committed rocprofv3 --pmc passes of this same command
-        # (profiles/r01_pmc_attention.json: 2 x FETCH_SIZE + WRITE_SIZE, guide's gfx950 correction)
+        att_flops = 2 * B * 4 * 2 * (2.0 * nk * nk * 64)
+        att_tf = att_flops / (att_ms * 1e-3) / 1e12 if att_ms else None
+        # Winograd F(2x2,3x3) conv1b (64 -> 64 channels, 2B images, HxW): the flops the kernel executes on the matrix cores
+        # are 16 GEMMs of [Cout x Cin] x [Cin x tiles]; a direct 3x3 convolution of the same layer is 2.25x that
+        tiles = ((H + 1) // 2) * ((W + 1) // 2)
+        conv_flops = 16 * 2.0 * 64 * 64 * tiles * 2 * B
+        conv_direct = 2.0 * 9 * 64 * 64 * H * W * 2 * B
+        achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms else None
+        # HBM traffic of the dominant kernel: PMC counters cannot be read inside this process, so the per-launch
+        # figure comes from the committed rocprofv3 --pmc passes of this same command (profiles/r01_pmc_wino.json:
+        # 2 x FETCH_SIZE + WRITE_SIZE, guide's gfx950 correction)
         traffic = None
         try:
-            pj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_attention.json")))
+            pj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_wino.json")))
             if B == 16:
                 traffic = {"bytes_per_launch": round(pj["hbm_bytes_per_launch"]), "algorithmic_bytes_per_launch": pj["algorithmic_bytes_per_launch"],
-                           "source": "profiles/r01_pmc_attention.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"}
+                           "source": "profiles/r01_pmc_wino.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"}
         except Exception:
             pass
         line = {
@@ -223,11 +232,17 @@ def main():
                        "pnp_iters": 1000, "parallelism": f"pair-sharded x{world}",
                        "pairs_solved_last_step": n_ok, "mean_matches_last_step": float(o["n_corr"].float().mean()),
                        "gathered_records": int(rec.shape[0])},
-            "roofline": {"kernel": "sg_attention_kernel (dominant hand-written kernel)", "bound": "mfma",
-                         "achieved": round(achieved, 2) if achieved else None, "peak": FP32_MFMA_PEAK_TFLOPS,
+            "roofline": {"kernel": "wino_conv3x3_kernel, conv1b launch (dominant kernel: fused Winograd F(2x2,3x3) convolution)",
+                         "bound": "mfma", "achieved": round(achieved, 2) if achieved else None, "peak": FP32_MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4) if achieved else None,
-                         "traffic": traffic, "avg_launch_ms": round(att_ms, 4) if att_ms else None,
-                         "launches_timed": len(timer.events)},
+                         "traffic": traffic, "avg_launch_ms": round(conv_ms, 4) if conv_ms else None,
+                         "launches_timed": len(conv_timer.events),
+                         "flops_per_launch": conv_flops, "note": "achieved = flops executed on the fp32 matrix cores (16 Winograd GEMMs); "
+                         "a direct 3x3 convolution of the layer is 2.25x that",
+                         "direct_equivalent_tflops": round(conv_direct / (conv_ms * 1e-3) / 1e12, 2) if conv_ms else None,
+                         "other_kernels": [{"kernel": "sg_attention_kernel", "bound": "mfma", "achieved": round(att_tf, 2) if att_tf else None,
+                                            "peak": FP32_MFMA_PEAK_TFLOPS, "frac": round(att_tf / FP32_MFMA_PEAK_TFLOPS, 4) if att_tf else None,
+                                            "avg_launch_ms": round(att_ms, 4) if att_ms else None, "launches_timed": len(timer.events)}]},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline_subprocess(args.cpu_pairs, args.cpu_threads)

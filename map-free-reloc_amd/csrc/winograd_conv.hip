@@ -13,19 +13,25 @@
 //   => 16 independent GEMMs  M_xi[cout, tile] = sum_cin U_xi[cout, cin] V_xi[cin, tile]
 //
 // Mapping to CDNA4:
-//   * workgroup = 4 wavefronts = 4 tile rows x 16 tiles (8 x 32 output pixels) x 32 output channels;
-//     wavefront w owns tile row w: 16 tiles = the N dimension of the 16x16x4 MFMA, 2 M-blocks of 16 couts,
-//     all 16 Winograd positions xi -> 16 x 2 accumulators of 4 VGPRs = 128 accumulator registers.
+//   * workgroup = 4 wavefronts = 4 tile rows x 16 tiles (8 x 32 output pixels) x 16*NBLK output channels;
+//     wavefront w owns tile row w: 16 tiles = the N dimension of the 16x16x4 MFMA, NBLK M-blocks of 16 couts,
+//     all 16 Winograd positions xi -> 16 x NBLK accumulators of 4 registers.  NBLK = 2: 128 accumulator
+//     registers, two workgroups per CU; NBLK = 4: 256 accumulator registers (the whole AGPR file), one
+//     wavefront per SIMD -- the input patch loads and the input transform are amortised over twice the MFMAs
+//     (the NBLK = 2 stream is issue-bound: ~3 non-MFMA instructions per MFMA with two waves per SIMD).
 //   * the K dimension is cin, 4 per MFMA.  Lane (kq = lane>>4, col = lane&15) loads the 4x4 input patch of
 //     (cin = 4c + kq, tile col), transforms it in registers (32 adds) -- and the 16 results ARE that lane's
 //     B operands for the 16 xi MFMAs: the input transform never touches LDS.
 //   * U (transformed filters) is pre-packed once per weight set in exactly the order the lanes consume it;
-//     an 8 KB slab per (cin chunk, cout block) is staged through LDS (double buffered, one barrier per
+//     a 4*NBLK KB slab per (cin chunk, cout block) is staged through LDS (double buffered, one barrier per
 //     chunk) and read back as conflict-free ds_read_b128: one read = A operands of 4 MFMAs.
+//   * input patches come through buffer loads: zero padding = out-of-range offsets (hardware returns 0); each
+//     lane loads its two own columns as one dwordx2 and takes the other two from its neighbours' registers
+//     with DPP row shifts (16-lane row = one tile row); only the edge lanes fetch a halo element.
 //   * all 16 xi of a (tile, cout) end in the same lane, so the output transform, bias, ReLU and the 2x2
 //     max-pool (= exactly one Winograd tile) run in registers; the activation is written once.
 //   * grid: 1-D, remapped so the cout blocks of one spatial block land on the same XCD (shared input in L2).
-// Per cin chunk and wavefront: 16 dword loads, 32 VALU adds, 8 ds_read_b128, 32 MFMAs (1024 MFMA cycles).
+// Per cin chunk and wavefront: 8 buffer loads, 8 DPP moves + 32 adds, 4*NBLK ds_read_b128, 16*NBLK MFMAs.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -38,11 +44,24 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define WN_TX 16                 // tiles along x per workgroup
 #define WN_TY 4                  // tile rows per workgroup (= wavefronts)
-#define WN_CO 32                 // output channels per workgroup
-#define WN_SLAB 2048             // floats of packed U per (cin chunk of 4, cout block of 32)
 
-// packed index of U_xi[cout][cin]: [chunk c = cin/4][cout block cb][q = xi/4][blk][lane = (cin%4)*16 + cout%16][e = xi%4]
-__global__ void __launch_bounds__(256) wino_filter_kernel(const float *__restrict__ w, int Cin, int Cout, float *__restrict__ upk)
+// dword3 of a raw buffer descriptor on gfx9-family CDNA (32-bit data format); out-of-range reads return 0,
+// which is how the zero padding of the convolution is produced: padded taps get an offset beyond the buffer
+#define WN_RSRC_FLAGS 0x00020000
+#define WN_OOB 0x80000000u
+
+// NBLK (16-cout MFMA blocks per workgroup).  Measured on the SuperPoint layers (B = 32 images): NBLK = 2 (two
+// workgroups per CU) 12.2 ms for the nine layers, NBLK = 4 (one wavefront per SIMD) 14.3 ms -- the un-overlapped
+// prologue/epilogue and barrier skew of a lone wavefront cost more than the halved transform work saves, so 2 is
+// the default; MFR_WINO_NBLK=4 selects the other instantiation (tuning aid, needs Cout % 64 == 0).
+static inline int wn_nblk(int Cout)
+{
+    const char *ev = getenv("MFR_WINO_NBLK");
+    return (ev && atoi(ev) == 4 && Cout % 64 == 0) ? 4 : 2;
+}
+
+// packed U_xi[cout][cin]: [chunk c = cin/4][cout block cb][q = xi/4][blk][lane = (cin%4)*16 + cout%16][e = xi%4]
+__global__ void __launch_bounds__(256) wino_filter_kernel(const float *__restrict__ w, int Cin, int Cout, int nblk, float *__restrict__ upk)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= Cin * Cout) return;
@@ -54,32 +73,29 @@ __global__ void __launch_bounds__(256) wino_filter_kernel(const float *__restric
         const float g0 = g[j], g1 = g[3 + j], g2 = g[6 + j];
         t[0][j] = g0; t[1][j] = 0.5f * (g0 + g1 + g2); t[2][j] = 0.5f * (g0 - g1 + g2); t[3][j] = g2;
     }
-    const int ncb = Cout / WN_CO;
-    const int c = ci >> 2, kq = ci & 3, cb = co / WN_CO, blk = (co % WN_CO) >> 4, row = co & 15;
-    float *dst = upk + ((size_t)c * ncb + cb) * WN_SLAB;
+    const int wco = 16 * nblk, ncb = Cout / wco, slab = 1024 * nblk;
+    const int c = ci >> 2, kq = ci & 3, cb = co / wco, blk = (co % wco) >> 4, row = co & 15;
+    float *dst = upk + ((size_t)c * ncb + cb) * slab;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         float u[4];
         u[0] = t[r][0]; u[1] = 0.5f * (t[r][0] + t[r][1] + t[r][2]); u[2] = 0.5f * (t[r][0] - t[r][1] + t[r][2]); u[3] = t[r][2];
         // xi = 4 r + j  ->  q = r, e = j
-        *(float4 *)(dst + (((size_t)r * 2 + blk) * 64 + kq * 16 + row) * 4) = make_float4(u[0], u[1], u[2], u[3]);
+        *(float4 *)(dst + (((size_t)r * nblk + blk) * 64 + kq * 16 + row) * 4) = make_float4(u[0], u[1], u[2], u[3]);
     }
 }
 
-// dword3 of a raw buffer descriptor on gfx9-family CDNA (32-bit data format); out-of-range reads return 0,
-// which is how the zero padding of the convolution is produced: padded taps get an offset beyond the buffer
-#define WN_RSRC_FLAGS 0x00020000
-#define WN_OOB 0x80000000u
-
-// PAIR: W even -> each lane loads its two own columns as one aligned dwordx2 and takes the other two
-// from its neighbours' registers (DPP row shifts inside the 16-lane tile row); only the two edge lanes of a row
-// fetch a halo element.  8 vector-memory instructions per 4x4x(4 cin) patch instead of 16.
-template <bool POOL, bool PAIR, int ABL>
-__global__ void __launch_bounds__(256, 2) wino_conv3x3_kernel(
+// LOAD: 0 = 16 dword loads per patch (any layout); 1 = dwordx2 + neighbour sharing, W even; 2 = same, W odd (the
+// last column's pair partner belongs to the next row and is masked)
+template <bool POOL, int LOAD, int NBLK>
+__global__ void __launch_bounds__(256, NBLK == 2 ? 2 : 1) wino_conv3x3_kernel(
     const float *__restrict__ x, const float *__restrict__ upk, const float *__restrict__ bias, float *__restrict__ y,
     int Cin, int Cout, int H, int W, int nbx, int nby, int S, int ncb, int relu)
 {
-    __shared__ __attribute__((aligned(16))) float Us[2][WN_SLAB];         // double-buffered U slab of one cin chunk
+    constexpr int SLAB = 1024 * NBLK;                        // floats of packed U per (cin chunk of 4, cout block)
+    constexpr int WCO = 16 * NBLK;                           // output channels per workgroup
+    constexpr bool PAIR = LOAD != 0;
+    __shared__ __attribute__((aligned(16))) float Us[2][SLAB];
     const int id = blockIdx.x;
     const int xcd = id & 7, jj = id >> 3;
     const int cb = jj % ncb;
@@ -113,14 +129,14 @@ __global__ void __launch_bounds__(256, 2) wino_conv3x3_kernel(
             }
         }
     }
-    const float4 *ub = (const float4 *)(upk + (size_t)cb * WN_SLAB) + tid;
-    const size_t ustride = (size_t)ncb * (WN_SLAB / 4);      // float4 per chunk
+    const bool p1ok = 2 * tx + 1 < W;                        // LOAD == 2 only
+    const float4 *ub = (const float4 *)(upk + (size_t)cb * SLAB) + tid;
+    const size_t ustride = (size_t)ncb * (SLAB / 4);         // float4 per chunk
     const int nchunks = Cin >> 2;
     const unsigned cstep = 16u * HW;                         // bytes per 4-channel chunk
 
     auto gload = [&](unsigned (&raw)[NRAW], int c) {
         const unsigned so = (unsigned)c * cstep;
-        if (ABL & 1) return;
         if (PAIR) {
 #pragma unroll
             for (int a = 0; a < 4; ++a) {
@@ -139,7 +155,8 @@ __global__ void __launch_bounds__(256, 2) wino_conv3x3_kernel(
         if (PAIR) {
 #pragma unroll
             for (int a = 0; a < 4; ++a) {
-                const int p0 = (int)raw[3 * a], p1 = (int)raw[3 * a + 1], hv = (int)raw[3 * a + 2];
+                const int p0 = (int)raw[3 * a], hv = (int)raw[3 * a + 2];
+                const int p1 = (LOAD == 2 && !p1ok) ? 0 : (int)raw[3 * a + 1];
                 // column 2tx-1 = left neighbour's second element, column 2tx+2 = right neighbour's first; the edge
                 // lanes of the 16-lane row have no neighbour and keep `old` = their halo load
                 d[4 * a] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(hv, p1, 0x111 /* row_shr:1 */, 0xf, 0xf, false));
@@ -168,43 +185,45 @@ __global__ void __launch_bounds__(256, 2) wino_conv3x3_kernel(
         }
     };
 
-    f32x4 acc[16][2];
+    f32x4 acc[16][NBLK];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { acc[i][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[i][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    for (int i = 0; i < 16; ++i)
+#pragma unroll
+        for (int k = 0; k < NBLK; ++k) acc[i][k] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    auto mfma_chunk = [&](const float *slab, const float (&v)[16]) {
+    // NBLK == 4 runs one wavefront per SIMD: nobody else hides the LDS latency, so the A operands of the whole chunk
+    // are requested first and the input transform runs underneath them
+    auto aload = [&](const float *slab, float4 (&a)[4 * NBLK]) {
         const float4 *us = (const float4 *)slab + lane;
 #pragma unroll
+        for (int i = 0; i < 4 * NBLK; ++i) a[i] = us[i * 64];
+    };
+    auto mfma_chunk = [&](const float4 (&a)[4 * NBLK], const float (&v)[16]) {
+#pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const float4 a0 = us[(q * 2) * 64], a1 = us[(q * 2 + 1) * 64];
-            acc[4 * q][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, v[4 * q], acc[4 * q][0], 0, 0, 0);
-            acc[4 * q][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, v[4 * q], acc[4 * q][1], 0, 0, 0);
-            acc[4 * q + 1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, v[4 * q + 1], acc[4 * q + 1][0], 0, 0, 0);
-            acc[4 * q + 1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, v[4 * q + 1], acc[4 * q + 1][1], 0, 0, 0);
-            acc[4 * q + 2][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, v[4 * q + 2], acc[4 * q + 2][0], 0, 0, 0);
-            acc[4 * q + 2][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, v[4 * q + 2], acc[4 * q + 2][1], 0, 0, 0);
-            acc[4 * q + 3][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, v[4 * q + 3], acc[4 * q + 3][0], 0, 0, 0);
-            acc[4 * q + 3][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, v[4 * q + 3], acc[4 * q + 3][1], 0, 0, 0);
+#pragma unroll
+            for (int k = 0; k < NBLK; ++k) acc[4 * q][k] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q * NBLK + k].x, v[4 * q], acc[4 * q][k], 0, 0, 0);
+#pragma unroll
+            for (int k = 0; k < NBLK; ++k) acc[4 * q + 1][k] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q * NBLK + k].y, v[4 * q + 1], acc[4 * q + 1][k], 0, 0, 0);
+#pragma unroll
+            for (int k = 0; k < NBLK; ++k) acc[4 * q + 2][k] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q * NBLK + k].z, v[4 * q + 2], acc[4 * q + 2][k], 0, 0, 0);
+#pragma unroll
+            for (int k = 0; k < NBLK; ++k) acc[4 * q + 3][k] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q * NBLK + k].w, v[4 * q + 3], acc[4 * q + 3][k], 0, 0, 0);
         }
     };
 
     unsigned raw[NRAW];
-    float4 u0, u1;
-    auto uload = [&](int c) {                                // the chunk's 8 KB slab: 2 float4 per thread
-        if (ABL & 2) return;
+    float4 u0, u1, u2, u3;                                   // the chunk's slab: NBLK float4 per thread
+    auto uload = [&](int c) {
         const float4 *q = ub + (size_t)c * ustride;
         u0 = q[0]; u1 = q[256];
+        if (NBLK == 4) { u2 = q[512]; u3 = q[768]; }
     };
     auto ustore = [&](int st) {
-        if (ABL & 2) return;
         float4 *d0 = (float4 *)Us[st] + tid;
         d0[0] = u0; d0[256] = u1;
+        if (NBLK == 4) { d0[512] = u2; d0[768] = u3; }
     };
-    if (ABL & 1) {
-#pragma unroll
-        for (int i = 0; i < NRAW; ++i) raw[i] = off[i % NOFF] ^ (unsigned)i;
-    }
-    if (ABL & 2) { u0 = make_float4(0.f, 0.f, 0.f, 0.f); u1 = u0; }
     gload(raw, 0);
     uload(0);
     ustore(0);
@@ -213,22 +232,25 @@ __global__ void __launch_bounds__(256, 2) wino_conv3x3_kernel(
     for (int c = 0; c < nchunks; ++c) {
         const bool more = c + 1 < nchunks;
         float v[16];
+        float4 a[4 * NBLK];
+        aload(Us[c & 1], a);
+        if (NBLK == 4) __builtin_amdgcn_sched_barrier(0);
         transform(raw, v);
-        if (more) { gload(raw, c + 1); uload(c + 1); }       // in flight during the 32 MFMAs below
-        mfma_chunk(Us[c & 1], v);
+        if (more) { gload(raw, c + 1); uload(c + 1); }       // in flight during the MFMAs below
+        if (NBLK == 4) __builtin_amdgcn_sched_barrier(0);
+        mfma_chunk(a, v);
         if (more) ustore((c + 1) & 1);
-        if (!(ABL & 2)) __syncthreads();
+        __syncthreads();
     }
-    if (ABL & 4) { if (acc[0][0][0] != 123.456f) return; }
 
     // output transform A^T M A + bias (+ReLU) (+2x2 max-pool) in registers; accumulator register r of
-    // M-block blk = cout cb*32 + blk*16 + 4 kq + r, column = this lane's tile
+    // M-block blk = cout cb*WCO + blk*16 + 4 kq + r, column = this lane's tile
     const int Ho = POOL ? (H >> 1) : H, Wo = POOL ? (W >> 1) : W;
 #pragma unroll
-    for (int blk = 0; blk < 2; ++blk) {
+    for (int blk = 0; blk < NBLK; ++blk) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int co = cb * WN_CO + blk * 16 + 4 * kq + r;
+            const int co = cb * WCO + blk * 16 + 4 * kq + r;
             float a0[4], a1[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -247,7 +269,7 @@ __global__ void __launch_bounds__(256, 2) wino_conv3x3_kernel(
                 if (relu) { y00 = fmaxf(y00, 0.f); y01 = fmaxf(y01, 0.f); y10 = fmaxf(y10, 0.f); y11 = fmaxf(y11, 0.f); }
                 const int oy = 2 * ty, ox = 2 * tx;
                 if (ox + 1 < W) {
-                    if (!(W & 1)) {
+                    if (LOAD == 1) {                         // W even: 8-byte aligned pairs
                         if (oy < H) *(float2 *)(yo + (size_t)oy * W + ox) = make_float2(y00, y01);
                         if (oy + 1 < H) *(float2 *)(yo + (size_t)(oy + 1) * W + ox) = make_float2(y10, y11);
                     } else {
@@ -263,18 +285,26 @@ __global__ void __launch_bounds__(256, 2) wino_conv3x3_kernel(
     }
 }
 
+template <bool POOL, int LOAD, int NBLK>
+static void wn_launch(long long grid, hipStream_t st, const float *x, const float *upk, const float *bias, float *y, int Cin, int Cout,
+                      int H, int W, int nbx, int nby, int S, int ncb, int relu)
+{
+    hipLaunchKernelGGL((wino_conv3x3_kernel<POOL, LOAD, NBLK>), dim3((unsigned)grid), dim3(256), 0, st, x, upk, bias, y, Cin, Cout, H, W,
+                       nbx, nby, S, ncb, relu);
+}
+
 extern "C" {
 
 size_t mfr_wino_filter_bytes(int Cin, int Cout)
 {
-    if (Cin <= 0 || Cout <= 0 || (Cin & 3) || (Cout % WN_CO)) return 0;
+    if (Cin <= 0 || Cout <= 0 || (Cin & 3) || (Cout % 32)) return 0;
     return sizeof(float) * 16 * (size_t)Cin * Cout;
 }
 
 int mfr_wino_filter_transform(const float *w, int Cin, int Cout, float *upk, void *stream)
 {
-    if (!w || !upk || Cin <= 0 || Cout <= 0 || (Cin & 3) || (Cout % WN_CO)) return MFR_E_ARG;
-    hipLaunchKernelGGL(wino_filter_kernel, dim3((Cin * Cout + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, Cin, Cout, upk);
+    if (!w || !upk || Cin <= 0 || Cout <= 0 || (Cin & 3) || (Cout % 32)) return MFR_E_ARG;
+    hipLaunchKernelGGL(wino_filter_kernel, dim3((Cin * Cout + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, Cin, Cout, wn_nblk(Cout), upk);
     CHECK_LAUNCH();
     return 0;
 }
@@ -282,35 +312,25 @@ int mfr_wino_filter_transform(const float *w, int Cin, int Cout, float *upk, voi
 int mfr_conv3x3_wino(const float *x, const float *upk, const float *bias, int B, int Cin, int Cout, int H, int W,
                      int relu, int pool, float *y, void *stream)
 {
-    if (!x || !upk || !y || B <= 0 || Cin <= 0 || Cout <= 0 || (Cin & 3) || (Cout % WN_CO) || H <= 0 || W <= 0) return MFR_E_ARG;
+    if (!x || !upk || !y || B <= 0 || Cin <= 0 || Cout <= 0 || (Cin & 3) || (Cout % 32) || H <= 0 || W <= 0) return MFR_E_ARG;
     if (pool && (H < 2 || W < 2)) return MFR_E_ARG;
     if ((size_t)4 * Cin * H * W >= 0x7fffffffull) return MFR_E_ARG;    // one image must fit a 2 GB buffer descriptor
+    const int nblk = wn_nblk(Cout);
     const int nbx = ((W + 1) / 2 + WN_TX - 1) / WN_TX, nby = ((H + 1) / 2 + WN_TY - 1) / WN_TY;
-    const int ncb = Cout / WN_CO;
+    const int ncb = Cout / (16 * nblk);
     const long long S = (long long)nbx * nby * B;
     const long long grid = (S + 7) / 8 * 8 * ncb;
     if (grid > 0x7fffffffll) return MFR_E_ARG;
-    const bool pair = !(W & 1) && !((uintptr_t)x & 7);
-#define WN_LAUNCH(P, Q, A) hipLaunchKernelGGL((wino_conv3x3_kernel<P, Q, A>), dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, x, upk, bias, \
-                                              y, Cin, Cout, H, W, nbx, nby, (int)S, ncb, relu)
-    const char *ev = getenv("MFR_WINO_ABL");
-    const int abl = ev ? atoi(ev) : 0;
-    if (abl && pool && pair) {
-        switch (abl) {
-        case 1: WN_LAUNCH(true, true, 1); break;
-        case 2: WN_LAUNCH(true, true, 2); break;
-        case 3: WN_LAUNCH(true, true, 3); break;
-        case 4: WN_LAUNCH(true, true, 4); break;
-        case 7: WN_LAUNCH(true, true, 7); break;
-        case 16: WN_LAUNCH(true, false, 0); break;
-        default: return MFR_E_ARG;
-        }
-        CHECK_LAUNCH();
-        return 0;
-    }
-    if (pool) { if (pair) WN_LAUNCH(true, true, 0); else WN_LAUNCH(true, false, 0); }
-    else { if (pair) WN_LAUNCH(false, true, 0); else WN_LAUNCH(false, false, 0); }
-#undef WN_LAUNCH
+    const char *ev = getenv("MFR_WINO_LOAD");                // tuning aid: 0 forces the 16-dword path
+    const int load = (ev && atoi(ev) == 0) ? 0 : ((W & 1) ? 2 : 1);
+    hipStream_t st = (hipStream_t)stream;
+#define WN_ARGS grid, st, x, upk, bias, y, Cin, Cout, H, W, nbx, nby, (int)S, ncb, relu
+#define WN_PICK_LOAD(P, N) do { if (load == 0) wn_launch<P, 0, N>(WN_ARGS); else if (load == 1) wn_launch<P, 1, N>(WN_ARGS); \
+                                else wn_launch<P, 2, N>(WN_ARGS); } while (0)
+    if (nblk == 4) { if (pool) WN_PICK_LOAD(true, 4); else WN_PICK_LOAD(false, 4); }
+    else { if (pool) WN_PICK_LOAD(true, 2); else WN_PICK_LOAD(false, 2); }
+#undef WN_PICK_LOAD
+#undef WN_ARGS
     CHECK_LAUNCH();
     return 0;
 }

@@ -22,45 +22,69 @@ def _fold_bn(w, b, sd, bn):
     return w * s[:, None], (b - mean) * s + beta
 
 
+def fold_weights(state_dict, n_layers=18):
+    """Upstream SuperGlue parameters -> the fused f32 operands the GPU path multiplies with (pure host code).
+
+    Per GNN layer the upstream graph is  x <- x + W2 relu(BN(W1 [x ; Wm a + bm] + b1)) + b2  with a = attention(...).
+    Exact re-associations, done once in float64:
+      * BatchNorm folded into mlp.0 (and into the keypoint encoder);
+      * the merge projection only feeds the MLP:  W1 [x ; Wm a + bm] = [W1x | W1m Wm] [x ; a] + W1m bm
+        -> one 256x256 GEMM per layer disappears and [x ; a] is a single buffer the attention kernel writes into;
+      * the constant b2 is carried as an offset c (x = x~ + c, c <- c + b2) folded into the NEXT layer's biases
+        (Wqkv c, W1x c) and into final_proj -> the residual update is a pure in-place GEMM epilogue;
+      * upstream's [dim, head] channel split (channel c = 4 d + h) re-ordered to head-major (64 h + d) by permuting
+        the q/k/v output rows and the merge input columns.
+    No elementwise kernel (cat / relu / add) is left between the GEMMs.
+    Returns dict(kenc=[(w,b)...], layers=[dict(wqkv,bqkv,w1,b1,w2,cross)...], wf, bf, bin_score)."""
+    sd = {k: v.double() for k, v in state_dict.items()}
+    lin = lambda n: sd[n + ".weight"].squeeze(-1)
+    f32 = lambda t: t.float().contiguous()
+    kenc = []
+    for i in range(4):
+        w, b = _fold_bn(lin(f"kenc.encoder.{3 * i}"), sd[f"kenc.encoder.{3 * i}.bias"], sd, f"kenc.encoder.{3 * i + 1}")
+        kenc.append((f32(w), f32(b)))
+    kenc.append((f32(lin("kenc.encoder.12")), f32(sd["kenc.encoder.12.bias"])))
+    perm = torch.tensor([(c % 64) * 4 + c // 64 for c in range(256)])          # head-major <- upstream channel
+    layers = []
+    c = torch.zeros(256, dtype=torch.float64)
+    for l in range(n_layers):
+        p = f"gnn.layers.{l}"
+        wqkv = torch.cat([lin(f"{p}.attn.proj.{j}")[perm] for j in range(3)], 0)
+        bqkv = torch.cat([sd[f"{p}.attn.proj.{j}.bias"][perm] for j in range(3)], 0)
+        wm, bm = lin(f"{p}.attn.merge")[:, perm], sd[f"{p}.attn.merge.bias"]
+        w1, b1 = _fold_bn(lin(f"{p}.mlp.0"), sd[f"{p}.mlp.0.bias"], sd, f"{p}.mlp.1")
+        w1x, w1m = w1[:, :256], w1[:, 256:]
+        layers.append(dict(wqkv=f32(wqkv), bqkv=f32(bqkv + wqkv @ c), w1=f32(torch.cat([w1x, w1m @ wm], 1)),
+                           b1=f32(b1 + w1m @ bm + w1x @ c), w2=f32(lin(f"{p}.mlp.3")), cross=(l % 2 == 1)))
+        c = c + sd[f"{p}.mlp.3.bias"]
+    wf = lin("final_proj")
+    return dict(kenc=kenc, layers=layers, wf=f32(wf), bf=f32(sd["final_proj.bias"] + wf @ c), bin_score=float(sd["bin_score"]))
+
+
 class SuperGlueHIP:
     def __init__(self, state_dict, device="cuda", sinkhorn_iterations=20, match_threshold=0.2, n_layers=18):
         _lib.load(require_gpu=True)
         self.device = torch.device(device)
         self.iters, self.match_thr = int(sinkhorn_iterations), float(match_threshold)
-        sd = {k: v.float() for k, v in state_dict.items()}
+        fw = fold_weights(state_dict, n_layers)
         dev = lambda t: t.to(self.device).contiguous()
-        lin = lambda n: sd[n + ".weight"].squeeze(-1)
-        # keypoint encoder MLP [3,32,64,128,256,256] with BN folded
-        self.kenc = []
-        for i in range(4):
-            w, b = _fold_bn(lin(f"kenc.encoder.{3 * i}"), sd[f"kenc.encoder.{3 * i}.bias"], sd, f"kenc.encoder.{3 * i + 1}")
-            self.kenc.append((dev(w), dev(b)))
-        self.kenc.append((dev(lin("kenc.encoder.12")), dev(sd["kenc.encoder.12.bias"])))
-        perm = torch.tensor([(c % 64) * 4 + c // 64 for c in range(256)])      # head-major <- upstream channel
-        self.layers = []
-        for l in range(n_layers):
-            p = f"gnn.layers.{l}"
-            wq = [lin(f"{p}.attn.proj.{j}")[perm] for j in range(3)]
-            bq = [sd[f"{p}.attn.proj.{j}.bias"][perm] for j in range(3)]
-            wm = lin(f"{p}.attn.merge")[:, perm]
-            w1, b1 = _fold_bn(lin(f"{p}.mlp.0"), sd[f"{p}.mlp.0.bias"], sd, f"{p}.mlp.1")
-            self.layers.append(dict(
-                wqkv=dev(torch.cat(wq, 0)), bqkv=dev(torch.cat(bq, 0)), wm=dev(wm), bm=dev(sd[f"{p}.attn.merge.bias"]),
-                w1=dev(w1), b1=dev(b1), w2=dev(lin(f"{p}.mlp.3")), b2=dev(sd[f"{p}.mlp.3.bias"]),
-                cross=(l % 2 == 1)))
-        self.wf, self.bf = dev(lin("final_proj")), dev(sd["final_proj.bias"])
-        self.bin_score = float(sd["bin_score"])
+        self.kenc = [(dev(w), dev(b)) for w, b in fw["kenc"]]
+        self.layers = [dict(wqkv=dev(L["wqkv"]), bqkv=dev(L["bqkv"]), w1t=dev(L["w1"]).t(), b1=dev(L["b1"]), w2t=dev(L["w2"]).t(),
+                            cross=L["cross"]) for L in fw["layers"]]
+        self.wf, self.bf = dev(fw["wf"]), dev(fw["bf"])
+        self.bin_score = fw["bin_score"]
         self._ws = None
         self._size = {}
 
-    def attention(self, qkv, n_tok, cross):
-        """qkv [B2,K,768] (q | k | v, each head-major) -> message [B2,K,256]"""
+    def attention(self, qkv, n_tok, cross, out=None, ldo=256):
+        """qkv [B2,K,768] (q | k | v, each head-major) -> message [B2,K,256] (or into `out`, row stride ldo floats)"""
         lib = _lib.load()
         B2, K, _ = qkv.shape
-        out = torch.empty(B2, K, 256, dtype=torch.float32, device=qkv.device)
+        if out is None:
+            out = torch.empty(B2, K, 256, dtype=torch.float32, device=qkv.device)
         base = qkv.data_ptr()
         _lib.check(lib.mfr_sg_attention(base, base + 256 * 4, base + 512 * 4, 768, B2, K, 4, _lib.ptr(n_tok),
-                                        1 if cross else 0, _lib.ptr(out), 256, _lib.stream_ptr()), "mfr_sg_attention")
+                                        1 if cross else 0, out.data_ptr(), ldo, _lib.stream_ptr()), "mfr_sg_attention")
         return out
 
     def sinkhorn_match(self, S, n0, n1, kpts0, kpts1, maxN=None):
@@ -98,14 +122,16 @@ class SuperGlueHIP:
             h = F.linear(h, w, b)
             if i < len(self.kenc) - 1:
                 h = F.relu_(h)
-        x = desc + h
+        # xa = [x~ | a]: the running descriptors (minus the folded bias offset) and the attention output side by side
+        xa = torch.empty(B2 * K, 512, dtype=torch.float32, device=kpts.device)
+        xv, av = xa[:, :256], xa[:, 256:]
+        torch.add(desc.reshape(B2 * K, 256), h.reshape(B2 * K, 256), out=xv)
         for L in self.layers:
-            qkv = F.linear(x, L["wqkv"], L["bqkv"])
-            msg = self.attention(qkv, n, L["cross"])
-            msg = F.linear(msg, L["wm"], L["bm"])
-            hid = F.relu_(F.linear(torch.cat([x, msg], -1), L["w1"], L["b1"]))
-            x = x + F.linear(hid, L["w2"], L["b2"])
-        return F.linear(x, self.wf, self.bf)
+            qkv = torch.addmm(L["bqkv"], xv, L["wqkv"].t()).view(B2, K, 768)
+            self.attention(qkv, n, L["cross"], out=av, ldo=512)
+            hid = torch._addmm_activation(L["b1"], xa, L["w1t"])          # relu(W1' [x~ ; a] + b1') in the GEMM epilogue
+            xv.addmm_(hid, L["w2t"])                                      # x~ += W2 hid, in place
+        return torch.addmm(self.bf, xv, self.wf.t()).view(B2, K, 256)
 
     @torch.no_grad()
     def __call__(self, sp_out, image_hw, maxN=None):

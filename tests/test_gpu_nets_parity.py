@@ -136,13 +136,21 @@ def test_attention_matches_upstream_head_layout(sg_pair):
     layer = ref.gnn.layers[1]                                         # a cross layer
     with torch.no_grad():
         want0 = x0 + layer(x0, x1); want1 = x1 + layer(x1, x0)
+    # the GPU path runs the fused form of the layer (nets/superglue.fold_weights): x = x~ + c with c = the mlp.3 biases
+    # of the layers before it, merge projection folded into mlp.0, [x~ ; a] as one buffer the attention kernel writes into
     L = hip.layers[1]
+    c1 = ref.gnn.layers[0].mlp[3].bias.detach().to(DEV)
+    b2 = layer.mlp[3].bias.detach().to(DEV)
     x = torch.stack([x0[0].t(), x1[0].t()]).to(DEV).contiguous()      # [2,N,256]
     n = torch.tensor([N, N], dtype=torch.int32, device=DEV)
-    qkv = F.linear(x, L["wqkv"], L["bqkv"])
-    msg = F.linear(hip.attention(qkv, n, True), L["wm"], L["bm"])
-    hid = F.relu(F.linear(torch.cat([x, msg], -1), L["w1"], L["b1"]))
-    out = (x + F.linear(hid, L["w2"], L["b2"])).cpu()
+    xa = torch.empty(2 * N, 512, device=DEV)
+    xv, av = xa[:, :256], xa[:, 256:]
+    xv.copy_((x - c1).reshape(2 * N, 256))
+    qkv = torch.addmm(L["bqkv"], xv, L["wqkv"].t()).view(2, N, 768)
+    hip.attention(qkv, n, True, out=av, ldo=512)
+    hid = torch._addmm_activation(L["b1"], xa, L["w1t"])
+    xv.addmm_(hid, L["w2t"])
+    out = (xv + c1 + b2).view(2, N, 256).cpu()
     np.testing.assert_allclose(out[0].t().numpy(), want0[0].numpy(), rtol=1e-4, atol=1e-4)
     np.testing.assert_allclose(out[1].t().numpy(), want1[0].numpy(), rtol=1e-4, atol=1e-4)
 

@@ -210,3 +210,63 @@ def test_mapfree_scene_reader_on_synthetic_tree(tmp_path):
     np.testing.assert_allclose(d["T_0to1"][:3, 3].numpy(), t2, atol=1e-6)
     b = collate_batch1(d)
     assert b["depth0"].shape == (1, 48, 36) and b["scene_id"] == ["s00460"] and b["pair_names"][1] == ["seq1/frame_00005.jpg"]
+
+
+def test_superglue_weight_folding_is_exact_algebra():
+    """nets/superglue.fold_weights re-associates the upstream GNN layer (merge projection folded into mlp.0, b2 carried
+    as an offset, BatchNorm folded, head-major channels): the fused f32 operands, driven by a plain float64 softmax
+    attention, must reproduce the upstream graph (oracle/nets_ref.SuperGlueRef, a restatement with upstream
+    parameter names) to rounding."""
+    import torch
+    from mapfree_reloc_amd.nets import weights as WT
+    from mapfree_reloc_amd.nets.superglue import fold_weights
+    from oracle import nets_ref
+    torch.manual_seed(0)
+    sd = WT.superglue_state_dict()
+    # make every folded term matter: random biases and non-trivial BatchNorm statistics
+    g = torch.Generator().manual_seed(1)
+    for k in sd:
+        if k.endswith(".bias") and ("gnn" in k or "final_proj" in k):
+            sd[k] = 0.1 * torch.randn(sd[k].shape, generator=g)
+        if k.endswith("running_mean"):
+            sd[k] = 0.1 * torch.randn(sd[k].shape, generator=g)
+        if k.endswith("running_var"):
+            sd[k] = 0.5 + torch.rand(sd[k].shape, generator=g)
+    ref = nets_ref.SuperGlueRef().double().eval()
+    ref.load_state_dict({k: v.double() for k, v in sd.items()})
+    n0, n1, H, W = 37, 29, 120, 160
+    k0 = torch.rand(1, n0, 2, generator=g).double() * torch.tensor([W, H]); k1 = torch.rand(1, n1, 2, generator=g).double() * torch.tensor([W, H])
+    s0, s1 = torch.rand(1, n0, generator=g).double(), torch.rand(1, n1, generator=g).double()
+    d0 = torch.nn.functional.normalize(torch.randn(1, 256, n0, generator=g).double(), dim=1)
+    d1 = torch.nn.functional.normalize(torch.randn(1, 256, n1, generator=g).double(), dim=1)
+    out = ref(k0, s0, d0, k1, s1, d1, (H, W))
+
+    fw = fold_weights(sd)
+
+    def run(kp, sc, de, kp_o, sc_o, de_o):
+        def enc(kp, sc, de):
+            kn = (kp[0] - torch.tensor([W / 2, H / 2])) / (max(W, H) * 0.7)
+            h = torch.cat([kn, sc[0, :, None]], -1)
+            for i, (w, b) in enumerate(fw["kenc"]):
+                h = h @ w.double().t() + b.double()
+                if i < 4:
+                    h = h.relu()
+            return de[0].t() + h
+        xs = [enc(kp, sc, de), enc(kp_o, sc_o, de_o)]
+        for L in fw["layers"]:
+            qkv = [x @ L["wqkv"].double().t() + L["bqkv"].double() for x in xs]
+            new = []
+            for i in (0, 1):
+                src = qkv[1 - i] if L["cross"] else qkv[i]
+                a = []
+                for h in range(4):
+                    q, k, v = qkv[i][:, 64 * h:64 * h + 64], src[:, 256 + 64 * h:256 + 64 * h + 64], src[:, 512 + 64 * h:512 + 64 * h + 64]
+                    a.append(torch.softmax(q @ k.t() / 8.0, -1) @ v)
+                hid = (torch.cat([xs[i]] + a, -1) @ L["w1"].double().t() + L["b1"].double()).relu()
+                new.append(xs[i] + hid @ L["w2"].double().t())
+            xs = new
+        return [x @ fw["wf"].double().t() + fw["bf"].double() for x in xs]
+
+    m0, m1 = run(k0, s0, d0, k1, s1, d1)
+    np.testing.assert_allclose(m0.t().numpy(), out["mdesc0"][0].numpy(), rtol=0, atol=2e-5)
+    np.testing.assert_allclose(m1.t().numpy(), out["mdesc1"][0].numpy(), rtol=0, atol=2e-5)

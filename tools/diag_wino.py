@@ -11,9 +11,10 @@ sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(_
 import mapfree_reloc_amd as m  # noqa: E402
 from mapfree_reloc_amd import _lib  # noqa: E402
 
-LAYERS = [("conv1b", 64, 64, 540, 720, 1), ("conv2a", 64, 64, 270, 360, 0), ("conv2b", 64, 64, 270, 360, 1),
-          ("conv3a", 64, 128, 135, 180, 0), ("conv3b", 128, 128, 135, 180, 1), ("conv4a", 128, 128, 67, 90, 0),
-          ("conv4b", 128, 128, 67, 90, 0), ("convPa", 128, 256, 67, 90, 0), ("convDa", 128, 256, 67, 90, 0)]
+# Map-free frames are 540 wide x 720 tall
+LAYERS = [("conv1b", 64, 64, 720, 540, 1), ("conv2a", 64, 64, 360, 270, 0), ("conv2b", 64, 64, 360, 270, 1),
+          ("conv3a", 64, 128, 180, 135, 0), ("conv3b", 128, 128, 180, 135, 1), ("conv4a", 128, 128, 90, 67, 0),
+          ("conv4b", 128, 128, 90, 67, 0), ("convPa", 128, 256, 90, 67, 0), ("convDa", 128, 256, 90, 67, 0)]
 
 
 def wino(x, w, b, relu, pool):
@@ -63,6 +64,33 @@ def main():
         print(f"shape B{B} {ci}->{co} {H}x{W} relu{relu} pool{pool} bias{bias}: max|err| {err:.3e} (library conv {lib_err:.3e}) "
               f"{'OK' if good else 'FAIL'}", flush=True)
     if "--no-time" in sys.argv:
+        return 0 if ok else 1
+    import os
+    for nblk in ("2", "4"):
+        os.environ["MFR_WINO_NBLK"] = nblk
+        tot_w = 0.0
+        for name, ci, co, H, W, pool in LAYERS:
+            x = torch.randn(32, ci, H, W, device=dev)
+            w = torch.randn(co, ci, 3, 3, device=dev) * (1.0 / (3.0 * ci ** 0.5))
+            b = torch.randn(co, device=dev)
+            y, run = wino(x, w, b, 1, pool)
+            for _ in range(2):
+                run()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(8):
+                run()
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 8
+            gf = 2 * 9 * ci * co * H * W * 32 / 1e9
+            tot_w += ms
+            print(f"NBLK<={nblk} {name}: {ms:7.3f} ms ({gf / 2.25 / ms:6.1f} TF on the MFMA pipe)", flush=True)
+            del x, y
+        print(f"NBLK<={nblk} total {tot_w:.3f} ms", flush=True)
+    os.environ.pop("MFR_WINO_NBLK")
+    if "--no-lib" in sys.argv:
         return 0 if ok else 1
     tot_w = tot_l = 0.0
     for name, ci, co, H, W, pool in LAYERS:
