@@ -30,7 +30,8 @@
 //     with DPP row shifts (16-lane row = one tile row); only the edge lanes fetch a halo element.
 //   * all 16 xi of a (tile, cout) end in the same lane, so the output transform, bias, ReLU and the 2x2
 //     max-pool (= exactly one Winograd tile) run in registers; the activation is written once.
-//   * grid: 1-D, remapped so the cout blocks of one spatial block land on the same XCD (shared input in L2).
+//   * grid: 1-D, remapped so that every XCD walks one contiguous raster range of spatial blocks (cout blocks
+//     innermost): halo rows/columns and the second cout block are L2 hits.
 // Per cin chunk and wavefront: 8 buffer loads, 8 DPP moves + 32 adds, 4*NBLK ds_read_b128, 16*NBLK MFMAs.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -90,17 +91,22 @@ __global__ void __launch_bounds__(256) wino_filter_kernel(const float *__restric
 template <bool POOL, int LOAD, int NBLK>
 __global__ void __launch_bounds__(256, NBLK == 2 ? 2 : 1) wino_conv3x3_kernel(
     const float *__restrict__ x, const float *__restrict__ upk, const float *__restrict__ bias, float *__restrict__ y,
-    int Cin, int Cout, int H, int W, int nbx, int nby, int S, int ncb, int relu)
+    int Cin, int Cout, int H, int W, int nbx, int nby, int S, int Sx, int ncb, int relu)
 {
     constexpr int SLAB = 1024 * NBLK;                        // floats of packed U per (cin chunk of 4, cout block)
     constexpr int WCO = 16 * NBLK;                           // output channels per workgroup
     constexpr bool PAIR = LOAD != 0;
     __shared__ __attribute__((aligned(16))) float Us[2][SLAB];
+    // workgroup id -> (XCD, position in that XCD's queue): ids are dealt round-robin to the 8 XCDs, so XCD x runs ids
+    // x, x+8, x+16, ...  Each XCD gets one CONTIGUOUS raster range of spatial blocks, cout blocks innermost: the
+    // cout blocks of a spatial block and its row/column neighbours (which share the 2-pixel halo) then run back to back
+    // on the same L2 instead of on 8 different ones (PMC: HBM-side reads 2.3x the input with the interleaved map).
     const int id = blockIdx.x;
     const int xcd = id & 7, jj = id >> 3;
     const int cb = jj % ncb;
-    const int s = (jj / ncb) * 8 + xcd;
-    if (s >= S) return;
+    const int sl = jj / ncb;
+    const int s = xcd * Sx + sl;
+    if (sl >= Sx || s >= S) return;
     const int bx = s % nbx, by = (s / nbx) % nby, b = s / (nbx * nby);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int col = lane & 15, kq = lane >> 4;
@@ -212,7 +218,6 @@ __global__ void __launch_bounds__(256, NBLK == 2 ? 2 : 1) wino_conv3x3_kernel(
         }
     };
 
-    unsigned raw[NRAW];
     float4 u0, u1, u2, u3;                                   // the chunk's slab: NBLK float4 per thread
     auto uload = [&](int c) {
         const float4 *q = ub + (size_t)c * ustride;
@@ -224,6 +229,7 @@ __global__ void __launch_bounds__(256, NBLK == 2 ? 2 : 1) wino_conv3x3_kernel(
         d0[0] = u0; d0[256] = u1;
         if (NBLK == 4) { d0[512] = u2; d0[768] = u3; }
     };
+    unsigned raw[NRAW];
     gload(raw, 0);
     uload(0);
     ustore(0);
@@ -287,10 +293,10 @@ __global__ void __launch_bounds__(256, NBLK == 2 ? 2 : 1) wino_conv3x3_kernel(
 
 template <bool POOL, int LOAD, int NBLK>
 static void wn_launch(long long grid, hipStream_t st, const float *x, const float *upk, const float *bias, float *y, int Cin, int Cout,
-                      int H, int W, int nbx, int nby, int S, int ncb, int relu)
+                      int H, int W, int nbx, int nby, int S, int Sx, int ncb, int relu)
 {
     hipLaunchKernelGGL((wino_conv3x3_kernel<POOL, LOAD, NBLK>), dim3((unsigned)grid), dim3(256), 0, st, x, upk, bias, y, Cin, Cout, H, W,
-                       nbx, nby, S, ncb, relu);
+                       nbx, nby, S, Sx, ncb, relu);
 }
 
 extern "C" {
@@ -319,12 +325,13 @@ int mfr_conv3x3_wino(const float *x, const float *upk, const float *bias, int B,
     const int nbx = ((W + 1) / 2 + WN_TX - 1) / WN_TX, nby = ((H + 1) / 2 + WN_TY - 1) / WN_TY;
     const int ncb = Cout / (16 * nblk);
     const long long S = (long long)nbx * nby * B;
-    const long long grid = (S + 7) / 8 * 8 * ncb;
+    const long long Sx = (S + 7) / 8;                        // spatial blocks per XCD
+    const long long grid = Sx * 8 * ncb;
     if (grid > 0x7fffffffll) return MFR_E_ARG;
     const char *ev = getenv("MFR_WINO_LOAD");                // tuning aid: 0 forces the 16-dword path
     const int load = (ev && atoi(ev) == 0) ? 0 : ((W & 1) ? 2 : 1);
     hipStream_t st = (hipStream_t)stream;
-#define WN_ARGS grid, st, x, upk, bias, y, Cin, Cout, H, W, nbx, nby, (int)S, ncb, relu
+#define WN_ARGS grid, st, x, upk, bias, y, Cin, Cout, H, W, nbx, nby, (int)S, (int)Sx, ncb, relu
 #define WN_PICK_LOAD(P, N) do { if (load == 0) wn_launch<P, 0, N>(WN_ARGS); else if (load == 1) wn_launch<P, 1, N>(WN_ARGS); \
                                 else wn_launch<P, 2, N>(WN_ARGS); } while (0)
     if (nblk == 4) { if (pool) WN_PICK_LOAD(true, 4); else WN_PICK_LOAD(false, 4); }
