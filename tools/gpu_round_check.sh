@@ -15,7 +15,7 @@ for C in FETCH_SIZE WRITE_SIZE; do
 done
 cd /root/repo
 F=$(find gpurun_out/final/pmc_FETCH_SIZE -name '*counter_collection.csv' | head -1); Wr=$(find gpurun_out/final/pmc_WRITE_SIZE -name '*counter_collection.csv' | head -1)
-python tools/pmc_traffic.py "$F" "$Wr" gpurun_out/final/pmc_hbm.csv gpurun_out/final/pmc_wino.json wino_conv3x3 3981312000
+python tools/pmc_traffic.py "$F" "$Wr" gpurun_out/final/pmc_hbm.csv gpurun_out/final/pmc_wino.json wino_conv3x3 7962624000 32
 find gpurun_out/final -name '*counter_collection.csv' -size +8M -delete; find gpurun_out/final -name '*kernel_trace.csv' -size +8M -delete
 head -8 gpurun_out/final/pmc_hbm.csv; cat gpurun_out/final/pmc_wino.json
 tail -3 gpurun_out/final/pytest.log; cat gpurun_out/final/smoke.log | tail -2; cat gpurun_out/final/bench.json

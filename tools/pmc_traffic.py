@@ -1,6 +1,6 @@
 """Per-kernel HBM traffic from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate passes, as
 MI355X_MICROARCH.md prescribes).  Usage:
-  pmc_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> <out.csv> [<json out> <kernel substr> <algorithmic bytes>]
+  pmc_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> <out.csv> [<json out> <kernel substr> <algorithmic bytes> <pairs per step>]
 The CSV lists mean KB per dispatch for every kernel; the JSON singles out the LARGEST-GRID dispatch family of the
 named kernel (for the Winograd convolution: the conv1b launch).  gfx950 correction: FETCH_SIZE x2 (the counter reports half
 of wide coalesced reads; verified on this box on an HBM-streaming kernel), WRITE_SIZE as reported."""
@@ -35,7 +35,7 @@ def main(a):
         cand = [r for r in rows if a[4] in r[0]]
         best = max(cand, key=lambda r: r[1])
         json.dump({"kernel": best[0][:80], "grid_size": best[1], "dispatches": best[2], "FETCH_SIZE_KB": best[3], "WRITE_SIZE_KB": best[4],
-                   "hbm_bytes_per_launch": best[5], "algorithmic_bytes_per_launch": int(a[5]),
+                   "hbm_bytes_per_launch": best[5], "algorithmic_bytes_per_launch": int(a[5]), "pairs_per_step": int(a[6]) if len(a) > 6 else None,
                    "correction": "FETCH_SIZE doubled (gfx950 reports 1/2 of wide coalesced reads, MI355X_MICROARCH.md HBM section); "
                                  "WRITE_SIZE as reported; separate --pmc passes",
                    "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python bench.py --steps 2 --warmup 0 --no-cpu-baseline",
