@@ -263,16 +263,19 @@ int mfr_desc_ratio_match(const float *des0, const float *des1, const float *norm
  * 3x3 / stride 1 / pad 1 convolutions of the SuperPoint encoder (conv1b..conv4b, convPa, convDa; same
  * call site as the SuperPoint kernels above) as a fused Winograd F(2x2,3x3) kernel on the fp32 matrix
  * cores, with +bias, ReLU and the optional 2x2 max-pool in the output transform (csrc/winograd_conv.hip).
- *   mfr_wino_filter_bytes      size of the packed transformed filter (16*Cin*Cout floats); 0 if unsupported
+ *   mfr_wino_filter_bytes      size of the packed transformed filter (16*Cin*ceil32(Cout) floats); 0 if unsupported
  *   mfr_wino_filter_transform  w [Cout,Cin,3,3] f32 -> upk (G g G^T, packed in MFMA operand order); once per weight set
  *   mfr_conv3x3_wino           x [B,Cin,H,W] -> y [B,Cout,H,W] (pool=0) or [B,Cout,H/2,W/2] (pool=1; = max_pool2d(2,2)
- *                              of the ReLU'd activation); bias may be NULL; Cin % 4 == 0, Cout % 32 == 0.
+ *                              of the activation); y = act(conv(x) + bias + residual): bias, residual ([B,Cout,H,W],
+ *                              pool=0 only) may be NULL; act 0 none, 1 ReLU, 2 LeakyReLU(0.01).  Cin % 4 == 0; any Cout
+ *                              (padded to a multiple of 32 inside the packed filter).  Also serves the stride-1 3x3
+ *                              convolutions of LoFTR's ResNet-FPN backbone (BatchNorm folded into w / bias).
  * f32 Winograd arithmetic: agrees with a direct f32 convolution to ~1e-6 relative (not bit-identical).
  * ------------------------------------------------------------------------------------------ */
 size_t mfr_wino_filter_bytes(int Cin, int Cout);
 int mfr_wino_filter_transform(const float *w, int Cin, int Cout, float *upk, void *stream);
-int mfr_conv3x3_wino(const float *x, const float *upk, const float *bias, int B, int Cin, int Cout, int H, int W,
-                     int relu, int pool, float *y, void *stream);
+int mfr_conv3x3_wino(const float *x, const float *upk, const float *bias, const float *residual, int B, int Cin, int Cout,
+                     int H, int W, int act, int pool, float *y, void *stream);
 
 #ifdef __cplusplus
 }

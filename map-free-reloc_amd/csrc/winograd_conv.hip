@@ -62,7 +62,7 @@ static inline int wn_nblk(int Cout)
 }
 
 // packed U_xi[cout][cin]: [chunk c = cin/4][cout block cb][q = xi/4][blk][lane = (cin%4)*16 + cout%16][e = xi%4]
-__global__ void __launch_bounds__(256) wino_filter_kernel(const float *__restrict__ w, int Cin, int Cout, int nblk, float *__restrict__ upk)
+__global__ void __launch_bounds__(256) wino_filter_kernel(const float *__restrict__ w, int Cin, int Cout, int CoutP, int nblk, float *__restrict__ upk)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= Cin * Cout) return;
@@ -74,7 +74,7 @@ __global__ void __launch_bounds__(256) wino_filter_kernel(const float *__restric
         const float g0 = g[j], g1 = g[3 + j], g2 = g[6 + j];
         t[0][j] = g0; t[1][j] = 0.5f * (g0 + g1 + g2); t[2][j] = 0.5f * (g0 - g1 + g2); t[3][j] = g2;
     }
-    const int wco = 16 * nblk, ncb = Cout / wco, slab = 1024 * nblk;
+    const int wco = 16 * nblk, ncb = CoutP / wco, slab = 1024 * nblk;   // couts >= Cout stay zero (buffer pre-cleared)
     const int c = ci >> 2, kq = ci & 3, cb = co / wco, blk = (co % wco) >> 4, row = co & 15;
     float *dst = upk + ((size_t)c * ncb + cb) * slab;
 #pragma unroll
@@ -91,7 +91,7 @@ __global__ void __launch_bounds__(256) wino_filter_kernel(const float *__restric
 template <bool POOL, int LOAD, int NBLK>
 __global__ void __launch_bounds__(256, NBLK == 2 ? 2 : 1) wino_conv3x3_kernel(
     const float *__restrict__ x, const float *__restrict__ upk, const float *__restrict__ bias, float *__restrict__ y,
-    int Cin, int Cout, int H, int W, int nbx, int nby, int S, int Sx, int ncb, int relu)
+    const float *__restrict__ residual, int Cin, int Cout, int H, int W, int nbx, int nby, int S, int Sx, int ncb, int act)
 {
     constexpr int SLAB = 1024 * NBLK;                        // floats of packed U per (cin chunk of 4, cout block)
     constexpr int WCO = 16 * NBLK;                           // output channels per workgroup
@@ -263,17 +263,30 @@ __global__ void __launch_bounds__(256, NBLK == 2 ? 2 : 1) wino_conv3x3_kernel(
                 a0[j] = acc[j][blk][r] + acc[4 + j][blk][r] + acc[8 + j][blk][r];
                 a1[j] = acc[4 + j][blk][r] - acc[8 + j][blk][r] - acc[12 + j][blk][r];
             }
+            if (co >= Cout) continue;                        // padded output channels (Cout not a multiple of 32)
             const float bv = bias ? bias[co] : 0.f;
             float y00 = a0[0] + a0[1] + a0[2] + bv, y01 = a0[1] - a0[2] - a0[3] + bv;
             float y10 = a1[0] + a1[1] + a1[2] + bv, y11 = a1[1] - a1[2] - a1[3] + bv;
-            float *yo = y + ((size_t)b * Cout + co) * ((size_t)Ho * Wo);
+            const size_t plane = ((size_t)b * Cout + co) * ((size_t)Ho * Wo);
+            float *yo = y + plane;
             if (POOL) {
-                float m = fmaxf(fmaxf(y00, y01), fmaxf(y10, y11));
-                if (relu) m = fmaxf(m, 0.f);
+                float m = fmaxf(fmaxf(y00, y01), fmaxf(y10, y11));   // act is monotone: act(max) = max(act)
+                m = (act == 1) ? fmaxf(m, 0.f) : (act == 2) ? (m > 0.f ? m : 0.01f * m) : m;
                 if (ty < Ho && tx < Wo) yo[(size_t)ty * Wo + tx] = m;
             } else {
-                if (relu) { y00 = fmaxf(y00, 0.f); y01 = fmaxf(y01, 0.f); y10 = fmaxf(y10, 0.f); y11 = fmaxf(y11, 0.f); }
                 const int oy = 2 * ty, ox = 2 * tx;
+                if (residual) {
+                    const float *ro = residual + plane;
+                    if (oy < H && ox < W) y00 += ro[(size_t)oy * W + ox];
+                    if (oy < H && ox + 1 < W) y01 += ro[(size_t)oy * W + ox + 1];
+                    if (oy + 1 < H && ox < W) y10 += ro[(size_t)(oy + 1) * W + ox];
+                    if (oy + 1 < H && ox + 1 < W) y11 += ro[(size_t)(oy + 1) * W + ox + 1];
+                }
+                if (act == 1) { y00 = fmaxf(y00, 0.f); y01 = fmaxf(y01, 0.f); y10 = fmaxf(y10, 0.f); y11 = fmaxf(y11, 0.f); }
+                else if (act == 2) {
+                    y00 = y00 > 0.f ? y00 : 0.01f * y00; y01 = y01 > 0.f ? y01 : 0.01f * y01;
+                    y10 = y10 > 0.f ? y10 : 0.01f * y10; y11 = y11 > 0.f ? y11 : 0.01f * y11;
+                }
                 if (ox + 1 < W) {
                     if (LOAD == 1) {                         // W even: 8-byte aligned pairs
                         if (oy < H) *(float2 *)(yo + (size_t)oy * W + ox) = make_float2(y00, y01);
@@ -292,38 +305,42 @@ __global__ void __launch_bounds__(256, NBLK == 2 ? 2 : 1) wino_conv3x3_kernel(
 }
 
 template <bool POOL, int LOAD, int NBLK>
-static void wn_launch(long long grid, hipStream_t st, const float *x, const float *upk, const float *bias, float *y, int Cin, int Cout,
-                      int H, int W, int nbx, int nby, int S, int Sx, int ncb, int relu)
+static void wn_launch(long long grid, hipStream_t st, const float *x, const float *upk, const float *bias, float *y, const float *residual,
+                      int Cin, int Cout, int H, int W, int nbx, int nby, int S, int Sx, int ncb, int act)
 {
-    hipLaunchKernelGGL((wino_conv3x3_kernel<POOL, LOAD, NBLK>), dim3((unsigned)grid), dim3(256), 0, st, x, upk, bias, y, Cin, Cout, H, W,
-                       nbx, nby, S, Sx, ncb, relu);
+    hipLaunchKernelGGL((wino_conv3x3_kernel<POOL, LOAD, NBLK>), dim3((unsigned)grid), dim3(256), 0, st, x, upk, bias, y, residual, Cin, Cout,
+                       H, W, nbx, nby, S, Sx, ncb, act);
 }
+
+static inline int wn_coutp(int Cout, int nblk) { const int q = 16 * nblk; return (Cout + q - 1) / q * q; }
 
 extern "C" {
 
 size_t mfr_wino_filter_bytes(int Cin, int Cout)
 {
-    if (Cin <= 0 || Cout <= 0 || (Cin & 3) || (Cout % 32)) return 0;
-    return sizeof(float) * 16 * (size_t)Cin * Cout;
+    if (Cin <= 0 || Cout <= 0 || (Cin & 3)) return 0;
+    return sizeof(float) * 16 * (size_t)Cin * wn_coutp(Cout, wn_nblk(Cout));
 }
 
 int mfr_wino_filter_transform(const float *w, int Cin, int Cout, float *upk, void *stream)
 {
-    if (!w || !upk || Cin <= 0 || Cout <= 0 || (Cin & 3) || (Cout % 32)) return MFR_E_ARG;
-    hipLaunchKernelGGL(wino_filter_kernel, dim3((Cin * Cout + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, Cin, Cout, wn_nblk(Cout), upk);
+    if (!w || !upk || Cin <= 0 || Cout <= 0 || (Cin & 3)) return MFR_E_ARG;
+    const int nblk = wn_nblk(Cout), CoutP = wn_coutp(Cout, nblk);
+    if (CoutP != Cout && hipMemsetAsync(upk, 0, sizeof(float) * 16 * (size_t)Cin * CoutP, (hipStream_t)stream) != hipSuccess) return MFR_E_LAUNCH;
+    hipLaunchKernelGGL(wino_filter_kernel, dim3((Cin * Cout + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, Cin, Cout, CoutP, nblk, upk);
     CHECK_LAUNCH();
     return 0;
 }
 
-int mfr_conv3x3_wino(const float *x, const float *upk, const float *bias, int B, int Cin, int Cout, int H, int W,
-                     int relu, int pool, float *y, void *stream)
+int mfr_conv3x3_wino(const float *x, const float *upk, const float *bias, const float *residual, int B, int Cin, int Cout, int H, int W,
+                     int act, int pool, float *y, void *stream)
 {
-    if (!x || !upk || !y || B <= 0 || Cin <= 0 || Cout <= 0 || (Cin & 3) || (Cout % 32) || H <= 0 || W <= 0) return MFR_E_ARG;
-    if (pool && (H < 2 || W < 2)) return MFR_E_ARG;
+    if (!x || !upk || !y || B <= 0 || Cin <= 0 || Cout <= 0 || (Cin & 3) || H <= 0 || W <= 0 || act < 0 || act > 2) return MFR_E_ARG;
+    if (pool && (H < 2 || W < 2 || residual)) return MFR_E_ARG;
     if ((size_t)4 * Cin * H * W >= 0x7fffffffull) return MFR_E_ARG;    // one image must fit a 2 GB buffer descriptor
     const int nblk = wn_nblk(Cout);
     const int nbx = ((W + 1) / 2 + WN_TX - 1) / WN_TX, nby = ((H + 1) / 2 + WN_TY - 1) / WN_TY;
-    const int ncb = Cout / (16 * nblk);
+    const int ncb = wn_coutp(Cout, nblk) / (16 * nblk);
     const long long S = (long long)nbx * nby * B;
     const long long Sx = (S + 7) / 8;                        // spatial blocks per XCD
     const long long grid = Sx * 8 * ncb;
@@ -331,7 +348,7 @@ int mfr_conv3x3_wino(const float *x, const float *upk, const float *bias, int B,
     const char *ev = getenv("MFR_WINO_LOAD");                // tuning aid: 0 forces the 16-dword path
     const int load = (ev && atoi(ev) == 0) ? 0 : ((W & 1) ? 2 : 1);
     hipStream_t st = (hipStream_t)stream;
-#define WN_ARGS grid, st, x, upk, bias, y, Cin, Cout, H, W, nbx, nby, (int)S, (int)Sx, ncb, relu
+#define WN_ARGS grid, st, x, upk, bias, y, residual, Cin, Cout, H, W, nbx, nby, (int)S, (int)Sx, ncb, act
 #define WN_PICK_LOAD(P, N) do { if (load == 0) wn_launch<P, 0, N>(WN_ARGS); else if (load == 1) wn_launch<P, 1, N>(WN_ARGS); \
                                 else wn_launch<P, 2, N>(WN_ARGS); } while (0)
     if (nblk == 4) { if (pool) WN_PICK_LOAD(true, 4); else WN_PICK_LOAD(false, 4); }

@@ -61,6 +61,22 @@ class LoFTRHIP:
         convbn("l2out2.0", "backbone.layer2_outconv2.0", "backbone.layer2_outconv2.1"); conv("l2out2.3", "backbone.layer2_outconv2.3")
         convbn("l1out2.0", "backbone.layer1_outconv2.0", "backbone.layer1_outconv2.1"); conv("l1out2.3", "backbone.layer1_outconv2.3")
         self.w = w
+        # stride-1 3x3 convolutions go through the fused Winograd/MFMA kernel (csrc/winograd_conv.hip): transformed
+        # filters packed once here; BatchNorm is already folded into (w, b).  MFR_CONV=miopen keeps the library path.
+        import os
+        self.upk = {}
+        lib = _lib.load()
+        if os.environ.get("MFR_CONV", "wino") == "wino":
+            for name, (cw, _) in w.items():
+                if tuple(cw.shape[2:]) != (3, 3) or name.endswith(".ds") or name == "conv1":
+                    continue
+                co, ci = int(cw.shape[0]), int(cw.shape[1])
+                nbytes = lib.mfr_wino_filter_bytes(ci, co)
+                if nbytes == 0:
+                    continue
+                u = torch.empty(nbytes // 4, dtype=torch.float32, device=self.device)
+                _lib.check(lib.mfr_wino_filter_transform(_lib.ptr(cw), ci, co, _lib.ptr(u), _lib.stream_ptr()), "mfr_wino_filter_transform")
+                self.upk[name] = u
 
         def encoder(prefix, n):
             layers = []
@@ -80,9 +96,22 @@ class LoFTRHIP:
         self._pe = {}
 
     # ------------------------------------------------------------------ backbone (torch / MIOpen)
-    def _c(self, x, name, stride=1, act=None):
+    def _c(self, x, name, stride=1, act=None, residual=None):
+        """conv (+folded BN) [+ residual] [+ activation]; stride-1 3x3 layers: one fused Winograd launch"""
         cw, cb = self.w[name]
+        if stride == 1 and name in self.upk:
+            lib = _lib.load()
+            x = x.contiguous()
+            B, C, H, W = x.shape
+            co = int(cw.shape[0])
+            y = torch.empty(B, co, H, W, dtype=torch.float32, device=x.device)
+            code = {None: 0, "relu": 1, "leaky": 2}[act]
+            _lib.check(lib.mfr_conv3x3_wino(_lib.ptr(x), _lib.ptr(self.upk[name]), _lib.ptr(cb), _lib.ptr(residual.contiguous()) if residual is not None else None,
+                                            B, C, co, H, W, code, 0, _lib.ptr(y), _lib.stream_ptr()), "mfr_conv3x3_wino")
+            return y
         x = F.conv2d(x, cw, cb, stride=stride, padding=cw.shape[-1] // 2)
+        if residual is not None:
+            x = x + residual
         if act == "relu":
             x = F.relu_(x)
         elif act == "leaky":
@@ -91,10 +120,9 @@ class LoFTRHIP:
 
     def _block(self, x, name, stride):
         y = self._c(x, f"{name}.c1", stride, "relu")
-        y = self._c(y, f"{name}.c2")
         if stride != 1:
             x = self._c(x, f"{name}.ds", stride)
-        return F.relu_(x + y)
+        return self._c(y, f"{name}.c2", 1, "relu", residual=x)          # relu(x + bn2(conv2(y)))
 
     def backbone(self, x):
         x0 = self._c(x, "conv1", 2, "relu")

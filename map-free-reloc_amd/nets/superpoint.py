@@ -55,7 +55,7 @@ class SuperPointHIP:
             B, C, H, W = x.shape
             co = int(w.shape[0])
             y = torch.empty((B, co, H // 2, W // 2) if pool else (B, co, H, W), dtype=torch.float32, device=x.device)
-            _lib.check(lib.mfr_conv3x3_wino(_lib.ptr(x), _lib.ptr(self.upk[name]), _lib.ptr(b), B, C, co, H, W, 1, int(pool),
+            _lib.check(lib.mfr_conv3x3_wino(_lib.ptr(x), _lib.ptr(self.upk[name]), _lib.ptr(b), None, B, C, co, H, W, 1, int(pool),
                                             _lib.ptr(y), _lib.stream_ptr()), "mfr_conv3x3_wino")
             return y
         if not relu:

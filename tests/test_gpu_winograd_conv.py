@@ -13,23 +13,26 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-def _wino(x, w, b, relu, pool):
+def _wino(x, w, b, relu, pool, residual=None):
     lib = _lib.load(require_gpu=True)
     B, ci, H, W = x.shape
     co = w.shape[0]
     nbytes = lib.mfr_wino_filter_bytes(ci, co)
-    assert nbytes == 16 * ci * co * 4
+    assert nbytes == 16 * ci * (-(-co // 32) * 32) * 4
     u = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)
     _lib.check(lib.mfr_wino_filter_transform(_lib.ptr(w), ci, co, _lib.ptr(u), _lib.stream_ptr()), "filter")
     y = torch.full((B, co, H // 2, W // 2) if pool else (B, co, H, W), float("nan"), dtype=torch.float32, device=x.device)
-    _lib.check(lib.mfr_conv3x3_wino(_lib.ptr(x), _lib.ptr(u), _lib.ptr(b) if b is not None else None, B, ci, co, H, W,
+    _lib.check(lib.mfr_conv3x3_wino(_lib.ptr(x), _lib.ptr(u), _lib.ptr(b) if b is not None else None,
+                                    _lib.ptr(residual) if residual is not None else None, B, ci, co, H, W,
                                     int(relu), int(pool), _lib.ptr(y), _lib.stream_ptr()), "conv")
     return y
 
 
-def _ref(x, w, b, relu, pool):
+def _ref(x, w, b, act, pool, residual=None):
     y = F.conv2d(x.double().cpu(), w.double().cpu(), None if b is None else b.double().cpu(), padding=1)
-    y = y.relu() if relu else y
+    if residual is not None:
+        y = y + residual.double().cpu()
+    y = y.relu() if act == 1 else F.leaky_relu(y, 0.01) if act == 2 else y
     return F.max_pool2d(y, 2, 2) if pool else y
 
 
@@ -62,9 +65,28 @@ def test_wino_linearity_and_shift():
     assert (ys[:, :, 5:-2, 7:-2] - y1[:, :, 2:-5, 2:-7]).abs().max().item() < 2e-5
 
 
+@pytest.mark.parametrize("B,ci,co,H,W,act,pool,res", [
+    (1, 196, 196, 23, 34, 1, 0, 0), (2, 196, 128, 20, 17, 2, 0, 0), (1, 128, 128, 30, 44, 1, 0, 1), (2, 8, 5, 9, 10, 2, 0, 1),
+    (1, 256, 196, 45, 34, 2, 1, 0), (1, 12, 40, 7, 9, 0, 0, 1)])
+def test_wino_padded_cout_residual_leaky(B, ci, co, H, W, act, pool, res):
+    """the LoFTR ResNet-FPN uses 196-channel stages (Cout padded to 224 inside the packed filter), LeakyReLU(0.01)
+    in the FPN heads and `relu(x + conv(y))` at the end of every BasicBlock"""
+    g = torch.Generator().manual_seed(ci * 7 + co)
+    x = torch.randn(B, ci, H, W, generator=g).to(DEV)
+    w = (torch.randn(co, ci, 3, 3, generator=g) / (3.0 * ci ** 0.5)).to(DEV)
+    b = torch.randn(co, generator=g).to(DEV)
+    r = torch.randn(B, co, H, W, generator=g).to(DEV) if res else None
+    y = _wino(x, w, b, act, pool, r)
+    want = _ref(x, w, b, act, pool, r)
+    assert y.shape == want.shape and torch.isfinite(y).all()
+    assert (y.double().cpu() - want).abs().max().item() < 2e-5
+
+
 def test_wino_rejects_unsupported():
     lib = _lib.load(require_gpu=True)
-    assert lib.mfr_wino_filter_bytes(3, 32) == 0 and lib.mfr_wino_filter_bytes(4, 48) == 0
+    assert lib.mfr_wino_filter_bytes(3, 32) == 0 and lib.mfr_wino_filter_bytes(4, 48) == 16 * 4 * 64 * 4
     x = torch.zeros(1, 4, 4, 4, device=DEV)
-    assert lib.mfr_conv3x3_wino(_lib.ptr(x), _lib.ptr(x), None, 1, 3, 32, 4, 4, 0, 0, _lib.ptr(x), None) != 0
-    assert lib.mfr_conv3x3_wino(_lib.ptr(x), _lib.ptr(x), None, 1, 4, 32, 1, 1, 0, 1, _lib.ptr(x), None) != 0   # pool needs H,W >= 2
+    assert lib.mfr_conv3x3_wino(_lib.ptr(x), _lib.ptr(x), None, None, 1, 3, 32, 4, 4, 0, 0, _lib.ptr(x), None) != 0
+    assert lib.mfr_conv3x3_wino(_lib.ptr(x), _lib.ptr(x), None, None, 1, 4, 32, 1, 1, 0, 1, _lib.ptr(x), None) != 0  # pool needs H,W >= 2
+    assert lib.mfr_conv3x3_wino(_lib.ptr(x), _lib.ptr(x), None, _lib.ptr(x), 1, 4, 32, 4, 4, 0, 1, _lib.ptr(x), None) != 0  # residual + pool
+    assert lib.mfr_conv3x3_wino(_lib.ptr(x), _lib.ptr(x), None, None, 1, 4, 32, 4, 4, 3, 0, _lib.ptr(x), None) != 0  # unknown act

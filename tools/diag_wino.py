@@ -26,7 +26,7 @@ def wino(x, w, b, relu, pool):
     y = torch.empty((B, co, H // 2, W // 2) if pool else (B, co, H, W), dtype=torch.float32, device=x.device)
 
     def run():
-        _lib.check(lib.mfr_conv3x3_wino(_lib.ptr(x), _lib.ptr(u), _lib.ptr(b) if b is not None else None, B, ci, co, H, W,
+        _lib.check(lib.mfr_conv3x3_wino(_lib.ptr(x), _lib.ptr(u), _lib.ptr(b) if b is not None else None, None, B, ci, co, H, W,
                                         int(relu), int(pool), _lib.ptr(y), _lib.stream_ptr()), "conv")
     run()
     return y, run

@@ -25,7 +25,7 @@ def main():
             os.environ["MFR_WINO_ABL"] = str(v)
 
             def run():
-                rc = lib.mfr_conv3x3_wino(_lib.ptr(x), _lib.ptr(u), _lib.ptr(b), B, ci, co, H, W, 1, 1, _lib.ptr(y), _lib.stream_ptr())
+                rc = lib.mfr_conv3x3_wino(_lib.ptr(x), _lib.ptr(u), _lib.ptr(b), None, B, ci, co, H, W, 1, 1, _lib.ptr(y), _lib.stream_ptr())
                 assert rc == 0, rc
             for _ in range(2):
                 run()
