@@ -203,6 +203,9 @@ int mfr_sg_sinkhorn_match(const float *S, int B, int ldS, const int32_t *n0, con
  *   mfr_loftr_linear_attention   LinearAttention of the coarse transformer (heads x 32, elu+1 feature
  *                                map, eps 1e-6): out = phi(Q) (phi(K)^T V/L) / (phi(Q).sum phi(K)) * L.
  *                                q [B,L,ldq], k,v [B,L,ld], out [B,L,ldo]; head h = channels [32h,32h+32)
+ *   mfr_loftr_fine_attention     the same LinearAttention for the fine transformer: d_model 128 (8 heads x 16), L = 25
+ *                                tokens per 5x5 window, Bw windows; one wavefront per window, no workspace.
+ *                                q [Bw,25,ldq], k,v [Bw,25,ld], out [Bw,25,ldo]; L, D, heads must be 25, 128, 8
  *   mfr_loftr_coarse_match       CoarseMatching(dual_softmax) + get_coarse_match: S [B,L0,L1] =
  *                                (f0/sqrt C)(f1/sqrt C)^T; conf = softmax_i(S/T) * softmax_j(S/T);
  *                                conf > thr, border removal, mutual max -> i_ids, j_ids [B,L0] i32
@@ -213,6 +216,8 @@ int mfr_sg_sinkhorn_match(const float *S, int B, int ldS, const int32_t *n0, con
 size_t mfr_loftr_linear_attention_workspace_bytes(int B, int L, int heads);
 int mfr_loftr_linear_attention(const float *q, int ldq, const float *k, const float *v, int ld, int B, int L, int heads,
                                void *workspace, size_t workspace_bytes, float *out, int ldo, void *stream);
+int mfr_loftr_fine_attention(const float *q, int ldq, const float *k, const float *v, int ld, int Bw, int L, int D, int heads,
+                             float *out, int ldo, void *stream);
 size_t mfr_loftr_coarse_match_workspace_bytes(int B, int L0, int L1);
 int mfr_loftr_coarse_match(const float *S, int B, int h0, int w0, int h1, int w1, float temperature, float thr, int border,
                            void *workspace, size_t workspace_bytes, int32_t *i_ids, int32_t *j_ids, float *mconf,

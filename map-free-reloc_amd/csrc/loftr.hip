@@ -283,6 +283,95 @@ __global__ void __launch_bounds__(256) fine_gather_kernel(const float *__restric
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// fine-level linear attention (LoFTR fine transformer: d_model 128, 8 heads x 16, L = W*W = 25 tokens per 5x5 window,
+// tens of thousands of windows).  Upstream LinearAttention per window and head:
+//     Q = elu(q)+1, K = elu(k)+1, V = v / L;  KV = K^T V (16x16);  Z = 1 / (Q . sum_s K + 1e-6);  out = (Q KV) Z L
+// Through the library this is three batched einsums over 16x16 / 25x16 matrices (<5 % of peak).  Here one wavefront owns
+// one window: lane (hh, j) owns channels c = 16 hh + j and 64 + c (heads hh and hh + 4); K stays in registers (own
+// channel only), V and later Q are broadcast inside the 16-lane head group through LDS, KV[h][d][:] accumulates in 16
+// registers per owned channel.  HBM traffic = q, k, v read once + message written once (51 KB per window).
+#define FA_L 25
+#define FA_D 128
+__global__ void __launch_bounds__(128) fine_attention_kernel(const float *__restrict__ Q, int ldq, const float *__restrict__ K,
+                                                             const float *__restrict__ V, int ld, int Bw, float *__restrict__ O, int ldo)
+{
+    __shared__ __attribute__((aligned(16))) float Xs[2][FA_L][FA_D];     // V, then phi(Q)
+    __shared__ __attribute__((aligned(16))) float KVs[2][FA_D][16];      // [channel (h, d)][v]
+    __shared__ float Kss[2][FA_D];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int win_raw = blockIdx.x * 2 + wv;
+    const bool live = win_raw < Bw;
+    const int win = live ? win_raw : Bw - 1;
+    const int hh = lane >> 4;
+    const float inv_len = 1.0f / FA_L;
+    const float *kb = K + (size_t)win * FA_L * ld, *vb = V + (size_t)win * FA_L * ld, *qb = Q + (size_t)win * FA_L * ldq;
+
+    float kq[2][FA_L];
+#pragma unroll
+    for (int s = 0; s < FA_L; ++s) {
+        kq[0][s] = phi(kb[(size_t)s * ld + lane]);
+        kq[1][s] = phi(kb[(size_t)s * ld + 64 + lane]);
+        Xs[wv][s][lane] = vb[(size_t)s * ld + lane] * inv_len;
+        Xs[wv][s][64 + lane] = vb[(size_t)s * ld + 64 + lane] * inv_len;
+    }
+    __syncthreads();
+    // KV[h][d = this lane's channel][v] = sum_s K[s][h,d] V[s][h,v]
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        float kv[16];
+#pragma unroll
+        for (int v = 0; v < 16; ++v) kv[v] = 0.f;
+        float ks = 0.f;
+        const int hb = (hh + 4 * t) * 16;
+#pragma unroll
+        for (int s = 0; s < FA_L; ++s) {
+            const float kk = kq[t][s];
+            ks += kk;
+            const float4 *vr = (const float4 *)&Xs[wv][s][hb];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 vv = vr[g];
+                kv[4 * g] = fmaf(kk, vv.x, kv[4 * g]); kv[4 * g + 1] = fmaf(kk, vv.y, kv[4 * g + 1]);
+                kv[4 * g + 2] = fmaf(kk, vv.z, kv[4 * g + 2]); kv[4 * g + 3] = fmaf(kk, vv.w, kv[4 * g + 3]);
+            }
+        }
+        float4 *dst = (float4 *)KVs[wv][64 * t + lane];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) dst[g] = make_float4(kv[4 * g], kv[4 * g + 1], kv[4 * g + 2], kv[4 * g + 3]);
+        Kss[wv][64 * t + lane] = ks;
+    }
+    __syncthreads();                                        // V fully consumed, KV / Ksum visible
+#pragma unroll
+    for (int s = 0; s < FA_L; ++s) {
+        Xs[wv][s][lane] = phi(qb[(size_t)s * ldq + lane]);
+        Xs[wv][s][64 + lane] = phi(qb[(size_t)s * ldq + 64 + lane]);
+    }
+    __syncthreads();
+    // out[l][h, v = this lane] = (sum_d Q[l][h,d] KV[h][d][v]) / (sum_d Q[l][h,d] Ksum[h,d] + eps) * L
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int hb = (hh + 4 * t) * 16, j = lane & 15;
+        float kvc[16], ksr[16];
+#pragma unroll
+        for (int d = 0; d < 16; ++d) { kvc[d] = KVs[wv][hb + d][j]; ksr[d] = Kss[wv][hb + d]; }
+#pragma unroll 5
+        for (int l = 0; l < FA_L; ++l) {
+            const float4 *qr = (const float4 *)&Xs[wv][l][hb];
+            float acc = 0.f, z = 0.f;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 qq = qr[g];
+                acc = fmaf(qq.x, kvc[4 * g], acc); acc = fmaf(qq.y, kvc[4 * g + 1], acc);
+                acc = fmaf(qq.z, kvc[4 * g + 2], acc); acc = fmaf(qq.w, kvc[4 * g + 3], acc);
+                z = fmaf(qq.x, ksr[4 * g], z); z = fmaf(qq.y, ksr[4 * g + 1], z);
+                z = fmaf(qq.z, ksr[4 * g + 2], z); z = fmaf(qq.w, ksr[4 * g + 3], z);
+            }
+            if (live) O[((size_t)win * FA_L + l) * ldo + 64 * t + lane] = acc * (1.0f / (z + 1e-6f)) * (float)FA_L;
+        }
+    }
+}
+
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 extern "C" {
@@ -355,6 +444,17 @@ int mfr_loftr_gather_windows(const float *feat, int Bimg, int Hf, int Wf, int C,
     if (M == 0) return 0;
     hipLaunchKernelGGL(fine_gather_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, feat, Hf, Wf, C, img_ids, cell_ids, wc,
                        stride, win, out);
+    CHECK_LAUNCH();
+    return 0;
+}
+
+// q [Bw,25,ldq], k,v [Bw,25,ld], out [Bw,25,ldo]; d_model 128 (8 heads x 16), 25 tokens per window
+int mfr_loftr_fine_attention(const float *q, int ldq, const float *k, const float *v, int ld, int Bw, int L, int D, int heads,
+                             float *out, int ldo, void *stream)
+{
+    if (!q || !k || !v || !out || Bw < 0 || L != FA_L || D != FA_D || heads != 8 || ldq < D || ld < D || ldo < D) return MFR_E_ARG;
+    if (Bw == 0) return 0;
+    hipLaunchKernelGGL(fine_attention_kernel, dim3((Bw + 1) / 2), dim3(128), 0, (hipStream_t)stream, q, ldq, k, v, ld, Bw, out, ldo);
     CHECK_LAUNCH();
     return 0;
 }

@@ -152,6 +152,18 @@ class LoFTRHIP:
                    "mfr_loftr_linear_attention")
         return out
 
+    def fine_attention(self, q, kv):
+        """q [Bw,25,128]; kv [Bw,25,256] (k | v) -> message [Bw,25,128]: LinearAttention of the fine transformer
+        (8 heads x 16, 5x5 windows), one wavefront per window (csrc/loftr.hip)"""
+        lib = _lib.load()
+        Bw, L, D = q.shape
+        q, kv = q.contiguous(), kv.contiguous()
+        out = torch.empty(Bw, L, D, dtype=torch.float32, device=q.device)
+        base = kv.data_ptr()
+        _lib.check(lib.mfr_loftr_fine_attention(_lib.ptr(q), D, base, base + D * 4, 2 * D, Bw, L, D, 8, _lib.ptr(out), D,
+                                                _lib.stream_ptr()), "mfr_loftr_fine_attention")
+        return out
+
     def coarse_match(self, S, hw0, hw1):
         lib = _lib.load()
         B, L0, L1 = S.shape
@@ -247,7 +259,7 @@ class LoFTRHIP:
             WW = self.W * self.W
             fcf = F.linear(torch.cat([torch.cat([w0, w1], 0), fcw[:, None].expand(-1, WW, -1)], -1), *self.merge_feat)
             g0, g1 = fcf[:M], fcf[M:]
-            g0, g1 = self._transformer(self.fine, g0, g1, self._torch_linear_attention(8))
+            g0, g1 = self._transformer(self.fine, g0, g1, self.fine_attention if self.W == 5 else self._torch_linear_attention(8))
             picked = g0[:, WW // 2]
             heat = torch.softmax(torch.einsum('mc,mrc->mr', picked, g1) / g0.shape[-1] ** .5, dim=1).view(-1, self.W, self.W)
             lin = torch.linspace(-1, 1, self.W, device=images.device)

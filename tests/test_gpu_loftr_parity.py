@@ -41,6 +41,21 @@ def test_linear_attention_ragged_length(pair):
     np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=2e-4, atol=2e-5)
 
 
+@pytest.mark.parametrize("Bw", [1, 2, 7, 4096])
+def test_fine_attention_vs_oracle(pair, Bw):
+    """fine transformer LinearAttention: 8 heads x 16, 25 tokens per window, one wavefront per window (odd window
+    counts exercise the idle half of the last workgroup)"""
+    ref, hip = pair
+    g = torch.Generator().manual_seed(Bw)
+    L = 25
+    q = torch.randn(Bw, L, 128, generator=g); k = torch.randn(Bw, L, 128, generator=g); v = torch.randn(Bw, L, 128, generator=g)
+    want = LR.linear_attention(q.double().view(Bw, L, 8, 16), k.double().view(Bw, L, 8, 16), v.double().view(Bw, L, 8, 16)).reshape(Bw, L, 128)
+    got = hip.fine_attention(q.to(DEV), torch.cat([k, v], -1).to(DEV)).cpu()
+    np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=1e-4, atol=1e-5)
+    legacy = hip._torch_linear_attention(8)(q.to(DEV), torch.cat([k, v], -1).to(DEV)).cpu()      # the einsum path it replaces
+    np.testing.assert_allclose(got.numpy(), legacy.numpy(), rtol=1e-4, atol=1e-5)
+
+
 def test_coarse_match_vs_oracle(pair):
     ref, hip = pair
     g = torch.Generator().manual_seed(2)
