@@ -45,8 +45,9 @@ class SuperPointHIP:
             self.upk[name] = u
 
     def _conv(self, x, name, relu=True, pool=False):
-        """conv (MIOpen, no bias) + ONE fused HIP epilogue pass: relu(x + b) in place, or
-        relu(max_pool2x2(x) + b) for the b-convolutions (csrc/elementwise.hip)"""
+        """3x3 layer = ONE launch of the fused Winograd/MFMA kernel (conv + bias + ReLU [+ 2x2 max-pool],
+        csrc/winograd_conv.hip).  MFR_CONV=miopen (or an unsupported shape): library conv without bias + one fused
+        HIP epilogue pass (csrc/elementwise.hip)."""
         lib = _lib.load()
         w, b = self.w[name + ".weight"], self.w[name + ".bias"]
         pad = w.shape[-1] // 2
