@@ -164,6 +164,9 @@ def main():
 
     for i in range(args.warmup):
         out = step(i)
+    if use_dist and args.warmup > 0:
+        # the collective is part of a step's tail: warm it up too (RCCL builds its channels on the first all_gather)
+        gather_pose_records(batches[(args.warmup - 1) & 1]["pair_ids"], {k: out[k] for k in ("R", "t", "n_inliers", "status")}, world)
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
