@@ -270,3 +270,19 @@ def test_superglue_weight_folding_is_exact_algebra():
     m0, m1 = run(k0, s0, d0, k1, s1, d1)
     np.testing.assert_allclose(m0.t().numpy(), out["mdesc0"][0].numpy(), rtol=0, atol=2e-5)
     np.testing.assert_allclose(m1.t().numpy(), out["mdesc1"][0].numpy(), rtol=0, atol=2e-5)
+
+
+def test_descriptor_matcher_packs_ragged_inputs():
+    """host-side packing of per-image (keypoints, descriptors) lists into the fixed-stride layout of the C-ABI
+    (descriptor_ops.DescriptorRatioMatcher._pack; pure host code, runs without a GPU)"""
+    import torch
+    from mapfree_reloc_amd.descriptor_ops import DescriptorRatioMatcher
+    rng = np.random.default_rng(0)
+    items = [(rng.random((n, 2)).astype(np.float32), rng.random((n, 128)).astype(np.float32)) for n in (5, 0, 17)]
+    kp, de, n = DescriptorRatioMatcher(0.8, "cpu")._pack(items)
+    assert kp.shape == (3, 17, 2) and de.shape == (3, 17, 128) and n.dtype == torch.int32 and n.tolist() == [5, 0, 17]
+    np.testing.assert_array_equal(kp[0, :5].numpy(), items[0][0]); assert (kp[0, 5:] == 0).all() and (de[1] == 0).all()
+    np.testing.assert_array_equal(de[2].numpy(), items[2][1])
+    # all-empty batch still yields a valid (1-row) stride
+    kp, de, n = DescriptorRatioMatcher(0.8, "cpu")._pack([(np.zeros((0, 2), np.float32), np.zeros((0, 128), np.float32))])
+    assert kp.shape == (1, 1, 2) and n.tolist() == [0]
