@@ -1,21 +1,28 @@
 #!/usr/bin/env python
-"""bench.py -- image-pairs/s of the fused SuperPoint+SuperGlue -> depth lift -> PnP-RANSAC hot
-path on MI355X (BASELINE.json configs[1]: "SuperPoint+SuperGlue matching + PnP w/ DPT depth,
-540x720, 1xMI355X"), synthetic pairs, seeded synthetic weights (no data / checkpoints offline).
+"""bench.py -- image-pairs/s of the fused matcher -> depth lift -> RANSAC pose hot path on MI355X.
 
-A "step" is one pass of the whole path over one batch of B image pairs per GPU, inputs already
-resident in HBM.  N > 1 GPUs: pairs shard embarrassingly (one process per GPU, no data-path
-collective); the only collective is ONE RCCL all_gather of the per-pair pose records at the end
-of the run (80 B/pair), inside the timed region.  weak scaling: per-GPU work fixed.
+  --config sg_pnp      (default) BASELINE.json configs[1]: SuperPoint+SuperGlue matching + PnP w/ DPT depth, 540x720
+  --config loftr_emat  BASELINE.json configs[2]: LoFTR coarse-to-fine matching + Essential-matrix RANSAC (+ metric
+                       scale from depth), 540x720 right-padded to 544 like the reference (quirk Q3)
+
+Synthetic pairs, seeded synthetic weights (no data / checkpoints offline).  A "step" is one pass of the whole
+path over one batch of B image pairs per GPU, inputs already resident in HBM.  N > 1 GPUs: pairs shard
+embarrassingly (one process per GPU, no data-path collective); the only collective is ONE RCCL all_gather of
+the per-pair pose records at the end of the run (80 B/pair), inside the timed region.  Weak scaling.
 
   python bench.py --gpus 1 --steps 10 --warmup 3
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-         --master-port P bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus 8                       # starts 8 ranks itself (torch.distributed.run, 127.0.0.1)
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W  # the driver's form: ranks already exist
+`n_gpus` in the JSON line is the world size RCCL actually formed; --gpus N on a box with fewer GPUs, or a
+mismatch between --gpus and WORLD_SIZE, is an error (exit code 2), never a silent 1-GPU run.
 """
 import argparse
 import json
 import os
+import socket
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -27,31 +34,39 @@ import torch
 import torch.distributed as dist
 
 H, W = 720, 540                      # config/mapfree.yaml:7-8, compute.py:42
-FP32_MFMA_PEAK_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md (v_mfma_f32_32x32x2_f32)
+FP32_MFMA_PEAK_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md (v_mfma_f32_32x32x2_f32 / 16x16x4_f32)
+HBM_PEAK_GBS = 8000.0                # same guide: 8.0 TB/s spec (6.3 TB/s achievable)
+CONFIGS = ("sg_pnp", "loftr_emat")
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=32, help="image pairs per GPU per step (32: the ~22 ms of host launch work per step hides behind ~52 ms of GPU work; at 8 pairs the step is host-bound)")
-    ap.add_argument("--cpu-pairs", type=int, default=6, help="pairs timed for the CPU baseline (rank 0, N=1)")
+    ap.add_argument("--config", choices=CONFIGS, default="sg_pnp")
+    ap.add_argument("--batch", type=int, default=0, help="image pairs per GPU per step (default 32 for sg_pnp, 16 for loftr_emat)")
+    ap.add_argument("--cpu-pairs", type=int, default=0, help="pairs timed for the CPU baseline (rank 0, N=1); default 6 / 3")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-threads", type=int, default=16, help="host threads for the CPU baseline")
+    ap.add_argument("--cpu-threads", type=int, default=16, help="host threads for the all-threads CPU baseline figure")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-out", default="", help=argparse.SUPPRESS)
     ap.add_argument("--no-kernel-timer", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--verbose", action="store_true")
-    return ap.parse_args()
+    a = ap.parse_args(argv)
+    if a.batch <= 0:
+        a.batch = 32 if a.config == "sg_pnp" else 16
+    if a.cpu_pairs <= 0:
+        a.cpu_pairs = 6 if a.config == "sg_pnp" else 3
+    return a
 
 
 class KernelTimer:
     """HIP-event timing of one kernel family on torch's current stream (the stream the C-ABI
     launches on), live inside the timed region."""
 
-    def __init__(self, every=9):
-        # HIP event pairs cost ~0.2 ms each on this stack, so every 9th launch is timed
-        # (4 of the 36 attention launches per step) to keep the probe out of the measurement
+    def __init__(self, every=1):
+        # HIP event pairs cost ~0.2 ms each on this stack: frequently launched kernels are sampled
         self.events, self.enabled, self.every, self.count = [], False, every, 0
 
     def wrap(self, fn):
@@ -73,37 +88,53 @@ class KernelTimer:
         return float(np.mean([a.elapsed_time(b) for a, b in self.events]))
 
 
-def cpu_baseline(n_pairs, seeds, threads):
-    """the oracle (CPU restatement of the reference path: PyTorch-CPU SuperPoint/SuperGlue +
-    C PnP solver) timed on this box's host cores -- a reported baseline, never the product path.
-    `threads` host threads (the reference itself is single-process; more threads than ~16 make the
-    small SuperGlue ops slower, and 256 OpenMP threads stall outright on the GPU box)."""
-    from oracle import nets_ref as NR, oracle_lib as O
-    from mapfree_reloc_amd.nets import weights as WT
+# ----------------------------------------------------------------------------------------------------------------
+# CPU baseline + parity legs (the ONLY places that touch oracle/)
+# ----------------------------------------------------------------------------------------------------------------
+def cpu_baseline(config, n_pairs, seeds, threads, out_path=""):
+    """the oracle (CPU restatement of the reference path: PyTorch-CPU networks + C solvers, oracle/pipeline_ref.py)
+    timed on this box's host cores -- a reported baseline, never the product path.  Two figures: `threads` host
+    threads over the first n_pairs pairs, and ONE thread on the first pair (the reference itself is a single
+    process; SURVEY.md 8d asks for both).  The per-pair oracle results go to `out_path` for the parity leg."""
+    from oracle import pipeline_ref as PR
     from mapfree_reloc_amd import images as IM
-    cores = max(1, min(threads, os.cpu_count() or 1))
-    torch.set_num_threads(cores)
-    sp = NR.SuperPointRef().eval(); sp.load_state_dict(WT.superpoint_state_dict())
-    sg = NR.SuperGlueRef().eval(); sg.load_state_dict(WT.superglue_state_dict())
+    host = os.cpu_count() or 1
+    cores = max(1, min(threads, host))
     prs = [IM.synthetic_pair(s, H, W) for s in seeds[:n_pairs]]
+
+    def run(p, s):
+        if config == "sg_pnp":
+            return PR.sg_pnp_pair(p["img0"], p["img1"], p["depth0"], p["K"], p["K"], s)
+        return PR.loftr_emat_pair(p["img0"], p["img1"], p["depth0"], p["depth1"], p["K"], p["K"], s)
+    torch.set_num_threads(cores)
+    run(prs[0], seeds[0])                                      # weights / libraries loaded outside the timed region
     t0 = time.perf_counter()
-    for s, p in zip(seeds, prs):
-        pts = NR.superglue_match_pair(sp, sg, torch.from_numpy(p["img0"])[None, None], torch.from_numpy(p["img1"])[None, None])
-        if not np.isnan(pts).any():
-            O.pnp_solve(pts[:, :2], pts[:, 2:], p["depth0"], p["K"], p["K"], 1000, 3.0, 0.9999, seed=0, pair_id=int(s))
+    res = [run(p, s) for p, s in zip(prs, seeds)]
     dt = time.perf_counter() - t0
+    torch.set_num_threads(1)
+    t1 = time.perf_counter()
+    run(prs[0], seeds[0])
+    d1 = time.perf_counter() - t1
+    if out_path:
+        np.savez(out_path, seeds=np.asarray(seeds[:n_pairs]), **{f"{k}{i}": np.asarray(r[k]) for i, r in enumerate(res)
+                                                               for k in ("pts", "status", "R", "t", "n_inliers")})
+    nets = "SuperPoint+SuperGlue" if config == "sg_pnp" else "LoFTR"
+    solver = "C PnP oracle" if config == "sg_pnp" else "C E-mat + scale oracle"
     return dict(value=round(n_pairs / dt, 4), unit="image-pairs/s", cores=cores, kind="port",
-                sample=f"{n_pairs} synthetic 540x720 pairs, PyTorch-CPU fp32 SuperPoint+SuperGlue ({cores} threads) + C PnP oracle, {dt:.1f}s")
+                sample=f"{n_pairs} synthetic 540x720 pairs, PyTorch-CPU fp32 {nets} ({cores} threads) + {solver}, {dt:.1f}s; "
+                       f"1 pair on 1 thread, {d1:.1f}s", single_thread_value=round(1.0 / d1, 4), host_cores=host)
 
 
-def cpu_baseline_subprocess(n_pairs, threads, budget_s=240):
-    """run the CPU baseline in a child process with a hard time budget so that it can never block
-    the bench line"""
+def cpu_baseline_subprocess(config, n_pairs, threads, out_path, budget_s=300):
+    """run the CPU baseline in a child process (no GPU visible) with a hard time budget so that it can never
+    block the bench line"""
     import subprocess
     env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads), HIP_VISIBLE_DEVICES="")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
     try:
-        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--cpu-pairs", str(n_pairs),
-                            "--cpu-threads", str(threads)], capture_output=True, text=True, timeout=budget_s, env=env)
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--config", config, "--cpu-pairs", str(n_pairs),
+                            "--cpu-threads", str(threads), "--cpu-out", out_path], capture_output=True, text=True, timeout=budget_s, env=env)
         for ln in reversed(r.stdout.strip().splitlines()):
             if ln.startswith("{"):
                 return json.loads(ln)
@@ -112,27 +143,213 @@ def cpu_baseline_subprocess(n_pairs, threads, budget_s=240):
         return {"value": None, "error": f"CPU baseline exceeded its {budget_s}s budget"}
 
 
+def parity_leg(wl, oracle_npz, dev):
+    """whole HIP pipeline vs whole CPU-oracle pipeline on the CPU baseline's pairs: per pair, is the match set
+    identical, pose delta, inlier-count delta (north-star bar: 1e-4 rad / 1e-4 m).  -> config.parity"""
+    from oracle import pipeline_ref as PR
+    from mapfree_reloc_amd import images as IM
+    z = np.load(oracle_npz)
+    seeds = [int(s) for s in z["seeds"]]
+    sb = IM.synthetic_batch(seeds, H, W)
+    d = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in sb.items()}
+    out = wl.run(d)
+    torch.cuda.synchronize()
+    o = {k: v.cpu().numpy() for k, v in out.items() if isinstance(v, torch.Tensor)}
+    recs = []
+    for i in range(len(seeds)):
+        ref = {k: z[f"{k}{i}"] for k in ("pts", "status", "R", "t", "n_inliers")}
+        ref["status"], ref["n_inliers"] = int(ref["status"]), int(ref["n_inliers"])
+        n = int(o["n_corr"][i])
+        recs.append(PR.compare_pair(ref, np.concatenate([o["pts0"][i, :n], o["pts1"][i, :n]], 1), o["R"][i], o["t"][i],
+                                    o["n_inliers"][i], o["status"][i]))
+    s = PR.summarize(recs)
+    s["against"] = "oracle/pipeline_ref.py (CPU restatement of the reference path) on the cpu_baseline pairs; full census: profiles/r02_parity_census.json"
+    return s
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# workloads
+# ----------------------------------------------------------------------------------------------------------------
+class SgPnpWorkload:
+    name = "sg_pnp"
+    metric = "image-pairs/sec @ 540x720 (SuperPoint+SuperGlue + PnP w/ depth)"
+    workload = "configs[1]: SuperPoint+SuperGlue matching + PnP w/ depth, 540x720"
+
+    def __init__(self, dev, B, timers):
+        from mapfree_reloc_amd.pipeline import SuperGluePnPPipeline
+        self.B = B
+        self.pipe = SuperGluePnPPipeline(dev, seed=0)
+        self.att_timer, self.conv_timer = KernelTimer(every=9), KernelTimer(every=1)
+        if timers:
+            self.pipe.sg.attention = self.att_timer.wrap(self.pipe.sg.attention)
+            sp_conv, timed_conv = self.pipe.sp._conv, self.conv_timer.wrap(self.pipe.sp._conv)
+            self.pipe.sp._conv = lambda x, name, **kw: (timed_conv if name == "conv1b" else sp_conv)(x, name, **kw)
+        self.kp_sum, self.kp_cnt = 0.0, 0
+
+    def timers(self):
+        return [self.att_timer, self.conv_timer]
+
+    def run(self, d):
+        return self.pipe(d["images"], d["depth0"], d["K0"], d["K1"], d["pair_ids"])
+
+    def config(self, out):
+        c = {"max_keypoints": 1024, "sinkhorn_iters": 20, "pnp_iters": 1000}
+        if "n_kpts" in out:
+            c["mean_keypoints_per_image_last_step"] = float(out["n_kpts"].float().mean())
+        return c
+
+    def roofline(self, out):
+        B = self.B
+        att_ms, conv_ms = self.att_timer.mean_ms(), self.conv_timer.mean_ms()
+        # attention: 2B images x 4 heads x (QK^T + PV) = 2 * 2*n*n*64 flops each, n = the keypoints the step really had
+        nk = float(out["n_kpts"].float().mean()) if "n_kpts" in out else 1024.0
+        att_flops = float((2.0 * 2.0 * out["n_kpts"].double() ** 2 * 64 * 4).sum()) if "n_kpts" in out else 2 * B * 4 * 2 * (2.0 * 1024 * 1024 * 64)
+        att_tf = att_flops / (att_ms * 1e-3) / 1e12 if att_ms else None
+        # Winograd F(2x2,3x3) conv1b (64 -> 64 channels, 2B images, HxW): the flops the kernel executes on the matrix cores
+        # are 16 GEMMs of [Cout x Cin] x [Cin x tiles]; a direct 3x3 convolution of the same layer is 2.25x that
+        tiles = ((H + 1) // 2) * ((W + 1) // 2)
+        conv_flops = 16 * 2.0 * 64 * 64 * tiles * 2 * B
+        conv_direct = 2.0 * 9 * 64 * 64 * H * W * 2 * B
+        achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms else None
+        return {"kernel": "wino_conv3x3 conv1b launch (dominant kernel: fused Winograd F(2x2,3x3) convolution, 64->64 ch, pooled output)",
+                "bound": "mfma", "achieved": round(achieved, 2) if achieved else None, "peak": FP32_MFMA_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4) if achieved else None,
+                "traffic": _traffic("conv1b", B), "avg_launch_ms": round(conv_ms, 4) if conv_ms else None,
+                "launches_timed": len(self.conv_timer.events), "flops_per_launch": conv_flops,
+                "note": "achieved = flops executed on the fp32 matrix cores (16 Winograd GEMMs); a direct 3x3 convolution of the layer is 2.25x that",
+                "direct_equivalent_tflops": round(conv_direct / (conv_ms * 1e-3) / 1e12, 2) if conv_ms else None,
+                "other_kernels": [{"kernel": "sg_attention_kernel", "bound": "mfma", "achieved": round(att_tf, 2) if att_tf else None,
+                                   "peak": FP32_MFMA_PEAK_TFLOPS, "frac": round(att_tf / FP32_MFMA_PEAK_TFLOPS, 4) if att_tf else None,
+                                   "avg_launch_ms": round(att_ms, 4) if att_ms else None, "launches_timed": len(self.att_timer.events),
+                                   "mean_keypoints_per_image": round(nk, 1)}]}
+
+
+class LoftrEmatWorkload:
+    name = "loftr_emat"
+    metric = "image-pairs/sec @ 540x720 (LoFTR + E-mat RANSAC w/ scale from depth)"
+    workload = "configs[2]: LoFTR coarse-to-fine matching + Essential-matrix RANSAC + metric scale, 540x720 (padded to 544)"
+
+    def __init__(self, dev, B, timers):
+        from mapfree_reloc_amd.pipeline import LoFTREmatPipeline
+        self.B = B
+        self.pipe = LoFTREmatPipeline(dev, seed=0)
+        self.conv_timer, self.cm_timer = KernelTimer(every=1), KernelTimer(every=1)
+        if timers:
+            lo = self.pipe.loftr
+            c0, ct = lo._c, self.conv_timer.wrap(lo._c)
+            lo._c = lambda x, name, *a, **kw: (ct if name == "layer1.0.c1" else c0)(x, name, *a, **kw)
+            lo.coarse_match_features = self.cm_timer.wrap(lo.coarse_match_features)
+
+    def timers(self):
+        return [self.conv_timer, self.cm_timer]
+
+    def run(self, d):
+        return self.pipe(d["images"], d["depth0"], d["depth1"], d["K0"], d["K1"], d["pair_ids"])
+
+    def config(self, out):
+        return {"coarse_tokens_per_image": 90 * 68, "emat_iters": 1000, "pix_threshold": 2.0, "scale_threshold": 0.1}
+
+    def roofline(self, out):
+        B = self.B
+        conv_ms, cm_ms = self.conv_timer.mean_ms(), self.cm_timer.mean_ms()
+        # layer1.0.conv1: 128 -> 128 channels at 1/2 resolution (360 x 272), 2B images; largest single launch of the backbone
+        tiles = (360 // 2) * (272 // 2)
+        conv_flops = 16 * 2.0 * 128 * 128 * tiles * 2 * B
+        achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms else None
+        # dual-softmax coarse matching: algorithmic bytes = the two coarse feature maps in (2 x 6120 x 256 f32 = 12.5 MB/pair)
+        L = 90 * 68
+        cm_bytes = 2.0 * L * 256 * 4 * B
+        cm_gbs = cm_bytes / (cm_ms * 1e-3) / 1e9 if cm_ms else None
+        return {"kernel": "wino_conv3x3 layer1.0.conv1 launch (dominant kernel family: fused Winograd F(2x2,3x3) convolutions of the ResNet-FPN backbone)",
+                "bound": "mfma", "achieved": round(achieved, 2) if achieved else None, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4) if achieved else None, "traffic": _traffic("loftr_layer1", B),
+                "avg_launch_ms": round(conv_ms, 4) if conv_ms else None, "launches_timed": len(self.conv_timer.events), "flops_per_launch": conv_flops,
+                "other_kernels": [{"kernel": "dual-softmax coarse matching (similarity + row/col softmax statistics + mutual-NN selection)",
+                                   "bound": "hbm", "achieved": round(cm_gbs, 1) if cm_gbs else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": round(cm_gbs / HBM_PEAK_GBS, 5) if cm_gbs else None, "avg_launch_ms": round(cm_ms, 4) if cm_ms else None,
+                                   "algorithmic_bytes_per_launch": cm_bytes,
+                                   "note": "algorithmic bytes = coarse features in (12.5 MB/pair, SURVEY 8d); the stage is a 19 GFLOP/pair "
+                                           "contraction evaluated on the fp32 matrix cores, so its floor is MFMA time, not HBM time"}]}
+
+
+def _traffic(tag, B):
+    """HBM traffic of the dominant kernel: PMC counters cannot be read inside this process, so the per-launch figure
+    comes from the committed rocprofv3 --pmc passes of this same command (2 x FETCH_SIZE + WRITE_SIZE, the guide's
+    gfx950 correction), profiles/r02_pmc_<tag>.json"""
+    for rnd in ("r02", "r01"):
+        try:
+            name = {"conv1b": "wino"}.get(tag, tag) if rnd == "r01" else tag
+            pj = json.load(open(os.path.join(ROOT, "profiles", f"{rnd}_pmc_{name}.json")))
+            if pj.get("pairs_per_step") == B:
+                return {"bytes_per_launch": round(pj["hbm_bytes_per_launch"]), "algorithmic_bytes_per_launch": pj["algorithmic_bytes_per_launch"],
+                        "source": f"profiles/{rnd}_pmc_{name}.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"}
+        except Exception:
+            continue
+    return None
+
+
+def _pose_error(o, gtb):
+    """second half of BASELINE's metric ("median rot/trans error on val"): no val data offline, so the error is taken
+    against the known pose of the synthetic scenes of the last step (every pair has an exact ground truth)"""
+    try:
+        ok = (o["status"] == 0).cpu().numpy()
+        Rg, tg = gtb["R_gt"].cpu().numpy(), gtb["t_gt"].cpu().numpy()
+        Re, te = o["R"].cpu().numpy().reshape(-1, 3, 3), o["t"].cpu().numpy().reshape(-1, 3)
+        if not ok.any():
+            return None
+        idx = np.nonzero(ok)[0]
+        rot = [float(np.degrees(np.arccos(np.clip((np.trace(Rg[i].T @ Re[i]) - 1) / 2, -1, 1)))) for i in idx]
+        tr = [float(np.linalg.norm(te[i] - tg[i])) for i in idx]
+        return {"median_rot_deg": round(float(np.median(rot)), 6), "median_trans_m": round(float(np.median(tr)), 6),
+                "pairs": int(ok.sum()), "against": "known pose of the synthetic scenes (last step)"}
+    except Exception as e:       # never lose the bench line over the accuracy side-note
+        return {"error": str(e)[:200]}
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _fail(msg):
+    print(f"bench.py: error: {msg}", file=sys.stderr)
+    sys.exit(2)
+
+
 def main():
     args = parse()
     if args.cpu_baseline_only:
-        print(json.dumps(cpu_baseline(args.cpu_pairs, [1000 + i for i in range(args.cpu_pairs)], args.cpu_threads)))
+        print(json.dumps(cpu_baseline(args.config, args.cpu_pairs, [1000 + i for i in range(args.cpu_pairs)], args.cpu_threads, args.cpu_out)))
         return
+    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if args.gpus < 1:
+        _fail("--gpus must be >= 1")
+    if not launched and args.gpus > 1:
+        # start the ranks ourselves: one process per GPU through torch.distributed.run on 127.0.0.1
+        n_dev = torch.cuda.device_count()
+        if n_dev < args.gpus:
+            _fail(f"--gpus {args.gpus} requested but only {n_dev} HIP device(s) are visible; refusing to report a smaller run as {args.gpus} GPUs")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        os.execv(sys.executable, cmd)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    use_dist = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)
-    if use_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl")
-    if args.gpus != world and rank == 0 and world > 1:
-        print(f"warning: --gpus {args.gpus} != WORLD_SIZE {world}", file=sys.stderr)
+    if args.gpus != world:
+        _fail(f"--gpus {args.gpus} != WORLD_SIZE {world}: launch exactly one rank per GPU")
+    if not torch.cuda.is_available() or local_rank >= torch.cuda.device_count():
+        _fail(f"rank {rank}: HIP device {local_rank} is not visible (device_count = {torch.cuda.device_count()}); there is no CPU fallback")
+    use_dist = launched
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)        # backend "nccl" is RCCL on ROCm
+        world = dist.get_world_size()                         # what RCCL actually formed
 
     import mapfree_reloc_amd as mfr
     from mapfree_reloc_amd import images as IM
-    from mapfree_reloc_amd.pipeline import SuperGluePnPPipeline
     from mapfree_reloc_amd.parallel import gather_pose_records
     mfr._lib.load(require_gpu=True)
 
@@ -143,22 +360,15 @@ def main():
         seeds = [1000 * rank + 100 * k + i for i in range(B)]
         sb = IM.synthetic_batch(seeds, H, W)
         batches.append({key: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for key, v in sb.items()})
-    pipe = SuperGluePnPPipeline(dev, seed=0)
-    timer = KernelTimer()               # SuperGlue attention launches (every 9th)
-    conv_timer = KernelTimer(every=1)   # the conv1b launch of the Winograd convolution: the largest single launch
-    if not args.no_kernel_timer:
-        pipe.sg.attention = timer.wrap(pipe.sg.attention)
-        sp_conv, timed_conv = pipe.sp._conv, conv_timer.wrap(pipe.sp._conv)
-        pipe.sp._conv = lambda x, name, **kw: (timed_conv if name == "conv1b" else sp_conv)(x, name, **kw)
+    wl = (SgPnpWorkload if args.config == "sg_pnp" else LoftrEmatWorkload)(dev, B, not args.no_kernel_timer)
 
     def step(i):
-        d = batches[i & 1]
-        return pipe(d["images"], d["depth0"], d["K0"], d["K1"], d["pair_ids"])
+        return wl.run(batches[i & 1])
 
-    # initialisation, not warm-up: the first calls on a fresh box pay MIOpen's lazy solution selection /
-    # code-object loading and the GPU's clock ramp (measured: the first process on a cold box ran the
-    # same steps 1.5x slower when timed right after 3 calls)
-    for i in range(6):
+    # initialisation, not warm-up: the first calls on a fresh box pay lazy library initialisation (hipBLASLt / MIOpen
+    # solution selection, code-object loading) and the GPU's clock ramp (measured: the first process on a cold box ran
+    # the same steps 1.5x slower when timed right after 3 calls)
+    for i in range(6 if args.config == "sg_pnp" else 3):
         step(i)
     torch.cuda.synchronize()
 
@@ -171,7 +381,8 @@ def main():
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
-    timer.enabled = conv_timer.enabled = True
+    for t in wl.timers():
+        t.enabled = True
     t0 = time.perf_counter()
     results = []
     for i in range(args.steps):
@@ -191,7 +402,8 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    timer.enabled = conv_timer.enabled = False
+    for t in wl.timers():
+        t.enabled = False
     if use_dist:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -201,69 +413,26 @@ def main():
         total_pairs = B * args.steps * world
         value = total_pairs / elapsed
         o = results[-1][1]
-        n_ok = int((o["status"] == 0).sum())
-        att_ms, conv_ms = timer.mean_ms(), conv_timer.mean_ms()
-        # attention: 2B images x 4 heads x (QK^T + PV) = 2 * 2*N*N*64 flops each
-        nk = 1024
-        att_flops = 2 * B * 4 * 2 * (2.0 * nk * nk * 64)
-        att_tf = att_flops / (att_ms * 1e-3) / 1e12 if att_ms else None
-        # Winograd F(2x2,3x3) conv1b (64 -> 64 channels, 2B images, HxW): the flops the kernel executes on the matrix cores
-        # are 16 GEMMs of [Cout x Cin] x [Cin x tiles]; a direct 3x3 convolution of the same layer is 2.25x that
-        tiles = ((H + 1) // 2) * ((W + 1) // 2)
-        conv_flops = 16 * 2.0 * 64 * 64 * tiles * 2 * B
-        conv_direct = 2.0 * 9 * 64 * 64 * H * W * 2 * B
-        achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms else None
-        # HBM traffic of the dominant kernel: PMC counters cannot be read inside this process, so the per-launch
-        # figure comes from the committed rocprofv3 --pmc passes of this same command (profiles/r01_pmc_wino.json:
-        # 2 x FETCH_SIZE + WRITE_SIZE, guide's gfx950 correction)
-        traffic = None
-        try:
-            pj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_wino.json")))
-            if pj.get("pairs_per_step") == B:
-                traffic = {"bytes_per_launch": round(pj["hbm_bytes_per_launch"]), "algorithmic_bytes_per_launch": pj["algorithmic_bytes_per_launch"],
-                           "source": "profiles/r01_pmc_wino.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"}
-        except Exception:
-            pass
-        # second half of BASELINE's metric ("median rot/trans error on val"): no val data offline, so the error is taken
-        # against the known pose of the synthetic scenes of the last step (every pair has an exact ground truth)
-        pose_err = None
-        try:
-            gtb = batches[(args.steps - 1) & 1]
-            ok = (o["status"] == 0).cpu().numpy()
-            Rg, tg = gtb["R_gt"].cpu().numpy(), gtb["t_gt"].cpu().numpy()
-            Re, te = o["R"].cpu().numpy().reshape(-1, 3, 3), o["t"].cpu().numpy().reshape(-1, 3)
-            if ok.any():
-                rot = [float(np.degrees(np.arccos(np.clip((np.trace(Rg[i].T @ Re[i]) - 1) / 2, -1, 1)))) for i in np.nonzero(ok)[0]]
-                tr = [float(np.linalg.norm(te[i] - tg[i])) for i in np.nonzero(ok)[0]]
-                pose_err = {"median_rot_deg": round(float(np.median(rot)), 6), "median_trans_m": round(float(np.median(tr)), 6),
-                            "pairs": int(ok.sum()), "against": "known pose of the synthetic scenes (last step)"}
-        except Exception as e:       # never lose the bench line over the accuracy side-note
-            pose_err = {"error": str(e)[:200]}
+        cfg = {"workload": wl.workload, "pairs_per_gpu_per_step": B, "parallelism": f"pair-sharded x{world}",
+               "pairs_solved_last_step": int((o["status"] == 0).sum()), "mean_matches_last_step": float(o["n_corr"].float().mean()),
+               "gathered_records": int(rec.shape[0]), "synthetic_pose_error": _pose_error(o, batches[(args.steps - 1) & 1])}
+        cfg.update(wl.config(o))
         line = {
-            "metric": "image-pairs/sec @ 540x720 (SuperPoint+SuperGlue + PnP w/ depth)",
-            "value": round(value, 3), "unit": "image-pairs/s", "n_gpus": world, "steps": args.steps,
+            "metric": wl.metric, "value": round(value, 3), "unit": "image-pairs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 (matcher) / f64 (solver)",
             "data": "synthetic (3-band planar scenes, seeded random weights; no dataset/checkpoints offline)",
-            "config": {"workload": "configs[1]: SuperPoint+SuperGlue matching + PnP w/ depth, 540x720",
-                       "pairs_per_gpu_per_step": B, "max_keypoints": 1024, "sinkhorn_iters": 20,
-                       "pnp_iters": 1000, "parallelism": f"pair-sharded x{world}",
-                       "pairs_solved_last_step": n_ok, "mean_matches_last_step": float(o["n_corr"].float().mean()),
-                       "gathered_records": int(rec.shape[0]), "synthetic_pose_error": pose_err},
-            "roofline": {"kernel": "wino_conv3x3_kernel, conv1b launch (dominant kernel: fused Winograd F(2x2,3x3) convolution)",
-                         "bound": "mfma", "achieved": round(achieved, 2) if achieved else None, "peak": FP32_MFMA_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4) if achieved else None,
-                         "traffic": traffic, "avg_launch_ms": round(conv_ms, 4) if conv_ms else None,
-                         "launches_timed": len(conv_timer.events),
-                         "flops_per_launch": conv_flops, "note": "achieved = flops executed on the fp32 matrix cores (16 Winograd GEMMs); "
-                         "a direct 3x3 convolution of the layer is 2.25x that",
-                         "direct_equivalent_tflops": round(conv_direct / (conv_ms * 1e-3) / 1e12, 2) if conv_ms else None,
-                         "other_kernels": [{"kernel": "sg_attention_kernel", "bound": "mfma", "achieved": round(att_tf, 2) if att_tf else None,
-                                            "peak": FP32_MFMA_PEAK_TFLOPS, "frac": round(att_tf / FP32_MFMA_PEAK_TFLOPS, 4) if att_tf else None,
-                                            "avg_launch_ms": round(att_ms, 4) if att_ms else None, "launches_timed": len(timer.events)}]},
+            "config": cfg, "roofline": wl.roofline(o),
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline_subprocess(args.cpu_pairs, args.cpu_threads)
+            with tempfile.TemporaryDirectory() as td:
+                npz = os.path.join(td, "oracle_pairs.npz")
+                line["cpu_baseline"] = cpu_baseline_subprocess(args.config, args.cpu_pairs, args.cpu_threads, npz)
+                if os.path.exists(npz):
+                    try:
+                        cfg["parity"] = parity_leg(wl, npz, dev)
+                    except Exception as e:        # never lose the bench line over the parity side-note
+                        cfg["parity"] = {"error": str(e)[:300]}
         print(json.dumps(line))
     if use_dist:
         dist.destroy_process_group()

@@ -179,6 +179,12 @@ class LoFTRHIP:
                    "mfr_loftr_coarse_match")
         return i_ids, j_ids, mconf, n
 
+    def coarse_match_features(self, f0, f1, hw):
+        """coarse features [B,L,256] x2 -> dual-softmax mutual-NN matches (upstream CoarseMatching, dual_softmax)"""
+        C = f0.shape[-1]
+        S = torch.bmm(f0 / C ** .5, (f1 / C ** .5).transpose(1, 2))
+        return self.coarse_match(S, hw, hw)
+
     def gather_windows(self, feat_nhwc, img_ids, cell_ids, wc, stride):
         lib = _lib.load()
         Bimg, Hf, Wf, C = feat_nhwc.shape
@@ -236,9 +242,7 @@ class LoFTRHIP:
         fc = (fc + self._pe[key][None]).flatten(2).transpose(1, 2).contiguous()        # [2B, L, 256]
         f0, f1 = fc[0::2].contiguous(), fc[1::2].contiguous()
         f0, f1 = self._transformer(self.coarse, f0, f1, self.linear_attention)
-        C = f0.shape[-1]
-        S = torch.bmm(f0 / C ** .5, (f1 / C ** .5).transpose(1, 2))
-        i_ids, j_ids, mconf, n = self.coarse_match(S, (hc, wc), (hc, wc))
+        i_ids, j_ids, mconf, n = self.coarse_match_features(f0, f1, (hc, wc))
         L0 = hc * wc
         scale = H // hc
         # coarse keypoints (padded layout)

@@ -32,14 +32,17 @@ class SuperGluePnPPipeline:
     def match(self, images):
         """images [2B,1,H,W] -> dict(pts0, pts1 [B,K,2], n_corr [B], ...)  (SuperGlue_matcher.match)"""
         H, W = images.shape[-2:]
-        return self.sg(self.sp(images), (H, W), maxN=self.K)
+        sp = self.sp(images)
+        m = self.sg(sp, (H, W), maxN=self.K)
+        m["n_kpts"] = sp["n"]
+        return m
 
     @torch.no_grad()
     def __call__(self, images, depth0, K0, K1, pair_ids, want_mask=False):
         m = self.match(images)
         out = self.pnp(m["pts0"], m["pts1"], m["n_corr"], depth0, K0, K1, pair_ids, want_mask=want_mask)
         out["n_corr"] = m["n_corr"]
-        out["pts0"], out["pts1"] = m["pts0"], m["pts1"]
+        out["pts0"], out["pts1"], out["n_kpts"] = m["pts0"], m["pts1"], m["n_kpts"]
         return out
 
 
@@ -75,4 +78,4 @@ class LoFTREmatPipeline:
         s = self.scale(m["pts0"], m["pts1"], e["mask"], m["n_corr"], depth0, depth1, K0, K1, e["R"], e["t"], e["status"])
         return dict(R=torch.where((s["status"] == 0)[:, None, None], e["R"], torch.full_like(e["R"], float("nan"))),
                     t=s["t_metric"], n_inliers=s["n_inliers"], status=s["status"], n_corr=m["n_corr"],
-                    emat_inliers=e["n_inliers"])
+                    emat_inliers=e["n_inliers"], pts0=m["pts0"], pts1=m["pts1"], emat_mask=e["mask"])
