@@ -3,8 +3,11 @@ regression / training keys are kept so that the reference's dataset yamls still 
 keys this implementation adds (declared here because unknown keys are rejected on merge):
 
   FEATURE_MATCHING   additionally accepts 'SuperGlue' (online SuperPoint+SuperGlue on the GPU)
+  DATASET.SYNTHETIC  explicit opt-in to the synthetic stand-in dataset (a missing DATA_ROOT is otherwise an error)
   RANSAC.SEED        seed of the counter-based RANSAC RNG (the reference has no seed knob)
   HIP.*              batch size / keypoint budget of the fused device pipeline
+  LOFTR.WEIGHTS      checkpoint of the online LoFTR matcher ('LoFTR' feature matching)
+  ALLOW_SYNTHETIC_WEIGHTS  hand out seeded synthetic network weights when no checkpoint is configured (tests / benches)
   SUPERGLUE.*        matcher hyper-parameters of record (matchers.py:65-71) and weight paths
 """
 from .node import CfgNode as CN
@@ -26,7 +29,7 @@ def get_cfg_defaults():
         c.HEAD[k] = v
     c.BACKPROJECT_ANCHORS = None
     # feature matching options (config/default.py:39-66)
-    c.FEATURE_MATCHING = None      # 'SIFT' | 'Precomputed' | 'SuperGlue' (new: online, on the GPU)
+    c.FEATURE_MATCHING = None      # 'SIFT' | 'Precomputed' | 'SuperGlue' | 'LoFTR' (new: online, on the GPU)
     c.POSE_SOLVER = None           # 'EssentialMatrix' | 'EssentialMatrixMetric' | 'Procrustes' | 'PNP'
     c.SIFT = CN(); c.SIFT.NUM_FEATURES = None; c.SIFT.RATIO_THRESHOLD = None
     c.MATCHES_FILE_PATH = None
@@ -40,6 +43,7 @@ def get_cfg_defaults():
                      MAX_OVERLAP_SCORE=None, AUGMENTATION_TYPE=None, BLACK_WHITE=False, HEIGHT=None, WIDTH=None,
                      ESTIMATED_DEPTH=None, QUERY_FRAME_COUNT=1).items():
         c.DATASET[k] = v
+    c.DATASET.SYNTHETIC = None      # [n_scenes, frames_per_scene]: run on the synthetic stand-in ON PURPOSE (no data offline)
     c.DATASET.PAIRS_TXT = CN(); c.DATASET.PAIRS_TXT.TRAIN = None; c.DATASET.PAIRS_TXT.VAL = None
     c.DATASET.PAIRS_TXT.TEST = None; c.DATASET.PAIRS_TXT.ONE_NN = False
     # training (config/default.py:94-112) -- out of scope here, declared so dataset yamls merge
@@ -56,6 +60,8 @@ def get_cfg_defaults():
     for k, v in dict(NMS_RADIUS=4, KEYPOINT_THRESHOLD=0.005, MAX_KEYPOINTS=1024, SINKHORN_ITERATIONS=20,
                      MATCH_THRESHOLD=0.2, SUPERPOINT_WEIGHTS=None, SUPERGLUE_WEIGHTS=None, SYNTHETIC_SEED=1234).items():
         c.SUPERGLUE[k] = v
+    c.LOFTR = CN(); c.LOFTR.WEIGHTS = None
+    c.ALLOW_SYNTHETIC_WEIGHTS = False
     return c
 
 

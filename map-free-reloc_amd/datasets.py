@@ -31,19 +31,22 @@ def read_depth_image(path):
     return torch.from_numpy((d / 1000).astype(np.float32))
 
 
-class SyntheticMapFree(torch.utils.data.Dataset if hasattr(torch.utils, "data") else object):
-    """n_scenes x frames_per_scene synthetic pairs with the reference's sample schema"""
+class SyntheticScene:
+    """one synthetic scene: `frames` query frames against the keyframe, the reference's sample schema"""
 
-    def __init__(self, n_scenes=2, frames_per_scene=4, H=720, W=540, sample_factor=5, seed=0):
-        self.items = [(s, f) for s in range(n_scenes) for f in range(frames_per_scene)]
-        self.H, self.W, self.sample_factor, self.seed = H, W, sample_factor, seed
+    def __init__(self, scene_index, frames=4, H=720, W=540, sample_factor=5, seed=0):
+        self.s, self.frames, self.H, self.W, self.sample_factor, self.seed = scene_index, frames, H, W, sample_factor, seed
+        self.scene_id = f"s{scene_index:05d}"
+        self.scene_root = f"/synthetic/{self.scene_id}"
 
     def __len__(self):
-        return len(self.items)
+        return self.frames
 
-    def __getitem__(self, i):
-        s, f = self.items[i]
-        p = IM.synthetic_pair(self.seed + 1000 * s + f, self.H, self.W)
+    def pair_name(self, f):
+        return f"seq1/frame_{f * self.sample_factor:05d}.jpg"
+
+    def __getitem__(self, f):
+        p = IM.synthetic_pair(self.seed + 1000 * self.s + f, self.H, self.W)
         rgb = lambda im: torch.from_numpy(im)[None].expand(3, -1, -1).contiguous()
         T = np.eye(4, dtype=np.float32); T[:3, :3] = p["R_gt"]; T[:3, 3] = p["t_gt"]
         return {
@@ -51,9 +54,24 @@ class SyntheticMapFree(torch.utils.data.Dataset if hasattr(torch.utils, "data") 
             "depth0": torch.from_numpy(p["depth0"]), "depth1": torch.from_numpy(p["depth1"]),
             "K_color0": torch.from_numpy(p["K"]), "K_color1": torch.from_numpy(p["K"]),
             "T_0to1": torch.from_numpy(T), "pair_id": f * self.sample_factor,
-            "scene_id": f"s{s:05d}", "scene_root": f"/synthetic/s{s:05d}",
+            "scene_id": self.scene_id, "scene_root": self.scene_root,
             "pair_names": ("seq0/frame_00000.jpg", f"seq1/frame_{f * self.sample_factor:05d}.jpg"),
         }
+
+
+class SyntheticMapFree(torch.utils.data.Dataset if hasattr(torch.utils, "data") else object):
+    """n_scenes x frames_per_scene synthetic pairs with the reference's sample schema"""
+
+    def __init__(self, n_scenes=2, frames_per_scene=4, H=720, W=540, sample_factor=5, seed=0):
+        self.scenes = [SyntheticScene(s, frames_per_scene, H, W, sample_factor, seed) for s in range(n_scenes)]
+        self.items = [(s, f) for s in range(n_scenes) for f in range(frames_per_scene)]
+
+    def __len__(self):
+        return len(self.items)
+
+    def __getitem__(self, i):
+        s, f = self.items[i]
+        return self.scenes[s][f]
 
 
 def collate_batch1(sample):
@@ -89,6 +107,7 @@ class MapFreeScene:
     def __init__(self, scene_root, resize, sample_factor=5, estimated_depth=None):
         import re
         self.scene_root, self.resize = str(scene_root), resize
+        self.scene_id = os.path.basename(self.scene_root.rstrip("/"))
         self.sample_factor, self.estimated_depth = sample_factor, estimated_depth
         self.poses, self.K = {}, {}
         with open(os.path.join(self.scene_root, "poses.txt")) as f:
@@ -117,6 +136,10 @@ class MapFreeScene:
     def __len__(self):
         return len(self.pairs)
 
+    def pair_name(self, index):
+        sa, ia, sb, ib = self.pairs[index]
+        return f"seq{sb}/frame_{ib:05}.jpg"
+
     def __getitem__(self, index):
         from . import evaluation as E
         sa, ia, sb, ib = self.pairs[index]
@@ -138,21 +161,154 @@ class MapFreeScene:
                 "scene_root": self.scene_root, "pair_id": index * self.sample_factor, "pair_names": (p1, p2)}
 
 
-def make_loader(cfg, split="val"):
-    """batch-1 iterator over the split (submission.py:76-79); real data when DATA_ROOT/<split> exists,
-    otherwise the synthetic stand-in"""
-    root = cfg.DATASET.DATA_ROOT
-    if root and os.path.isdir(os.path.join(str(root), split)):
-        resize = (cfg.DATASET.WIDTH, cfg.DATASET.HEIGHT)
-        scenes = sorted(d for d in os.listdir(os.path.join(str(root), split)) if os.path.isdir(os.path.join(str(root), split, d)))
-        if cfg.DATASET.SCENES:
-            scenes = [s for s in scenes if s in cfg.DATASET.SCENES]
+class MissingDataError(FileNotFoundError):
+    pass
 
-        def gen():
-            for s in scenes:
-                sc = MapFreeScene(os.path.join(str(root), split, s), resize, 5, cfg.DATASET.ESTIMATED_DEPTH)
-                for i in range(len(sc)):
-                    yield collate_batch1(sc[i])
-        return gen()
-    ds = SyntheticMapFree(H=cfg.DATASET.HEIGHT or 720, W=cfg.DATASET.WIDTH or 540)
-    return (collate_batch1(ds[i]) for i in range(len(ds)))
+
+def list_scenes(cfg, split="val"):
+    """the split's scenes as indexable per-scene datasets (MapFreeScene for a real tree under
+    DATASET.DATA_ROOT/<split>, SyntheticScene when DATASET.SYNTHETIC is set).  A missing data root is an ERROR
+    unless the synthetic stand-in was asked for explicitly: a submission must never be built silently from fake
+    scenes."""
+    root = cfg.DATASET.DATA_ROOT
+    syn = cfg.DATASET.SYNTHETIC if "SYNTHETIC" in cfg.DATASET else None
+    if syn:
+        n_scenes, frames = (int(syn[0]), int(syn[1])) if isinstance(syn, (list, tuple)) else (2, 4)
+        return [SyntheticScene(s, frames, cfg.DATASET.HEIGHT or 720, cfg.DATASET.WIDTH or 540) for s in range(n_scenes)]
+    if not (root and os.path.isdir(os.path.join(str(root), split))):
+        raise MissingDataError(
+            f"DATASET.DATA_ROOT/{split} = {os.path.join(str(root), split)!r} does not exist.  Point DATASET.DATA_ROOT at a Map-free tree, or "
+            f"set DATASET.SYNTHETIC: [n_scenes, frames_per_scene] (CLI: --synthetic) to run on the synthetic stand-in on purpose.")
+    resize = (cfg.DATASET.WIDTH, cfg.DATASET.HEIGHT) if cfg.DATASET.WIDTH else None
+    names = sorted(d for d in os.listdir(os.path.join(str(root), split)) if os.path.isdir(os.path.join(str(root), split, d)))
+    if cfg.DATASET.SCENES:
+        names = [s for s in names if s in cfg.DATASET.SCENES]
+    return [MapFreeScene(os.path.join(str(root), split, s), resize, 5, cfg.DATASET.ESTIMATED_DEPTH) for s in names]
+
+
+def make_loader(cfg, split="val"):
+    """batch-1 iterator over the split in (scene, frame) order (submission.py:76-79)"""
+    scenes = list_scenes(cfg, split)
+    return (collate_batch1(sc[i]) for sc in scenes for i in range(len(sc)))
+
+
+def to_gray(img):
+    """[3,H,W] or [1,H,W] float in [0,1] -> [H,W] float32 luma (BT.601 weights, what cv2.imread(GRAYSCALE) computes)"""
+    if img.shape[0] == 1:
+        return img[0]
+    return 0.299 * img[0] + 0.587 * img[1] + 0.114 * img[2]
+
+
+class PairBatchLoader:
+    """Loader adjacency of the fused path (replaces the batch-1 DataLoader of
+    lib/datasets/datamodules.py:42-46 + lib/datasets/utils.py:58-81 on the hot path): `items` = [(scene, index)]
+    in submission order, grouped into batches of <= B pairs that never cross a scene boundary.  A background
+    thread decodes the next batches into PINNED host buffers (queue depth `prefetch`), so JPEG/PNG decode and
+    the H2D copy of batch i+1 overlap the kernels of batch i (DevicePrefetcher below issues the copies on a
+    side stream).  Yields dict(images [2b,1,H,W] f32 gray interleaved (2p = reference view), depth0/depth1 [b,H,W],
+    K0/K1 [b,3,3] f32, seed_ids [b] i64 (= data['pair_id'], the RANSAC stream id the per-pair plugin uses),
+    global_ids [b] i64, names [b], scene_id)."""
+
+    def __init__(self, scenes, batch_pairs=32, prefetch=2, pin=None, global_offsets=None):
+        self.scenes, self.B, self.prefetch = list(scenes), int(batch_pairs), int(prefetch)
+        self.pin = torch.cuda.is_available() if pin is None else pin
+        self.offsets = global_offsets
+        if self.offsets is None:
+            self.offsets, acc = [], 0
+            for sc in self.scenes:
+                self.offsets.append(acc); acc += len(sc)
+        self.batches = [(si, lo, min(lo + self.B, len(sc))) for si, sc in enumerate(self.scenes) for lo in range(0, len(sc), self.B)]
+
+    def __len__(self):
+        return len(self.batches)
+
+    def _load(self, si, lo, hi):
+        sc = self.scenes[si]
+        samples = [sc[i] for i in range(lo, hi)]
+        b = len(samples)
+        Hh, Ww = samples[0]["image0"].shape[-2:]
+        mk = (lambda *shape, dtype=torch.float32: torch.empty(*shape, dtype=dtype, pin_memory=True)) if self.pin else \
+             (lambda *shape, dtype=torch.float32: torch.empty(*shape, dtype=dtype))
+        images = mk(2 * b, 1, Hh, Ww); K0 = mk(b, 3, 3); K1 = mk(b, 3, 3)
+        has_depth = samples[0]["depth0"].numel() > 0
+        depth0 = mk(b, Hh, Ww) if has_depth else None
+        depth1 = mk(b, Hh, Ww) if has_depth else None
+        for p, smp in enumerate(samples):
+            images[2 * p, 0] = to_gray(smp["image0"]); images[2 * p + 1, 0] = to_gray(smp["image1"])
+            K0[p] = smp["K_color0"].to(torch.float32); K1[p] = smp["K_color1"].to(torch.float32)
+            if has_depth:
+                depth0[p] = smp["depth0"]; depth1[p] = smp["depth1"]
+        return dict(images=images, depth0=depth0, depth1=depth1, K0=K0, K1=K1,
+                    seed_ids=torch.tensor([int(smp["pair_id"]) for smp in samples], dtype=torch.int64),
+                    global_ids=torch.arange(self.offsets[si] + lo, self.offsets[si] + hi, dtype=torch.int64),
+                    names=[smp["pair_names"][1] for smp in samples], scene_id=sc.scene_id, scene_root=sc.scene_root, scene_index=si,
+                    last_of_scene=hi == len(sc))
+
+    def __iter__(self):
+        if self.prefetch <= 0:
+            for b in self.batches:
+                yield self._load(*b)
+            return
+        import queue
+        import threading
+        q = queue.Queue(maxsize=self.prefetch)
+        stop = threading.Event()
+
+        def work():
+            try:
+                for b in self.batches:
+                    if stop.is_set():
+                        return
+                    q.put(self._load(*b))
+                q.put(None)
+            except BaseException as e:          # surface loader errors in the consumer
+                q.put(e)
+        th = threading.Thread(target=work, daemon=True)
+        th.start()
+        try:
+            while True:
+                item = q.get()
+                if item is None:
+                    return
+                if isinstance(item, BaseException):
+                    raise item
+                yield item
+        finally:
+            stop.set()
+            while not q.empty():
+                q.get_nowait()
+
+
+class DevicePrefetcher:
+    """host batches -> device batches, one batch ahead: the H2D copies of batch i+1 run on a side HIP stream from
+    pinned memory while the compute stream works on batch i; an event makes the compute stream wait only for its own batch"""
+
+    def __init__(self, loader, device):
+        self.loader, self.device = loader, torch.device(device)
+        self.stream = torch.cuda.Stream(self.device) if self.device.type == "cuda" else None
+
+    def _put(self, hb):
+        if self.stream is None:
+            return dict(hb), None
+        with torch.cuda.stream(self.stream):
+            db = {k: (v.to(self.device, non_blocking=True) if isinstance(v, torch.Tensor) else v) for k, v in hb.items()}
+            ev = torch.cuda.Event(); ev.record(self.stream)
+        return db, ev
+
+    def __iter__(self):
+        nxt = None
+        for hb in self.loader:
+            cur, nxt = nxt, self._put(hb)
+            if cur is not None:
+                yield self._ready(cur)
+        if nxt is not None:
+            yield self._ready(nxt)
+
+    def _ready(self, item):
+        db, ev = item
+        if ev is not None:
+            torch.cuda.current_stream(self.device).wait_event(ev)
+            for v in db.values():
+                if isinstance(v, torch.Tensor):
+                    v.record_stream(torch.cuda.current_stream(self.device))
+        return db

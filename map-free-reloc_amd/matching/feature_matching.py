@@ -6,6 +6,7 @@ pixel frame, N may be 0 (np.array([])).  Mirrors lib/models/matching/feature_mat
                        semantics incl. lazy per-scene reload, float32 cast and NaN stripping
   SuperGlueMatching    NEW: online SuperPoint+SuperGlue on the GPU (the reference only has it
                        offline, etc/feature_matching_baselines/matchers.py:62-120)
+  LoFTRMatching        NEW: online LoFTR on the GPU (reference: offline only, matchers.py:12-59)
   SIFTMatching         feature_matching.py:53-118: detectAndCompute from OpenCV (or a caller-supplied
                        detector; raises ImportError when neither exists), rootSIFT + exact 2-NN + ratio
                        test on the GPU (csrc/descriptor_match.hip) instead of FLANN
@@ -39,12 +40,7 @@ class PrecomputedMatching:
         return wire.strip_nan(self.correspondences[pair_id])
 
 
-def _to_gray(img):
-    """[3,H,W] or [1,H,W] float tensor in [0,1] -> [H,W] float32 luma (BT.601, what
-    cv2.imread(GRAYSCALE) / COLOR_RGB2GRAY compute)"""
-    if img.shape[0] == 1:
-        return img[0]
-    return 0.299 * img[0] + 0.587 * img[1] + 0.114 * img[2]
+from ..datasets import to_gray as _to_gray   # BT.601 luma, what cv2.imread(GRAYSCALE) / COLOR_RGB2GRAY compute
 
 
 class SuperGlueMatching:
@@ -56,8 +52,9 @@ class SuperGlueMatching:
         from ..nets.superpoint import SuperPointHIP
         from ..nets.superglue import SuperGlueHIP
         sg = cfg.SUPERGLUE
-        sp_sd = WT.load_checkpoint(sg.SUPERPOINT_WEIGHTS) if sg.SUPERPOINT_WEIGHTS else WT.superpoint_state_dict(sg.SYNTHETIC_SEED)
-        sg_sd = WT.load_checkpoint(sg.SUPERGLUE_WEIGHTS) if sg.SUPERGLUE_WEIGHTS else WT.superglue_state_dict()
+        sp_sd = WT.load_checkpoint(sg.SUPERPOINT_WEIGHTS) if sg.SUPERPOINT_WEIGHTS else \
+            WT.synthetic_or_raise("SuperPoint", cfg, lambda: WT.superpoint_state_dict(sg.SYNTHETIC_SEED))
+        sg_sd = WT.load_checkpoint(sg.SUPERGLUE_WEIGHTS) if sg.SUPERGLUE_WEIGHTS else WT.synthetic_or_raise("SuperGlue", cfg, WT.superglue_state_dict)
         self.device = torch.device("cuda")
         self.sp = SuperPointHIP(sp_sd, self.device, sg.NMS_RADIUS, sg.KEYPOINT_THRESHOLD, sg.MAX_KEYPOINTS)
         self.sg = SuperGlueHIP(sg_sd, self.device, sg.SINKHORN_ITERATIONS, sg.MATCH_THRESHOLD)
@@ -67,6 +64,33 @@ class SuperGlueMatching:
         im0, im1 = _to_gray(data['image0'][0]), _to_gray(data['image1'][0])
         ims = torch.stack([im0, im1])[:, None].to(self.device, torch.float32).contiguous()
         out = self.sg(self.sp(ims), tuple(ims.shape[-2:]))
+        n = int(out["n_corr"][0])
+        if n == 0:
+            e = np.array([])
+            return e, e
+        return out["pts0"][0, :n].cpu().numpy(), out["pts1"][0, :n].cpu().numpy()
+
+
+class LoFTRMatching:
+    """online matcher: LoFTR coarse-to-fine on the GPU (the reference only has it offline,
+    etc/feature_matching_baselines/matchers.py:12-59), incl. the right-padding to a multiple of 8 (quirk Q3)"""
+
+    def __init__(self, cfg):
+        import torch
+        from ..nets import weights as WT
+        from ..nets.loftr import LoFTRHIP
+        lw = cfg.LOFTR.WEIGHTS
+        sd = WT.strip_prefix(WT.load_checkpoint(lw), "matcher.") if lw else WT.synthetic_or_raise("LoFTR", cfg, WT.loftr_state_dict)
+        self.device = torch.device("cuda")
+        self.net = LoFTRHIP(sd, self.device)
+
+    def get_correspondences(self, data):
+        import torch
+        im0, im1 = _to_gray(data['image0'][0]), _to_gray(data['image1'][0])
+        ims = torch.stack([im0, im1])[:, None].to(self.device, torch.float32)
+        H, W = ims.shape[-2:]
+        ims = torch.nn.functional.pad(ims, (0, (-W) % 8, 0, (-H) % 8)).contiguous()
+        out = self.net(ims)
         n = int(out["n_corr"][0])
         if n == 0:
             e = np.array([])

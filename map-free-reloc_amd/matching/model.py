@@ -1,39 +1,56 @@
-"""FeatureMatchingModel: same dispatch, batch-1 contract and output packing as
-lib/models/matching/model.py:7-40 (R [1,3,3] f32, t [1,1,3] f32, data['inliers'] = confidence)."""
+"""FeatureMatchingModel -- the model plugin of the matching path (contract: lib/models/matching/model.py:7-40):
+
+    build_model(cfg)(data) -> (R [1,3,3] f32, t [1,1,3] f32), and data['inliers'] = the solver's confidence.
+
+Two registries replace the reference's dispatch chains; `cfg.FEATURE_MATCHING` / `cfg.POSE_SOLVER` name the
+entries, so a new correspondence source or solver is one `register_*` call.  Batch size is 1 on this surface
+(the reference's contract); submission.predict_fused / pipeline.FusedPosePipeline are the batched twins.
+"""
+import numpy as np
 import torch
 
-from .feature_matching import PrecomputedMatching, SIFTMatching, SuperGlueMatching
-from .pose_solver import EssentialMatrixSolver, EssentialMatrixMetricSolver, PnPSolver, ProcrustesSolver
+from . import feature_matching as _fm
+from . import pose_solver as _ps
+
+FEATURE_MATCHERS = {
+    'SIFT': _fm.SIFTMatching,
+    'Precomputed': _fm.PrecomputedMatching,
+    'SuperGlue': _fm.SuperGlueMatching,      # online, GPU (new)
+    'LoFTR': _fm.LoFTRMatching,              # online, GPU (new)
+}
+POSE_SOLVERS = {
+    'EssentialMatrix': _ps.EssentialMatrixSolver,
+    'EssentialMatrixMetric': _ps.EssentialMatrixMetricSolver,
+    'Procrustes': _ps.ProcrustesSolver,
+    'PNP': _ps.PnPSolver,
+}
+
+
+def register_feature_matcher(name, cls):
+    FEATURE_MATCHERS[name] = cls
+
+
+def register_pose_solver(name, cls):
+    POSE_SOLVERS[name] = cls
+
+
+def _lookup(table, key, what):
+    if key not in table:
+        raise NotImplementedError(f'Invalid {what}: {key!r} (known: {sorted(table)})')
+    return table[key]
 
 
 class FeatureMatchingModel(torch.nn.Module):
     def __init__(self, cfg):
         super().__init__()
-        if cfg.FEATURE_MATCHING == 'SIFT':
-            self.feature_matching = SIFTMatching(cfg)
-        elif cfg.FEATURE_MATCHING == 'Precomputed':
-            self.feature_matching = PrecomputedMatching(cfg)
-        elif cfg.FEATURE_MATCHING == 'SuperGlue':
-            self.feature_matching = SuperGlueMatching(cfg)
-        else:
-            raise NotImplementedError('Invalid feature matching')
-
-        if cfg.POSE_SOLVER == 'EssentialMatrix':
-            self.pose_solver = EssentialMatrixSolver(cfg)
-        elif cfg.POSE_SOLVER == 'EssentialMatrixMetric':
-            self.pose_solver = EssentialMatrixMetricSolver(cfg)
-        elif cfg.POSE_SOLVER == 'Procrustes':
-            self.pose_solver = ProcrustesSolver(cfg)
-        elif cfg.POSE_SOLVER == 'PNP':
-            self.pose_solver = PnPSolver(cfg)
-        else:
-            raise NotImplementedError('Invalid pose solver')
+        self.feature_matching = _lookup(FEATURE_MATCHERS, cfg.FEATURE_MATCHING, 'feature matching')(cfg)
+        self.pose_solver = _lookup(POSE_SOLVERS, cfg.POSE_SOLVER, 'pose solver')(cfg)
 
     def forward(self, data):
-        assert data['depth0'].shape[0] == 1, 'Baseline models require batch size of 1'
-        pts1, pts2 = self.feature_matching.get_correspondences(data)
-        R, t, inliers = self.pose_solver.estimate_pose(pts1, pts2, data)
-        data['inliers'] = inliers
-        R = torch.from_numpy(R.copy()).unsqueeze(0).float()
-        t = torch.from_numpy(t.copy()).view(1, 3).unsqueeze(0).float()
-        return R, t
+        if data['depth0'].shape[0] != 1:
+            raise AssertionError('Baseline models require batch size of 1')
+        kpts0, kpts1 = self.feature_matching.get_correspondences(data)
+        R, t, confidence = self.pose_solver.estimate_pose(kpts0, kpts1, data)
+        data['inliers'] = confidence
+        as_f32 = lambda a, shape: torch.from_numpy(np.array(a, dtype=np.float32, copy=True).reshape(shape))
+        return as_f32(R, (1, 3, 3)), as_f32(t, (1, 1, 3))

@@ -125,8 +125,28 @@ def loftr_state_dict(seed=2468, feat_gain=20.0, msg_gain=0.1):
 
 
 def load_checkpoint(path):
-    """upstream .pth / .ckpt -> flat state dict (Lightning checkpoints keep it under 'state_dict')"""
-    sd = torch.load(path, map_location="cpu")
+    """upstream .pth / .ckpt -> flat state dict.  superpoint_v1.pth / superglue_*.pth are plain state dicts;
+    LoFTR's *_ot.ckpt are Lightning checkpoints that keep it under 'state_dict' with a `matcher.` prefix
+    (matchers.py:17-18 loads them strict=False after upstream strips nothing -- see strip_prefix).  Tensors only:
+    weights_only=True refuses pickled code in user-supplied files."""
+    sd = torch.load(path, map_location="cpu", weights_only=True)
     if isinstance(sd, dict) and "state_dict" in sd:
         sd = sd["state_dict"]
     return sd
+
+
+def strip_prefix(sd, prefix):
+    return {(k[len(prefix):] if k.startswith(prefix) else k): v for k, v in sd.items()}
+
+
+def synthetic_or_raise(what, cfg, maker):
+    """seeded synthetic weights are only handed out when the config opted into synthetic operation
+    (DATASET.SYNTHETIC or ALLOW_SYNTHETIC_WEIGHTS): a real run without checkpoints must not produce
+    plausible-looking poses from random networks"""
+    import warnings
+    allow = bool(cfg.get("ALLOW_SYNTHETIC_WEIGHTS", False)) or bool(cfg.DATASET.get("SYNTHETIC", None))
+    if not allow:
+        raise FileNotFoundError(f"{what}: no checkpoint configured (set the *_WEIGHTS key), and synthetic weights were not "
+                                f"requested (ALLOW_SYNTHETIC_WEIGHTS: True or DATASET.SYNTHETIC)")
+    warnings.warn(f"{what}: seeded synthetic weights in use (results are NOT meaningful)")
+    return maker()

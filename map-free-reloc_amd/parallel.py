@@ -64,8 +64,10 @@ def rotmat_to_quat(R):
 
 
 def pose_records(pair_ids, out):
-    """device tensors -> [n, 10] f64 records"""
-    R, t = out["R"], out["t"]
+    """device tensors -> [n, 10] f64 records.  R and t pass through float32 first, exactly like the model plugin's
+    outputs do (lib/models/matching/model.py:38-39 `.float()`) before submission.py:53 turns R into a quaternion --
+    so a record formats to the same text line as the per-pair path."""
+    R, t = out["R"].to(torch.float32).to(torch.float64), out["t"].to(torch.float32).to(torch.float64)
     q = rotmat_to_quat(R)
     q = torch.where(torch.isnan(R).any(-1).any(-1, keepdim=True), torch.full_like(q, float("nan")), q)
     return torch.cat([pair_ids.to(torch.float64)[:, None], q, t, out["n_inliers"].to(torch.float64)[:, None],
@@ -74,7 +76,11 @@ def pose_records(pair_ids, out):
 
 def gather_pose_records(pair_ids, out, world=None):
     """all ranks -> every rank gets the concatenated [sum n, 10] records (padding rows removed)"""
-    rec = pose_records(pair_ids, out)
+    return gather_records(pose_records(pair_ids, out), world)
+
+
+def gather_records(rec, world=None):
+    """the one collective of the path: ragged [n_r, 10] record blocks of all ranks -> [sum n_r, 10] on every rank"""
     if world is None:
         world = dist.get_world_size() if dist.is_initialized() else 1
     if not dist.is_initialized():

@@ -79,3 +79,88 @@ class LoFTREmatPipeline:
         return dict(R=torch.where((s["status"] == 0)[:, None, None], e["R"], torch.full_like(e["R"], float("nan"))),
                     t=s["t_metric"], n_inliers=s["n_inliers"], status=s["status"], n_corr=m["n_corr"],
                     emat_inliers=e["n_inliers"], pts0=m["pts0"], pts1=m["pts1"], emat_mask=e["mask"])
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# config-driven fused pipeline: any matcher stage x any solver stage, batched (what submission.predict_fused runs)
+# ---------------------------------------------------------------------------------------------------------------
+class _PrecomputedStage:
+    """cfg.FEATURE_MATCHING == 'Precomputed' (feature_matching.py:5-50) for a batch: npz rows -> device layout"""
+
+    def __init__(self, cfg, device):
+        from .matching.feature_matching import PrecomputedMatching
+        self.pm, self.device = PrecomputedMatching(cfg), device
+
+    def __call__(self, batch):
+        import numpy as np
+        from . import wire
+        rows = []
+        for pid in batch["seed_ids"].tolist():
+            p1, p2 = self.pm.get_correspondences({"scene_id": [batch["scene_id"]], "scene_root": [batch.get("scene_root", "")], "pair_id": pid})
+            rows.append(np.concatenate([p1, p2], 1) if len(p1) else np.zeros((0, 4), np.float32))
+        p0, p1, n = wire.pts_rows_to_device_batch(rows)
+        d = lambda a: torch.from_numpy(a).to(self.device)
+        return dict(pts0=d(p0), pts1=d(p1), n_corr=d(n))
+
+
+class FusedPosePipeline:
+    """The batched twin of FeatureMatchingModel (lib/models/matching/model.py:7-40): the same two config keys pick the
+    stages -- FEATURE_MATCHING in {'Precomputed', 'SuperGlue', 'LoFTR'} x POSE_SOLVER in {'PNP', 'EssentialMatrix',
+    'EssentialMatrixMetric', 'Procrustes'} -- but every stage consumes / produces a device-resident batch of pairs.
+    __call__(batch) with the dict PairBatchLoader yields -> dict(R [b,3,3] f64, t [b,3] f64, n_inliers, status, n_corr)."""
+
+    def __init__(self, cfg, device="cuda"):
+        from . import solver_ops as ops
+        _lib.load(require_gpu=True)
+        self.device = torch.device(device)
+        seed = int(cfg.RANSAC.SEED) if "RANSAC" in cfg else 0
+        fm = cfg.FEATURE_MATCHING
+        if fm == "Precomputed":
+            self.match = _PrecomputedStage(cfg, self.device)
+        elif fm == "SuperGlue":
+            sg = cfg.SUPERGLUE
+            sp_sd = WT.load_checkpoint(sg.SUPERPOINT_WEIGHTS) if sg.SUPERPOINT_WEIGHTS else WT.synthetic_or_raise("SuperPoint", cfg, WT.superpoint_state_dict)
+            sg_sd = WT.load_checkpoint(sg.SUPERGLUE_WEIGHTS) if sg.SUPERGLUE_WEIGHTS else WT.synthetic_or_raise("SuperGlue", cfg, WT.superglue_state_dict)
+            sp = SuperPointHIP(sp_sd, self.device, sg.NMS_RADIUS, sg.KEYPOINT_THRESHOLD, sg.MAX_KEYPOINTS)
+            net = SuperGlueHIP(sg_sd, self.device, sg.SINKHORN_ITERATIONS, sg.MATCH_THRESHOLD)
+            self.match = lambda b: net(sp(b["images"]), tuple(b["images"].shape[-2:]), maxN=sg.MAX_KEYPOINTS)
+        elif fm == "LoFTR":
+            lw = cfg.LOFTR.WEIGHTS
+            sd = WT.strip_prefix(WT.load_checkpoint(lw), "matcher.") if lw else WT.synthetic_or_raise("LoFTR", cfg, WT.loftr_state_dict)
+            lp = LoFTREmatPipeline.__new__(LoFTREmatPipeline)
+            from .nets.loftr import LoFTRHIP
+            lp.loftr, lp.pad_to, lp.device = LoFTRHIP(sd, self.device), 8, self.device
+            self.match = lambda b: lp.match(b["images"])
+        else:
+            raise NotImplementedError(f"FEATURE_MATCHING={fm!r} has no batched stage (SIFT detection is OpenCV / per pair)")
+        ps = cfg.POSE_SOLVER
+        if ps == "PNP":
+            pnp = ops.PnPBatchSolver(cfg.PNP.RANSAC_ITER, cfg.PNP.REPROJECTION_INLIER_THRESHOLD, cfg.PNP.CONFIDENCE, seed)
+            self.solve = lambda m, b: pnp(m["pts0"], m["pts1"], m["n_corr"], b["depth0"], b["K0"], b["K1"], b["seed_ids"])
+        elif ps in ("EssentialMatrix", "EssentialMatrixMetric"):
+            em = ops.EssentialBatchSolver(cfg.EMAT_RANSAC.PIX_THRESHOLD, cfg.EMAT_RANSAC.CONFIDENCE, seed)
+            sc = ops.ScaleFromDepthBatch(cfg.EMAT_RANSAC.SCALE_THRESHOLD) if ps == "EssentialMatrixMetric" else None
+
+            def solve(m, b):
+                e = em(m["pts0"], m["pts1"], m["n_corr"], b["K0"], b["K1"], b["seed_ids"])
+                if sc is None:
+                    return e
+                s = sc(m["pts0"], m["pts1"], e["mask"], m["n_corr"], b["depth0"], b["depth1"], b["K0"], b["K1"], e["R"], e["t"], e["status"])
+                return dict(R=e["R"], t=s["t_metric"], n_inliers=s["n_inliers"], status=s["status"])
+            self.solve = solve
+        elif ps == "Procrustes":
+            pr = ops.ProcrustesBatchSolver(cfg.PROCRUSTES.MAX_CORR_DIST, 0.999, seed)
+            self.solve = lambda m, b: pr(m["pts0"], m["pts1"], m["n_corr"], b["depth0"], b["depth1"], b["K0"], b["K1"], b["seed_ids"])
+        else:
+            raise NotImplementedError(f"POSE_SOLVER={ps!r}")
+
+    @torch.no_grad()
+    def __call__(self, batch):
+        m = self.match(batch)
+        out = self.solve(m, batch)
+        ok = (out["status"] == 0)
+        nan = float("nan")
+        return dict(R=torch.where(ok[:, None, None], out["R"], torch.full_like(out["R"], nan)),
+                    t=torch.where(ok[:, None], out["t"], torch.full_like(out["t"], nan)),
+                    n_inliers=torch.where(ok, out["n_inliers"], torch.zeros_like(out["n_inliers"])), status=out["status"],
+                    n_corr=m["n_corr"])

@@ -1,16 +1,22 @@
-"""Submission driver: same Pose line format, NaN filtering, per-scene grouping and zip layout as the
-reference's submission.py:18-65 (`pose_{scene}.txt`, lines
-`seq1/frame_XXXXX.jpg qw qx qy qz tx ty tz confidence`, README.md:182-212), on top of
-build_model() -- plus a batched, pair-sharded fast path (predict_fused) that runs the fused GPU
-pipeline and gathers the pose records over RCCL.
+"""Submission driver.
 
+Per-pair path (`predict`): the reference's loop (submission.py:33-58) over build_model(cfg)(data), batch 1.
+Fused path (`predict_fused`): what replaces that serial loop on BASELINE configs[3] (full split, 8 GPUs) --
+scenes sharded over the ranks in contiguous blocks balanced by pair count (parallel.shard_scenes), each rank
+running pipeline.FusedPosePipeline on batches of pairs fed by a pinned-memory prefetching loader, one atomic
+`pose_{scene}.txt` per finished scene (skip-if-present = per-scene resume), ONE all_gather of the 80-byte pose
+records (RCCL on GPUs, gloo in the CPU tests) and the zip written by rank 0.
+
+Output format (README.md:182-212, submission.py:18-30,60-65): zip of `pose_{scene}.txt`, lines
+`seq1/frame_XXXXX.jpg qw qx qy qz tx ty tz confidence`, q and t with 6 decimals, pairs without a pose skipped.
 mat2quat is restated (transforms3d is not installed offline): w >= 0 convention.
 """
 import argparse
+import os
 from collections import defaultdict
 from dataclasses import dataclass
 from pathlib import Path
-from zipfile import ZipFile
+from zipfile import ZipFile, ZipInfo, ZIP_STORED
 
 import numpy as np
 import torch
@@ -23,81 +29,181 @@ def mat2quat(M):
     return rotmat_to_quat(torch.as_tensor(np.asarray(M, dtype=np.float64))).numpy()
 
 
+def _fmt(v):
+    return np.array2string(np.asarray(v), formatter={'float': lambda x: f'{x:.6f}'}, max_line_width=1000)[1:-1]
+
+
 @dataclass
 class Pose:
+    """one line of pose_{scene}.txt (submission.py:18-30)"""
     image_name: str
     q: np.ndarray
     t: np.ndarray
     inliers: float
 
     def __str__(self) -> str:
-        formatter = {'float': lambda v: f'{v:.6f}'}
-        max_line_width = 1000
-        q_str = np.array2string(self.q, formatter=formatter, max_line_width=max_line_width)[1:-1]
-        t_str = np.array2string(self.t, formatter=formatter, max_line_width=max_line_width)[1:-1]
-        return f'{self.image_name} {q_str} {t_str} {self.inliers}'
+        return f'{self.image_name} {_fmt(self.q)} {_fmt(self.t)} {self.inliers}'
+
+
+def _has_pose(R, t):
+    return not (np.isnan(R).any() or np.isnan(t).any() or np.isinf(t).any())       # submission.py:48-49
 
 
 def predict(loader, model):
-    """per-pair loop of submission.py:33-58 (batch 1)"""
-    results_dict = defaultdict(list)
+    """scene -> [Pose] over a batch-1 loader; pairs without an estimate are left out"""
+    results = defaultdict(list)
     for data in loader:
         with torch.no_grad():
             R, t = model(data)
-        R = R.detach().cpu().numpy()
-        t = t.reshape(-1).detach().cpu().numpy()
-        inliers = data['inliers']
-        scene = data['scene_id'][0]
-        query_img = data['pair_names'][1][0]
-        if np.isnan(R).any() or np.isnan(t).any() or np.isinf(t).any():      # :48-49
+        R, t = R.detach().cpu().numpy(), t.detach().cpu().numpy().reshape(-1)
+        if not _has_pose(R, t):
             continue
-        results_dict[scene].append(Pose(image_name=query_img, q=mat2quat(R).reshape(-1), t=t.reshape(-1), inliers=inliers))
-    return results_dict
-
-
-def records_to_results(records, id_to_name):
-    """gathered [n,10] pose records (parallel.pose_records) -> results_dict; id_to_name maps
-    pair_id -> (scene, query image name).  Failed pairs (NaN pose) are dropped like :48-49."""
-    results = defaultdict(list)
-    rec = np.asarray(records)
-    for r in rec[np.argsort(rec[:, 0], kind="stable")]:
-        if np.isnan(r[1:8]).any() or np.isinf(r[5:8]).any():
-            continue
-        scene, name = id_to_name[int(r[0])]
-        results[scene].append(Pose(image_name=name, q=r[1:5].astype(np.float32), t=r[5:8].astype(np.float32), inliers=int(r[8])))
+        results[data['scene_id'][0]].append(Pose(data['pair_names'][1][0], mat2quat(R).reshape(-1), t, data['inliers']))
     return results
 
 
-def save_submission(results_dict: dict, output_path: Path):
-    with ZipFile(output_path, 'w') as zip:
+def records_to_results(records, id_to_name):
+    """gathered [n,10] pose records (parallel.pose_records) -> results_dict; id_to_name maps the record id ->
+    (scene, query image name).  Failed pairs (NaN pose) are dropped like submission.py:48-49."""
+    results = defaultdict(list)
+    rec = np.asarray(records)
+    for r in rec[np.argsort(rec[:, 0], kind="stable")]:
+        if not _has_pose(r[1:5], r[5:8]):
+            continue
+        scene, name = id_to_name[int(r[0])]
+        results[scene].append(Pose(image_name=name, q=r[1:5].copy(), t=r[5:8].astype(np.float32), inliers=int(r[8])))
+    return results
+
+
+def scene_text(poses):
+    return '\n'.join(str(p) for p in poses)
+
+
+def save_submission(results_dict: dict, output_path: Path, deterministic=False):
+    """zip of pose_{scene}.txt in dict order (submission.py:60-65).  deterministic=True pins the member timestamps so
+    that equal results give byte-equal archives (used to compare world sizes)."""
+    with ZipFile(output_path, 'w') as zf:
         for scene, poses in results_dict.items():
-            poses_str = '\n'.join((str(pose) for pose in poses))
-            zip.writestr(f'pose_{scene}.txt', poses_str.encode('utf-8'))
+            text = (poses if isinstance(poses, str) else scene_text(poses)).encode('utf-8')
+            name = f'pose_{scene}.txt'
+            zf.writestr(ZipInfo(name, (1980, 1, 1, 0, 0, 0)) if deterministic else name, text, ZIP_STORED)
+
+
+def _atomic_write(path: Path, text: str):
+    tmp = path.with_name(path.name + f'.tmp{os.getpid()}')
+    tmp.write_text(text, encoding='utf-8')
+    os.replace(tmp, path)
+
+
+def predict_fused(cfg, split, output_root, pipeline=None, batch_pairs=None, resume=True, scenes=None, prefetch=2):
+    """Scene-sharded, batched replacement of the reference's serial loop (submission.py:33-58) -> path of the zip
+    (rank 0) or None (other ranks).  Works with or without an initialised torch.distributed process group
+    (one process per GPU; backend nccl = RCCL on GPUs, gloo on CPU-only test boxes).
+
+    Every rank: its contiguous scene block -> for each scene not yet on disk, batches of <= batch_pairs pairs through
+    `pipeline` (default: FusedPosePipeline(cfg) on this rank's GPU; anything with `.device` and __call__(batch) -> dict(R, t,
+    n_inliers, status) works) -> `pose_{scene}.txt` written atomically into output_root/poses (= the resume marker).
+    Then ONE all_gather of the pose records of the pairs solved in this run; rank 0 assembles the zip in global scene
+    order from those records (scenes finished in an earlier run: from their files)."""
+    import torch.distributed as dist
+    from . import parallel
+    from .datasets import list_scenes, PairBatchLoader, DevicePrefetcher
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    scenes = list(scenes) if scenes is not None else list_scenes(cfg, split)
+    counts = [len(s) for s in scenes]
+    offsets = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    lo, hi = parallel.shard_scenes(counts, world)[rank] if scenes else (0, 0)
+    out_dir = Path(output_root) / 'poses'
+    out_dir.mkdir(parents=True, exist_ok=True)
+    if pipeline is None:
+        from .pipeline import FusedPosePipeline
+        dev = torch.device('cuda', torch.cuda.current_device())
+        pipeline = FusedPosePipeline(cfg, dev)
+    device = torch.device(pipeline.device)
+    B = int(batch_pairs or cfg.HIP.BATCH_PAIRS)
+
+    todo = [i for i in range(lo, hi) if not (resume and (out_dir / f'pose_{scenes[i].scene_id}.txt').exists())]
+    loader = PairBatchLoader([scenes[i] for i in todo], B, prefetch=prefetch, pin=device.type == 'cuda',
+                             global_offsets=[int(offsets[i]) for i in todo])
+    recs, names, acc = [], {}, []
+    for batch in DevicePrefetcher(loader, device):
+        out = pipeline(batch)
+        rec = parallel.pose_records(batch['global_ids'].to(out['R'].device), out)
+        acc.append(rec)
+        for gid, nm in zip(batch['global_ids'].tolist(), batch['names']):
+            names[gid] = (batch['scene_id'], nm)
+        if batch['last_of_scene']:                      # scene complete -> its file (one D2H copy per scene)
+            srec = torch.cat(acc).cpu().numpy(); acc = []
+            res = records_to_results(srec, names)
+            _atomic_write(out_dir / f'pose_{batch["scene_id"]}.txt', scene_text(res.get(batch['scene_id'], [])))
+            recs.append(srec)
+    mine = torch.from_numpy(np.concatenate(recs) if recs else np.zeros((0, parallel.REC_W))).to(device)
+    allrec = parallel.gather_records(mine, world).cpu().numpy()
+    if rank != 0:
+        return None
+    id_to_name = {}
+    for si, sc in enumerate(scenes):                    # names of every pair (cheap: the naming rule, no IO)
+        for k in range(len(sc)):
+            id_to_name[int(offsets[si]) + k] = (sc.scene_id, sc.pair_name(k))
+    fresh = records_to_results(allrec, id_to_name)
+    solved_now = {id_to_name[int(g)][0] for g in allrec[:, 0]} if len(allrec) else set()
+    ordered = {}
+    for sc in scenes:
+        if sc.scene_id in solved_now:
+            if sc.scene_id in fresh:
+                ordered[sc.scene_id] = scene_text(fresh[sc.scene_id])
+        else:                                           # finished by an earlier run: take its file
+            f = out_dir / f'pose_{sc.scene_id}.txt'
+            text = f.read_text(encoding='utf-8') if f.exists() else ''
+            if text:
+                ordered[sc.scene_id] = text
+    zpath = Path(output_root) / 'submission.zip'
+    save_submission(ordered, zpath, deterministic=True)
+    return zpath
 
 
 def eval(args):
     """submission.py:68-91 on the datasets this repository can read (datasets.py)."""
     from .config import get_cfg_defaults
-    from .builder import build_model
-    from .datasets import make_loader
     cfg = get_cfg_defaults()
     if args.dataset_config:
         cfg.merge_from_file(args.dataset_config)
     cfg.merge_from_file(args.config)
-    loader = make_loader(cfg, args.split)
-    model = build_model(cfg, args.checkpoint)
-    results_dict = predict(loader, model)
+    if args.synthetic:
+        cfg.DATASET.SYNTHETIC = [int(v) for v in args.synthetic]
+        cfg.DATASET.HEIGHT = cfg.DATASET.HEIGHT or 720
+        cfg.DATASET.WIDTH = cfg.DATASET.WIDTH or 540
     args.output_root.mkdir(parents=True, exist_ok=True)
-    save_submission(results_dict, args.output_root / 'submission.zip')
+    if args.fused:
+        import torch.distributed as dist
+        launched = 'RANK' in os.environ and 'WORLD_SIZE' in os.environ
+        if launched and not dist.is_initialized():
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
+            dist.init_process_group('nccl')
+        predict_fused(cfg, args.split, args.output_root, batch_pairs=args.batch_pairs, resume=not args.no_resume)
+        if launched:
+            dist.destroy_process_group()
+        return
+    from .builder import build_model
+    from .datasets import make_loader
+    model = build_model(cfg, args.checkpoint)
+    save_submission(predict(make_loader(cfg, args.split), model), args.output_root / 'submission.zip')
 
 
 def main(argv=None):
     parser = argparse.ArgumentParser()
     parser.add_argument('config', help='path to config file')
-    parser.add_argument('--dataset_config', default='config/mapfree.yaml')
+    parser.add_argument('--dataset_config', default=None, help="dataset yaml merged first (the reference hard-codes config/mapfree.yaml)")
     parser.add_argument('--checkpoint', default='')
     parser.add_argument('--output_root', '-o', type=Path, default=Path('results/'))
     parser.add_argument('--split', choices=('val', 'test'), default='test')
+    parser.add_argument('--fused', action='store_true', help='batched, scene-sharded GPU path (one rank per GPU under torch.distributed.run)')
+    parser.add_argument('--batch_pairs', type=int, default=None)
+    parser.add_argument('--no_resume', action='store_true', help='recompute scenes whose pose file already exists')
+    parser.add_argument('--synthetic', nargs=2, metavar=('N_SCENES', 'FRAMES'), default=None,
+                        help='run on the synthetic stand-in dataset ON PURPOSE (no Map-free data offline)')
     eval(parser.parse_args(argv))
 
 

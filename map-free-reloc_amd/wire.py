@@ -26,7 +26,7 @@ def save_correspondences(path, pts_list):
 
 
 def load_correspondences(path):
-    return np.load(path, allow_pickle=True)['correspondences'].astype(np.float32)
+    return np.load(path, allow_pickle=False)['correspondences'].astype(np.float32)
 
 
 def strip_nan(row):
