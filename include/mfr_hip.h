@@ -281,6 +281,11 @@ size_t mfr_wino_filter_bytes(int Cin, int Cout);
 int mfr_wino_filter_transform(const float *w, int Cin, int Cout, float *upk, void *stream);
 int mfr_conv3x3_wino(const float *x, const float *upk, const float *bias, const float *residual, int B, int Cin, int Cout,
                      int H, int W, int act, int pool, float *y, void *stream);
+/* the same convolution through a named kernel variant: 0 default, 1 classic, 2 software-pipelined K loop (bit-identical to 1),
+ * 4 shared-transform (two cout slices split every patch transform; bias folded into an accumulator: f32-roundoff differences);
+ * other values are timing ablations of tools/tune_wino.py -- for A/B timing and parity tests */
+int mfr_conv3x3_wino_variant(const float *x, const float *upk, const float *bias, const float *residual, int B, int Cin, int Cout,
+                             int H, int W, int act, int pool, int variant, float *y, void *stream);
 
 #ifdef __cplusplus
 }

@@ -53,6 +53,7 @@ SIGNATURES = {
     "mfr_wino_filter_bytes": (_sz, [_i, _i]),
     "mfr_wino_filter_transform": (_i, [_vp, _i, _i, _vp, _vp]),
     "mfr_conv3x3_wino": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "mfr_conv3x3_wino_variant": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "mfr_rootsift": (_i, [_vp, _i, _vp, _vp, _vp]),
     "mfr_desc_ratio_match": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _d, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "mfr_scale_workspace_bytes": (_sz, [_i, _i]),

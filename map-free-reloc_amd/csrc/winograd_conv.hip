@@ -35,7 +35,6 @@
 // Per cin chunk and wavefront: 8 buffer loads, 8 DPP moves + 32 adds, 4*NBLK ds_read_b128, 16*NBLK MFMAs.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include <stdlib.h>
 
 #include "../../include/mfr_hip.h"
 
@@ -54,15 +53,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define WN_RSRC_FLAGS 0x00020000
 #define WN_OOB 0x80000000u
 
-// NBLK (16-cout MFMA blocks per workgroup).  Measured on the SuperPoint layers (B = 32 images): NBLK = 2 (two
-// workgroups per CU) 12.2 ms for the nine layers, NBLK = 4 (one wavefront per SIMD) 14.3 ms -- the un-overlapped
-// prologue/epilogue and barrier skew of a lone wavefront cost more than the halved transform work saves, so 2 is
-// the default; MFR_WINO_NBLK=4 selects the other instantiation (tuning aid, needs Cout % 64 == 0).
-static inline int wn_nblk(int Cout)
-{
-    const char *ev = getenv("MFR_WINO_NBLK");
-    return (ev && atoi(ev) == 4 && Cout % 64 == 0) ? 4 : 2;
-}
+// NBLK (16-cout MFMA blocks per workgroup) is 2: 128 accumulator registers, two workgroups per CU.  (A one-wavefront-per-SIMD
+// NBLK = 4 instantiation was measured in round 1 -- 14.3 vs 12.2 ms over the nine SuperPoint layers, its un-overlapped
+// prologue / epilogue cost more than the halved transform work saved -- and is no longer built.)  The packed-filter layout
+// depends on NBLK only, so it is a compile-time constant of the library: no environment variable, no hidden state.
+#define WN_NBLK 2
+static inline int wn_nblk(int) { return WN_NBLK; }
 
 // packed U_xi[cout][cin]: [chunk c = cin/4][cout block cb][q = xi/4][blk][lane = (cin%4)*16 + cout%16][e = xi%4]
 __global__ void __launch_bounds__(256) wino_filter_kernel(const float *__restrict__ w, int Cin, int Cout, int CoutP, int nblk, float *__restrict__ upk)
@@ -84,8 +80,70 @@ __global__ void __launch_bounds__(256) wino_filter_kernel(const float *__restric
     for (int r = 0; r < 4; ++r) {
         float u[4];
         u[0] = t[r][0]; u[1] = 0.5f * (t[r][0] + t[r][1] + t[r][2]); u[2] = 0.5f * (t[r][0] - t[r][1] + t[r][2]); u[3] = t[r][2];
+        if (r == 3) { u[0] = -u[0]; u[1] = -u[1]; u[2] = -u[2]; u[3] = -u[3]; }   // row 3 is carried negated on both operands (see wino_conv3x3_shared_kernel)
         // xi = 4 r + j  ->  q = r, e = j
         *(float4 *)(dst + (((size_t)r * nblk + blk) * 64 + kq * 16 + row) * 4) = make_float4(u[0], u[1], u[2], u[3]);
+    }
+}
+
+// output transform + bias + activation (+ 2x2 max-pool) + store, shared by the kernel variants
+template <bool POOL, int LOAD, int NBLK>
+__device__ __forceinline__ void wn_epilogue(f32x4 (&acc)[16][NBLK], const float *__restrict__ bias, float *__restrict__ y,
+                                            const float *__restrict__ residual, int Cout, int H, int W, int act, int b, int cb, int kq, int ty, int tx)
+{
+    constexpr int WCO = 16 * NBLK;
+    // output transform A^T M A + bias (+ReLU) (+2x2 max-pool) in registers; accumulator register r of
+    // M-block blk = cout cb*WCO + blk*16 + 4 kq + r, column = this lane's tile
+    const int Ho = POOL ? (H >> 1) : H, Wo = POOL ? (W >> 1) : W;
+#pragma unroll
+    for (int blk = 0; blk < NBLK; ++blk) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int co = cb * WCO + blk * 16 + 4 * kq + r;
+            float a0[4], a1[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                a0[j] = acc[j][blk][r] + acc[4 + j][blk][r] + acc[8 + j][blk][r];
+                a1[j] = acc[4 + j][blk][r] - acc[8 + j][blk][r] - acc[12 + j][blk][r];
+            }
+            if (co >= Cout) continue;                        // padded output channels (Cout not a multiple of 32)
+            const float bv = bias ? bias[co] : 0.f;
+            float y00 = a0[0] + a0[1] + a0[2] + bv, y01 = a0[1] - a0[2] - a0[3] + bv;
+            float y10 = a1[0] + a1[1] + a1[2] + bv, y11 = a1[1] - a1[2] - a1[3] + bv;
+            const size_t plane = ((size_t)b * Cout + co) * ((size_t)Ho * Wo);
+            float *yo = y + plane;
+            if (POOL) {
+                float m = fmaxf(fmaxf(y00, y01), fmaxf(y10, y11));   // act is monotone: act(max) = max(act)
+                m = (act == 1) ? fmaxf(m, 0.f) : (act == 2) ? (m > 0.f ? m : 0.01f * m) : m;
+                if (ty < Ho && tx < Wo) yo[(size_t)ty * Wo + tx] = m;
+            } else {
+                const int oy = 2 * ty, ox = 2 * tx;
+                if (residual) {
+                    const float *ro = residual + plane;
+                    if (oy < H && ox < W) y00 += ro[(size_t)oy * W + ox];
+                    if (oy < H && ox + 1 < W) y01 += ro[(size_t)oy * W + ox + 1];
+                    if (oy + 1 < H && ox < W) y10 += ro[(size_t)(oy + 1) * W + ox];
+                    if (oy + 1 < H && ox + 1 < W) y11 += ro[(size_t)(oy + 1) * W + ox + 1];
+                }
+                if (act == 1) { y00 = fmaxf(y00, 0.f); y01 = fmaxf(y01, 0.f); y10 = fmaxf(y10, 0.f); y11 = fmaxf(y11, 0.f); }
+                else if (act == 2) {
+                    y00 = y00 > 0.f ? y00 : 0.01f * y00; y01 = y01 > 0.f ? y01 : 0.01f * y01;
+                    y10 = y10 > 0.f ? y10 : 0.01f * y10; y11 = y11 > 0.f ? y11 : 0.01f * y11;
+                }
+                if (ox + 1 < W) {
+                    if (LOAD == 1) {                         // W even: 8-byte aligned pairs
+                        if (oy < H) *(float2 *)(yo + (size_t)oy * W + ox) = make_float2(y00, y01);
+                        if (oy + 1 < H) *(float2 *)(yo + (size_t)(oy + 1) * W + ox) = make_float2(y10, y11);
+                    } else {
+                        if (oy < H) { yo[(size_t)oy * W + ox] = y00; yo[(size_t)oy * W + ox + 1] = y01; }
+                        if (oy + 1 < H) { yo[(size_t)(oy + 1) * W + ox] = y10; yo[(size_t)(oy + 1) * W + ox + 1] = y11; }
+                    }
+                } else if (ox < W) {
+                    if (oy < H) yo[(size_t)oy * W + ox] = y00;
+                    if (oy + 1 < H) yo[(size_t)(oy + 1) * W + ox] = y10;
+                }
+            }
+        }
     }
 }
 
@@ -184,7 +242,7 @@ __global__ void __launch_bounds__(256, NBLK == 2 ? 2 : 1) wino_conv3x3_kernel(
             t[j] = d[j] - d[8 + j];
             t[4 + j] = d[4 + j] + d[8 + j];
             t[8 + j] = d[8 + j] - d[4 + j];
-            t[12 + j] = d[4 + j] - d[12 + j];
+            t[12 + j] = d[12 + j] - d[4 + j];               // = -(B^T d)[3][j]: the packed filters carry the same sign
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -253,67 +311,404 @@ __global__ void __launch_bounds__(256, NBLK == 2 ? 2 : 1) wino_conv3x3_kernel(
         __syncthreads();
     }
 
-    // output transform A^T M A + bias (+ReLU) (+2x2 max-pool) in registers; accumulator register r of
-    // M-block blk = cout cb*WCO + blk*16 + 4 kq + r, column = this lane's tile
-    const int Ho = POOL ? (H >> 1) : H, Wo = POOL ? (W >> 1) : W;
-#pragma unroll
-    for (int blk = 0; blk < NBLK; ++blk) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int co = cb * WCO + blk * 16 + 4 * kq + r;
-            float a0[4], a1[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                a0[j] = acc[j][blk][r] + acc[4 + j][blk][r] + acc[8 + j][blk][r];
-                a1[j] = acc[4 + j][blk][r] - acc[8 + j][blk][r] - acc[12 + j][blk][r];
-            }
-            if (co >= Cout) continue;                        // padded output channels (Cout not a multiple of 32)
-            const float bv = bias ? bias[co] : 0.f;
-            float y00 = a0[0] + a0[1] + a0[2] + bv, y01 = a0[1] - a0[2] - a0[3] + bv;
-            float y10 = a1[0] + a1[1] + a1[2] + bv, y11 = a1[1] - a1[2] - a1[3] + bv;
-            const size_t plane = ((size_t)b * Cout + co) * ((size_t)Ho * Wo);
-            float *yo = y + plane;
-            if (POOL) {
-                float m = fmaxf(fmaxf(y00, y01), fmaxf(y10, y11));   // act is monotone: act(max) = max(act)
-                m = (act == 1) ? fmaxf(m, 0.f) : (act == 2) ? (m > 0.f ? m : 0.01f * m) : m;
-                if (ty < Ho && tx < Wo) yo[(size_t)ty * Wo + tx] = m;
-            } else {
-                const int oy = 2 * ty, ox = 2 * tx;
-                if (residual) {
-                    const float *ro = residual + plane;
-                    if (oy < H && ox < W) y00 += ro[(size_t)oy * W + ox];
-                    if (oy < H && ox + 1 < W) y01 += ro[(size_t)oy * W + ox + 1];
-                    if (oy + 1 < H && ox < W) y10 += ro[(size_t)(oy + 1) * W + ox];
-                    if (oy + 1 < H && ox + 1 < W) y11 += ro[(size_t)(oy + 1) * W + ox + 1];
-                }
-                if (act == 1) { y00 = fmaxf(y00, 0.f); y01 = fmaxf(y01, 0.f); y10 = fmaxf(y10, 0.f); y11 = fmaxf(y11, 0.f); }
-                else if (act == 2) {
-                    y00 = y00 > 0.f ? y00 : 0.01f * y00; y01 = y01 > 0.f ? y01 : 0.01f * y01;
-                    y10 = y10 > 0.f ? y10 : 0.01f * y10; y11 = y11 > 0.f ? y11 : 0.01f * y11;
-                }
-                if (ox + 1 < W) {
-                    if (LOAD == 1) {                         // W even: 8-byte aligned pairs
-                        if (oy < H) *(float2 *)(yo + (size_t)oy * W + ox) = make_float2(y00, y01);
-                        if (oy + 1 < H) *(float2 *)(yo + (size_t)(oy + 1) * W + ox) = make_float2(y10, y11);
-                    } else {
-                        if (oy < H) { yo[(size_t)oy * W + ox] = y00; yo[(size_t)oy * W + ox + 1] = y01; }
-                        if (oy + 1 < H) { yo[(size_t)(oy + 1) * W + ox] = y10; yo[(size_t)(oy + 1) * W + ox + 1] = y11; }
-                    }
-                } else if (ox < W) {
-                    if (oy < H) yo[(size_t)oy * W + ox] = y00;
-                    if (oy + 1 < H) yo[(size_t)(oy + 1) * W + ox] = y10;
-                }
-            }
-        }
-    }
+    wn_epilogue<POOL, LOAD, NBLK>(acc, bias, y, residual, Cout, H, W, act, b, cb, kq, ty, tx);
 }
 
-template <bool POOL, int LOAD, int NBLK>
-static void wn_launch(long long grid, hipStream_t st, const float *x, const float *upk, const float *bias, float *y, const float *residual,
-                      int Cin, int Cout, int H, int W, int nbx, int nby, int S, int Sx, int ncb, int act)
+// ---------------------------------------------------------------------------------------------------------------------
+// Software-pipelined variant (NBLK = 2, Cin % 8 == 0).  Same mapping, operands and arithmetic as the kernel above (the
+// results are bit-identical); what changes is the instruction stream of the K loop.  The kernel above runs a chunk as
+// [56 VALU of input transform] -> [32 MFMAs back to back]: two wavefronts that share a SIMD fall into lock step (both in
+// their MFMA run, then both in their VALU run), the matrix pipe idles during the VALU runs and PMC shows it 54 % busy with
+// 60 % of the wave time issue-stalled.  Here the transform of chunk c+1 is issued UNDER the MFMAs of chunk c, one or two
+// VALU instructions per MFMA (sched_group_barrier pins the interleave), so every wavefront's stream is balanced at the
+// granularity of a single 32-cycle MFMA and any phase relation between the co-resident wavefronts keeps the pipe fed.
+// The loop body is branch-free (one scheduling region): prefetches beyond the last chunk are out-of-range buffer loads
+// (return 0) and the loop is unrolled by two so the patch / operand registers ping-pong without copies.
+// ---------------------------------------------------------------------------------------------------------------------
+#define WN_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
+#define WN_M_VALU 0x2
+#define WN_M_MFMA 0x8
+#define WN_M_VMEM_RD 0x20
+#define WN_M_DS_RD 0x100
+#define WN_M_DS_WR 0x200
+
+// MODE 0: pinned interleave (sched_group_barrier); MODE 1: the same software pipeline, placement left to the compiler
+// ABL (timing ablations, results are WRONG when != 0; tools/tune_wino.py only): 1 = no output transform / stores,
+// 2 = no workgroup barrier in the K loop, 4 = no input transform arithmetic, 8 = no patch loads
+template <bool POOL, int LOAD, int MODE, int ABL = 0>
+__global__ void __launch_bounds__(256, 2) wino_conv3x3_pipe_kernel(
+    const float *__restrict__ x, const float *__restrict__ upk, const float *__restrict__ bias, float *__restrict__ y,
+    const float *__restrict__ residual, int Cin, int Cout, int H, int W, int nbx, int nby, int S, int Sx, int ncb, int act)
 {
-    hipLaunchKernelGGL((wino_conv3x3_kernel<POOL, LOAD, NBLK>), dim3((unsigned)grid), dim3(256), 0, st, x, upk, bias, y, residual, Cin, Cout,
-                       H, W, nbx, nby, S, Sx, ncb, act);
+    constexpr int NBLK = 2;
+    constexpr int SLAB = 1024 * NBLK;
+    static_assert(LOAD == 1 || LOAD == 2, "paired loads only");
+    __shared__ __attribute__((aligned(16))) float Us[2][SLAB];
+    const int id = blockIdx.x;
+    const int xcd = id & 7, jj = id >> 3;
+    const int cb = jj % ncb;
+    const int sl = jj / ncb;
+    const int s = xcd * Sx + sl;
+    if (sl >= Sx || s >= S) return;
+    const int bx = s % nbx, by = (s / nbx) % nby, b = s / (nbx * nby);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int col = lane & 15, kq = lane >> 4;
+    const int ty = by * WN_TY + w, tx = bx * WN_TX + col;
+    const int HW = H * W;
+
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(x + (size_t)b * Cin * HW), 0, Cin * HW * 4, WN_RSRC_FLAGS);
+    // packed filters as a buffer too: chunk prefetches past the end read zeros instead of needing a branch
+    const int nchunks = Cin >> 2;
+    const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc((void *)upk, 0, nchunks * ncb * SLAB * 4, WN_RSRC_FLAGS);
+    unsigned off[8];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const int iy = 2 * ty - 1 + a;
+        const bool rv = iy >= 0 && iy < H;
+        const unsigned rowb = (unsigned)(kq * HW + iy * W) * 4u;
+        off[a] = (rv && 2 * tx < W) ? rowb + 8u * tx : WN_OOB;
+        const int hx = (col == 0) ? 2 * tx - 1 : 2 * tx + 2;
+        off[4 + a] = (rv && (col == 0 || col == 15) && hx >= 0 && hx < W) ? rowb + 4u * hx : WN_OOB;
+    }
+    const bool p1ok = 2 * tx + 1 < W;
+    const unsigned cstep = 16u * HW;
+    const unsigned uoff = (unsigned)(cb * SLAB + tid * 4) * 4u;      // this thread's first float4 of a chunk's slab
+    const unsigned ustep = (unsigned)ncb * SLAB * 4u;                // bytes per chunk
+
+    struct Patch { unsigned p0[4], p1[4], h[4]; };                   // 4 rows: own column pair + halo element
+    auto gload = [&](Patch &r, int c) {
+        const unsigned so = (unsigned)c * cstep;
+        if (ABL & 8) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a) { r.p0[a] = so + a; r.p1[a] = so ^ a; r.h[a] = so; }
+            return;
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const auto pr = __builtin_amdgcn_raw_buffer_load_b64(rs, off[a], so, 0);
+            r.p0[a] = pr[0]; r.p1[a] = pr[1];
+            r.h[a] = __builtin_amdgcn_raw_buffer_load_b32(rs, off[4 + a], so, 0);
+        }
+    };
+    auto transform = [&](const Patch &r, float (&v)[16]) {
+        float d[16];
+        if (ABL & 4) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                v[4 * a] = __builtin_bit_cast(float, r.p0[a]); v[4 * a + 1] = __builtin_bit_cast(float, r.p1[a]);
+                v[4 * a + 2] = __builtin_bit_cast(float, r.h[a]); v[4 * a + 3] = __builtin_bit_cast(float, r.p0[a] ^ r.h[a]);
+            }
+            return;
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int p0 = (int)r.p0[a], hv = (int)r.h[a];
+            const int p1 = (LOAD == 2 && !p1ok) ? 0 : (int)r.p1[a];
+            d[4 * a] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(hv, p1, 0x111 /* row_shr:1 */, 0xf, 0xf, false));
+            d[4 * a + 1] = __builtin_bit_cast(float, p0);
+            d[4 * a + 2] = __builtin_bit_cast(float, p1);
+            d[4 * a + 3] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(hv, p0, 0x101 /* row_shl:1 */, 0xf, 0xf, false));
+        }
+        float t[16];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            t[j] = d[j] - d[8 + j];
+            t[4 + j] = d[4 + j] + d[8 + j];
+            t[8 + j] = d[8 + j] - d[4 + j];
+            t[12 + j] = d[12 + j] - d[4 + j];               // = -(B^T d)[3][j]: the packed filters carry the same sign
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[4 * i] = t[4 * i] - t[4 * i + 2];
+            v[4 * i + 1] = t[4 * i + 1] + t[4 * i + 2];
+            v[4 * i + 2] = t[4 * i + 2] - t[4 * i + 1];
+            v[4 * i + 3] = t[4 * i + 1] - t[4 * i + 3];
+        }
+    };
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    auto uload = [&](f4 &u0, f4 &u1, int c) {
+        const unsigned so = (unsigned)c * ustep;
+        u0 = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(ru, uoff, so, 0));
+        u1 = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(ru, uoff + 4096u, so, 0));
+    };
+    auto ustore = [&](int st, const f4 &u0, const f4 &u1) {
+        f4 *d0 = (f4 *)Us[st] + tid;
+        d0[0] = u0; d0[256] = u1;
+    };
+
+    f32x4 acc[16][NBLK];
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+#pragma unroll
+        for (int k = 0; k < NBLK; ++k) acc[i][k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // one K step: MFMAs of chunk c (operands vc, slab Us[c & 1]) with, underneath them, the transform of chunk c + 1
+    // (patch pin -> vn), the patch prefetch of chunk c + 2 (-> pout), the LDS store of slab c + 1 and the slab
+    // prefetch of chunk c + 2
+    auto kstep = [&](int c, const Patch &pin, Patch &pout, const float (&vc)[16], float (&vn)[16], f4 &u0, f4 &u1) {
+        f4 a[8];
+        const f4 *us = (const f4 *)Us[c & 1] + lane;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a[i] = us[i * 64];
+        transform(pin, vn);
+        const int cn = min(c + 2, nchunks - 1);      // prefetch index clamped (scalar): never reads past the tensors
+        gload(pout, cn);
+        ustore((c + 1) & 1, u0, u1);
+        uload(u0, u1, cn);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                for (int k = 0; k < NBLK; ++k) acc[4 * q + e][k] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q * NBLK + k][e], vc[4 * q + e], acc[4 * q + e][k], 0, 0, 0);
+            }
+        }
+        // pinned interleave: the 8 operand reads first, a dozen transform instructions while they are in flight, then one
+        // MFMA : one or two other instructions
+        if (MODE == 0) {
+        WN_SGB(WN_M_DS_RD, 8);
+        WN_SGB(WN_M_VALU, 12);
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            WN_SGB(WN_M_MFMA, 1);
+            if (i < 16) WN_SGB(WN_M_VALU, 2); else WN_SGB(WN_M_VALU, 1);
+            if (i % 3 == 1 && i < 30) WN_SGB(WN_M_VMEM_RD, 1);
+            if (i == 20 || i == 24) WN_SGB(WN_M_DS_WR, 1);
+        }
+        }
+        if (!(ABL & 2)) __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);          // the next step's transform must not be hoisted above its patch loads' latency
+    };
+
+    Patch pa, pb;
+    float va[16], vb[16];
+    f4 u0, u1;
+    gload(pa, 0);
+    uload(u0, u1, 0);
+    gload(pb, min(1, nchunks - 1));
+    ustore(0, u0, u1);
+    uload(u0, u1, min(1, nchunks - 1));
+    transform(pa, va);
+    __syncthreads();
+    int c = 0;
+    for (; c + 1 < nchunks; c += 2) {
+        kstep(c, pb, pa, va, vb, u0, u1);          // chunk c: transforms c+1 (in pb) -> vb, prefetches c+2 -> pa
+        kstep(c + 1, pa, pb, vb, va, u0, u1);      // chunk c+1: transforms c+2 (in pa) -> va, prefetches c+3 -> pb
+    }
+    if (nchunks & 1) kstep(c, pb, pa, va, vb, u0, u1);   // odd chunk count: one more step (its look-ahead work is discarded)
+    if (ABL & 1) {
+        f32x4 t = acc[0][0];
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+#pragma unroll
+            for (int k = 0; k < NBLK; ++k) if (i | k) t += acc[i][k];
+        if (t[0] + t[1] + t[2] + t[3] == 12345.678f) y[tid] = t[0];
+        return;
+    }
+    wn_epilogue<POOL, LOAD, NBLK>(acc, bias, y, residual, Cout, H, W, act, b, cb, kq, ty, tx);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Shared-transform variant.  Measured on gfx950 (tools/ubench/mfma_valu.hip): next to v_mfma_f32_16x16x4_f32 a VALU
+// instruction is NOT hidden -- it costs ~3 cycles with two wavefronts per SIMD (5.5 with one), s_nop / SALU cost nothing:
+// the f32 MFMA and the vector ALU serialise, so   time = 32 * n_mfma + 3 * n_valu   and the only lever left is the VALU
+// count.  Ablations of the pipelined kernel on conv1b: input transform 20 %, patch loads 14 %, output transform 11 %.
+//   * a workgroup = 2 tile rows x 2 cout slices of 32: the two wavefronts that own the same 16 tiles each transform HALF of
+//     every 4x4 patch (two of the four Winograd rows: 16 adds instead of 32, 3 patch rows instead of 4) and exchange the
+//     halves through LDS in MFMA operand order (2 ds_write_b128 + 4 ds_read_b128 per chunk, which the MFMAs do hide);
+//   * slice 0 computes rows {0, 1} from patch rows (0, 1, 2), slice 1 rows {3, 2} from patch rows (3, 2, 1) with the SAME
+//     instruction stream:  first = dA - dC,  second = dB + sgn * dC  (sgn = +1 / -1, one fma) -- slice 1's first row is
+//     -(B^T d)[3], which is why row 3 is carried negated in the packed filters as well (products unchanged);
+//   * the bias is folded into the accumulator of Winograd position (1, 1), whose output-transform weight is +1 for all four
+//     outputs: no bias instruction in the epilogue.
+// K loop software-pipelined and pinned like the pipelined kernel; one barrier per chunk.
+// ---------------------------------------------------------------------------------------------------------------------
+template <bool POOL, int LOAD, int ABL = 0>
+__global__ void __launch_bounds__(256, 2) wino_conv3x3_shared_kernel(
+    const float *__restrict__ x, const float *__restrict__ upk, const float *__restrict__ bias, float *__restrict__ y,
+    const float *__restrict__ residual, int Cin, int Cout, int H, int W, int nbx, int nby, int S, int Sx, int ncb, int ncb32, int act)
+{
+    constexpr int NBLK = 2;
+    constexpr int SLAB = 1024 * NBLK;
+    static_assert(LOAD == 1 || LOAD == 2, "paired loads only");
+    __shared__ __attribute__((aligned(16))) float Us[2][2][SLAB];          // [buffer][cout slice]           32 KB
+    __shared__ __attribute__((aligned(16))) float Vs[2][2][1024];          // [buffer][tile row][q][lane][e] 16 KB
+    const int id = blockIdx.x;
+    const int xcd = id & 7, jj = id >> 3;
+    const int cb = jj % ncb;                                                // 64-cout block
+    const int sl = jj / ncb;
+    const int s = xcd * Sx + sl;
+    if (sl >= Sx || s >= S) return;
+    const int bx = s % nbx, by = (s / nbx) % nby, b = s / (nbx * nby);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tr = w >> 1, cs = w & 1;
+    const int col = lane & 15, kq = lane >> 4;
+    const int ty = by * 2 + tr, tx = bx * WN_TX + col;
+    const int HW = H * W;
+    const int nchunks = Cin >> 2;
+
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(x + (size_t)b * Cin * HW), 0, Cin * HW * 4, WN_RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc((void *)upk, 0, nchunks * ncb32 * SLAB * 4, WN_RSRC_FLAGS);
+    // patch rows this wavefront needs: slice 0 rows (0, 1, 2), slice 1 rows (3, 2, 1) of the 4x4 patch
+    unsigned off[6];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const int pr = cs ? 3 - a : a;
+        const int iy = 2 * ty - 1 + pr;
+        const bool rv = iy >= 0 && iy < H;
+        const unsigned rowb = (unsigned)(kq * HW + iy * W) * 4u;
+        off[a] = (rv && 2 * tx < W) ? rowb + 8u * tx : WN_OOB;
+        const int hx = (col == 0) ? 2 * tx - 1 : 2 * tx + 2;
+        off[3 + a] = (rv && (col == 0 || col == 15) && hx >= 0 && hx < W) ? rowb + 4u * hx : WN_OOB;
+    }
+    const float sgn = cs ? -1.f : 1.f;
+    const bool p1ok = 2 * tx + 1 < W;
+    const unsigned cstep = 16u * HW;
+    // packed filters: the workgroup stages the two 32-cout slabs of its 64-cout block; thread tid moves float4 tid and tid + 256 of each
+    const unsigned uoff = (unsigned)(2 * cb * SLAB + tid * 4) * 4u;
+    const unsigned ustep = (unsigned)ncb32 * SLAB * 4u;
+    const bool s1ok = 2 * cb + 1 < ncb32;                                   // odd number of 32-cout blocks: the last slice 1 does not exist
+
+    struct Patch { unsigned p0[3], p1[3], h[3]; };
+    auto gload = [&](Patch &r, int c) {
+        const unsigned so = (unsigned)c * cstep;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const auto pr = __builtin_amdgcn_raw_buffer_load_b64(rs, off[a], so, 0);
+            r.p0[a] = pr[0]; r.p1[a] = pr[1];
+            r.h[a] = __builtin_amdgcn_raw_buffer_load_b32(rs, off[3 + a], so, 0);
+        }
+    };
+    // half transform: o[0..3] = "first" Winograd row, o[4..7] = "second" row of this slice
+    auto htransform = [&](const Patch &r, float (&o)[8]) {
+        float d[3][4];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const int p0 = (int)r.p0[a], hv = (int)r.h[a];
+            const int p1 = (LOAD == 2 && !p1ok) ? 0 : (int)r.p1[a];
+            d[a][0] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(hv, p1, 0x111 /* row_shr:1 */, 0xf, 0xf, false));
+            d[a][1] = __builtin_bit_cast(float, p0);
+            d[a][2] = __builtin_bit_cast(float, p1);
+            d[a][3] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(hv, p0, 0x101 /* row_shl:1 */, 0xf, 0xf, false));
+        }
+        float tf[4], ts[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            tf[j] = d[0][j] - d[2][j];
+            ts[j] = __builtin_fmaf(d[2][j], sgn, d[1][j]);
+        }
+        o[0] = tf[0] - tf[2]; o[1] = tf[1] + tf[2]; o[2] = tf[2] - tf[1]; o[3] = tf[1] - tf[3];
+        o[4] = ts[0] - ts[2]; o[5] = ts[1] + ts[2]; o[6] = ts[2] - ts[1]; o[7] = ts[1] - ts[3];
+    };
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    // slice 0 owns q = 0 (first), 1 (second); slice 1 owns q = 3 (first), 2 (second)
+    const int qf = cs ? 3 : 0, qs = cs ? 2 : 1;
+    auto vstore = [&](int st, const float (&o)[8]) {
+        f4 *dv = (f4 *)Vs[st][tr] + lane;
+        dv[qf * 64] = (f4){o[0], o[1], o[2], o[3]};
+        dv[qs * 64] = (f4){o[4], o[5], o[6], o[7]};
+    };
+    struct UReg { f4 u[4]; };
+    auto uload = [&](UReg &r, int c) {
+        const unsigned so = (unsigned)c * ustep;
+        r.u[0] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(ru, uoff, so, 0));
+        r.u[1] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(ru, uoff + 4096u, so, 0));
+        r.u[2] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(ru, s1ok ? uoff + 8192u : WN_OOB, so, 0));
+        r.u[3] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(ru, s1ok ? uoff + 12288u : WN_OOB, so, 0));
+    };
+    auto ustore = [&](int st, const UReg &r) {
+        f4 *d0 = (f4 *)Us[st][0] + tid;                                     // the two slabs are contiguous: [0] then [1]
+        d0[0] = r.u[0]; d0[256] = r.u[1]; d0[512] = r.u[2]; d0[768] = r.u[3];
+    };
+
+    f32x4 acc[16][NBLK];
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+#pragma unroll
+        for (int k = 0; k < NBLK; ++k) acc[i][k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (bias) {                                                             // position (1, 1) reaches all four outputs with weight +1
+#pragma unroll
+        for (int k = 0; k < NBLK; ++k)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = cb * 64 + cs * 32 + k * 16 + 4 * kq + r;
+                acc[5][k][r] = co < Cout ? bias[co] : 0.f;
+            }
+    }
+
+    auto kstep = [&](int c, const Patch &pin, Patch &pout, UReg &ur) {
+        f4 a[8], vv[4];
+        const f4 *us = (const f4 *)Us[c & 1][cs] + lane;
+        const f4 *vs = (const f4 *)Vs[c & 1][tr] + lane;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) vv[q] = vs[q * 64];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a[i] = us[i * 64];
+        float o[8];
+        if (!(ABL & 4)) htransform(pin, o);
+        else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] = __builtin_bit_cast(float, pin.p0[i % 3] ^ pin.h[i % 3] + i);
+        }
+        vstore((c + 1) & 1, o);
+        const int cn = min(c + 2, nchunks - 1);      // prefetch index clamped (scalar): never reads past the tensors
+        gload(pout, cn);
+        ustore((c + 1) & 1, ur);
+        uload(ur, cn);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                for (int k = 0; k < NBLK; ++k) acc[4 * q + e][k] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q * NBLK + k][e], vv[q][e], acc[4 * q + e][k], 0, 0, 0);
+            }
+        }
+        // pinned interleave: 12 operand reads, the first transform instructions while they fly, then MFMA : 1 other
+        WN_SGB(WN_M_DS_RD, 12);
+        WN_SGB(WN_M_VALU, 6);
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            WN_SGB(WN_M_MFMA, 1);
+            WN_SGB(WN_M_VALU, 1);
+            if (i % 3 == 0 && i < 30) WN_SGB(WN_M_VMEM_RD, 1);
+            if (i == 12 || i == 14) WN_SGB(WN_M_DS_WR, 1);                  // the two halves of V (needed first by the partner)
+            if (i >= 20 && i < 28 && (i & 1) == 0) WN_SGB(WN_M_DS_WR, 1);   // the next chunk's filter slabs
+        }
+        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    Patch pa, pb;
+    UReg ur;
+    gload(pa, 0);
+    uload(ur, 0);
+    gload(pb, min(1, nchunks - 1));
+    {
+        float o[8];
+        htransform(pa, o);
+        vstore(0, o);
+    }
+    ustore(0, ur);
+    uload(ur, min(1, nchunks - 1));
+    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+    int c = 0;
+    for (; c + 1 < nchunks; c += 2) {
+        kstep(c, pb, pa, ur);
+        kstep(c + 1, pa, pb, ur);
+    }
+    if (nchunks & 1) kstep(c, pb, pa, ur);              // odd chunk count: one more step (its look-ahead work is discarded)
+    if (ABL & 1) {
+        f32x4 t = acc[0][0];
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+#pragma unroll
+            for (int k = 0; k < NBLK; ++k) if (i | k) t += acc[i][k];
+        if (t[0] + t[1] + t[2] + t[3] == 12345.678f) y[tid] = t[0];
+        return;
+    }
+    wn_epilogue<POOL, LOAD, NBLK>(acc, nullptr, y, residual, Cout, H, W, act, b, 2 * cb + cs, kq, ty, tx);
 }
 
 static inline int wn_coutp(int Cout, int nblk) { const int q = 16 * nblk; return (Cout + q - 1) / q * q; }
@@ -336,31 +731,72 @@ int mfr_wino_filter_transform(const float *w, int Cin, int Cout, float *upk, voi
     return 0;
 }
 
-int mfr_conv3x3_wino(const float *x, const float *upk, const float *bias, const float *residual, int B, int Cin, int Cout, int H, int W,
-                     int act, int pool, float *y, void *stream)
+// variant: 0 = default (the faster measured one for the shape), 1 = classic (transform then MFMA run per chunk),
+// 2 = software-pipelined (transform of chunk c+1 under the MFMAs of chunk c), 3 = 2 without the pinned interleave,
+// 4 = shared-transform kernel (two cout slices split every patch transform; see wino_conv3x3_shared_kernel).  All variants give
+// bit-identical results; the selector exists for the A/B timing tool and the parity tests.
+int mfr_conv3x3_wino_variant(const float *x, const float *upk, const float *bias, const float *residual, int B, int Cin, int Cout, int H, int W,
+                             int act, int pool, int variant, float *y, void *stream)
 {
     if (!x || !upk || !y || B <= 0 || Cin <= 0 || Cout <= 0 || (Cin & 3) || H <= 0 || W <= 0 || act < 0 || act > 2) return MFR_E_ARG;
     if (pool && (H < 2 || W < 2 || residual)) return MFR_E_ARG;
+    if (variant < 0 || (variant > 4 && (variant < 10 || variant > 29)) ) return MFR_E_ARG;
     if ((size_t)4 * Cin * H * W >= 0x7fffffffull) return MFR_E_ARG;    // one image must fit a 2 GB buffer descriptor
-    const int nblk = wn_nblk(Cout);
+    const int nblk = WN_NBLK;
     const int nbx = ((W + 1) / 2 + WN_TX - 1) / WN_TX, nby = ((H + 1) / 2 + WN_TY - 1) / WN_TY;
     const int ncb = wn_coutp(Cout, nblk) / (16 * nblk);
+    if ((size_t)16 * Cin * wn_coutp(Cout, nblk) * 4 >= 0x7fffffffull) return MFR_E_ARG;
     const long long S = (long long)nbx * nby * B;
     const long long Sx = (S + 7) / 8;                        // spatial blocks per XCD
     const long long grid = Sx * 8 * ncb;
     if (grid > 0x7fffffffll) return MFR_E_ARG;
-    const char *ev = getenv("MFR_WINO_LOAD");                // tuning aid: 0 forces the 16-dword path
-    const int load = (ev && atoi(ev) == 0) ? 0 : ((W & 1) ? 2 : 1);
+    // default: the shared-transform kernel when the cout count fills whole 64-channel workgroups (an odd number of 32-channel
+    // blocks would idle one slice of the last block), else the pipelined kernel
+    if (variant == 0) variant = ((wn_coutp(Cout, nblk) / 32) & 1) ? 2 : 4;
+    const bool odd = W & 1;
     hipStream_t st = (hipStream_t)stream;
-#define WN_ARGS grid, st, x, upk, bias, y, residual, Cin, Cout, H, W, nbx, nby, (int)S, (int)Sx, ncb, act
-#define WN_PICK_LOAD(P, N) do { if (load == 0) wn_launch<P, 0, N>(WN_ARGS); else if (load == 1) wn_launch<P, 1, N>(WN_ARGS); \
-                                else wn_launch<P, 2, N>(WN_ARGS); } while (0)
-    if (nblk == 4) { if (pool) WN_PICK_LOAD(true, 4); else WN_PICK_LOAD(false, 4); }
-    else { if (pool) WN_PICK_LOAD(true, 2); else WN_PICK_LOAD(false, 2); }
-#undef WN_PICK_LOAD
+#define WN_ARGS x, upk, bias, y, residual, Cin, Cout, H, W, nbx, nby, (int)S, (int)Sx, ncb, act
+#define WN_GO(K) hipLaunchKernelGGL(K, dim3((unsigned)grid), dim3(256), 0, st, WN_ARGS)
+    if (variant == 4 || variant >= 26) {                   // shared-transform kernel: workgroup = 2 tile rows x 64 couts
+        const int nby2 = ((H + 1) / 2 + 1) / 2, ncb32 = wn_coutp(Cout, nblk) / 32, ncb64 = (ncb32 + 1) / 2;
+        const long long S2 = (long long)nbx * nby2 * B, Sx2 = (S2 + 7) / 8, grid2 = Sx2 * 8 * ncb64;
+        if (grid2 > 0x7fffffffll) return MFR_E_ARG;
+#define WN_GO2(K) hipLaunchKernelGGL(K, dim3((unsigned)grid2), dim3(256), 0, st, x, upk, bias, y, residual, Cin, Cout, H, W, nbx, nby2, (int)S2, (int)Sx2, ncb64, ncb32, act)
+        if (variant == 4) {
+            if (pool) { if (odd) WN_GO2((wino_conv3x3_shared_kernel<true, 2>)); else WN_GO2((wino_conv3x3_shared_kernel<true, 1>)); }
+            else { if (odd) WN_GO2((wino_conv3x3_shared_kernel<false, 2>)); else WN_GO2((wino_conv3x3_shared_kernel<false, 1>)); }
+        } else if (variant == 27) { if (pool) WN_GO2((wino_conv3x3_shared_kernel<true, 1, 1>)); else WN_GO2((wino_conv3x3_shared_kernel<false, 1, 1>)); }
+        else if (variant == 28) { if (pool) WN_GO2((wino_conv3x3_shared_kernel<true, 1, 4>)); else WN_GO2((wino_conv3x3_shared_kernel<false, 1, 4>)); }
+        else if (variant == 29) { if (pool) WN_GO2((wino_conv3x3_shared_kernel<true, 1, 5>)); else WN_GO2((wino_conv3x3_shared_kernel<false, 1, 5>)); }
+        else return MFR_E_ARG;
+#undef WN_GO2
+    } else if (variant == 2) {
+        if (pool) { if (odd) WN_GO((wino_conv3x3_pipe_kernel<true, 2, 0>)); else WN_GO((wino_conv3x3_pipe_kernel<true, 1, 0>)); }
+        else { if (odd) WN_GO((wino_conv3x3_pipe_kernel<false, 2, 0>)); else WN_GO((wino_conv3x3_pipe_kernel<false, 1, 0>)); }
+    } else if (variant >= 10) {                            // timing ablations of the pipelined kernel (even W, as launched by the tool)
+        switch (variant - 10) {
+#define WN_ABL(A) case A: if (pool) WN_GO((wino_conv3x3_pipe_kernel<true, 1, 0, A>)); else WN_GO((wino_conv3x3_pipe_kernel<false, 1, 0, A>)); break;
+        WN_ABL(1) WN_ABL(2) WN_ABL(3) WN_ABL(4) WN_ABL(8) WN_ABL(12) WN_ABL(15)
+#undef WN_ABL
+        default: return MFR_E_ARG;
+        }
+    } else if (variant == 3) {
+        if (pool) { if (odd) WN_GO((wino_conv3x3_pipe_kernel<true, 2, 1>)); else WN_GO((wino_conv3x3_pipe_kernel<true, 1, 1>)); }
+        else { if (odd) WN_GO((wino_conv3x3_pipe_kernel<false, 2, 1>)); else WN_GO((wino_conv3x3_pipe_kernel<false, 1, 1>)); }
+    } else {
+        if (pool) { if (odd) WN_GO((wino_conv3x3_kernel<true, 2, WN_NBLK>)); else WN_GO((wino_conv3x3_kernel<true, 1, WN_NBLK>)); }
+        else { if (odd) WN_GO((wino_conv3x3_kernel<false, 2, WN_NBLK>)); else WN_GO((wino_conv3x3_kernel<false, 1, WN_NBLK>)); }
+    }
+#undef WN_GO
 #undef WN_ARGS
     CHECK_LAUNCH();
     return 0;
+}
+
+int mfr_conv3x3_wino(const float *x, const float *upk, const float *bias, const float *residual, int B, int Cin, int Cout, int H, int W,
+                     int act, int pool, float *y, void *stream)
+{
+    return mfr_conv3x3_wino_variant(x, upk, bias, residual, B, Cin, Cout, H, W, act, pool, 0, y, stream);
 }
 
 }  // extern "C"

@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-def _wino(x, w, b, relu, pool, residual=None):
+def _wino(x, w, b, relu, pool, residual=None, variant=0):
     lib = _lib.load(require_gpu=True)
     B, ci, H, W = x.shape
     co = w.shape[0]
@@ -22,9 +22,12 @@ def _wino(x, w, b, relu, pool, residual=None):
     u = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)
     _lib.check(lib.mfr_wino_filter_transform(_lib.ptr(w), ci, co, _lib.ptr(u), _lib.stream_ptr()), "filter")
     y = torch.full((B, co, H // 2, W // 2) if pool else (B, co, H, W), float("nan"), dtype=torch.float32, device=x.device)
-    _lib.check(lib.mfr_conv3x3_wino(_lib.ptr(x), _lib.ptr(u), _lib.ptr(b) if b is not None else None,
-                                    _lib.ptr(residual) if residual is not None else None, B, ci, co, H, W,
-                                    int(relu), int(pool), _lib.ptr(y), _lib.stream_ptr()), "conv")
+    args = (_lib.ptr(x), _lib.ptr(u), _lib.ptr(b) if b is not None else None, _lib.ptr(residual) if residual is not None else None,
+            B, ci, co, H, W, int(relu), int(pool))
+    if variant == 0:
+        _lib.check(lib.mfr_conv3x3_wino(*args, _lib.ptr(y), _lib.stream_ptr()), "conv")
+    else:
+        _lib.check(lib.mfr_conv3x3_wino_variant(*args, variant, _lib.ptr(y), _lib.stream_ptr()), "conv")
     return y
 
 
@@ -50,6 +53,26 @@ def test_wino_conv_vs_float64(B, ci, co, H, W, relu, pool, bias):
     assert y.shape == r.shape
     assert torch.isfinite(y).all()                       # every output element written
     assert (y.double().cpu() - r).abs().max().item() < 2e-5
+
+
+@pytest.mark.parametrize("B,ci,co,H,W,act,pool,res", [
+    (2, 64, 64, 30, 52, 1, 1, 0), (1, 64, 128, 45, 67, 1, 0, 0), (1, 196, 196, 23, 34, 1, 0, 1), (1, 12, 40, 7, 9, 2, 0, 1),
+    (2, 4, 32, 5, 3, 0, 0, 0), (1, 132, 256, 19, 33, 1, 1, 0)])
+def test_wino_kernel_variants_agree(B, ci, co, H, W, act, pool, res):
+    """the three kernels behind mfr_conv3x3_wino (classic, software-pipelined, shared-transform) on the same operands: the
+    pipelined one is bit-identical to the classic one (same arithmetic, different schedule); the shared-transform one folds
+    the bias into an accumulator and carries one Winograd row negated -- f32-roundoff differences only.  Odd chunk counts
+    (Cin % 8 == 4), odd widths and padded cout blocks included."""
+    g = torch.Generator().manual_seed(ci + 13 * co + H)
+    x = torch.randn(B, ci, H, W, generator=g).to(DEV)
+    w = (torch.randn(co, ci, 3, 3, generator=g) / (3.0 * ci ** 0.5)).to(DEV)
+    b = torch.randn(co, generator=g).to(DEV)
+    r = torch.randn(B, co, H, W, generator=g).to(DEV) if res else None
+    y1, y2, y4 = (_wino(x, w, b, act, pool, r, variant=v) for v in (1, 2, 4))
+    want = _ref(x, w, b, act, pool, r)
+    assert torch.equal(y1, y2)
+    for y in (y1, y4):
+        assert torch.isfinite(y).all() and (y.double().cpu() - want).abs().max().item() < 2e-5
 
 
 def test_wino_linearity_and_shift():
