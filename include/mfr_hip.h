@@ -240,6 +240,19 @@ int mfr_bias_relu_nchw(float *x, const float *bias, int B, int C, int HW, void *
 int mfr_bias_pool2_relu_nchw(const float *x, const float *bias, int B, int C, int H, int W, float *y, void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * LoFTR transformer / FPN glue, fused (csrc/loftr_fused.hip).  Reference call site: LoFTR_matcher.match
+ * (etc/feature_matching_baselines/matchers.py:24-59) -> upstream LoFTREncoderLayer / ResNetFPN_8_2 (un-vendored).
+ *   mfr_layernorm       torch.nn.LayerNorm(C) over rows of x (row stride ldx floats), C in {128, 256}, + optional residual
+ *                       (row stride ldr; may alias out): out[r] = residual[r] + (x[r] - mean) * rstd * gamma + beta, row stride
+ *                       ldo.  Strides let norm1 write into the right half of the MLP's [x | message] operand (no cat) and
+ *                       norm2 + residual update x in place.  All pointers 16-byte aligned, strides multiples of 4.
+ *   mfr_upsample2x_add  y [planes,2H,2W] += F.interpolate(lo [planes,H,W], scale_factor=2, bilinear, align_corners=True)
+ */
+int mfr_layernorm(const float *x, int ldx, const float *gamma, const float *beta, const float *residual, int ldr, long long rows, int C,
+                  float eps, float *out, int ldo, void *stream);
+int mfr_upsample2x_add(const float *lo, float *y, int planes, int H, int W, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * SIFT-descriptor correspondence leg.  Reference call sites:
  * SIFTMatching.get_correspondences (lib/models/matching/feature_matching.py:75-118) and
  * SIFT_matcher.match (etc/feature_matching_baselines/matchers.py:135-188), everything AFTER

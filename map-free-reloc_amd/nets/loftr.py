@@ -130,10 +130,8 @@ class LoFTRHIP:
         x2 = self._block(self._block(x1, "layer2.0", 2), "layer2.1", 1)
         x3 = self._block(self._block(x2, "layer3.0", 2), "layer3.1", 1)
         x3_out = self._c(x3, "l3out")
-        x3_2x = F.interpolate(x3_out, scale_factor=2., mode='bilinear', align_corners=True)
-        x2_out = self._c(self._c(self._c(x2, "l2out") + x3_2x, "l2out2.0", 1, "leaky"), "l2out2.3")
-        x2_2x = F.interpolate(x2_out, scale_factor=2., mode='bilinear', align_corners=True)
-        x1_out = self._c(self._c(self._c(x1, "l1out") + x2_2x, "l1out2.0", 1, "leaky"), "l1out2.3")
+        x2_out = self._c(self._c(self.upsample2x_add(x3_out, self._c(x2, "l2out")), "l2out2.0", 1, "leaky"), "l2out2.3")
+        x1_out = self._c(self._c(self.upsample2x_add(x2_out, self._c(x1, "l1out")), "l1out2.0", 1, "leaky"), "l1out2.3")
         return x3_out, x1_out
 
     # ------------------------------------------------------------------ HIP stage wrappers
@@ -179,29 +177,61 @@ class LoFTRHIP:
                    "mfr_loftr_coarse_match")
         return i_ids, j_ids, mconf, n
 
+    def upsample2x_add(self, lo, y):
+        """y += F.interpolate(lo, scale_factor=2, bilinear, align_corners=True), one pass (csrc/loftr_fused.hip)"""
+        lib = _lib.load()
+        B, C, H, W = lo.shape
+        assert y.shape == (B, C, 2 * H, 2 * W) and y.is_contiguous()
+        _lib.check(lib.mfr_upsample2x_add(_lib.ptr(lo.contiguous()), _lib.ptr(y), B * C, H, W, _lib.stream_ptr()), "mfr_upsample2x_add")
+        return y
+
+    @staticmethod
+    def layernorm(x, norm, out, residual=None):
+        """out = [residual +] LayerNorm(x) over the last dim (128 / 256); x, out, residual are 2-D row-strided views
+        (csrc/loftr_fused.hip: strides let the result land inside the MLP's [x | message] operand / update x in place)"""
+        lib = _lib.load()
+        rows, C = x.shape
+        assert x.stride(1) == 1 and out.stride(1) == 1 and out.shape == x.shape
+        _lib.check(lib.mfr_layernorm(x.data_ptr(), x.stride(0), _lib.ptr(norm[0]), _lib.ptr(norm[1]),
+                                     residual.data_ptr() if residual is not None else None, residual.stride(0) if residual is not None else 0,
+                                     rows, C, 1e-5, out.data_ptr(), out.stride(0), _lib.stream_ptr()), "mfr_layernorm")
+        return out
+
     def coarse_match_features(self, f0, f1, hw):
         """coarse features [B,L,256] x2 -> dual-softmax mutual-NN matches (upstream CoarseMatching, dual_softmax)"""
         C = f0.shape[-1]
-        S = torch.bmm(f0 / C ** .5, (f1 / C ** .5).transpose(1, 2))
+        S = torch.bmm(f0, f1.transpose(1, 2))            # strided operands are fine for the batched GEMM
+        S.mul_(1.0 / C)                                  # (f0 / sqrt C) . (f1 / sqrt C)
         return self.coarse_match(S, hw, hw)
 
-    def gather_windows(self, feat_nhwc, img_ids, cell_ids, wc, stride):
+    def gather_windows(self, feat_nhwc, img_ids, cell_ids, wc, stride, out=None):
         lib = _lib.load()
         Bimg, Hf, Wf, C = feat_nhwc.shape
         M = img_ids.numel()
-        out = torch.empty(M, self.W * self.W, C, dtype=torch.float32, device=feat_nhwc.device)
+        if out is None:
+            out = torch.empty(M, self.W * self.W, C, dtype=torch.float32, device=feat_nhwc.device)
+        assert out.is_contiguous() and out.shape == (M, self.W * self.W, C)
         _lib.check(lib.mfr_loftr_gather_windows(_lib.ptr(feat_nhwc), Bimg, Hf, Wf, C, _lib.ptr(img_ids), _lib.ptr(cell_ids), M,
                                                 wc, stride, self.W, _lib.ptr(out), _lib.stream_ptr()), "mfr_loftr_gather_windows")
         return out
 
     # ------------------------------------------------------------------ transformer layers
-    def _layer(self, Lw, x, src, attn):
-        q = F.linear(x, Lw["wq"])
-        kv = F.linear(src, Lw["wkv"])
-        msg = attn(q, kv)
-        msg = F.layer_norm(F.linear(msg, Lw["wm"]), (x.shape[-1],), *Lw["n1"])
-        msg = F.linear(F.relu_(F.linear(torch.cat([x, msg], -1), Lw["w1"])), Lw["w2"])
-        return x + F.layer_norm(msg, (x.shape[-1],), *Lw["n2"])
+    # Features live in xm [2, n, 2C]: xm[s, :, :C] = tokens of side s (0 = image0 rows, 1 = image1 rows), xm[s, :, C:] = the
+    # layer's normalised message -- i.e. the MLP's cat([x, message]) operand exists in place and is never copied.
+    def _layer(self, Lw, xm, src, attn, nb, L):
+        """one LoFTREncoderLayer on the rows of xm [n, 2C] (updated in place) attending to src [n, C] (row-strided view)"""
+        n, C2 = xm.shape
+        C = C2 // 2
+        x = xm[:, :C]
+        q = torch.mm(x, Lw["wq"].t())
+        kv = torch.mm(src, Lw["wkv"].t())
+        msg = attn(q.view(nb, L, C), kv.view(nb, L, 2 * C))
+        self.layernorm(torch.mm(msg.view(n, C), Lw["wm"].t()), Lw["n1"], xm[:, C:])
+        if "zb" not in Lw:
+            Lw["zb"] = torch.zeros(C2, dtype=torch.float32, device=xm.device)
+        hid = torch._addmm_activation(Lw["zb"], xm, Lw["w1"].t())                  # relu([x | message] W1^T) in the GEMM epilogue
+        self.layernorm(torch.mm(hid, Lw["w2"].t()), Lw["n2"], x, residual=x)        # x += norm2(mlp)
+        return xm
 
     @staticmethod
     def _torch_linear_attention(nhead):
@@ -216,16 +246,18 @@ class LoFTRHIP:
             return (torch.einsum("nlhd,nhdv,nlh->nlhv", Q, KV, Z) * L).reshape(B, L, D)
         return attn
 
-    def _transformer(self, layers, f0, f1, attn):
+    def _transformer(self, layers, xm, attn, nb, L):
+        """xm [2, nb * L, 2C] in place: self layers on both sides at once, cross layers feat0 first, then feat1 against the
+        UPDATED feat0 (upstream order)"""
+        C = xm.shape[-1] // 2
+        both = xm.view(-1, 2 * C)
         for l, Lw in enumerate(layers):
-            if l % 2 == 0:      # self: both images independent -> one batched call
-                B = f0.shape[0]
-                x = self._layer(Lw, torch.cat([f0, f1], 0), torch.cat([f0, f1], 0), attn)
-                f0, f1 = x[:B], x[B:]
-            else:               # cross: feat1 attends to the UPDATED feat0 (upstream order)
-                f0 = self._layer(Lw, f0, f1, attn)
-                f1 = self._layer(Lw, f1, f0, attn)
-        return f0, f1
+            if l % 2 == 0:
+                self._layer(Lw, both, both[:, :C], attn, 2 * nb, L)
+            else:
+                self._layer(Lw, xm[0], xm[1][:, :C], attn, nb, L)
+                self._layer(Lw, xm[1], xm[0][:, :C], attn, nb, L)
+        return xm
 
     # ------------------------------------------------------------------ full forward
     @torch.no_grad()
@@ -239,11 +271,13 @@ class LoFTRHIP:
         key = (hc, wc)
         if key not in self._pe:
             self._pe[key] = position_encoding_sine(256, hc, wc, images.device)
-        fc = (fc + self._pe[key][None]).flatten(2).transpose(1, 2).contiguous()        # [2B, L, 256]
-        f0, f1 = fc[0::2].contiguous(), fc[1::2].contiguous()
-        f0, f1 = self._transformer(self.coarse, f0, f1, self.linear_attention)
-        i_ids, j_ids, mconf, n = self.coarse_match_features(f0, f1, (hc, wc))
         L0 = hc * wc
+        xm = torch.empty(2, B * L0, 512, dtype=torch.float32, device=images.device)
+        # + positional encoding, NCHW -> token-major, pairs de-interleaved (side-major): one strided copy into the left half
+        xm.view(2, B, L0, 512)[..., :256].copy_((fc + self._pe[key][None]).view(B, 2, 256, L0).permute(1, 0, 3, 2))
+        self._transformer(self.coarse, xm, self.linear_attention, B, L0)
+        f0, f1 = xm[0].view(B, L0, 512)[..., :256], xm[1].view(B, L0, 512)[..., :256]     # row-strided views
+        i_ids, j_ids, mconf, n = self.coarse_match_features(f0, f1, (hc, wc))
         scale = H // hc
         # coarse keypoints (padded layout)
         ii, jj = i_ids.long(), j_ids.long()
@@ -257,13 +291,19 @@ class LoFTRHIP:
             mi, mj = ii[b_ids, slot], jj[b_ids, slot]
             ff_nhwc = ff.permute(0, 2, 3, 1).contiguous()                           # [2B, Hf, Wf, 128]
             stride = ff.shape[2] // hc
-            w0 = self.gather_windows(ff_nhwc, (2 * b_ids).int(), mi.int(), wc, stride)
-            w1 = self.gather_windows(ff_nhwc, (2 * b_ids + 1).int(), mj.int(), wc, stride)
-            fcw = F.linear(torch.cat([f0[b_ids, mi], f1[b_ids, mj]], 0), *self.down_proj)
             WW = self.W * self.W
-            fcf = F.linear(torch.cat([torch.cat([w0, w1], 0), fcw[:, None].expand(-1, WW, -1)], -1), *self.merge_feat)
-            g0, g1 = fcf[:M], fcf[M:]
-            g0, g1 = self._transformer(self.fine, g0, g1, self.fine_attention if self.W == 5 else self._torch_linear_attention(8))
+            win = torch.empty(2 * M, WW, 128, dtype=torch.float32, device=images.device)
+            self.gather_windows(ff_nhwc, (2 * b_ids).int(), mi.int(), wc, stride, out=win[:M])
+            self.gather_windows(ff_nhwc, (2 * b_ids + 1).int(), mj.int(), wc, stride, out=win[M:])
+            fcw = F.linear(torch.cat([f0[b_ids, mi], f1[b_ids, mj]], 0), *self.down_proj)
+            # merge_feat(cat[window, coarse]) = window Wa^T + (coarse Wb^T + b): the coarse half is constant over the 25 taps
+            wmf, bmf = self.merge_feat
+            cw = torch.addmm(bmf, fcw, wmf[:, 128:].t())
+            xf = torch.empty(2, M * WW, 256, dtype=torch.float32, device=images.device)
+            torch.add(torch.mm(win.view(2 * M * WW, 128), wmf[:, :128].t()).view(2 * M, WW, 128), cw[:, None, :],
+                      out=xf.view(2 * M, WW, 256)[..., :128])
+            self._transformer(self.fine, xf, self.fine_attention if self.W == 5 else self._torch_linear_attention(8), M, WW)
+            g0, g1 = xf[0].view(M, WW, 256)[..., :128], xf[1].view(M, WW, 256)[..., :128]
             picked = g0[:, WW // 2]
             heat = torch.softmax(torch.einsum('mc,mrc->mr', picked, g1) / g0.shape[-1] ** .5, dim=1).view(-1, self.W, self.W)
             lin = torch.linspace(-1, 1, self.W, device=images.device)

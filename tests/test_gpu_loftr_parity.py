@@ -116,3 +116,38 @@ def test_loftr_end_to_end_vs_oracle(pair, hw):
     assert len(common) >= 0.97 * max(len(kw), len(kg)), (len(kw), len(kg), len(common))
     d = np.array([np.abs(kw[k] - kg[k]).max() for k in common])
     assert np.quantile(d, 0.99) < 2e-2, np.quantile(d, [0.5, 0.9, 0.99, 1.0])
+
+
+@pytest.mark.parametrize("rows,C", [(1, 256), (1031, 256), (777, 128), (6120 * 3, 256)])
+def test_fused_layernorm_vs_torch(rows, C):
+    """csrc/loftr_fused.hip layernorm: strided input / residual / output (the [x | message] layout of nets/loftr.py) against
+    torch.nn.functional.layer_norm in float64; in-place residual update included.  f32 tolerance 2e-6 * (1 + |y|)."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(rows + C)
+    xm = torch.randn(rows, 2 * C, generator=g).to(DEV)
+    m = (torch.randn(rows, C, generator=g) * 3 + 0.5).to(DEV)
+    gam, bet = torch.randn(C, generator=g).to(DEV), torch.randn(C, generator=g).to(DEV)
+    want1 = F.layer_norm(m.double().cpu(), (C,), gam.double().cpu(), bet.double().cpu(), 1e-5)
+    keep = xm.clone()
+    LoFTRHIP.layernorm(m, (gam, bet), xm[:, C:])                       # norm1 -> right half
+    got1 = xm[:, C:].double().cpu()
+    assert torch.equal(xm[:, :C], keep[:, :C])                         # left half untouched
+    assert ((got1 - want1).abs() / (1 + want1.abs())).max().item() < 2e-6
+    LoFTRHIP.layernorm(m, (gam, bet), xm[:, :C], residual=xm[:, :C])    # x += norm2(...) in place
+    want2 = keep[:, :C].double().cpu() + want1
+    assert ((xm[:, :C].double().cpu() - want2).abs() / (1 + want2.abs())).max().item() < 2e-6
+
+
+@pytest.mark.parametrize("B,C,H,W", [(1, 3, 5, 7), (2, 8, 45, 34), (1, 4, 90, 68), (1, 2, 1, 1)])
+def test_fused_upsample2x_add_vs_torch(pair, B, C, H, W):
+    import torch.nn.functional as F
+    _, hip = pair
+    g = torch.Generator().manual_seed(H * W)
+    lo = torch.randn(B, C, H, W, generator=g).to(DEV)
+    y = torch.randn(B, C, 2 * H, 2 * W, generator=g).to(DEV)
+    want = y.double().cpu() + F.interpolate(lo.double().cpu(), scale_factor=2.0, mode="bilinear", align_corners=True)
+    lib32 = (y + F.interpolate(lo, scale_factor=2.0, mode="bilinear", align_corners=True)).double().cpu()     # the f32 library path it replaces
+    got = hip.upsample2x_add(lo, y.clone()).double().cpu()
+    # the source coordinate o * (H-1)/(2H-1) is formed in f32 (as in torch's kernel): ~1e-5 of a pixel at 180 rows, so
+    # either f32 evaluation sits within a few 1e-5 of the f64 one (unit-scale data)
+    assert (got - lib32).abs().max().item() < 5e-5 and (got - want).abs().max().item() < 5e-5
