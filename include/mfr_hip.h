@@ -240,6 +240,18 @@ int mfr_bias_relu_nchw(float *x, const float *bias, int B, int C, int HW, void *
 int mfr_bias_pool2_relu_nchw(const float *x, const float *bias, int B, int C, int H, int W, float *y, void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * ProcrustesSolver's optional whole-cloud ICP refinement (PROCRUSTES.REFINE, lib/models/matching/pose_solver.py:290-319;
+ * config/matching/scannet/ *_icp.yaml): o3d registration_icp(point-to-point, max distance, init = RANSAC transform,
+ * ICPConvergenceCriteria(rel_fitness, rel_rmse, max_iter)) restated (csrc/procrustes_icp.hip); R, t are in/out, pairs whose
+ * `status` (may be NULL) is not MFR_ST_OK are left untouched with 0 inliers; n_inliers = int(fitness * |target cloud|) (:319).
+ */
+size_t mfr_procrustes_icp_workspace_bytes(int B, int H, int W);
+int mfr_procrustes_icp_refine(const float *depth0, const float *depth1, int B, int H, int W, const float *K0, const float *K1,
+                              double max_corr_dist, double rel_fitness, double rel_rmse, int max_iter, const int32_t *status,
+                              void *workspace, size_t workspace_bytes, double *R, double *t, int32_t *n_inliers, double *fitness,
+                              double *rmse, int32_t *iters, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * LoFTR transformer / FPN glue, fused (csrc/loftr_fused.hip).  Reference call site: LoFTR_matcher.match
  * (etc/feature_matching_baselines/matchers.py:24-59) -> upstream LoFTREncoderLayer / ResNetFPN_8_2 (un-vendored).
  *   mfr_layernorm       torch.nn.LayerNorm(C) over rows of x (row stride ldx floats), C in {128, 256}, + optional residual

@@ -33,6 +33,8 @@ SIGNATURES = {
     "mfr_procrustes_workspace_bytes": (_sz, [_i, _i, _i]),
     "mfr_procrustes_solve_batch": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _d, _d, _i, _u64, _vp, _vp, _sz,
                                         _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mfr_procrustes_icp_workspace_bytes": (_sz, [_i, _i, _i]),
+    "mfr_procrustes_icp_refine": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _d, _d, _d, _i, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mfr_sp_scoremap": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "mfr_sp_nms_candidates": (_i, [_vp, _i, _i, _i, _i, C.c_float, _i, _vp, _vp, _i, _vp, _vp]),
     "mfr_sp_select_topk": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),

@@ -5,7 +5,8 @@ keys this implementation adds (declared here because unknown keys are rejected o
   FEATURE_MATCHING   additionally accepts 'SuperGlue' (online SuperPoint+SuperGlue on the GPU)
   DATASET.SYNTHETIC  explicit opt-in to the synthetic stand-in dataset (a missing DATA_ROOT is otherwise an error)
   RANSAC.SEED        seed of the counter-based RANSAC RNG (the reference has no seed knob)
-  HIP.*              batch size / keypoint budget of the fused device pipeline
+  HIP.*              batch size / keypoint budget of the fused device pipeline; GRAPH_BATCH1: replay the batch-1 online
+                     matcher from one captured HIP graph (nets/graph.py; opt-in, see the limits recorded there)
   LOFTR.WEIGHTS      checkpoint of the online LoFTR matcher ('LoFTR' feature matching)
   ALLOW_SYNTHETIC_WEIGHTS  hand out seeded synthetic network weights when no checkpoint is configured (tests / benches)
   SUPERGLUE.*        matcher hyper-parameters of record (matchers.py:65-71) and weight paths
@@ -55,7 +56,7 @@ def get_cfg_defaults():
         c.TRAINING[k] = v
     # ---- additions of this implementation ----
     c.RANSAC = CN(); c.RANSAC.SEED = 0
-    c.HIP = CN(); c.HIP.BATCH_PAIRS = 16; c.HIP.MAX_KEYPOINTS = 1024; c.HIP.MAX_CORRESPONDENCES = 8192
+    c.HIP = CN(); c.HIP.BATCH_PAIRS = 16; c.HIP.MAX_KEYPOINTS = 1024; c.HIP.MAX_CORRESPONDENCES = 8192; c.HIP.GRAPH_BATCH1 = False
     c.SUPERGLUE = CN()
     for k, v in dict(NMS_RADIUS=4, KEYPOINT_THRESHOLD=0.005, MAX_KEYPOINTS=1024, SINKHORN_ITERATIONS=20,
                      MATCH_THRESHOLD=0.2, SUPERPOINT_WEIGHTS=None, SUPERGLUE_WEIGHTS=None, SYNTHETIC_SEED=1234).items():

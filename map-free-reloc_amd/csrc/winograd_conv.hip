@@ -155,7 +155,6 @@ __global__ void __launch_bounds__(256, NBLK == 2 ? 2 : 1) wino_conv3x3_kernel(
     const float *__restrict__ residual, int Cin, int Cout, int H, int W, int nbx, int nby, int S, int Sx, int ncb, int act)
 {
     constexpr int SLAB = 1024 * NBLK;                        // floats of packed U per (cin chunk of 4, cout block)
-    constexpr int WCO = 16 * NBLK;                           // output channels per workgroup
     constexpr bool PAIR = LOAD != 0;
     constexpr bool SCHED = WN_SCHED_ALL || NBLK == 4;
     __shared__ __attribute__((aligned(16))) float Us[2][SLAB];

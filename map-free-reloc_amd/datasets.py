@@ -196,6 +196,11 @@ def to_gray(img):
     """[3,H,W] or [1,H,W] float in [0,1] -> [H,W] float32 luma (BT.601 weights, what cv2.imread(GRAYSCALE) computes)"""
     if img.shape[0] == 1:
         return img[0]
+    if isinstance(img, torch.Tensor) and img.device.type == "cpu" and img.dtype == torch.float32:
+        # numpy on the calling thread: torch's CPU elementwise kernels fan a 1.5 MB image out over every host core (256 on the
+        # GPU boxes), which costs more in thread wake-ups than the arithmetic (measured ~20 ms vs < 1 ms per pair)
+        a = img.numpy()
+        return torch.from_numpy(np.float32(0.299) * a[0] + np.float32(0.587) * a[1] + np.float32(0.114) * a[2])
     return 0.299 * img[0] + 0.587 * img[1] + 0.114 * img[2]
 
 

@@ -58,17 +58,33 @@ class SuperGlueMatching:
         self.device = torch.device("cuda")
         self.sp = SuperPointHIP(sp_sd, self.device, sg.NMS_RADIUS, sg.KEYPOINT_THRESHOLD, sg.MAX_KEYPOINTS)
         self.sg = SuperGlueHIP(sg_sd, self.device, sg.SINKHORN_ITERATIONS, sg.MATCH_THRESHOLD)
+        self.use_graph = bool(cfg.HIP.GRAPH_BATCH1)
+        self._graphs = {}
+
+    def _forward(self, ims):
+        out = self.sg(self.sp(ims), tuple(ims.shape[-2:]))
+        # one packed result so that the host needs a single D2H copy: [n | pts0 (K x 2) | pts1 (K x 2)]
+        import torch
+        return torch.cat([out["n_corr"].to(torch.float32), out["pts0"].reshape(-1), out["pts1"].reshape(-1)])
 
     def get_correspondences(self, data):
         import torch
         im0, im1 = _to_gray(data['image0'][0]), _to_gray(data['image1'][0])
-        ims = torch.stack([im0, im1])[:, None].to(self.device, torch.float32).contiguous()
-        out = self.sg(self.sp(ims), tuple(ims.shape[-2:]))
-        n = int(out["n_corr"][0])
+        ims = torch.stack([im0, im1])[:, None].to(torch.float32)
+        if self.use_graph:                                   # batch 1 is launch-bound: replay the whole forward from one HIP graph
+            from ..nets.graph import GraphedCall
+            key = tuple(ims.shape)
+            if key not in self._graphs:
+                self._graphs[key] = GraphedCall(self._forward, [ims.to(self.device)])
+            flat = self._graphs[key](ims).cpu().numpy()
+        else:
+            flat = self._forward(ims.to(self.device).contiguous()).cpu().numpy()
+        n = int(flat[0])
         if n == 0:
             e = np.array([])
             return e, e
-        return out["pts0"][0, :n].cpu().numpy(), out["pts1"][0, :n].cpu().numpy()
+        K = (len(flat) - 1) // 4
+        return flat[1:1 + 2 * K].reshape(K, 2)[:n].copy(), flat[1 + 2 * K:].reshape(K, 2)[:n].copy()
 
 
 class LoFTRMatching:

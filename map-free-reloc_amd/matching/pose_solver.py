@@ -25,29 +25,82 @@ def _nan_pose(t_shape=(3, 1)):
     return np.full((3, 3), np.nan), np.full(t_shape, np.nan), 0
 
 
-def _dev(a, dtype):
-    return torch.as_tensor(np.ascontiguousarray(a), dtype=dtype).cuda()
-
-
 def _pair_id(data):
     pid = data.get('pair_id', 0) if isinstance(data, dict) else 0
     return int(pid.item()) if hasattr(pid, 'item') else int(pid)
+
+
+class _PairStage:
+    """Host->device hand-over of ONE pair for the per-pair plugin API (batch 1): everything the solver needs
+    -- correspondences, both depth maps, both intrinsics, count and RANSAC stream id -- is packed into one pinned host
+    buffer and crosses PCIe as ONE asynchronous copy into a persistent device buffer (the reference's flow hands numpy
+    arrays to OpenCV; the first version of this class issued 6-8 small synchronous copies per pair).  The device tensors
+    handed to the kernels are views into that buffer; results come back as one packed D2H copy (`fetch`)."""
+    CAP = 8192                                       # correspondences per pair (LoFTR yields <= 6120)
+
+    def __init__(self):
+        self.hw = None
+        self.host = self.dev = None
+
+    def _alloc(self, H, W):
+        self.hw = (H, W)
+        self.o_p0, self.o_p1 = 0, self.CAP * 2
+        self.o_k = self.CAP * 4                      # K0 (9) | K1 (9) | pad to 32
+        self.o_meta = self.o_k + 32                  # n (as i32 bits) | pad | pair id (i64 bits in 2 words) ; 8 words
+        self.o_d0 = self.o_meta + 8
+        self.o_d1 = self.o_d0 + H * W
+        n = self.o_d1 + H * W
+        self.host = torch.empty(n, dtype=torch.float32, pin_memory=True)
+        self.dev = torch.empty(n, dtype=torch.float32, device='cuda')
+        self.host_i32 = self.host.view(torch.int32)
+        self.host_i64 = self.host[self.o_meta + 2:self.o_meta + 4].view(torch.int64)
+
+    def put(self, kpts0, kpts1, data, need_depth1):
+        """-> dict of device views (pts0/pts1 [1,m,2], n [1] i32, depth0/depth1 [1,H,W], K0/K1 [1,3,3], pid [1] i64)"""
+        H, W = data['depth0'].shape[-2:]
+        if self.hw != (H, W):
+            self._alloc(H, W)
+        k0 = np.asarray(kpts0, dtype=np.float32).reshape(-1, 2)
+        k1 = np.asarray(kpts1, dtype=np.float32).reshape(-1, 2)
+        n = min(len(k0), self.CAP)
+        m = max(n, 1)
+        h = self.host
+        h[self.o_p0:self.o_p0 + 2 * n] = torch.from_numpy(k0[:n].reshape(-1))
+        h[self.o_p1:self.o_p1 + 2 * n] = torch.from_numpy(k1[:n].reshape(-1))
+        h[self.o_k:self.o_k + 9] = data['K_color0'].reshape(9).to(torch.float32)
+        h[self.o_k + 9:self.o_k + 18] = data['K_color1'].reshape(9).to(torch.float32)
+        self.host_i32[self.o_meta] = n
+        self.host_i64[0] = _pair_id(data)
+        # the small operands cross in ONE async copy from the pinned pack; the depth maps (1.5 MB each) go straight from the
+        # loader's pageable tensors into their slots of the persistent device buffer (CPU stores into pinned, uncached
+        # host memory were measured slower than the driver's own staging for MB-sized pieces)
+        d = self.dev
+        d[:self.o_d0].copy_(h[:self.o_d0], non_blocking=True)
+        d[self.o_d0:self.o_d0 + H * W].copy_(data['depth0'].reshape(-1), non_blocking=True)
+        if need_depth1:
+            d[self.o_d1:self.o_d1 + H * W].copy_(data['depth1'].reshape(-1), non_blocking=True)
+        di32 = d.view(torch.int32)
+        return dict(pts0=d[self.o_p0:self.o_p0 + 2 * m].view(1, m, 2), pts1=d[self.o_p1:self.o_p1 + 2 * m].view(1, m, 2),
+                    n=di32[self.o_meta:self.o_meta + 1], K0=d[self.o_k:self.o_k + 9].view(1, 3, 3),
+                    K1=d[self.o_k + 9:self.o_k + 18].view(1, 3, 3), pid=d[self.o_meta + 2:self.o_meta + 4].view(torch.int64),
+                    depth0=d[self.o_d0:self.o_d0 + H * W].view(1, H, W), depth1=d[self.o_d1:self.o_d1 + H * W].view(1, H, W), n_host=n)
+
+    @staticmethod
+    def fetch(*tensors):
+        """several small device results -> host float64 arrays with ONE D2H copy (and one sync)"""
+        flat = torch.cat([t.reshape(-1).to(torch.float64) for t in tensors]).cpu().numpy()
+        out, o = [], 0
+        for t in tensors:
+            k = t.numel()
+            out.append(flat[o:o + k]); o += k
+        return out
 
 
 class _Base:
     def __init__(self, cfg):
         _lib.load(require_gpu=True)
         self.seed = int(cfg.RANSAC.SEED) if 'RANSAC' in cfg else 0
-
-    @staticmethod
-    def _corr(kpts0, kpts1):
-        k0 = np.asarray(kpts0, dtype=np.float32).reshape(-1, 2)
-        k1 = np.asarray(kpts1, dtype=np.float32).reshape(-1, 2)
-        n = len(k0)
-        m = max(n, 1)
-        p0 = np.zeros((1, m, 2), np.float32); p1 = np.zeros((1, m, 2), np.float32)
-        p0[0, :n] = k0; p1[0, :n] = k1
-        return _dev(p0, torch.float32), _dev(p1, torch.float32), torch.tensor([n], dtype=torch.int32).cuda()
+        self._stage = _PairStage()
 
 
 class PnPSolver(_Base):
@@ -65,15 +118,12 @@ class PnPSolver(_Base):
     def estimate_pose(self, pts0, pts1, data):
         if len(pts0) < 4:                                                   # :188-189
             return _nan_pose()
-        p0, p1, n = self._corr(pts0, pts1)
-        depth0 = data['depth0'].reshape(1, *data['depth0'].shape[-2:]).to(torch.float32).cuda()
-        K0 = data['K_color0'].reshape(1, 3, 3).to(torch.float32).cuda()
-        K1 = data['K_color1'].reshape(1, 3, 3).to(torch.float32).cuda()
-        pid = torch.tensor([_pair_id(data)], dtype=torch.int64).cuda()
-        out = self._solver(p0, p1, n, depth0, K0, K1, pid)
-        if int(out["status"][0]) != ops.ST_OK:
+        d = self._stage.put(pts0, pts1, data, need_depth1=False)
+        out = self._solver(d["pts0"], d["pts1"], d["n"], d["depth0"], d["K0"], d["K1"], d["pid"])
+        st, R, t, ninl = self._stage.fetch(out["status"], out["R"], out["t"], out["n_inliers"])
+        if int(st[0]) != ops.ST_OK:
             return _nan_pose()
-        return out["R"][0].cpu().numpy(), out["t"][0].cpu().numpy().reshape(3, 1), int(out["n_inliers"][0])
+        return R.reshape(3, 3), t.reshape(3, 1), int(ninl[0])
 
 
 class EssentialMatrixSolver(_Base):
@@ -86,22 +136,20 @@ class EssentialMatrixSolver(_Base):
         self._emat = ops.EssentialBatchSolver(self.ransac_pix_threshold, self.ransac_confidence, self.seed)
         self.mask = None
 
-    def _run(self, kpts0, kpts1, data):
-        p0, p1, n = self._corr(kpts0, kpts1)
-        K0 = data['K_color0'].reshape(1, 3, 3).to(torch.float32).cuda()
-        K1 = data['K_color1'].reshape(1, 3, 3).to(torch.float32).cuda()
-        pid = torch.tensor([_pair_id(data)], dtype=torch.int64).cuda()
-        out = self._emat(p0, p1, n, K0, K1, pid)
-        return p0, p1, n, K0, K1, out
+    def _run(self, kpts0, kpts1, data, need_depth):
+        d = self._stage.put(kpts0, kpts1, data, need_depth1=need_depth)
+        out = self._emat(d["pts0"], d["pts1"], d["n"], d["K0"], d["K1"], d["pid"])
+        return d, out
 
     def estimate_pose(self, kpts0, kpts1, data):
         if len(kpts0) < 5:                                                  # :32-33
             return _nan_pose()
-        _, _, n, _, _, out = self._run(kpts0, kpts1, data)
-        self.mask = out["mask"][0, :int(n[0])].cpu().numpy().reshape(-1, 1)      # :49 (cheirality-filtered, Q7)
-        if int(out["status"][0]) != ops.ST_OK:
+        d, out = self._run(kpts0, kpts1, data, need_depth=False)
+        st, R, t, ninl, mask = self._stage.fetch(out["status"], out["R"], out["t"], out["n_inliers"], out["mask"][0, :d["n_host"]])
+        self.mask = mask.astype(np.uint8).reshape(-1, 1)                     # :49 (cheirality-filtered, Q7)
+        if int(st[0]) != ops.ST_OK:
             return _nan_pose()
-        return out["R"][0].cpu().numpy(), out["t"][0].cpu().numpy(), int(out["n_inliers"][0])   # t shape [3] (Q10)
+        return R.reshape(3, 3), t.reshape(3), int(ninl[0])                   # t shape [3] (Q10)
 
 
 class EssentialMatrixMetricSolver(EssentialMatrixSolver):
@@ -115,42 +163,37 @@ class EssentialMatrixMetricSolver(EssentialMatrixSolver):
     def estimate_pose(self, kpts0, kpts1, data):
         if len(kpts0) < 5:
             return _nan_pose()
-        p0, p1, n, K0, K1, out = self._run(kpts0, kpts1, data)
-        self.mask = out["mask"][0, :int(n[0])].cpu().numpy().reshape(-1, 1)
-        if int(out["status"][0]) != ops.ST_OK:                              # :131-132 (inliers == 0 -> return)
+        d, out = self._run(kpts0, kpts1, data, need_depth=True)
+        # the scale stage is launched unconditionally (it propagates a failed E-mat status itself): no host round trip in between
+        sc = self._scale(d["pts0"], d["pts1"], out["mask"], d["n"], d["depth0"], d["depth1"], d["K0"], d["K1"], out["R"], out["t"], out["status"])
+        est, sst, R, tm, ninl, mask = self._stage.fetch(out["status"], sc["status"], out["R"], sc["t_metric"], sc["n_inliers"],
+                                                       out["mask"][0, :d["n_host"]])
+        self.mask = mask.astype(np.uint8).reshape(-1, 1)
+        if int(est[0]) != ops.ST_OK or int(sst[0]) != ops.ST_OK:             # :131-132, :145-149
             return _nan_pose()
-        hw = data['depth0'].shape[-2:]
-        depth0 = data['depth0'].reshape(1, *hw).to(torch.float32).cuda()
-        depth1 = data['depth1'].reshape(1, *hw).to(torch.float32).cuda()
-        sc = self._scale(p0, p1, out["mask"], n, depth0, depth1, K0, K1, out["R"], out["t"], out["status"])
-        if int(sc["status"][0]) != ops.ST_OK:                               # :145-149
-            return _nan_pose()
-        return out["R"][0].cpu().numpy(), sc["t_metric"][0].cpu().numpy().reshape(3, 1), int(sc["n_inliers"][0])
+        return R.reshape(3, 3), tm.reshape(3, 1), int(ninl[0])
 
 
 class ProcrustesSolver(_Base):
-    '''Estimate relative pose (metric) using 3D-3D correspondences (pose_solver.py:238-320).
-    PROCRUSTES.REFINE (full-cloud ICP, :291-315) is not built: requesting it raises.'''
+    '''Estimate relative pose (metric) using 3D-3D correspondences (pose_solver.py:238-320), incl. the optional
+    whole-cloud ICP refinement (PROCRUSTES.REFINE, :290-315; csrc/procrustes_icp.hip)'''
 
     def __init__(self, cfg):
         super().__init__(cfg)
         self.ransac_max_corr_distance = cfg.PROCRUSTES.MAX_CORR_DIST
         self.refine = cfg.PROCRUSTES.REFINE
-        if self.refine:
-            raise NotImplementedError("PROCRUSTES.REFINE (Open3D ICP, pose_solver.py:291-315) is not built")
         self._solver = ops.ProcrustesBatchSolver(self.ransac_max_corr_distance, 0.999, self.seed)
+        self._icp = ops.ProcrustesIcpRefine(self.ransac_max_corr_distance, 1e-4, 1e-4, 30) if self.refine else None     # :302-304
 
     def estimate_pose(self, pts0, pts1, data):
         if len(pts0) < 3:                                                   # :252-253
             return _nan_pose()
-        p0, p1, n = self._corr(pts0, pts1)
-        hw = data['depth0'].shape[-2:]
-        depth0 = data['depth0'].reshape(1, *hw).to(torch.float32).cuda()
-        depth1 = data['depth1'].reshape(1, *hw).to(torch.float32).cuda()
-        K0 = data['K_color0'].reshape(1, 3, 3).to(torch.float32).cuda()
-        K1 = data['K_color1'].reshape(1, 3, 3).to(torch.float32).cuda()
-        pid = torch.tensor([_pair_id(data)], dtype=torch.int64).cuda()
-        out = self._solver(p0, p1, n, depth0, depth1, K0, K1, pid)
-        if int(out["status"][0]) != ops.ST_OK:
+        d = self._stage.put(pts0, pts1, data, need_depth1=True)
+        out = self._solver(d["pts0"], d["pts1"], d["n"], d["depth0"], d["depth1"], d["K0"], d["K1"], d["pid"])
+        if self._icp is not None:                                            # :290-319, launched back to back: no host round trip
+            ref = self._icp(d["depth0"], d["depth1"], d["K0"], d["K1"], out["R"], out["t"], out["status"])
+            out = dict(out, n_inliers=ref["n_inliers"])
+        st, R, t, ninl = self._stage.fetch(out["status"], out["R"], out["t"], out["n_inliers"])
+        if int(st[0]) != ops.ST_OK:
             return _nan_pose()
-        return out["R"][0].cpu().numpy(), out["t"][0].cpu().numpy().reshape(3, 1), int(out["n_inliers"][0])
+        return R.reshape(3, 3), t.reshape(3, 1), int(ninl[0])

@@ -150,7 +150,14 @@ class FusedPosePipeline:
             self.solve = solve
         elif ps == "Procrustes":
             pr = ops.ProcrustesBatchSolver(cfg.PROCRUSTES.MAX_CORR_DIST, 0.999, seed)
-            self.solve = lambda m, b: pr(m["pts0"], m["pts1"], m["n_corr"], b["depth0"], b["depth1"], b["K0"], b["K1"], b["seed_ids"])
+            icp = ops.ProcrustesIcpRefine(cfg.PROCRUSTES.MAX_CORR_DIST, 1e-4, 1e-4, 30) if cfg.PROCRUSTES.REFINE else None
+
+            def solve_pr(m, b):
+                o = pr(m["pts0"], m["pts1"], m["n_corr"], b["depth0"], b["depth1"], b["K0"], b["K1"], b["seed_ids"])
+                if icp is not None:
+                    o = dict(o, n_inliers=icp(b["depth0"], b["depth1"], b["K0"], b["K1"], o["R"], o["t"], o["status"])["n_inliers"])
+                return o
+            self.solve = solve_pr
         else:
             raise NotImplementedError(f"POSE_SOLVER={ps!r}")
 

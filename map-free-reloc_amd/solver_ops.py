@@ -198,6 +198,37 @@ class ProcrustesBatchSolver:
         return out
 
 
+class ProcrustesIcpRefine:
+    """PROCRUSTES.REFINE (pose_solver.py:290-319): whole-cloud point-to-point ICP from the RANSAC transform, for a batch of
+    pairs (csrc/procrustes_icp.hip).  R [B,3,3], t [B,3] f64 are refined IN PLACE; returns n_inliers / fitness / rmse / iters."""
+
+    def __init__(self, max_corr_dist=0.05, rel_fitness=1e-4, rel_rmse=1e-4, max_iter=30):
+        self.max_corr_dist, self.rel_fitness, self.rel_rmse = float(max_corr_dist), float(rel_fitness), float(rel_rmse)
+        self.max_iter = int(max_iter)
+        self._ws = None
+
+    def __call__(self, depth0, depth1, K0, K1, R, t, status=None):
+        lib = _lib.load(require_gpu=True)
+        depth0 = _chk(depth0, torch.float32, "depth0"); depth1 = _chk(depth1, torch.float32, "depth1")
+        K0 = _chk(K0, torch.float32, "K0"); K1 = _chk(K1, torch.float32, "K1")
+        R = _chk(R, torch.float64, "R"); t = _chk(t, torch.float64, "t")
+        if status is not None:
+            status = _chk(status, torch.int32, "status")
+        B, H, W = depth0.shape
+        dev = depth0.device
+        need = lib.mfr_procrustes_icp_workspace_bytes(B, H, W)
+        if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
+            self._ws = _ws(need, dev)
+        ni = torch.empty(B, dtype=torch.int32, device=dev)
+        fit = torch.empty(B, dtype=torch.float64, device=dev); rm = torch.empty(B, dtype=torch.float64, device=dev)
+        it = torch.empty(B, dtype=torch.int32, device=dev)
+        _lib.check(lib.mfr_procrustes_icp_refine(_lib.ptr(depth0), _lib.ptr(depth1), B, H, W, _lib.ptr(K0), _lib.ptr(K1), self.max_corr_dist,
+                                                 self.rel_fitness, self.rel_rmse, self.max_iter, _lib.ptr(status), _lib.ptr(self._ws),
+                                                 self._ws.numel(), _lib.ptr(R), _lib.ptr(t), _lib.ptr(ni), _lib.ptr(fit), _lib.ptr(rm),
+                                                 _lib.ptr(it), _lib.stream_ptr()), "mfr_procrustes_icp_refine")
+        return dict(R=R, t=t, n_inliers=ni, fitness=fit, rmse=rm, iters=it)
+
+
 class ScaleFromDepthBatch:
     """EssentialMatrixMetricSolver's own part (pose_solver.py:137-172) for a batch of pairs."""
 

@@ -96,3 +96,27 @@ def make_batch(seeds, n_list, maxN=None, **kw):
 def rot_err_deg(Ra, Rb):
     c = (np.trace(Ra.T @ Rb) - 1) / 2
     return float(np.degrees(np.arccos(np.clip(c, -1, 1))))
+
+
+def render_room_depth(H, W, f, R, t, noise=0.0, seed=0):
+    """depth map (f32, metres, uint16-mm quantised like lib/datasets/utils.py:77-81) of an analytic scene -- floor, back wall,
+    side wall and a slanted panel (four non-parallel planes n.X = c in the frame of camera 0) -- seen from the camera whose
+    pose is X_cam = R X_0 + t.  Used to give the whole-cloud ICP refinement (pose_solver.py:290-315) a known answer."""
+    planes = [(np.array([0.0, 1.0, 0.0]), 1.2), (np.array([0.0, 0.0, 1.0]), 4.0), (np.array([1.0, 0.0, 0.15]), 2.0),
+              (np.array([-0.5, -0.3, 1.0]) / np.linalg.norm([-0.5, -0.3, 1.0]), 2.6)]
+    K = np.array([[f, 0, W / 2 - 0.5], [0, f, H / 2 - 0.5], [0, 0, 1]], dtype=np.float32)
+    uu, vv = np.meshgrid(np.arange(W), np.arange(H))
+    d = np.stack([(uu - K[0, 2]) / f, (vv - K[1, 2]) / f, np.ones_like(uu, dtype=np.float64)], -1)     # rays, z = 1, camera frame
+    o = -R.T @ np.asarray(t, dtype=np.float64)                                                          # camera centre in frame 0
+    dw = d @ R                                                                                          # rows: R^T d
+    depth = np.full((H, W), np.inf)
+    for n, c in planes:
+        den = dw @ n
+        lam = (c - o @ n) / np.where(np.abs(den) < 1e-12, np.nan, den)
+        lam = np.where(lam > 0.05, lam, np.inf)
+        depth = np.minimum(depth, lam)
+    depth = np.where(np.isfinite(depth), depth, 0.0)
+    if noise > 0:
+        depth = depth * (1 + np.random.default_rng(seed).normal(0, noise, depth.shape)) * (depth > 0)
+    depth = np.clip(depth, 0, 65.0)
+    return (np.round(depth * 1000).astype(np.uint16) / 1000.0).astype(np.float32), K

@@ -83,6 +83,8 @@ static void kabsch_from_moments(const double *s, double *R, double *t)
     for (int i = 0; i < 3; ++i) t[i] = qc[i] - ((R[3 * i] * pc[0] + R[3 * i + 1] * pc[1]) + R[3 * i + 2] * pc[2]);
 }
 
+void mfr_ref_kabsch_from_moments(const double *s, double *R, double *t) { kabsch_from_moments(s, R, t); }
+
 static inline double dist2(const double *R, const double *t, const double *p, const double *q)
 {
     double d0 = (((R[0] * p[0] + R[1] * p[1]) + R[2] * p[2]) + t[0]) - q[0];

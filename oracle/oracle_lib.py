@@ -16,7 +16,7 @@ ST_OK, ST_TOO_FEW, ST_BAD_DEPTH, ST_NO_MODEL, ST_DEGENERATE = range(5)
 
 
 def build(force=False):
-    srcs = [os.path.join(_HERE, f) for f in ("mfr_oracle.c", "mfr_oracle_emat.c", "mfr_oracle_procrustes.c", "mfr_oracle_desc.c", "mfr_oracle.h", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("mfr_oracle.c", "mfr_oracle_emat.c", "mfr_oracle_procrustes.c", "mfr_oracle_icp.c", "mfr_oracle_desc.c", "mfr_oracle.h", "Makefile")]
     stale = (not os.path.exists(_SO)) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs)
     if force or stale:
         subprocess.check_call(["make", "-s", "-C", _HERE], stdout=subprocess.DEVNULL)
@@ -251,6 +251,18 @@ def procrustes_solve(pts0, pts1, depth0, depth1, K0, K1, max_dist=0.05, conf=0.9
                                         _p(_f32(K0).reshape(9)), _p(_f32(K1).reshape(9)), C.c_double(max_dist), C.c_double(conf),
                                         C.c_int(max_iters), C.c_uint64(seed), C.c_uint64(pair_id), _p(R), _p(t), C.byref(n_inl))
     return st, R, t.reshape(3, 1), n_inl.value
+
+
+def procrustes_icp(depth0, depth1, K0, K1, R, t, max_dist=0.05, rel_fitness=1e-4, rel_rmse=1e-4, max_iter=30):
+    """pose_solver.py:290-319 (PROCRUSTES.REFINE): -> dict(R, t, n_inliers, fitness, rmse, iters)"""
+    depth0, depth1 = _f32(depth0), _f32(depth1)
+    H, W = depth0.shape
+    R = _f64(R).reshape(9).copy(); t = _f64(t).reshape(3).copy()
+    n_inl = C.c_int(0); fit = C.c_double(0); rmse = C.c_double(0)
+    it = lib().mfr_ref_procrustes_icp(_p(depth0), _p(depth1), C.c_int(H), C.c_int(W), _p(_f32(K0).reshape(9)), _p(_f32(K1).reshape(9)),
+                                      C.c_double(max_dist), C.c_double(rel_fitness), C.c_double(rel_rmse), C.c_int(max_iter), _p(R), _p(t),
+                                      C.byref(n_inl), C.byref(fit), C.byref(rmse))
+    return dict(R=R.reshape(3, 3), t=t, n_inliers=n_inl.value, fitness=fit.value, rmse=rmse.value, iters=it)
 
 
 def rootsift(desc):

@@ -90,3 +90,23 @@ def test_unknown_config_values_raise(tmp_path):
     cfg = _cfg("PNP", tmp_path); cfg.MODEL = "Regression"
     with pytest.raises(NotImplementedError):
         build_model(cfg)
+
+
+@pytest.mark.skipif(os.environ.get("MFR_TEST_GRAPH") != "1", reason="HIP-graph replay of the batch-1 matcher is opt-in (nets/graph.py); MFR_TEST_GRAPH=1 runs it")
+def test_batch1_graph_replay_equals_eager():
+    """the batch-1 online SuperGlue matcher replayed from a captured HIP graph (nets/graph.py) returns exactly the eager result,
+    also after the static input buffer has been overwritten with another pair"""
+    from mapfree_reloc_amd.datasets import SyntheticScene, collate_batch1
+    from mapfree_reloc_amd.matching.feature_matching import SuperGlueMatching
+    cfg = _cfg("PNP", "", matcher="SuperGlue")
+    cfg.ALLOW_SYNTHETIC_WEIGHTS = True
+    sc = SyntheticScene(3, frames=3)
+    samples = [collate_batch1(sc[i]) for i in range(3)]
+    cfg.HIP.GRAPH_BATCH1 = False
+    eager = SuperGlueMatching(cfg)
+    cfg.HIP.GRAPH_BATCH1 = True
+    graphed = SuperGlueMatching(cfg)
+    for s in samples + samples[:1]:
+        a0, a1 = eager.get_correspondences(s)
+        b0, b1 = graphed.get_correspondences(s)
+        assert len(a0) > 100 and np.array_equal(a0, b0) and np.array_equal(a1, b1)

@@ -69,6 +69,70 @@ def test_procrustes_plugin_class():
     R, t, inl = ProcrustesSolver(cfg).estimate_pose(p["pts0"], p["pts1"], data)
     st, Rr, tr, ninl = O.procrustes_solve(p["pts0"], p["pts1"], p["depth0"], p["depth1"], p["K0"], p["K1"], seed=0, pair_id=31)
     assert inl == ninl and np.array_equal(R, Rr) and t.shape == (3, 1)
+    # with the ICP refinement: RANSAC stage then oracle ICP from its transform == the plugin, bit for bit
     cfg.PROCRUSTES.REFINE = True
-    with pytest.raises(NotImplementedError):
-        ProcrustesSolver(cfg)
+    R2, t2, inl2 = ProcrustesSolver(cfg).estimate_pose(p["pts0"], p["pts1"], data)
+    ref = O.procrustes_icp(p["depth0"], p["depth1"], p["K0"], p["K1"], Rr, tr.reshape(3), 0.05)
+    assert np.array_equal(R2, ref["R"]) and np.array_equal(t2.ravel(), ref["t"]) and inl2 == ref["n_inliers"]
+
+
+def _room_pair(seed, H, W, f):
+    rng = np.random.default_rng(seed)
+    a = rng.uniform(0.03, 0.08)
+    Rg = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]])
+    tg = rng.uniform(-0.12, 0.12, 3)
+    d0, K = synth.render_room_depth(H, W, f, np.eye(3), np.zeros(3))
+    d1, _ = synth.render_room_depth(H, W, f, Rg, tg)
+    b = a + rng.uniform(-0.03, 0.03)
+    R0 = np.array([[np.cos(b), 0, np.sin(b)], [0, 1, 0], [-np.sin(b), 0, np.cos(b)]])
+    return d0, d1, K, R0, tg + rng.uniform(-0.03, 0.03, 3), Rg, tg
+
+
+def test_icp_refine_bit_exact_vs_oracle():
+    """PROCRUSTES.REFINE (pose_solver.py:290-319) on the device == oracle/mfr_oracle_icp.c bit for bit: refined pose, fitness,
+    inlier RMSE, iteration count and int(fitness * |target|); pairs of a batch converge after different numbers of steps, one
+    has holes in both depth maps, one enters with a failed RANSAC status and must come back untouched."""
+    H, W, f = 72, 96, 80.0
+    prs = [_room_pair(s, H, W, f) for s in (1, 2, 3, 4)]
+    prs[2][0][20:40, 10:50] = 0; prs[2][1][5:15, 60:90] = 0
+    st = lambda k: np.stack([p[k] for p in prs])
+    R = st(3).copy(); t = st(4).copy()
+    status = np.array([0, 0, 0, 3], np.int32)
+    R[3] = np.nan; t[3] = np.nan
+    icp = ops.ProcrustesIcpRefine(0.05, 1e-4, 1e-4, 30)
+    Rd, td = _dev(R), _dev(t)
+    out = icp(_dev(st(0)), _dev(st(1)), _dev(st(2)), _dev(st(2)), Rd, td, _dev(status))
+    o = {k: v.cpu().numpy() for k, v in out.items()}
+    iters = []
+    for b in range(3):
+        ref = O.procrustes_icp(prs[b][0], prs[b][1], prs[b][2], prs[b][2], prs[b][3], prs[b][4], 0.05)
+        assert np.array_equal(o["R"][b], ref["R"]) and np.array_equal(o["t"][b], ref["t"])
+        assert o["fitness"][b] == ref["fitness"] and o["rmse"][b] == ref["rmse"]
+        assert o["n_inliers"][b] == ref["n_inliers"] and o["iters"][b] == ref["iters"]
+        iters.append(ref["iters"])
+        assert ref["fitness"] > 0.5
+    assert np.isnan(o["R"][3]).all() and o["n_inliers"][3] == 0
+    assert len(set(iters)) > 1 or max(iters) < 30
+
+
+def test_procrustes_plugin_with_refine():
+    """ProcrustesSolver with PROCRUSTES.REFINE True through the plugin API: RANSAC on correspondences then whole-cloud ICP;
+    the confidence is int(fitness * |pcl_1|) of the ICP result (pose_solver.py:319)"""
+    from mapfree_reloc_amd.config import get_cfg_defaults
+    from mapfree_reloc_amd.matching.pose_solver import ProcrustesSolver
+    H, W, f = 72, 96, 80.0
+    d0, d1, K, _, _, Rg, tg = _room_pair(7, H, W, f)
+    # correspondences from the ground truth: project back-projected depth0 pixels into view 1
+    rng = np.random.default_rng(0)
+    uv0 = np.stack([rng.integers(2, W - 2, 300), rng.integers(2, H - 2, 300)], 1)
+    X = d0[uv0[:, 1], uv0[:, 0], None] * np.stack([(uv0[:, 0] - K[0, 2]) / f, (uv0[:, 1] - K[1, 2]) / f, np.ones(300)], 1)
+    Y = X @ Rg.T + tg
+    uv1 = np.stack([f * Y[:, 0] / Y[:, 2] + K[0, 2], f * Y[:, 1] / Y[:, 2] + K[1, 2]], 1)
+    keep = (uv1[:, 0] > 1) & (uv1[:, 0] < W - 2) & (uv1[:, 1] > 1) & (uv1[:, 1] < H - 2)
+    cfg = get_cfg_defaults(); cfg.PROCRUSTES.MAX_CORR_DIST = 0.05; cfg.PROCRUSTES.REFINE = True
+    data = {"depth0": torch.from_numpy(d0)[None], "depth1": torch.from_numpy(d1)[None], "K_color0": torch.from_numpy(K)[None],
+            "K_color1": torch.from_numpy(K)[None], "pair_id": torch.tensor([0])}
+    R, t, inl = ProcrustesSolver(cfg).estimate_pose(np.float32(uv0[keep]), np.float32(np.round(uv1[keep])), data)
+    assert R.shape == (3, 3) and t.shape == (3, 1) and inl > 0.5 * (d1 > 0).sum()
+    ang = np.degrees(np.arccos(np.clip((np.trace(R.T @ Rg) - 1) / 2, -1, 1)))
+    assert ang < 1.0 and np.linalg.norm(t.ravel() - tg) < 0.1

@@ -5,7 +5,7 @@ import numpy as np, torch
 from mapfree_reloc_amd import images as IM
 from mapfree_reloc_amd.pipeline import SuperGluePnPPipeline
 dev = torch.device("cuda:0")
-B = 16
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 sb = IM.synthetic_batch(list(range(B)))
 d = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in sb.items()}
 sb2 = IM.synthetic_batch(list(range(100, 100 + B)))
