@@ -3,8 +3,8 @@
 // Replaces EssentialMatrixSolver.estimate_pose (lib/models/matching/pose_solver.py:29-61) for a
 // BATCH of image pairs:
 //   emat_prep_kernel    K-normalise both views in f32 (:39-40), thr = PIX_THRESHOLD / mean f (:43, Q8)
-//   emat_hyp_kernel     cv.findEssentialMat hypotheses: one LANE per 5-point minimal solve
-//                       (Nister; <= 10 candidate E each)                                  (:46-48)
+//   emat_hyp_kernel     cv.findEssentialMat hypotheses: one LANE per 5-point minimal solve (Nister; <= 10 candidate E
+//                       each), working set in LDS (emat_lds.h: 145 KB per 64-lane workgroup)       (:46-48)
 //   emat_score_kernel   one WAVEFRONT per hypothesis: lanes stride over the LDS-staged
 //                       correspondences, squared Sampson distance <= thr^2, ballot + popcount
 //   emat_select_kernel  RANSAC replay (adaptive iteration cap) -> best E -> cv.recoverPose
@@ -19,6 +19,7 @@
 
 #include "../../include/mfr_hip.h"
 #include "emat_dev.h"
+#include "emat_lds.h"
 
 using namespace mfr;
 
@@ -52,12 +53,15 @@ __global__ void __launch_bounds__(64) emat_hyp_kernel(
     int max_iters, uint64_t seed, const int64_t *__restrict__ pair_ids, double *__restrict__ Es /*[B,iters,10,9]*/,
     int32_t *__restrict__ nsol /*[B,iters]*/)
 {
+    // the solver's working set (Gauss-Jordan tableaux, monomial tables, derivative stack) in LDS, lane-interleaved: emat_lds.h
+    __shared__ double fp_lds[FP_LDS_DOUBLES * 64];
+    __shared__ int fp_colp[9 * 64];
     const int b = blockIdx.y, it = blockIdx.x * 64 + threadIdx.x;
     if (it >= max_iters) return;
     int n = n_corr[b];
     if (n > maxN) n = maxN;
     int ns = 0;
-    double E[90];
+    double *o = Es + ((size_t)b * max_iters + it) * 90;
     if (n >= 5 && (n > 5 || it == 0)) {
         int s[5];
         if (n == 5) { for (int k = 0; k < 5; ++k) s[k] = k; }
@@ -68,11 +72,9 @@ __global__ void __launch_bounds__(64) emat_hyp_kernel(
             a[2 * k] = p0[2 * s[k]]; a[2 * k + 1] = p0[2 * s[k] + 1];
             c[2 * k] = p1[2 * s[k]]; c[2 * k + 1] = p1[2 * s[k] + 1];
         }
-        ns = fivept(a, c, E);
+        ns = fivept_lds(a, c, o, fp_lds + threadIdx.x, fp_colp + threadIdx.x);
     }
     nsol[(size_t)b * max_iters + it] = ns;
-    double *o = Es + ((size_t)b * max_iters + it) * 90;
-    for (int k = 0; k < ns * 9; ++k) o[k] = E[k];
 }
 
 // grid (ceil(iters/64), B), 4 wavefronts; wavefront w scores hypotheses w, w+4, ... of the block's 64
