@@ -1,0 +1,82 @@
+"""Pins the restated OpenCV / Open3D arithmetic against fixtures produced by tests/external/gen_cv_golden.py (run once where
+opencv-python 4.8 / open3d 0.17 exist).  Without the fixtures the tests are SKIPPED -- and DESIGN.md keeps saying "parity
+unpinned vs OpenCV" for those rows.  The libraries draw different RANSAC samples (and OpenCV scores with MAGSAC++), so the
+comparison is statistical, on the SURVEY.md 8d known-answer sets: pose within the resolution RANSAC itself has on 1 px noise,
+inlier sets overlapping."""
+import os
+
+import numpy as np
+import pytest
+
+import mapfree_reloc_amd  # noqa: F401
+from mapfree_reloc_amd import synth
+from oracle import oracle_lib as O
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _load(name):
+    path = os.path.join(GOLD, name)
+    if not os.path.exists(path):
+        pytest.skip(f"{name} absent: run tests/external/gen_cv_golden.py where opencv-python / open3d are installed")
+    return np.load(path, allow_pickle=False)
+
+
+def _cases(z):
+    return [(int(s), int(n), float(o)) for s, n, o in z["cases"]]
+
+
+def _ang(Ra, Rb):
+    return synth.rot_err_deg(np.asarray(Ra), np.asarray(Rb))
+
+
+def test_oracle_pnp_vs_opencv_golden():
+    z = _load("cv_pnp.npz")
+    for seed, n, outl in _cases(z):
+        p = synth.make_pair(seed, n, outlier_frac=outl, noise_px=1.0, depth_noise=0.002)
+        st, R, t, ninl = O.pnp_solve(p["pts0"], p["pts1"], p["depth0"], p["K0"], p["K1"], 1000, 3.0, 0.9999, 0, seed)
+        assert st == 0
+        # both solvers vs each other and vs the ground truth: the restatement may not be worse than OpenCV by more than the
+        # RANSAC-to-RANSAC spread on this noise level
+        assert _ang(R, z[f"s{seed}_R"]) < 0.15 and np.linalg.norm(t.ravel() - z[f"s{seed}_t"]) < 0.02
+        assert _ang(R, p["R_gt"]) < _ang(z[f"s{seed}_R"], p["R_gt"]) + 0.1
+        assert abs(ninl - int(z[f"s{seed}_ninl"])) <= 0.03 * int(z[f"s{seed}_ninl"]) + 4
+
+
+def test_oracle_emat_vs_opencv_golden():
+    z = _load("cv_emat.npz")
+    for seed, n, outl in _cases(z):
+        p = synth.make_pair(seed, n, outlier_frac=outl, noise_px=1.0, depth_noise=0.002)
+        out = O.emat_solve(p["pts0"], p["pts1"], p["K0"], p["K1"], 2.0, 0.9999, 1000, 0, seed)
+        assert out["status"] == 0
+        assert _ang(out["R"], z[f"s{seed}_R"]) < 0.3
+        cosang = abs(float(out["t"].reshape(3) @ z[f"s{seed}_t"].reshape(3)))
+        assert np.degrees(np.arccos(np.clip(cosang, -1, 1))) < 2.0
+        m_cv = z[f"s{seed}_mask"].astype(bool)
+        inter = (out["mask"].astype(bool) & m_cv).sum()
+        assert inter >= 0.9 * min(m_cv.sum(), out["mask"].sum())            # MAGSAC++ vs inlier counting: near-identical consensus sets
+
+
+def test_oracle_procrustes_vs_open3d_golden():
+    z = _load("o3d_procrustes.npz")
+    for key in [k for k in z.files if k.endswith("_T")]:
+        seed = int(key[1:-2])
+        n, outl = {1000: (256, 0.2), 1001: (256, 0.5), 1010: (1024, 0.2), 1011: (1024, 0.5)}[seed]
+        p = synth.make_pair(seed, n, outlier_frac=outl, noise_px=1.0, depth_noise=0.002)
+        st, R, t, ninl = O.procrustes_solve(p["pts0"], p["pts1"], p["depth0"], p["depth1"], p["K0"], p["K1"], 0.05, 0.999, 4096, 0, seed)
+        T = z[key]
+        assert st == 0 and _ang(R, T[:3, :3]) < 0.5 and np.linalg.norm(t.ravel() - T[:3, 3]) < 0.05
+        assert abs(ninl - int(float(z[f"s{seed}_fitness"]) * int(z[f"s{seed}_n"]))) <= 0.05 * ninl + 3
+
+
+@pytest.mark.gpu
+def test_hip_solvers_vs_opencv_golden():
+    """the HIP solvers are bit-identical to the oracle (tests/test_gpu_*_parity.py), so one representative case per file suffices"""
+    import torch
+    from mapfree_reloc_amd import solver_ops as ops
+    z = _load("cv_pnp.npz")
+    seed, n, outl = _cases(z)[2]
+    b = synth.make_batch([seed], [n], outlier_frac=outl, noise_px=1.0, depth_noise=0.002)
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    o = ops.PnPBatchSolver(1000, 3.0, 0.9999, 0)(d(b["pts0"]), d(b["pts1"]), d(b["n_corr"]), d(b["depth0"]), d(b["K0"]), d(b["K1"]), d(b["pair_ids"]))
+    assert int(o["status"][0]) == 0 and _ang(o["R"][0].cpu().numpy(), z[f"s{seed}_R"]) < 0.15
