@@ -237,7 +237,7 @@ class LoftrEmatWorkload:
         if timers:
             lo = self.pipe.loftr
             c0, ct = lo._c, self.conv_timer.wrap(lo._c)
-            lo._c = lambda x, name, *a, **kw: (ct if name == "layer1.0.c1" else c0)(x, name, *a, **kw)
+            lo._c = lambda x, name, *a, **kw: (ct if name == "l1out2.0" else c0)(x, name, *a, **kw)
             lo.coarse_match_features = self.cm_timer.wrap(lo.coarse_match_features)
 
     def timers(self):
@@ -252,17 +252,18 @@ class LoftrEmatWorkload:
     def roofline(self, out):
         B = self.B
         conv_ms, cm_ms = self.conv_timer.mean_ms(), self.cm_timer.mean_ms()
-        # layer1.0.conv1: 128 -> 128 channels at 1/2 resolution (360 x 272), 2B images; largest single launch of the backbone
+        # layer1_outconv2.0: 196 -> 196 channels at 1/2 resolution (360 x 272), 2B images: the largest single launch of the path
+        # (algorithmic flops: the 196 real output channels; the kernel also multiplies the 28 zero-padded ones of its 7th block)
         tiles = (360 // 2) * (272 // 2)
-        conv_flops = 16 * 2.0 * 128 * 128 * tiles * 2 * B
+        conv_flops = 16 * 2.0 * 196 * 196 * tiles * 2 * B
         achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms else None
         # dual-softmax coarse matching: algorithmic bytes = the two coarse feature maps in (2 x 6120 x 256 f32 = 12.5 MB/pair)
         L = 90 * 68
         cm_bytes = 2.0 * L * 256 * 4 * B
         cm_gbs = cm_bytes / (cm_ms * 1e-3) / 1e9 if cm_ms else None
-        return {"kernel": "wino_conv3x3 layer1.0.conv1 launch (dominant kernel family: fused Winograd F(2x2,3x3) convolutions of the ResNet-FPN backbone)",
+        return {"kernel": "wino_conv3x3 layer1_outconv2.0 launch, 196->196 ch at 360x272 (dominant kernel: fused Winograd F(2x2,3x3) convolutions of the ResNet-FPN backbone)",
                 "bound": "mfma", "achieved": round(achieved, 2) if achieved else None, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4) if achieved else None, "traffic": _traffic("loftr_layer1", B),
+                "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4) if achieved else None, "traffic": _traffic("loftr_l1out2", B),
                 "avg_launch_ms": round(conv_ms, 4) if conv_ms else None, "launches_timed": len(self.conv_timer.events), "flops_per_launch": conv_flops,
                 "other_kernels": [{"kernel": "dual-softmax coarse matching (similarity + row/col softmax statistics + mutual-NN selection)",
                                    "bound": "hbm", "achieved": round(cm_gbs, 1) if cm_gbs else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",

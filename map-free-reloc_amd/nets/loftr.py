@@ -109,7 +109,17 @@ class LoFTRHIP:
             _lib.check(lib.mfr_conv3x3_wino(_lib.ptr(x), _lib.ptr(self.upk[name]), _lib.ptr(cb), _lib.ptr(residual.contiguous()) if residual is not None else None,
                                             B, C, co, H, W, code, 0, _lib.ptr(y), _lib.stream_ptr()), "mfr_conv3x3_wino")
             return y
-        x = F.conv2d(x, cw, cb, stride=stride, padding=cw.shape[-1] // 2)
+        if cw.shape[-1] == 1:
+            # 1x1 convolutions (FPN lateral / output convs, the stride-2 downsample of a BasicBlock) are plain matrix products:
+            # one batched library GEMM [Cout,Cin] x [Cin,HW] per image; stride 2 = the same on the even-pixel sub-grid
+            if stride != 1:
+                x = x[:, :, ::stride, ::stride]
+            B, C, H, W = x.shape
+            w3 = cw.view(1, cw.shape[0], C).expand(B, -1, -1)
+            x3 = x.reshape(B, C, H * W)
+            x = (torch.baddbmm(cb.view(1, -1, 1), w3, x3) if cb is not None else torch.bmm(w3, x3)).view(B, -1, H, W)
+        else:
+            x = F.conv2d(x, cw, cb, stride=stride, padding=cw.shape[-1] // 2)
         if residual is not None:
             x = x + residual
         if act == "relu":

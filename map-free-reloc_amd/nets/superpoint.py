@@ -60,6 +60,9 @@ class SuperPointHIP:
                                             _lib.ptr(y), _lib.stream_ptr()), "mfr_conv3x3_wino")
             return y
         if not relu:
+            if w.shape[-1] == 1:            # 1x1 head (convPb): one batched library GEMM [Cout,Cin] x [Cin,HW] per image, no MIOpen
+                B, C, H, W = x.shape
+                return torch.baddbmm(b.view(1, -1, 1), w.view(1, w.shape[0], C).expand(B, -1, -1), x.reshape(B, C, H * W)).view(B, -1, H, W)
             return F.conv2d(x, w, b, padding=pad)
         if self.fused_conv_relu and not pool:
             return torch.ops.aten.miopen_convolution_relu(x, w, b, [1, 1], [pad, pad], [1, 1], 1)

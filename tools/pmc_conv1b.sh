@@ -34,7 +34,7 @@ for f in glob.glob("gpurun_out/sq/p1/*kernel_trace.csv"):
             dur.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
 out = {k: sum(v) / len(v) for k, v in acc.items()}
 out["launch_ms_under_pmc"] = sum(dur) / max(len(dur), 1)
-out["kernel"] = "wino_conv3x3_kernel<pool, pair loads, NBLK 2>, conv1b: 64->64 ch, 64 images 720x540"
+out["kernel"] = "wino_conv3x3_shared_kernel<pool, pair loads> (default variant), conv1b: 64->64 ch, 64 images 720x540"
 out["note"] = "SQ_* cycle counters are summed over all SIMDs; WAVE_CYCLES / WAIT_* / ACTIVE_INST_* count quad-cycles (MI355X_MICROARCH.md)"
 json.dump(out, open("gpurun_out/sq/pmc_wino_sq.json", "w"), indent=1)
 print(json.dumps(out, indent=1))
