@@ -84,7 +84,17 @@ MFR_DEV double reg_refine_root(const double (&c)[11], const double (&dc)[10], do
     return x;
 }
 
-// poly_real_roots<10> with d[10][11], crit[12], cur[12] in LDS (ws: 134 doubles); c_in / roots are LDS arrays too
+// poly_real_roots<10> with d[10][11], crit[12], cur[12] in LDS (ws: 134 doubles); c_in / roots are LDS arrays too.
+//
+// Control flow: the textbook form (for each derivative level, for each bracket, refine to convergence) makes a wavefront pay,
+// for every bracket, the iteration count of its SLOWEST lane -- with 64 independent polynomials per wavefront and up to 200
+// safeguarded-Newton steps per bracket that was ~6 ms per launch on LoFTR's correspondences
+// (measured on random two-view geometry: 2.8 ms nested -> 2.3 ms as a state machine; a variant with one shared evaluation per
+// trip was slower, 3.6 ms).  Here every lane runs the same
+// computation as a small state machine (LEVEL: load a level's coefficients, SCAN: evaluate the next bracket end, REFINE: one
+// rtsafe step) and the wavefront loops until all lanes are DONE: a lane never waits inside somebody else's bracket, the cost
+// is the slowest lane's TOTAL work.  Each lane executes exactly the statement sequence of geom_dev.h poly_real_roots /
+// refine_root on its own data, so the roots are bit-identical.
 MFR_DEV_NOINLINE int lds_poly_real_roots10(LdsArr c_in, int deg, LdsArr roots, LdsArr ws)
 {
     const LdsArr d = ws, crit = ws.at(110), cur = ws.at(122);
@@ -103,31 +113,81 @@ MFR_DEV_NOINLINE int lds_poly_real_roots10(LdsArr c_in, int deg, LdsArr roots, L
         for (int i = 0; i <= deg - L; ++i) d[L * 11 + i] = d[(L - 1) * 11 + i + 1] * (double)(i + 1);
     int nc = 1;
     crit[0] = -d[(deg - 1) * 11] / d[(deg - 1) * 11 + 1];
-    for (int L = deg - 2; L >= 0; --L) {
-        const int m = deg - L;
-        double pc[11], dpc[10];                                     // this level and its derivative, zero-padded above their degrees
+
+    enum { M_LEVEL = 0, M_SCAN = 1, M_REFINE = 2, M_DONE = 3 };
+    int mode = (deg >= 2) ? M_LEVEL : M_DONE;
+    int L = deg - 2, i = 0, nr = 0, it = 0;
+    double pc[11], dpc[10];
+    double xl = 0.0, fl = 0.0, xh = 0.0, fh = 0.0;                       // bracket scan state
+    double x = 0.0, lo = 0.0, hi = 0.0, dx = 0.0, dxold = 0.0, fx = 0.0, dfx = 0.0, flo = 0.0;   // rtsafe state
+    while (__ballot(mode != M_DONE)) {
+        if (mode == M_LEVEL) {
+            const int m = deg - L;
 #pragma unroll
-        for (int i = 0; i < 11; ++i) pc[i] = (i <= m) ? d[L * 11 + i] : 0.0;
+            for (int k = 0; k < 11; ++k) pc[k] = (k <= m) ? d[L * 11 + k] : 0.0;
 #pragma unroll
-        for (int i = 0; i < 10; ++i) dpc[i] = (i <= m - 1) ? d[(L + 1) * 11 + i] : 0.0;
-        int nr = 0;
-        double xl = -bound, fl = horner_reg(pc, xl);
-        for (int i = 0; i <= nc; ++i) {
-            const double xh = (i < nc) ? crit[i] : bound;
-            if (i < nc && !(xh > xl)) continue;
-            const double fh = horner_reg(pc, xh);
-            if (fl == 0.0) {
-                if (nr == 0 || cur[nr - 1] != xl) cur[nr++] = xl;
-            } else if (fh != 0.0 && ((fl < 0.0) != (fh < 0.0))) {
-                cur[nr++] = reg_refine_root(pc, dpc, xl, xh, fl);
+            for (int k = 0; k < 10; ++k) dpc[k] = (k <= m - 1) ? d[(L + 1) * 11 + k] : 0.0;
+            nr = 0; i = 0;
+            xl = -bound; fl = horner_reg(pc, xl);
+            mode = M_SCAN;
+        } else if (mode == M_SCAN) {
+            if (i > nc) {                                                 // after the bracket loop of this level
+                if (fl == 0.0 && (nr == 0 || cur[nr - 1] != xl)) cur[nr++] = xl;
+                nc = nr;
+                for (int k = 0; k < nr; ++k) crit[k] = cur[k];
+                --L;
+                mode = (L >= 0) ? M_LEVEL : M_DONE;
+            } else {
+                xh = (i < nc) ? crit[i] : bound;
+                if (i < nc && !(xh > xl)) { ++i; }                        // `continue`
+                else {
+                    fh = horner_reg(pc, xh);
+                    bool advance = true;
+                    if (fl == 0.0) {
+                        if (nr == 0 || cur[nr - 1] != xl) cur[nr++] = xl;
+                    } else if (fh != 0.0 && ((fl < 0.0) != (fh < 0.0))) {
+                        // refine_root(p, dp, m, xl, xh, fl): set up, the iterations run in M_REFINE
+                        lo = xl; hi = xh; flo = fl;
+                        x = 0.5 * (lo + hi); dxold = hi - lo; dx = dxold;
+                        fx = horner_reg(pc, x); dfx = horner_reg(dpc, x);
+                        it = 0;
+                        mode = M_REFINE;
+                        advance = false;
+                    }
+                    if (advance) { xl = xh; fl = fh; ++i; }
+                }
             }
-            xl = xh; fl = fh;
+        } else if (mode == M_REFINE) {
+            bool stop = (it >= 200) || (fx == 0.0);
+            if (!stop) {
+                if ((fx < 0.0) == (flo < 0.0)) lo = x; else hi = x;
+                const double a = (x - hi) * dfx - fx, b = (x - lo) * dfx - fx;
+                double tf = 2.0 * fx;
+                if (tf < 0.0) tf = -tf;
+                double td = dxold * dfx;
+                if (td < 0.0) td = -td;
+                const bool newton = ((a < 0.0) != (b < 0.0)) && (tf <= td);
+                double xn;
+                dxold = dx;
+                if (newton) { dx = fx / dfx; xn = x - dx; }
+                else { dx = 0.5 * (hi - lo); xn = lo + dx; }
+                if (!(xn > lo && xn < hi)) { dx = 0.5 * (hi - lo); xn = lo + dx; }
+                if (xn == x) stop = true;
+                else {
+                    const double adx = dx < 0.0 ? -dx : dx, ax = xn < 0.0 ? -xn : xn;
+                    x = xn;
+                    if (adx <= 2e-16 * ax || adx < 1e-300) stop = true;
+                    else { fx = horner_reg(pc, x); dfx = horner_reg(dpc, x); ++it; }
+                }
+            }
+            if (stop) {                                                   // cur[nr++] = refine_root(...); xl = xh; fl = fh
+                cur[nr++] = x;
+                xl = xh; fl = fh; ++i;
+                mode = M_SCAN;
+            }
         }
-        if (fl == 0.0 && (nr == 0 || cur[nr - 1] != xl)) cur[nr++] = xl;
-        nc = nr;
-        for (int i = 0; i < nr; ++i) crit[i] = cur[i];
     }
-    for (int i = 0; i < nc; ++i) roots[i] = crit[i];
+    for (int k = 0; k < nc; ++k) roots[k] = crit[k];
     return nc;
 }
 
