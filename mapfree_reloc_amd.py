@@ -17,7 +17,8 @@ if _root not in sys.path:
 class _AliasFinder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
     def find_spec(self, fullname, path=None, target=None):
         if fullname.startswith(_ALIAS + "."):
-            return importlib.util.spec_from_loader(fullname, self)
+            real = importlib.util.find_spec(_REAL + fullname[len(_ALIAS):])
+            return importlib.util.spec_from_loader(fullname, self, origin=real.origin if real else None)
         return None
 
     def create_module(self, spec):
@@ -28,6 +29,14 @@ class _AliasFinder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
     def exec_module(self, module):
         if getattr(self, "_spec", None) is not None:       # keep the real module's own spec
             module.__spec__ = self._spec
+
+    def get_code(self, fullname):                          # `python -m mapfree_reloc_amd.<sub>`: run the real module's code
+        real = importlib.util.find_spec(_REAL + fullname[len(_ALIAS):])
+        return real.loader.get_code(real.name)
+
+    def is_package(self, fullname):
+        real = importlib.util.find_spec(_REAL + fullname[len(_ALIAS):])
+        return real.submodule_search_locations is not None
 
 
 if not any(isinstance(f, _AliasFinder) for f in sys.meta_path):

@@ -88,3 +88,18 @@ def test_online_fused_vs_per_pair_loop(tmp_path, matcher, solver):
                 # batch 2 vs batch 1 through fp32 library GEMMs: the poses agree far below the benchmark's resolution
                 np.testing.assert_allclose(np.array(f[1:8], float), np.array(p[1:8], float), atol=2e-3)
                 assert abs(int(f[8]) - int(p[8])) <= max(3, int(0.02 * int(p[8])))
+
+
+def test_submission_cli_fused_on_synthetic(tmp_path):
+    """python -m mapfree_reloc_amd.submission <yaml> --synthetic 2 2 --fused end to end (single process): config merge, scene
+    listing, pinned prefetching loader, fused pipeline, per-scene files, zip"""
+    y = tmp_path / "sg_pnp.yaml"
+    y.write_text("MODEL: 'FeatureMatching'\nFEATURE_MATCHING: 'SuperGlue'\nPOSE_SOLVER: 'PNP'\nALLOW_SYNTHETIC_WEIGHTS: True\n"
+                 "DATASET:\n  HEIGHT: 720\n  WIDTH: 540\nPNP:\n  RANSAC_ITER: 1000\n  REPROJECTION_INLIER_THRESHOLD: 3\n  CONFIDENCE: 0.9999\n")
+    out = tmp_path / "res"
+    submission.main([str(y), "-o", str(out), "--fused", "--synthetic", "2", "2", "--batch_pairs", "2"])
+    with zipfile.ZipFile(out / "submission.zip") as z:
+        assert z.namelist() == ["pose_s00000.txt", "pose_s00001.txt"]
+        lines = z.read("pose_s00001.txt").decode().split("\n")
+    assert len(lines) == 2 and lines[0].startswith("seq1/frame_00000.jpg ") and len(lines[0].split(" ")) == 9
+    assert (out / "poses" / "pose_s00000.txt").exists()
