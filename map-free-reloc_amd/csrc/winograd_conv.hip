@@ -87,10 +87,13 @@ __global__ void __launch_bounds__(256) wino_filter_kernel(const float *__restric
 }
 
 // output transform + bias + activation (+ 2x2 max-pool) + store, shared by the kernel variants
-template <bool POOL, int LOAD, int NBLK>
+// BIAS = false: the caller folded the bias into an accumulator; ACT >= 0: the activation is a compile-time constant (every VALU
+// instruction counts next to the f32 MFMAs, also the selects of a run-time activation code)
+template <bool POOL, int LOAD, int NBLK, bool BIAS = true, int ACT = -1>
 __device__ __forceinline__ void wn_epilogue(f32x4 (&acc)[16][NBLK], const float *__restrict__ bias, float *__restrict__ y,
-                                            const float *__restrict__ residual, int Cout, int H, int W, int act, int b, int cb, int kq, int ty, int tx)
+                                            const float *__restrict__ residual, int Cout, int H, int W, int act_rt, int b, int cb, int kq, int ty, int tx)
 {
+    const int act = ACT >= 0 ? ACT : act_rt;
     constexpr int WCO = 16 * NBLK;
     // output transform A^T M A + bias (+ReLU) (+2x2 max-pool) in registers; accumulator register r of
     // M-block blk = cout cb*WCO + blk*16 + 4 kq + r, column = this lane's tile
@@ -107,9 +110,12 @@ __device__ __forceinline__ void wn_epilogue(f32x4 (&acc)[16][NBLK], const float 
                 a1[j] = acc[4 + j][blk][r] - acc[8 + j][blk][r] - acc[12 + j][blk][r];
             }
             if (co >= Cout) continue;                        // padded output channels (Cout not a multiple of 32)
-            const float bv = bias ? bias[co] : 0.f;
-            float y00 = a0[0] + a0[1] + a0[2] + bv, y01 = a0[1] - a0[2] - a0[3] + bv;
-            float y10 = a1[0] + a1[1] + a1[2] + bv, y11 = a1[1] - a1[2] - a1[3] + bv;
+            float y00 = a0[0] + a0[1] + a0[2], y01 = a0[1] - a0[2] - a0[3];
+            float y10 = a1[0] + a1[1] + a1[2], y11 = a1[1] - a1[2] - a1[3];
+            if (BIAS) {
+                const float bv = bias ? bias[co] : 0.f;
+                y00 += bv; y01 += bv; y10 += bv; y11 += bv;
+            }
             const size_t plane = ((size_t)b * Cout + co) * ((size_t)Ho * Wo);
             float *yo = y + plane;
             if (POOL) {
@@ -522,7 +528,7 @@ __global__ void __launch_bounds__(256, 2) wino_conv3x3_pipe_kernel(
 //     outputs: no bias instruction in the epilogue.
 // K loop software-pipelined and pinned like the pipelined kernel; one barrier per chunk.
 // ---------------------------------------------------------------------------------------------------------------------
-template <bool POOL, int LOAD, int ABL = 0>
+template <bool POOL, int LOAD, int ABL = 0, int ACT = -1>
 __global__ void __launch_bounds__(256, 2) wino_conv3x3_shared_kernel(
     const float *__restrict__ x, const float *__restrict__ upk, const float *__restrict__ bias, float *__restrict__ y,
     const float *__restrict__ residual, int Cin, int Cout, int H, int W, int nbx, int nby, int S, int Sx, int ncb, int ncb32, int act)
@@ -572,6 +578,11 @@ __global__ void __launch_bounds__(256, 2) wino_conv3x3_shared_kernel(
     struct Patch { unsigned p0[3], p1[3], h[3]; };
     auto gload = [&](Patch &r, int c) {
         const unsigned so = (unsigned)c * cstep;
+        if (ABL & 8) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) { r.p0[a] = so + a; r.p1[a] = so ^ a; r.h[a] = so; }
+            return;
+        }
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
             const auto pr = __builtin_amdgcn_raw_buffer_load_b64(rs, off[a], so, 0);
@@ -653,8 +664,7 @@ __global__ void __launch_bounds__(256, 2) wino_conv3x3_shared_kernel(
         vstore((c + 1) & 1, o);
         const int cn = min(c + 2, nchunks - 1);      // prefetch index clamped (scalar): never reads past the tensors
         gload(pout, cn);
-        ustore((c + 1) & 1, ur);
-        uload(ur, cn);
+        if (!(ABL & 16)) { ustore((c + 1) & 1, ur); uload(ur, cn); }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
 #pragma unroll
@@ -692,6 +702,8 @@ __global__ void __launch_bounds__(256, 2) wino_conv3x3_shared_kernel(
     uload(ur, min(1, nchunks - 1));
     __syncthreads();
     __builtin_amdgcn_sched_barrier(0);
+    // (a variant that prefetched the patches two chunks ahead -- three rotating register sets, loop unrolled by six -- hit the
+    // 256-register limit and measured slower: 8.78 vs 8.27 ms on conv1b)
     int c = 0;
     for (; c + 1 < nchunks; c += 2) {
         kstep(c, pb, pa, ur);
@@ -707,7 +719,7 @@ __global__ void __launch_bounds__(256, 2) wino_conv3x3_shared_kernel(
         if (t[0] + t[1] + t[2] + t[3] == 12345.678f) y[tid] = t[0];
         return;
     }
-    wn_epilogue<POOL, LOAD, NBLK>(acc, nullptr, y, residual, Cout, H, W, act, b, 2 * cb + cs, kq, ty, tx);
+    wn_epilogue<POOL, LOAD, NBLK, false, ACT>(acc, nullptr, y, residual, Cout, H, W, act, b, 2 * cb + cs, kq, ty, tx);
 }
 
 static inline int wn_coutp(int Cout, int nblk) { const int q = 16 * nblk; return (Cout + q - 1) / q * q; }
@@ -739,7 +751,7 @@ int mfr_conv3x3_wino_variant(const float *x, const float *upk, const float *bias
 {
     if (!x || !upk || !y || B <= 0 || Cin <= 0 || Cout <= 0 || (Cin & 3) || H <= 0 || W <= 0 || act < 0 || act > 2) return MFR_E_ARG;
     if (pool && (H < 2 || W < 2 || residual)) return MFR_E_ARG;
-    if (variant < 0 || (variant > 4 && (variant < 10 || variant > 29)) ) return MFR_E_ARG;
+    if (variant < 0 || (variant > 4 && (variant < 10 || variant > 33)) ) return MFR_E_ARG;
     if ((size_t)4 * Cin * H * W >= 0x7fffffffull) return MFR_E_ARG;    // one image must fit a 2 GB buffer descriptor
     const int nblk = WN_NBLK;
     const int nbx = ((W + 1) / 2 + WN_TX - 1) / WN_TX, nby = ((H + 1) / 2 + WN_TY - 1) / WN_TY;
@@ -756,17 +768,24 @@ int mfr_conv3x3_wino_variant(const float *x, const float *upk, const float *bias
     hipStream_t st = (hipStream_t)stream;
 #define WN_ARGS x, upk, bias, y, residual, Cin, Cout, H, W, nbx, nby, (int)S, (int)Sx, ncb, act
 #define WN_GO(K) hipLaunchKernelGGL(K, dim3((unsigned)grid), dim3(256), 0, st, WN_ARGS)
-    if (variant == 4 || variant >= 26) {                   // shared-transform kernel: workgroup = 2 tile rows x 64 couts
+    if (variant == 4 || variant >= 26) {                   // 27..33: timing ablations of the shared kernel                   // shared-transform kernel: workgroup = 2 tile rows x 64 couts
         const int nby2 = ((H + 1) / 2 + 1) / 2, ncb32 = wn_coutp(Cout, nblk) / 32, ncb64 = (ncb32 + 1) / 2;
         const long long S2 = (long long)nbx * nby2 * B, Sx2 = (S2 + 7) / 8, grid2 = Sx2 * 8 * ncb64;
         if (grid2 > 0x7fffffffll) return MFR_E_ARG;
 #define WN_GO2(K) hipLaunchKernelGGL(K, dim3((unsigned)grid2), dim3(256), 0, st, x, upk, bias, y, residual, Cin, Cout, H, W, nbx, nby2, (int)S2, (int)Sx2, ncb64, ncb32, act)
         if (variant == 4) {
-            if (pool) { if (odd) WN_GO2((wino_conv3x3_shared_kernel<true, 2>)); else WN_GO2((wino_conv3x3_shared_kernel<true, 1>)); }
-            else { if (odd) WN_GO2((wino_conv3x3_shared_kernel<false, 2>)); else WN_GO2((wino_conv3x3_shared_kernel<false, 1>)); }
+#define WN_GO2_ACT(P, L) do { if (act == 1) WN_GO2((wino_conv3x3_shared_kernel<P, L, 0, 1>)); else if (act == 2) WN_GO2((wino_conv3x3_shared_kernel<P, L, 0, 2>)); \
+                              else WN_GO2((wino_conv3x3_shared_kernel<P, L, 0, 0>)); } while (0)
+            if (pool) { if (odd) WN_GO2_ACT(true, 2); else WN_GO2_ACT(true, 1); }
+            else { if (odd) WN_GO2_ACT(false, 2); else WN_GO2_ACT(false, 1); }
+#undef WN_GO2_ACT
         } else if (variant == 27) { if (pool) WN_GO2((wino_conv3x3_shared_kernel<true, 1, 1>)); else WN_GO2((wino_conv3x3_shared_kernel<false, 1, 1>)); }
         else if (variant == 28) { if (pool) WN_GO2((wino_conv3x3_shared_kernel<true, 1, 4>)); else WN_GO2((wino_conv3x3_shared_kernel<false, 1, 4>)); }
         else if (variant == 29) { if (pool) WN_GO2((wino_conv3x3_shared_kernel<true, 1, 5>)); else WN_GO2((wino_conv3x3_shared_kernel<false, 1, 5>)); }
+        else if (variant == 30) { if (pool) WN_GO2((wino_conv3x3_shared_kernel<true, 1, 8>)); else WN_GO2((wino_conv3x3_shared_kernel<false, 1, 8>)); }
+        else if (variant == 31) { if (pool) WN_GO2((wino_conv3x3_shared_kernel<true, 1, 16>)); else WN_GO2((wino_conv3x3_shared_kernel<false, 1, 16>)); }
+        else if (variant == 32) { if (pool) WN_GO2((wino_conv3x3_shared_kernel<true, 1, 29>)); else WN_GO2((wino_conv3x3_shared_kernel<false, 1, 29>)); }
+        else if (variant == 33) { if (pool) WN_GO2((wino_conv3x3_shared_kernel<true, 1, 13>)); else WN_GO2((wino_conv3x3_shared_kernel<false, 1, 13>)); }
         else return MFR_E_ARG;
 #undef WN_GO2
     } else if (variant == 2) {
