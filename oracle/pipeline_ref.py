@@ -89,7 +89,7 @@ def compare_pair(ref, hip_pts, hip_R, hip_t, hip_ninl, hip_status):
     # coarse identity (same keypoint pairing after rounding to 1/64 px: fp32 sub-pixel noise of LoFTR's fine stage)
     rq = {tuple(np.round(np.asarray(r) * 64).astype(np.int64).tolist()) for r in rs}
     hq = {tuple(np.round(np.asarray(r) * 64).astype(np.int64).tolist()) for r in hs}
-    rec = dict(n_ref=rn, n_hip=len(hp), identical_matches=bool(same), common_exact=both, common_q64=len(rq & hq),
+    rec = dict(n_ref=rn, n_hip=len(hp), identical_matches=bool(same), identical_set=bool(rs == hs), common_exact=both, common_q64=len(rq & hq),
                status_ref=int(ref["status"]), status_hip=int(hip_status), inliers_ref=int(ref["n_inliers"]), inliers_hip=int(hip_ninl))
     if ref["status"] == 0 and hip_status == 0:
         Rr, Rh = np.asarray(ref["R"], dtype=np.float64), np.asarray(hip_R, dtype=np.float64).reshape(3, 3)
@@ -106,6 +106,7 @@ def summarize(records):
     ident = [r for r in records if r["identical_matches"]]
     posed = [r for r in records if "rot_rad" in r]
     out = dict(pairs=n, identical_match_sets=len(ident), identical_fraction=round(len(ident) / max(n, 1), 4),
+               identical_as_sets=sum(r.get("identical_set", False) for r in records),
                status_agree=sum(r["status_ref"] == r["status_hip"] for r in records),
                mean_common_fraction=round(float(np.mean([r["common_q64"] / max(r["n_ref"], 1) for r in records])), 5) if n else None,
                inlier_count_equal=sum(r["inliers_ref"] == r["inliers_hip"] for r in records))

@@ -77,6 +77,11 @@ def test_coarse_match_vs_oracle(pair):
         gi, gj, gc = i_ids[b, :n[b]].long(), j_ids[b, :n[b]].long(), mconf[b, :n[b]]
         safe_g = (gc - 0.2).abs() > 1e-3
         assert len(wi) > L // 4
+        # the near-threshold band is counted, not hidden: thin, and what differs inside it is printed
+        n_band = int((~safe_w).sum()) + int((~safe_g).sum())
+        pw = {(int(a), int(c)) for a, c in zip(wi.tolist(), wj.tolist())}; pg = {(int(a), int(c)) for a, c in zip(gi.tolist(), gj.tolist())}
+        print(f"dual-softmax pair {b}: {len(pw)} oracle / {len(pg)} HIP matches, {n_band} within 1e-3 of the 0.2 threshold, {len(pw ^ pg)} differ in all")
+        assert n_band <= max(4, len(wi) // 50) and len(pw ^ pg) <= n_band
         np.testing.assert_array_equal(gi[safe_g].numpy(), wi[safe_w].numpy())
         np.testing.assert_array_equal(gj[safe_g].numpy(), wj[safe_w].numpy())
         np.testing.assert_allclose(gc[safe_g].numpy(), wc[safe_w].numpy(), rtol=2e-4)

@@ -183,9 +183,13 @@ def test_sinkhorn_match_vs_oracle(sg_pair):
         ms0 = torch.where(mutual0, max0.values[0].exp(), torch.tensor(0.0))
         valid0 = mutual0 & (ms0 > 0.2)
         want = torch.where(valid0, i0, torch.tensor(-1))
-        # decisions within 1e-3 of the threshold may legitimately differ in fp32
+        # decisions within 1e-3 of the threshold may legitimately differ in fp32: they are COUNTED, not hidden -- the band must be
+        # thin and the number of decisions that really flip inside it is printed ("report the mismatch rate")
         safe = (ms0 - 0.2).abs() > 1e-3
         got = out["matches0"][b, :m].long()
+        n_band = int((~safe).sum()); n_flip = int((got[~safe] != want[~safe]).sum())
+        print(f"sinkhorn pair {b}: {n_band} of {m} rows within 1e-3 of the 0.2 threshold, {n_flip} of them decided differently")
+        assert n_band <= max(2, m // 100) and n_flip <= n_band
         np.testing.assert_array_equal(got[safe].numpy(), want[safe].numpy())
         np.testing.assert_allclose(out["matching_scores0"][b, :m][safe].numpy(), ms0[safe].numpy(), rtol=2e-4, atol=2e-5)
         nv = int((got > -1).sum())

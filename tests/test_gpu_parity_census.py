@@ -28,18 +28,20 @@ def _check(recs, min_identical, min_common):
 
 def test_census_superglue_pnp_32_pairs():
     s = _check(census("sg_pnp", [5000 + i for i in range(32)]), SG_MIN_IDENTICAL, 0.97)
+    assert s["identical_as_sets"] >= 28 and s["inlier_count_equal"] >= 28 and s["pose_within_bar"] >= 30, s     # measured: 32 / 32 / 32
     # fp32 near-tie decisions (keypoint order at equal scores, Sinkhorn scores next to the 0.2 threshold) may flip a match in
     # some pairs; the pose must still be the oracle's far below the benchmark's resolution (0.25 m / 5 deg)
     assert s["max_rot_rad"] < 5e-3 and s["max_trans_m"] < 5e-3, s
 
 
 def test_census_loftr_emat_8_pairs():
-    s = _check(census("loftr_emat", [5000 + i for i in range(8)], chunk=4), LOFTR_MIN_IDENTICAL, 0.95)
+    s = _check(census("loftr_emat", [5000 + i for i in range(8)], chunk=4), LOFTR_MIN_IDENTICAL, 0.99)
+    assert s["pose_within_bar"] >= 7 and s["inlier_count_equal"] >= 6, s                                        # measured: 8 / 8
     assert s["max_rot_rad"] < 2e-2 and s["max_trans_m"] < 2e-2, s
 
 
 # lower bounds on the fraction of pairs whose whole match set is bit-identical to the oracle's (measured:
 # profiles/r02_parity_census.json); LoFTR's fine stage is a sub-pixel fp32 expectation, so exact equality of every
 # coordinate is not expected there and the common-fraction (1/64 px quantised) carries the check
-SG_MIN_IDENTICAL = 0.0
+SG_MIN_IDENTICAL = 0.4        # measured 0.66: the other pairs hold the same SET in another keypoint order (equal-score ties)
 LOFTR_MIN_IDENTICAL = 0.0
