@@ -23,6 +23,9 @@
 
 #define CHECK_LAUNCH() do { if (hipGetLastError() != hipSuccess) return MFR_E_LAUNCH; } while (0)
 
+// u / v row stride: ldS + 1 entries (dustbin) padded to a multiple of 4 floats so that rows of v are 16-byte aligned
+#define SG_LDV(ldS) (((ldS) + 4) & ~3)
+
 struct Lse { float m, s; };
 static __device__ __forceinline__ void lse_add(Lse &a, float x)
 {
@@ -37,20 +40,44 @@ static __device__ __forceinline__ void lse_merge(Lse &a, float m, float s)
 }
 static __device__ __forceinline__ float lse_val(const Lse &a) { return a.m + __logf(a.s); }
 
-// rows 0..m (row m = dustbin row).  S: [B, ldS, ldS] raw scores (already / sqrt(256)).
+// rows 0..m (row m = dustbin row).  S: [B, ldS, ldS] raw scores (already / sqrt(256)).  One wavefront per row; a lane takes
+// float4 pieces (16-byte loads of the row and of v, all issued before the first use), reduces them with max-then-sum (no
+// data-dependent branch per element) and the 64 partial (max, sum) pairs merge in a butterfly.
 __global__ void __launch_bounds__(256) sg_row_kernel(const float *__restrict__ S, int ldS, const int *__restrict__ n0,
                                                      const int *__restrict__ n1, float alpha,
-                                                     const float *__restrict__ v /*[B, ldS+1]*/,
-                                                     float *__restrict__ u /*[B, ldS+1]*/)
+                                                     const float *__restrict__ v /*[B, SG_LDV]*/,
+                                                     float *__restrict__ u /*[B, SG_LDV]*/)
 {
     const int b = blockIdx.y, lane = threadIdx.x & 63;
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int m = n0[b], n = n1[b];
     if (i > m || m == 0 || n == 0) return;
-    const float *vb = v + (size_t)b * (ldS + 1);
+    const float *vb = v + (size_t)b * SG_LDV(ldS);
     const float norm = -__logf((float)(m + n));
     Lse a = { -INFINITY, 0.f };
-    if (i < m) {
+    if (i < m && !(ldS & 3) && ldS <= 1024) {
+        const float4 *row4 = (const float4 *)(S + ((size_t)b * ldS + i) * ldS), *v4 = (const float4 *)vb;
+        float x[16];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int j4 = lane + 64 * k;                         // float4 index: columns 4 j4 .. 4 j4 + 3
+            float4 r = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY), w = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (4 * j4 < n) { r = row4[j4]; w = v4[j4]; }
+            x[4 * k] = (4 * j4 < n) ? r.x + w.x : -INFINITY;
+            x[4 * k + 1] = (4 * j4 + 1 < n) ? r.y + w.y : -INFINITY;
+            x[4 * k + 2] = (4 * j4 + 2 < n) ? r.z + w.z : -INFINITY;
+            x[4 * k + 3] = (4 * j4 + 3 < n) ? r.w + w.w : -INFINITY;
+        }
+        float mx = x[0];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) mx = fmaxf(mx, x[k]);
+        if (mx > -INFINITY) {
+            float sum = 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) sum += __expf(x[k] - mx);
+            a.m = mx; a.s = sum;
+        }
+    } else if (i < m) {
         const float *row = S + ((size_t)b * ldS + i) * ldS;
         for (int j = lane; j < n; j += 64) lse_add(a, row[j] + vb[j]);
     } else {
@@ -64,7 +91,7 @@ __global__ void __launch_bounds__(256) sg_row_kernel(const float *__restrict__ S
     }
     if (lane == 0) {
         const float log_mu = (i < m) ? norm : (__logf((float)n) + norm);
-        u[(size_t)b * (ldS + 1) + i] = log_mu - lse_val(a);
+        u[(size_t)b * SG_LDV(ldS) + i] = log_mu - lse_val(a);
     }
 }
 
@@ -78,12 +105,21 @@ __global__ void __launch_bounds__(1024) sg_col_kernel(const float *__restrict__ 
     const int j = blockIdx.x * 64 + lane;
     const int m = n0[b], n = n1[b];
     if (m == 0 || n == 0) return;
-    const float *ub = u + (size_t)b * (ldS + 1);
+    const float *ub = u + (size_t)b * SG_LDV(ldS);
     Lse a = { -INFINITY, 0.f };
     if (j <= n) {
         if (j < n) {
+            // four independent accumulators: four rows in flight per lane instead of one dependent exp chain
             const float *col = S + (size_t)b * ldS * ldS + j;
-            for (int i = g; i < m; i += 16) lse_add(a, col[(size_t)i * ldS] + ub[i]);
+            Lse a1 = { -INFINITY, 0.f }, a2 = a1, a3 = a1;
+            int i = g;
+            for (; i + 48 < m; i += 64) {
+                const float x0 = col[(size_t)i * ldS] + ub[i], x1 = col[(size_t)(i + 16) * ldS] + ub[i + 16];
+                const float x2 = col[(size_t)(i + 32) * ldS] + ub[i + 32], x3 = col[(size_t)(i + 48) * ldS] + ub[i + 48];
+                lse_add(a, x0); lse_add(a1, x1); lse_add(a2, x2); lse_add(a3, x3);
+            }
+            for (; i < m; i += 16) lse_add(a, col[(size_t)i * ldS] + ub[i]);
+            lse_merge(a, a1.m, a1.s); lse_merge(a2, a3.m, a3.s); lse_merge(a, a2.m, a2.s);
         } else {
             for (int i = g; i < m; i += 16) lse_add(a, alpha + ub[i]);
         }
@@ -95,7 +131,7 @@ __global__ void __launch_bounds__(1024) sg_col_kernel(const float *__restrict__ 
         for (int k = 1; k < 16; ++k) lse_merge(a, sm[k][lane], ss[k][lane]);
         const float norm = -__logf((float)(m + n));
         const float log_nu = (j < n) ? norm : (__logf((float)m) + norm);
-        v[(size_t)b * (ldS + 1) + j] = log_nu - lse_val(a);
+        v[(size_t)b * SG_LDV(ldS) + j] = log_nu - lse_val(a);
     }
 }
 
@@ -110,7 +146,7 @@ __global__ void __launch_bounds__(256) sg_rowmax_kernel(const float *__restrict_
     const int m = n0[b], n = n1[b];
     if (i >= m || n == 0) return;
     const float *row = S + ((size_t)b * ldS + i) * ldS;
-    const float *vb = v + (size_t)b * (ldS + 1);
+    const float *vb = v + (size_t)b * SG_LDV(ldS);
     float best = -INFINITY; int bi = 0x7fffffff;
     for (int j = lane; j < n; j += 64) {
         const float x = row[j] + vb[j];
@@ -134,7 +170,7 @@ __global__ void __launch_bounds__(1024) sg_colmax_kernel(const float *__restrict
     const int j = blockIdx.x * 64 + lane;
     const int m = n0[b], n = n1[b];
     if (m == 0 || n == 0) return;
-    const float *ub = u + (size_t)b * (ldS + 1);
+    const float *ub = u + (size_t)b * SG_LDV(ldS);
     float best = -INFINITY; int bi = 0x7fffffff;
     if (j < n) {
         const float *col = S + (size_t)b * ldS * ldS + j;
@@ -178,7 +214,7 @@ __global__ void __launch_bounds__(256) sg_match_kernel(
             j = idx0[(size_t)b * ldS + i];
             const bool mutual = idx1[(size_t)b * ldS + j] == i;
             // Z_ij = S_ij + u_i + v_j - norm ; val0 = S_ij + v_j
-            const float z = val0[(size_t)b * ldS + i] + u[(size_t)b * (ldS + 1) + i] - norm;
+            const float z = val0[(size_t)b * ldS + i] + u[(size_t)b * SG_LDV(ldS) + i] - norm;
             sc = mutual ? __expf(z) : 0.f;
             valid = mutual && (sc > thr);
         }
@@ -213,8 +249,8 @@ struct SgWs { size_t u, v, idx0, val0, idx1, total; };
 static SgWs sg_ws_layout(int B, int ldS)
 {
     SgWs w; size_t o = 0;
-    w.u = o;    o = align_up(o + sizeof(float) * (size_t)B * (ldS + 1), 256);
-    w.v = o;    o = align_up(o + sizeof(float) * (size_t)B * (ldS + 1), 256);
+    w.u = o;    o = align_up(o + sizeof(float) * (size_t)B * SG_LDV(ldS), 256);
+    w.v = o;    o = align_up(o + sizeof(float) * (size_t)B * SG_LDV(ldS), 256);
     w.idx0 = o; o = align_up(o + sizeof(int) * (size_t)B * ldS, 256);
     w.val0 = o; o = align_up(o + sizeof(float) * (size_t)B * ldS, 256);
     w.idx1 = o; o = align_up(o + sizeof(int) * (size_t)B * ldS, 256);
