@@ -544,12 +544,28 @@ __global__ void __launch_bounds__(256, 2) wino_conv3x3_shared_kernel(
     const int sl = jj / ncb;
     const int s = xcd * Sx + sl;
     if (sl >= Sx || s >= S) return;
-    const int bx = s % nbx, by = (s / nbx) % nby, b = s / (nbx * nby);
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tr = w >> 1, cs = w & 1;
     const int col = lane & 15, kq = lane >> 4;
-    const int ty = by * 2 + tr, tx = bx * WN_TX + col;
+    int b, ty, tx;
+    if (LOAD == 2) {
+        // odd W: LINEAR tiling.  The tile grid of an image (nbx = tiles per row) is one sequence, a wavefront takes 16 consecutive
+        // tiles wherever the rows break (nby = 32-tile groups per image) -- a 67-pixel row has 34 tiles, and 16-wide blocks would
+        // compute 48.  The neighbour exchange by DPP stays correct across a row break without any extra instruction BECAUSE W is
+        // odd: the last tile of a row has its second column outside the image (forced to 0 below), which is exactly the zero
+        // padding the first tile of the next row needs as left neighbour; and what the last tile receives from the next row's
+        // first tile only reaches its second output column (x = W), which does not exist and is never stored.
+        const int g = s % nby;
+        b = s / nby;
+        const int t = g * 32 + tr * 16 + col;
+        ty = t / nbx; tx = t - ty * nbx;
+        if (ty >= ((H + 1) >> 1)) { ty = H; tx = 0; }                      // past the last tile: every load out of range, nothing stored
+    } else {
+        const int bx = s % nbx, by = (s / nbx) % nby;
+        b = s / (nbx * nby);
+        ty = by * 2 + tr; tx = bx * WN_TX + col;
+    }
     const int HW = H * W;
     const int nchunks = Cin >> 2;
 
@@ -754,7 +770,8 @@ int mfr_conv3x3_wino_variant(const float *x, const float *upk, const float *bias
     if (variant < 0 || (variant > 4 && (variant < 10 || variant > 33)) ) return MFR_E_ARG;
     if ((size_t)4 * Cin * H * W >= 0x7fffffffull) return MFR_E_ARG;    // one image must fit a 2 GB buffer descriptor
     const int nblk = WN_NBLK;
-    const int nbx = ((W + 1) / 2 + WN_TX - 1) / WN_TX, nby = ((H + 1) / 2 + WN_TY - 1) / WN_TY;
+    int nbx = ((W + 1) / 2 + WN_TX - 1) / WN_TX;
+    const int nby = ((H + 1) / 2 + WN_TY - 1) / WN_TY;
     const int ncb = wn_coutp(Cout, nblk) / (16 * nblk);
     if ((size_t)16 * Cin * wn_coutp(Cout, nblk) * 4 >= 0x7fffffffull) return MFR_E_ARG;
     const long long S = (long long)nbx * nby * B;
@@ -769,8 +786,12 @@ int mfr_conv3x3_wino_variant(const float *x, const float *upk, const float *bias
 #define WN_ARGS x, upk, bias, y, residual, Cin, Cout, H, W, nbx, nby, (int)S, (int)Sx, ncb, act
 #define WN_GO(K) hipLaunchKernelGGL(K, dim3((unsigned)grid), dim3(256), 0, st, WN_ARGS)
     if (variant == 4 || variant >= 26) {                   // 27..33: timing ablations of the shared kernel                   // shared-transform kernel: workgroup = 2 tile rows x 64 couts
-        const int nby2 = ((H + 1) / 2 + 1) / 2, ncb32 = wn_coutp(Cout, nblk) / 32, ncb64 = (ncb32 + 1) / 2;
-        const long long S2 = (long long)nbx * nby2 * B, Sx2 = (S2 + 7) / 8, grid2 = Sx2 * 8 * ncb64;
+        const int ncb32 = wn_coutp(Cout, nblk) / 32, ncb64 = (ncb32 + 1) / 2;
+        // even W: blocks of 2 tile rows x 16 tile columns; odd W: linear tiling, nbx = tiles per row, nby2 = 32-tile groups per image
+        const int txn = (W + 1) / 2, tyn = (H + 1) / 2;
+        const int nby2 = odd ? (int)(((long long)txn * tyn + 31) / 32) : (tyn + 1) / 2;
+        if (odd) nbx = txn;
+        const long long S2 = odd ? (long long)nby2 * B : (long long)nbx * nby2 * B, Sx2 = (S2 + 7) / 8, grid2 = Sx2 * 8 * ncb64;
         if (grid2 > 0x7fffffffll) return MFR_E_ARG;
 #define WN_GO2(K) hipLaunchKernelGGL(K, dim3((unsigned)grid2), dim3(256), 0, st, x, upk, bias, y, residual, Cin, Cout, H, W, nbx, nby2, (int)S2, (int)Sx2, ncb64, ncb32, act)
         if (variant == 4) {

@@ -42,7 +42,10 @@ def _ref(x, w, b, act, pool, residual=None):
 @pytest.mark.parametrize("B,ci,co,H,W,relu,pool,bias", [
     (1, 4, 32, 8, 32, 0, 0, 0), (2, 8, 32, 11, 38, 1, 0, 1), (1, 64, 64, 17, 45, 1, 1, 1), (3, 12, 96, 9, 33, 0, 1, 1),
     (1, 4, 32, 2, 2, 1, 1, 1), (1, 4, 32, 1, 1, 0, 0, 1), (1, 16, 32, 12, 31, 1, 1, 1), (2, 20, 64, 40, 130, 1, 0, 1),
-    (1, 128, 256, 67, 90, 1, 0, 1), (2, 64, 128, 135, 180, 1, 1, 1), (1, 64, 64, 540, 720, 1, 1, 1)])
+    (1, 128, 256, 67, 90, 1, 0, 1), (2, 64, 128, 135, 180, 1, 1, 1), (1, 64, 64, 540, 720, 1, 1, 1),
+    # odd widths (linear tiling across row breaks): the SuperPoint layers at 1/4 and 1/8 resolution of a 720x540 image, + small ones
+    (2, 128, 256, 90, 67, 1, 0, 1), (2, 64, 128, 180, 135, 1, 0, 1), (1, 128, 128, 180, 135, 1, 1, 1), (3, 8, 64, 7, 5, 0, 0, 1),
+    (1, 16, 64, 6, 33, 1, 1, 1), (2, 8, 128, 5, 1, 1, 0, 1), (1, 64, 64, 31, 35, 1, 1, 0)])
 def test_wino_conv_vs_float64(B, ci, co, H, W, relu, pool, bias):
     g = torch.Generator().manual_seed(B * 1000 + ci + H)
     x = torch.randn(B, ci, H, W, generator=g).to(DEV)
@@ -57,7 +60,7 @@ def test_wino_conv_vs_float64(B, ci, co, H, W, relu, pool, bias):
 
 @pytest.mark.parametrize("B,ci,co,H,W,act,pool,res", [
     (2, 64, 64, 30, 52, 1, 1, 0), (1, 64, 128, 45, 67, 1, 0, 0), (1, 196, 196, 23, 34, 1, 0, 1), (1, 12, 40, 7, 9, 2, 0, 1),
-    (2, 4, 32, 5, 3, 0, 0, 0), (1, 132, 256, 19, 33, 1, 1, 0)])
+    (2, 4, 32, 5, 3, 0, 0, 0), (1, 132, 256, 19, 33, 1, 1, 0), (2, 64, 64, 23, 67, 1, 0, 1), (1, 64, 128, 40, 135, 2, 0, 1)])
 def test_wino_kernel_variants_agree(B, ci, co, H, W, act, pool, res):
     """the three kernels behind mfr_conv3x3_wino (classic, software-pipelined, shared-transform) on the same operands: the
     pipelined one is bit-identical to the classic one (same arithmetic, different schedule); the shared-transform one folds
