@@ -72,9 +72,20 @@ __global__ void __launch_bounds__(64) emat_hyp_kernel(
             a[2 * k] = p0[2 * s[k]]; a[2 * k + 1] = p0[2 * s[k] + 1];
             c[2 * k] = p1[2 * s[k]]; c[2 * k + 1] = p1[2 * s[k] + 1];
         }
-        ns = fivept_lds(a, c, o, fp_lds + threadIdx.x, fp_colp + threadIdx.x);
+        ns = fivept_lds(a, c, o, fp_lds + threadIdx.x, fp_colp + threadIdx.x, true);      // -1: front end done, 86 doubles in the slot
     }
     nsol[(size_t)b * max_iters + it] = ns;
+}
+
+// root stage: 8 lanes per hypothesis, 32 hypotheses per workgroup (emat_lds.h fp_roots_group); turns the 86-double front-end
+// record of a hypothesis into its <= 10 essential matrices in place
+__global__ void __launch_bounds__(256) emat_roots_kernel(double *__restrict__ Es, int32_t *__restrict__ nsol, int total)
+{
+    __shared__ FprShared sh[FPR_HYP_PER_WG];
+    const int g = threadIdx.x / FPR_GROUP, sub = threadIdx.x % FPR_GROUP;
+    const int h = blockIdx.x * FPR_HYP_PER_WG + g;
+    const bool active = h < total && nsol[h < total ? h : 0] == -1;
+    fp_roots_group(Es + (size_t)(h < total ? h : 0) * 90, nsol + (h < total ? h : 0), &sh[g], sub, active);
 }
 
 // grid (ceil(iters/64), B), 4 wavefronts; wavefront w scores hypotheses w, w+4, ... of the block's 64
@@ -475,6 +486,9 @@ int mfr_emat_solve_batch(const float *pts0, const float *pts1, const int32_t *n_
     CHECK_LAUNCH();
     const dim3 hgrid((max_iters + 63) / 64, B);
     hipLaunchKernelGGL(emat_hyp_kernel, hgrid, dim3(64), 0, s, x0, x1, n_corr, maxN, max_iters, seed, pair_ids, Es, nsol);
+    CHECK_LAUNCH();
+    const int total = B * max_iters;
+    hipLaunchKernelGGL(emat_roots_kernel, dim3((total + FPR_HYP_PER_WG - 1) / FPR_HYP_PER_WG), dim3(256), 0, s, Es, nsol, total);
     CHECK_LAUNCH();
     hipLaunchKernelGGL(emat_score_kernel, hgrid, dim3(256), 0, s, x0, x1, n_corr, maxN, max_iters, thr2, Es, nsol,
                        counts, bestm);

@@ -219,7 +219,9 @@ MFR_DEV void lds_p_mul21_perm(LdsArr a, LdsArr b, LdsArr o)
 
 // x0, x1: 5 normalised points each (registers); Es: up to 10 E written to GLOBAL memory (row-major, unit Frobenius norm).
 // S = this lane's LDS window (FP_LDS_DOUBLES doubles, stride 64), colp = this lane's int window (9 ints, stride 64).
-MFR_DEV_NOINLINE int fivept_lds(const double *x0, const double *x1, double *Es, double *lds_lane, int *colp_lane)
+// front_only: stop after the degree-10 polynomial and hand {Ep[36], Bx[12], By[12], B1[15], P[11]} (86 doubles) to the caller in
+// Es[0..86) (return -1); the root stage then runs in emat_roots_kernel with 8 lanes per hypothesis.
+MFR_DEV_NOINLINE int fivept_lds(const double *x0, const double *x1, double *Es, double *lds_lane, int *colp_lane, bool front_only = false)
 {
     const LdsArr S{ lds_lane };
     const LdsArr Ep = S, A = S.at(36), M = S.at(36), m = S.at(236), neg = S.at(246), EE = S.at(250), tr = S.at(280);
@@ -355,6 +357,12 @@ MFR_DEV_NOINLINE int fivept_lds(const double *x0, const double *x1, double *Es, 
     for (int a = 0; a < 5; ++a)
         for (int b = 0; b < 7; ++b) P[a + b] = P[a + b] + B1[a] * c2[b];
     FP_CUT(4);
+    if (front_only) {
+        for (int q = 0; q < 36; ++q) Es[q] = Ep[q];
+        for (int q = 0; q < 39; ++q) Es[36 + q] = Bx[q];          // Bx | By | B1 are contiguous
+        for (int q = 0; q < 11; ++q) Es[75 + q] = P[q];
+        return -1;
+    }
     const int nr = lds_poly_real_roots10(P, 10, roots, rws);
     if (FP_STAGE_LIMIT < 5) { double cs = (double)nr; for (int q = 0; q < 10; ++q) cs += roots[q]; Es[0] = cs; return 0; }
     int ns = 0;
@@ -392,6 +400,199 @@ MFR_DEV_NOINLINE int fivept_lds(const double *x0, const double *x1, double *Es, 
         ++ns;
     }
     return ns;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Root stage with EIGHT lanes per hypothesis (emat_roots_kernel).  The derivative-isolation root finder is sequential across
+// derivative levels but the brackets of one level are independent: the lanes of a group evaluate the bracket ends in parallel
+// and refine the sign-change brackets in parallel, so a level costs the iterations of its slowest bracket instead of their
+// sum, and 16 k hypotheses become 2000 wavefronts instead of 250 (one latency-bound wavefront per CU before).  Every
+// bracket's rtsafe iteration, every Horner evaluation and every derivative coefficient ((c[i+L] * (i+L)) * (i+L-1) ... * (i+1),
+// the multiplication order of the derivative tower) is the arithmetic of geom_dev.h poly_real_roots: bit-identical roots.
+// ---------------------------------------------------------------------------------------------------------------------
+MFR_DEV double fp_dcoef(const double (&c)[11], int L, int i)      // coefficient i of the L-th derivative
+{
+    double v = 0.0;
+#pragma unroll
+    for (int k = 0; k < 11; ++k) if (k == i + L) v = c[k];
+    for (int k = L; k >= 1; --k) v = v * (double)(i + k);
+    return v;
+}
+
+#define FPR_GROUP 8
+#define FPR_HYP_PER_WG 32
+struct FprShared {                                  // per hypothesis
+    double in[75];                                  // Ep[36] | Bx[12] | By[12] | B1[15]
+    double ends[12], fe[12], rr[12], crit[12];
+    int ne, nc;
+};
+
+MFR_DEV void fp_roots_group(double *slot, int32_t *nsol_out, volatile FprShared *sh, int sub, bool active)
+{
+    double c[11];
+#pragma unroll
+    for (int k = 0; k < 11; ++k) c[k] = active ? slot[75 + k] : 0.0;
+    if (active) {
+        for (int q = sub; q < 75; q += FPR_GROUP) sh->in[q] = slot[q];
+    }
+    int deg = 10;                                   // while (deg > 0 && c[deg] == 0) --deg, with static register indices
+#pragma unroll
+    for (int k = 10; k >= 1; --k) if (deg == k && c[k] == 0.0) deg = k - 1;
+    double bound = 0.0, cdeg = 0.0;
+#pragma unroll
+    for (int k = 0; k < 11; ++k) if (k == deg) cdeg = c[k];
+    bool live = active && deg > 0;
+    if (live) {
+        for (int i = 0; i < deg; ++i) {
+            double ci = 0.0;
+#pragma unroll
+            for (int k = 0; k < 11; ++k) if (k == i) ci = c[k];
+            double r = ci / cdeg;
+            if (r < 0.0) r = -r;
+            if (r > bound) bound = r;
+        }
+        bound = bound + 1.0;
+        if (!(bound < 1e300)) live = false;
+    }
+    int nc = 0;
+    if (live) {
+        nc = 1;
+        if (sub == 0) sh->crit[0] = -fp_dcoef(c, deg - 1, 0) / fp_dcoef(c, deg - 1, 1);
+    }
+    int L = live ? deg - 2 : -1;
+    while (__ballot(L >= 0)) {
+        const bool lv = L >= 0;
+        double pc[11], dpc[10];
+        const int m = deg - L;
+#pragma unroll
+        for (int k = 0; k < 11; ++k) pc[k] = (lv && k <= m) ? fp_dcoef(c, L, k) : 0.0;
+#pragma unroll
+        for (int k = 0; k < 10; ++k) dpc[k] = (lv && k <= m - 1) ? fp_dcoef(c, L + 1, k) : 0.0;
+        // bracket ends: -bound, the increasing critical points of the level above, +bound (the scan's `continue` rule)
+        if (lv && sub == 0) {
+            int ne = 0;
+            double last = -bound;
+            sh->ends[ne++] = last;
+            for (int i = 0; i <= nc; ++i) {
+                const double xh = (i < nc) ? sh->crit[i] : bound;
+                if (i < nc && !(xh > last)) continue;
+                sh->ends[ne++] = xh; last = xh;
+            }
+            sh->ne = ne;
+        }
+        const int ne = lv ? sh->ne : 0;
+        for (int j = sub; j < ne; j += FPR_GROUP) sh->fe[j] = horner_reg(pc, sh->ends[j]);
+        for (int j0 = 0; j0 < 12; j0 += FPR_GROUP) {                   // refinements of the sign-change brackets, one per lane
+            const int j = j0 + sub;
+            bool work = false;
+            double lo = 0.0, hi = 0.0, flo = 0.0;
+            if (lv && j + 1 < ne) {
+                const double fl = sh->fe[j], fh = sh->fe[j + 1];
+                if (fl != 0.0 && fh != 0.0 && ((fl < 0.0) != (fh < 0.0))) { work = true; lo = sh->ends[j]; hi = sh->ends[j + 1]; flo = fl; }
+            }
+            if (!__ballot(work)) continue;
+            // reg_refine_root, run in lock step by the lanes that have a bracket (statement for statement the same loop)
+            double x = 0.5 * (lo + hi), dxold = hi - lo, dx = dxold;
+            double fx = work ? horner_reg(pc, x) : 0.0, dfx = work ? horner_reg(dpc, x) : 1.0;
+            int it = 0;
+            bool run = work;
+            while (__ballot(run)) {
+                if (run) {
+                    if (it >= 200 || fx == 0.0) run = false;
+                    else {
+                        if ((fx < 0.0) == (flo < 0.0)) lo = x; else hi = x;
+                        const double a = (x - hi) * dfx - fx, b = (x - lo) * dfx - fx;
+                        double tf = 2.0 * fx;
+                        if (tf < 0.0) tf = -tf;
+                        double td = dxold * dfx;
+                        if (td < 0.0) td = -td;
+                        const bool newton = ((a < 0.0) != (b < 0.0)) && (tf <= td);
+                        double xn;
+                        dxold = dx;
+                        if (newton) { dx = fx / dfx; xn = x - dx; }
+                        else { dx = 0.5 * (hi - lo); xn = lo + dx; }
+                        if (!(xn > lo && xn < hi)) { dx = 0.5 * (hi - lo); xn = lo + dx; }
+                        if (xn == x) run = false;
+                        else {
+                            const double adx = dx < 0.0 ? -dx : dx, ax = xn < 0.0 ? -xn : xn;
+                            x = xn;
+                            if (adx <= 2e-16 * ax || adx < 1e-300) run = false;
+                            else { fx = horner_reg(pc, x); dfx = horner_reg(dpc, x); ++it; }
+                        }
+                    }
+                }
+            }
+            if (work) sh->rr[j] = x;
+        }
+        // the scan's bookkeeping, in bracket order (one lane; the refined roots are ready)
+        if (lv && sub == 0) {
+            int nr = 0;
+            double prev = 0.0;
+            for (int j = 0; j + 1 < ne; ++j) {
+                const double xl = sh->ends[j], fl = sh->fe[j], fh = sh->fe[j + 1];
+                if (fl == 0.0) { if (nr == 0 || prev != xl) { sh->crit[nr++] = xl; prev = xl; } }
+                else if (fh != 0.0 && ((fl < 0.0) != (fh < 0.0))) { prev = sh->rr[j]; sh->crit[nr++] = prev; }
+            }
+            const double xl = sh->ends[ne - 1], fl = sh->fe[ne - 1];
+            if (fl == 0.0 && (nr == 0 || prev != xl)) sh->crit[nr++] = xl;
+            sh->nc = nr;
+        }
+        if (lv) { nc = sh->nc; --L; }
+    }
+    // one E per real root (emat_dev.h fivept tail), roots handled in parallel, compacted in root order
+    int ns = 0;
+    for (int r0 = 0; r0 < 16; r0 += FPR_GROUP) {
+        const int r = r0 + sub;
+        bool ok = false;
+        double ev[9];
+        if (live && r < nc) {
+            const double z = sh->crit[r];
+            const volatile double *Ep = sh->in, *Bx = sh->in + 36, *By = sh->in + 48, *B1 = sh->in + 60;
+            double bx[3], by[3], b1[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                bx[k] = ((Bx[4 * k + 3] * z + Bx[4 * k + 2]) * z + Bx[4 * k + 1]) * z + Bx[4 * k];
+                by[k] = ((By[4 * k + 3] * z + By[4 * k + 2]) * z + By[4 * k + 1]) * z + By[4 * k];
+                b1[k] = (((B1[5 * k + 4] * z + B1[5 * k + 3]) * z + B1[5 * k + 2]) * z + B1[5 * k + 1]) * z + B1[5 * k];
+            }
+            double v0 = 0.0, v1 = 0.0, v2 = 0.0, bestw = -1.0;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const int p = a, q = (a + 1) % 3;
+                const double w0 = by[p] * b1[q] - b1[p] * by[q];
+                const double w1 = b1[p] * bx[q] - bx[p] * b1[q];
+                const double w2 = bx[p] * by[q] - by[p] * bx[q];
+                const double aw = w2 < 0.0 ? -w2 : w2;
+                if (aw > bestw) { bestw = aw; v0 = w0; v1 = w1; v2 = w2; }
+            }
+            if (bestw > 0.0) {
+                const double x = v0 / v2, y = v1 / v2;
+                double nn = 0.0;
+#pragma unroll
+                for (int e = 0; e < 9; ++e) {
+                    ev[e] = ((x * Ep[4 * e] + y * Ep[4 * e + 1]) + z * Ep[4 * e + 2]) + Ep[4 * e + 3];
+                    nn = nn + ev[e] * ev[e];
+                }
+                if ((nn > 0.0) && (nn < 1e300)) {
+                    const double s = 1.0 / sqrt(nn);
+#pragma unroll
+                    for (int e = 0; e < 9; ++e) ev[e] = ev[e] * s;
+                    ok = true;
+                }
+            }
+        }
+        const unsigned long long bal = __ballot(ok);
+        const int lane = (int)(threadIdx.x & 63), gbase = lane & ~(FPR_GROUP - 1);
+        const unsigned seg = (unsigned)((bal >> gbase) & 0xffull);
+        if (ok) {
+            double *E = slot + 9 * (ns + __popc(seg & ((1u << sub) - 1u)));
+#pragma unroll
+            for (int e = 0; e < 9; ++e) E[e] = ev[e];
+        }
+        ns += __popc(seg);
+    }
+    if (active && sub == 0) *nsol_out = ns;
 }
 
 }  // namespace mfr
