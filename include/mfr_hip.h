@@ -312,6 +312,27 @@ int mfr_conv3x3_wino(const float *x, const float *upk, const float *bias, const 
 int mfr_conv3x3_wino_variant(const float *x, const float *upk, const float *bias, const float *residual, int B, int Cin, int Cout,
                              int H, int W, int act, int pool, int variant, float *y, void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Relative-pose-regression aggregator (csrc/corr_warp.hip).  Reference call sites:
+ * CorrelationVolumeWarping.forward (lib/models/regression/aggregator.py:42-116) and
+ * CorrelationVolumeWarpingQKV.forward (aggregator.py:134-191), and autograd's backward through them in
+ * RegressionModel.training_step (lib/models/regression/model.py:87-97):
+ *     cvolume = softmax(q^T k, dim=2);  warped = v cvolume^T;  pos = grid cvolume^T;  max = max_j cvolume
+ * computed flash-style: the [B, N, N] volume never exists in memory, forward or backward.
+ *   mfr_corr_warp_fwd   q, k [B,Dq,N] (Dq 16 or 32), v [B,32,N], grid [2,N] or NULL -> warped [B,32,N], pos [B,2,N]
+ *                       (NULL iff grid NULL), max_score [B,N]; row_max / row_sum [B,N] are the softmax statistics
+ *                       (max of log2(e)*score, and the sum of exp) the backward needs.
+ *   mfr_corr_warp_bwd   d_warped [B,32,N], d_pos [B,2,N] or NULL, d_max [B,N] or NULL, delta [B,N] =
+ *                       sum_c d_warped*warped + sum d_pos*pos + d_max*max_score  ->  dq, dk [B,Dq,N], dv [B,32,N].
+ *                       One owner per output element (two kernels), no atomics: deterministic.
+ * fp32 on the exact-fp32 matrix cores; agrees with the materialised fp32 computation to f32 round-off.
+ * ------------------------------------------------------------------------------------------ */
+int mfr_corr_warp_fwd(const float *q, const float *k, const float *v, const float *grid, int B, int Dq, int N,
+                      float *warped, float *pos, float *max_score, float *row_max, float *row_sum, void *stream);
+int mfr_corr_warp_bwd(const float *q, const float *k, const float *v, const float *grid, int B, int Dq, int N,
+                      const float *d_warped, const float *d_pos, const float *d_max, const float *delta,
+                      const float *row_max, const float *row_sum, float *dq, float *dk, float *dv, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -58,6 +58,8 @@ SIGNATURES = {
     "mfr_conv3x3_wino_variant": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "mfr_layernorm": (_i, [_vp, _i, _vp, _vp, _vp, _i, C.c_longlong, _i, C.c_float, _vp, _i, _vp]),
     "mfr_upsample2x_add": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "mfr_corr_warp_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mfr_corr_warp_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mfr_rootsift": (_i, [_vp, _i, _vp, _vp, _vp]),
     "mfr_desc_ratio_match": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _d, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "mfr_scale_workspace_bytes": (_sz, [_i, _i]),

@@ -1,11 +1,12 @@
-"""build_model(cfg, checkpoint='') -> torch.nn.Module (lib/models/builder.py:8-26).  Only the
-'FeatureMatching' family is on the accelerated path; the regression models are out of scope."""
+"""build_model(cfg, checkpoint='') -> torch.nn.Module (lib/models/builder.py:8-27): the feature-matching family
+(SURVEY.md 8 rows a-*) and the regression family (row f-4; `checkpoint` = Lightning checkpoint of the reference)."""
 from .matching.model import FeatureMatchingModel
 
 
 def build_model(cfg, checkpoint=''):
     if cfg.MODEL == 'FeatureMatching':
         return FeatureMatchingModel(cfg)
-    raise NotImplementedError(
-        f"MODEL={cfg.MODEL!r}: only 'FeatureMatching' is implemented here (Regression models are out of "
-        f"scope, SURVEY.md 2 rows 9-10)")
+    if cfg.MODEL in ('Regression', 'RegressionMultiFrame'):
+        from .regression.model import build_regression_model
+        return build_regression_model(cfg, checkpoint)
+    raise NotImplementedError(f"MODEL={cfg.MODEL!r}")

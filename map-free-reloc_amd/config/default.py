@@ -9,6 +9,9 @@ keys this implementation adds (declared here because unknown keys are rejected o
                      matcher from one captured HIP graph (nets/graph.py; opt-in, see the limits recorded there)
   LOFTR.WEIGHTS      checkpoint of the online LoFTR matcher ('LoFTR' feature matching)
   ALLOW_SYNTHETIC_WEIGHTS  hand out seeded synthetic network weights when no checkpoint is configured (tests / benches)
+  TRAINING.PRECISION 'bf16' (autocast; the aggregator kernel and the pose algebra stay fp32) | 'fp32'
+  TRAINING.SIAMESE_BATCH  encode both images of a pair in one encoder pass (BatchNorm statistics over both)
+  TRAINING.DDP_BUCKET_MB  gradient all-reduce bucket size
   SUPERGLUE.*        matcher hyper-parameters of record (matchers.py:65-71) and weight paths
 """
 from .node import CfgNode as CN
@@ -47,12 +50,13 @@ def get_cfg_defaults():
     c.DATASET.SYNTHETIC = None      # [n_scenes, frames_per_scene]: run on the synthetic stand-in ON PURPOSE (no data offline)
     c.DATASET.PAIRS_TXT = CN(); c.DATASET.PAIRS_TXT.TRAIN = None; c.DATASET.PAIRS_TXT.VAL = None
     c.DATASET.PAIRS_TXT.TEST = None; c.DATASET.PAIRS_TXT.ONE_NN = False
-    # training (config/default.py:94-112) -- out of scope here, declared so dataset yamls merge
+    # training (config/default.py:94-112); PRECISION / SIAMESE_BATCH / DDP_BUCKET_MB are this implementation's (regression/train.py)
     c.TRAINING = CN()
     for k, v in dict(BATCH_SIZE=None, NUM_WORKERS=None, SAMPLER=None, N_SAMPLES_SCENE=None,
                      SAMPLE_WITH_REPLACEMENT=None, LR=None, LR_STEP_INTERVAL=None, LR_STEP_GAMMA=None,
                      VAL_INTERVAL=None, VAL_BATCHES=None, LOG_INTERVAL=None, EPOCHS=None, GRAD_CLIP=0.,
-                     ROT_LOSS='rot_frobenius_loss', TRANS_LOSS='trans_l2_loss', LAMBDA=1.0).items():
+                     ROT_LOSS='rot_frobenius_loss', TRANS_LOSS='trans_l2_loss', LAMBDA=1.0,
+                     PRECISION='bf16', SIAMESE_BATCH=False, DDP_BUCKET_MB=64).items():
         c.TRAINING[k] = v
     # ---- additions of this implementation ----
     c.RANSAC = CN(); c.RANSAC.SEED = 0

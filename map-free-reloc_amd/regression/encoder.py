@@ -1,0 +1,163 @@
+"""Image encoders of the regression model: pre-activation residual units, the strided ResNet and the ResUNet
+(reference: lib/models/regression/encoder/{preact.py:13-64, resnet.py:7-37, resunet.py:16-128}).
+
+Attribute names (bn1/conv1/.../shortcut.0, firstconv/firstbn, encoder1..3, upconv4.conv1.{conv,normalize}, iconv4, ...)
+are the reference's, so its checkpoints' `encoder.*` keys load unchanged.  The arithmetic is library convolutions
+(MIOpen through torch, bf16 under autocast, channels_last); the hand-written part of this row is the aggregator."""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+def _norm(planes, enabled=True):
+    return nn.BatchNorm2d(planes) if enabled else nn.Identity()
+
+
+class PreActUnit(nn.Module):
+    """BN-ReLU-conv residual unit (He et al., identity mappings), basic (two 3x3) or bottleneck (1x1, 3x3, 1x1 with
+    4x expansion).  The projection shortcut, when shapes change, is applied to the ACTIVATED input (preact.py:31-32)."""
+
+    def __init__(self, in_planes, planes, stride=1, bn=True, bottleneck=False):
+        super().__init__()
+        self.expansion = 4 if bottleneck else 1
+        out_planes = planes * self.expansion
+        if bottleneck:
+            shapes = [(in_planes, planes, 1, 1), (planes, planes, 3, stride), (planes, out_planes, 1, 1)]
+        else:
+            shapes = [(in_planes, planes, 3, stride), (planes, planes, 3, 1)]
+        for i, (cin, cout, k, s) in enumerate(shapes, 1):
+            setattr(self, f"bn{i}", _norm(cin, bn))
+            setattr(self, f"conv{i}", nn.Conv2d(cin, cout, k, stride=s, padding=k // 2, bias=False))
+        self.n_convs = len(shapes)
+        if stride != 1 or in_planes != out_planes:
+            self.shortcut = nn.Sequential(nn.Conv2d(in_planes, out_planes, 1, stride=stride, bias=False))
+        else:
+            self.shortcut = None
+
+    def forward(self, x):
+        a = F.relu(self.bn1(x))
+        skip = x if self.shortcut is None else self.shortcut(a)
+        y = self.conv1(a)
+        for i in range(2, self.n_convs + 1):
+            y = getattr(self, f"conv{i}")(F.relu(getattr(self, f"bn{i}")(y)))
+        return y + skip
+
+
+class PreActBlock(PreActUnit):
+    expansion_factor = 1
+
+    def __init__(self, in_planes, planes, stride=1, bn=True):
+        super().__init__(in_planes, planes, stride, bn, bottleneck=False)
+
+
+class PreActBottleneck(PreActUnit):
+    expansion_factor = 4
+
+    def __init__(self, in_planes, planes, stride=1):
+        super().__init__(in_planes, planes, stride, True, bottleneck=True)
+
+
+_BLOCKS = (PreActBlock, PreActBottleneck)
+
+
+def _stage(block, in_planes, planes, count, stride):
+    units = []
+    for i in range(count):
+        units.append(block(in_planes, planes, stride if i == 0 else 1))
+        in_planes = planes * block.expansion_factor
+    return nn.Sequential(*units), in_planes
+
+
+def _block_counts(cfg):
+    return [int(n) for n in str(cfg.NUM_BLOCKS).strip().split("-")]
+
+
+class ResNet(nn.Module):
+    """7x7/2 stem then three stages, each followed by a 2x2 average pool (resnet.py:7-37): 1/16 resolution."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        block, counts = _BLOCKS[cfg.BLOCK_TYPE], _block_counts(cfg)
+        self.conv1 = nn.Conv2d(3, 64, 7, stride=2, padding=1, bias=False)
+        self.layer1, c = _stage(block, 64, 64, counts[0], 1)
+        self.layer2, c = _stage(block, c, 128, counts[1], 2)
+        self.layer3, c = _stage(block, c, 256, counts[2], 2)
+        self.num_out_layers = c
+
+    def forward(self, x):
+        x = self.conv1(x)
+        for stage in (self.layer1, self.layer2, self.layer3):
+            x = F.avg_pool2d(stage(x), 2)
+        return x
+
+
+class conv(nn.Module):
+    """conv + BatchNorm + ELU (resunet.py:16-27); class and attribute names are state-dict keys"""
+
+    def __init__(self, cin, cout, kernel_size, stride):
+        super().__init__()
+        self.conv = nn.Conv2d(cin, cout, kernel_size, stride=stride, padding=(kernel_size - 1) // 2)
+        self.normalize = nn.BatchNorm2d(cout)
+
+    def forward(self, x):
+        return F.elu(self.normalize(self.conv(x)))
+
+
+class upconv(nn.Module):
+    """bilinear (align_corners) upsampling by `scale`, then conv+BN+ELU (resunet.py:30-38)"""
+
+    def __init__(self, cin, cout, kernel_size, scale):
+        super().__init__()
+        self.scale = scale
+        self.conv1 = conv(cin, cout, kernel_size, 1)
+
+    def forward(self, x):
+        return self.conv1(F.interpolate(x, scale_factor=self.scale, mode="bilinear", align_corners=True))
+
+
+def _centre_pad_to(x, ref):
+    """zero-pad x (odd sizes after the strided stages) to ref's spatial size, surplus on the bottom/right (resunet.py:93-100)"""
+    dy, dx = ref.shape[2] - x.shape[2], ref.shape[3] - x.shape[3]
+    if dy == 0 and dx == 0:
+        return x
+    return F.pad(x, (dx // 2, dx - dx // 2, dy // 2, dy - dy // 2))
+
+
+class ResUNet(nn.Module):
+    """ResNet stem + three stages down to 1/16, two upsample-and-merge steps back to 1/4, 1x1 projection to
+    NUM_OUT_LAYERS channels (resunet.py:41-128).  On the Map-free 360x270 input: 92x68 = 6256 positions x 32 channels."""
+
+    def __init__(self, cfg, num_in_layers=3):
+        super().__init__()
+        block, counts = _BLOCKS[cfg.BLOCK_TYPE], _block_counts(cfg)
+        self.firstconv = nn.Conv2d(num_in_layers, 64, 7, stride=2, padding=3, bias=False)
+        self.firstbn = nn.BatchNorm2d(64)
+        self.firstmaxpool = nn.MaxPool2d(3, stride=2, padding=1)
+        self.encoder1, c1 = _stage(block, 64, 64, counts[0], 1)
+        self.encoder2, c2 = _stage(block, c1, 128, counts[1], 2)
+        self.encoder3, c3 = _stage(block, c2, 256, counts[2], 2)
+        # decoder widths are fixed by the reference to the bottleneck layout (256/512/1024)
+        skip = [256, 512, 1024]
+        self.not_concat = bool(getattr(cfg, "NOT_CONCAT", False))
+        self.upconv4 = upconv(skip[2], 512, 3, 2)
+        self.iconv4 = conv(512 if self.not_concat else skip[1] + 512, 512, 3, 1)
+        self.upconv3 = upconv(512, 256, 3, 2)
+        self.iconv3 = conv(256 if self.not_concat else skip[0] + 256, 256, 3, 1)
+        self.num_out_layers = int(getattr(cfg, "NUM_OUT_LAYERS", None) or 128)
+        self.outconv = conv(256, self.num_out_layers, 1, 1)
+
+    def forward(self, x):
+        x1 = self.firstmaxpool(F.relu(self.firstbn(self.firstconv(x))))
+        x2 = self.encoder1(x1)
+        x3 = self.encoder2(x2)
+        x4 = self.encoder3(x3)
+        y = self.upconv4(x4)
+        if not self.not_concat:
+            y = torch.cat([y, _centre_pad_to(x3, y)], dim=1)
+        y = self.upconv3(self.iconv4(y))
+        if not self.not_concat:
+            y = torch.cat([y, _centre_pad_to(x2, y)], dim=1)
+        return self.outconv(self.iconv3(y))
+
+
+ENCODERS = {"ResNet": ResNet, "ResUNet": ResUNet}

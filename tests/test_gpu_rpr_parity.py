@@ -1,0 +1,112 @@
+"""-m gpu: csrc/corr_warp.hip (fused correlation-volume warping, forward + backward) through the C-ABI against
+(a) the reference-executed fixtures tests/golden/ref_rpr_aggregator.npz, (b) the oracle's materialised computation in
+fp64 at the Map-free size (6256 positions), and the whole RegressionModel (fused aggregator, MIOpen convolutions) against
+the reference's RegressionModel outputs / loss / gradients (ref_rpr_model_*.npz)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from mapfree_reloc_amd.config import get_cfg_defaults
+from mapfree_reloc_amd.regression import aggregator as A
+from oracle import rpr_ref
+from tests.test_rpr_oracle import GOLD, _t, build_case, check_case
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _agg_cfg(**kw):
+    c = get_cfg_defaults().AGGREGATOR
+    c.POSITION_ENCODER, c.POSITION_ENCODER_IM1, c.MAX_SCORE_CHANNEL = True, False, True
+    for k, v in kw.items():
+        c[k] = v
+    return c
+
+
+@pytest.mark.parametrize("name,kw", [("full", {}), ("half", {"CV_HALF_CHANNELS": True}), ("nopos", {"POSITION_ENCODER": False}),
+                                     ("norm_im1", {"NORMALISE_DOT": True, "POSITION_ENCODER_IM1": True}),
+                                     ("nomax", {"MAX_SCORE_CHANNEL": False})])
+def test_fused_aggregator_matches_reference_fixture(name, kw):
+    g = np.load(os.path.join(GOLD, "ref_rpr_aggregator.npz"))
+    agg = A.CorrelationVolumeWarping(_agg_cfg(**kw), 32).to(DEV)
+    v0, v1 = _t(g[f"{name}_vol0"]).to(DEV).requires_grad_(), _t(g[f"{name}_vol1"]).to(DEV).requires_grad_()
+    y = agg(v0, v1)
+    np.testing.assert_allclose(y.detach().cpu().numpy(), g[f"{name}_out"], rtol=2e-5, atol=2e-6)
+    (y * _t(g[f"{name}_w"]).to(DEV)).sum().backward()
+    for got, key in ((v0.grad, "dvol0"), (v1.grad, "dvol1")):
+        ref = g[f"{name}_{key}"]
+        assert np.abs(got.cpu().numpy() - ref).max() <= 2e-5 * np.abs(ref).max(), (name, key)
+
+
+@pytest.mark.parametrize("B,Dq,H,W", [(2, 32, 92, 68), (1, 16, 92, 68), (3, 32, 7, 5), (1, 32, 1, 1), (2, 32, 33, 31)])
+def test_corr_warp_vs_fp64_materialised(B, Dq, H, W):
+    """Map-free size (92x68 = 6256 positions: a ragged last tile), the half-channel variant, and degenerate sizes; forward
+    outputs and all three gradients against the oracle evaluated in fp64 on the device"""
+    torch.manual_seed(B * 100 + H)
+    N = H * W
+    q = (torch.randn(B, Dq, N, device=DEV) * 0.6).requires_grad_()
+    k = (torch.randn(B, Dq, N, device=DEV) * 0.6).requires_grad_()
+    v = torch.randn(B, 32, N, device=DEV).requires_grad_()
+    grid = A.position_grid(H, W, DEV)
+    w, p, m = A.corr_warp(q, k, v, grid)
+    gw, gp, gm = torch.randn_like(w), torch.randn_like(p), torch.randn_like(m)
+    (w * gw).sum().add((p * gp).sum()).add((m * gm).sum()).backward()
+    q64, k64, v64 = (t.detach().double().requires_grad_() for t in (q, k, v))
+    w64, p64, m64 = rpr_ref.corr_warp_materialised(q64, k64, v64, grid.double())
+    (w64 * gw.double()).sum().add((p64 * gp.double()).sum()).add((m64 * gm.double()).sum()).backward()
+    for got, ref, what in ((w, w64, "warped"), (p, p64, "pos"), (m, m64, "max"), (q.grad, q64.grad, "dq"), (k.grad, k64.grad, "dk"),
+                           (v.grad, v64.grad, "dv")):
+        err = (got.double() - ref).abs().max().item()
+        assert err <= 3e-5 * max(ref.abs().max().item(), 1e-2), (what, err, ref.abs().max().item())
+
+
+def test_corr_warp_deterministic_and_no_cpu_path():
+    torch.manual_seed(5)
+    q, k, v = (torch.randn(2, 32, 1000, device=DEV).requires_grad_() for _ in range(3))
+    outs = []
+    for _ in range(2):
+        for t in (q, k, v):
+            t.grad = None
+        w, p, m = A.corr_warp(q, k, v, A.position_grid(40, 25, DEV))
+        (w.sum() + p.sum() * 0.5 + m.sum()).backward()
+        outs.append([w.detach().clone(), q.grad.clone(), k.grad.clone(), v.grad.clone()])
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)                              # one owner per output element, no atomics
+    with pytest.raises(RuntimeError, match="HIP device only"):
+        A.corr_warp(q.detach().cpu(), k.detach().cpu(), v.detach().cpu(), None)
+
+
+@pytest.mark.parametrize("name", ["3d3d", "qkv_bins", "concat_resnet"])
+def test_model_matches_reference_gpu(name):
+    """the whole model on the device (fp32, fused aggregator) against the reference's CPU run: eval forward, training
+    forward (batch statistics), loss, d loss / d image0, per-parameter gradient norms.  MIOpen vs oneDNN convolution
+    round-off through ~25 layers sets the tolerance (2e-4 relative on activations)."""
+    torch.backends.cudnn.allow_tf32 = False
+    model, data, g = build_case(name, device=DEV, materialised=False)
+    check_case(model, data, g, tol=2e-4)
+
+
+def test_bf16_autocast_training_step_runs_and_tracks_fp32():
+    """TRAINING.PRECISION bf16: convolutions under autocast, aggregator + pose algebra in fp32.  The encoder volume stays
+    within bf16 round-off of the fp32 one (relative L2), the aggregator output is fp32, loss and gradients are finite.
+    (The pose itself is NOT compared: a seeded-random network with batch-of-2 BatchNorm statistics amplifies 3 significant
+    digits of activations into a different Kabsch solution.)"""
+    model, data, g = build_case("3d3d", device=DEV, materialised=False)
+    model.train()
+    d = dict(data)
+    with torch.no_grad():
+        ref = model.encoder(d["image0"])
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            low = model.encoder(d["image0"])
+    assert low.dtype == torch.bfloat16
+    assert ((low.float() - ref).norm() / ref.norm()).item() < 0.05
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        agg = model.aggregator(low, low)
+        assert agg.dtype == torch.float32
+        model(d)
+        loss = model.loss_fn(d)[2]
+    loss.backward()
+    assert torch.isfinite(loss.detach()).item()
+    assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
