@@ -4,6 +4,10 @@
   --config sg_pnp      (default) BASELINE.json configs[1]: SuperPoint+SuperGlue matching + PnP w/ DPT depth, 540x720
   --config loftr_emat  BASELINE.json configs[2]: LoFTR coarse-to-fine matching + Essential-matrix RANSAC (+ metric
                        scale from depth), 540x720 right-padded to 544 like the reference (quirk Q3)
+  --config rpr_train   BASELINE.json configs[4]: one bf16 training step (forward, loss, backward, gradient
+                       all-reduce over RCCL, clip, Adam) of the 3d3d relative-pose-regression model
+                       (config/regression/mapfree/3d3d.yaml: ResUNet 3-3-3, correlation-volume warping, Procrustes head)
+                       on synthetic 360x270 pairs, TRAINING.BATCH_SIZE 10 per GPU
 
 Synthetic pairs, seeded synthetic weights (no data / checkpoints offline).  A "step" is one pass of the whole
 path over one batch of B image pairs per GPU, inputs already resident in HBM.  N > 1 GPUs: pairs shard
@@ -36,7 +40,7 @@ import torch.distributed as dist
 H, W = 720, 540                      # config/mapfree.yaml:7-8, compute.py:42
 FP32_MFMA_PEAK_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md (v_mfma_f32_32x32x2_f32 / 16x16x4_f32)
 HBM_PEAK_GBS = 8000.0                # same guide: 8.0 TB/s spec (6.3 TB/s achievable)
-CONFIGS = ("sg_pnp", "loftr_emat")
+CONFIGS = ("sg_pnp", "loftr_emat", "rpr_train")
 
 
 def parse(argv=None):
@@ -55,9 +59,9 @@ def parse(argv=None):
     ap.add_argument("--verbose", action="store_true")
     a = ap.parse_args(argv)
     if a.batch <= 0:
-        a.batch = 32 if a.config == "sg_pnp" else 16
+        a.batch = {"sg_pnp": 32, "loftr_emat": 16, "rpr_train": 10}[a.config]
     if a.cpu_pairs <= 0:
-        a.cpu_pairs = 6 if a.config == "sg_pnp" else 3
+        a.cpu_pairs = {"sg_pnp": 6, "loftr_emat": 3, "rpr_train": 4}[a.config]
     return a
 
 
@@ -96,10 +100,12 @@ def cpu_baseline(config, n_pairs, seeds, threads, out_path=""):
     timed on this box's host cores -- a reported baseline, never the product path.  Two figures: `threads` host
     threads over the first n_pairs pairs, and ONE thread on the first pair (the reference itself is a single
     process; SURVEY.md 8d asks for both).  The per-pair oracle results go to `out_path` for the parity leg."""
-    from oracle import pipeline_ref as PR
-    from mapfree_reloc_amd import images as IM
     host = os.cpu_count() or 1
     cores = max(1, min(threads, host))
+    if config == "rpr_train":
+        return rpr_cpu_baseline(n_pairs, cores, host)
+    from oracle import pipeline_ref as PR
+    from mapfree_reloc_amd import images as IM
     prs = [IM.synthetic_pair(s, H, W) for s in seeds[:n_pairs]]
 
     def run(p, s):
@@ -273,6 +279,120 @@ class LoftrEmatWorkload:
                                            "contraction evaluated on the fp32 matrix cores, so its floor is MFMA time, not HBM time"}]}
 
 
+# ----------------------------------------------------------------------------------------------------------------
+# configs[4]: bf16 training step of the regression model
+# ----------------------------------------------------------------------------------------------------------------
+RPR_H, RPR_W = 360, 270              # config/regression/mapfree/3d3d.yaml:32-33
+RPR_3D3D = ["MODEL", "Regression", "ENCODER.TYPE", "ResUNet", "ENCODER.BLOCK_TYPE", 1, "ENCODER.NUM_BLOCKS", "3-3-3",
+            "ENCODER.NOT_CONCAT", False, "ENCODER.NUM_OUT_LAYERS", 32, "AGGREGATOR.TYPE", "CorrelationVolumeWarping",
+            "AGGREGATOR.POSITION_ENCODER", True, "AGGREGATOR.MAX_SCORE_CHANNEL", True, "HEAD.TYPE", "ProcrustesDeepResBlock",
+            "HEAD.ADD_BASIS", True, "HEAD.AVG_POOL", True, "TRAINING.LR", 1e-4, "TRAINING.ROT_LOSS", "rot_angle_loss",
+            "TRAINING.TRANS_LOSS", "trans_l1_loss", "TRAINING.LAMBDA", 1.0, "DATASET.HEIGHT", RPR_H, "DATASET.WIDTH", RPR_W]
+
+
+def rpr_cfg(precision):
+    from mapfree_reloc_amd.config import get_cfg_defaults
+    cfg = get_cfg_defaults()
+    cfg.merge_from_list(RPR_3D3D + ["TRAINING.PRECISION", precision])
+    return cfg
+
+
+def rpr_cpu_baseline(n_pairs, cores, host):
+    """the same training step on the host: this package's model with the aggregator swapped for the oracle's MATERIALISED
+    correlation volume (oracle/rpr_ref.py = the reference's aggregator.py:42-116 arithmetic), PyTorch-CPU fp32"""
+    from oracle import rpr_ref
+    from mapfree_reloc_amd.regression.train import SyntheticPairs, Trainer
+    torch.set_num_threads(cores)
+    cfg = rpr_cfg("fp32")
+    src = SyntheticPairs(n_pairs, RPR_H, RPR_W, "cpu", seed=0)
+    tr = Trainer(cfg, "cpu")
+    tr.model.aggregator = rpr_ref.MaterialisedAggregator(tr.model.aggregator)
+    b0, b1 = src.batch(), src.batch()
+    tr.materialise(b0)
+    tr.build()
+    tr.train_step(b0)
+    t0 = time.perf_counter()
+    tr.train_step(b1)
+    dt = time.perf_counter() - t0
+    return dict(value=round(n_pairs / dt, 4), unit="image-pairs/s", cores=cores, kind="port", host_cores=host,
+                sample=f"1 training step of {n_pairs} synthetic {RPR_H}x{RPR_W} pairs, PyTorch-CPU fp32 ({cores} threads), correlation "
+                       f"volume materialised like the reference, {dt:.1f}s")
+
+
+def rpr_train_bench(args, rank, world, dev, use_dist):
+    """python bench.py --config rpr_train: a step = forward + loss + backward (+ bucketed RCCL gradient all-reduce) + clip +
+    Adam on B pairs per GPU; value = pairs trained per second over all ranks (weak scaling)."""
+    import mapfree_reloc_amd as mfr
+    from mapfree_reloc_amd.regression.train import SyntheticPairs, Trainer
+    lib = mfr._lib.load(require_gpu=True)
+    B = args.batch
+    cfg = rpr_cfg("bf16")
+    src = SyntheticPairs(B, RPR_H, RPR_W, dev, seed=0, rank=rank)
+    batches = [src.batch() for _ in range(2)]            # resident in HBM before the timed region, alternated
+    torch.cuda.synchronize()
+    fwd_t, bwd_t = KernelTimer(), KernelTimer()
+    if not args.no_kernel_timer:
+        lib.mfr_corr_warp_fwd = fwd_t.wrap(lib.mfr_corr_warp_fwd)
+        lib.mfr_corr_warp_bwd = bwd_t.wrap(lib.mfr_corr_warp_bwd)
+    tr = Trainer(cfg, dev, sample=batches[0]).build()
+    for i in range(3 + args.warmup):                     # 3 initialisation steps (MIOpen solution search), then the warm-up
+        tr.train_step(batches[i & 1])
+    torch.cuda.synchronize()
+    if use_dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    fwd_t.enabled = bwd_t.enabled = True
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        losses = tr.train_step(batches[i & 1])
+    torch.cuda.synchronize()
+    if use_dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    fwd_t.enabled = bwd_t.enabled = False
+    if use_dist:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    if rank != 0:
+        return
+    with torch.no_grad():
+        vol = tr.model.encoder(batches[0]["image0"][:1])
+    D, N = vol.shape[1], vol.shape[2] * vol.shape[3]
+    n_param = sum(p.numel() for p in tr.model.parameters())
+    # the fused correlation-volume kernels: contractions over the [N, N] volume, per launch (B volumes)
+    f_fwd = 2.0 * N * N * (D + 32) * B                   # S = K^T Q, O = V P
+    f_bwd = 2.0 * N * N * ((D + 32 + D) + (D + 32 + D + 32)) * B     # query owner: S, dP, dQ; key owner: S, dP, dK, dV
+    fm, bm = fwd_t.mean_ms(), bwd_t.mean_ms()
+    ach_f = f_fwd / (fm * 1e-3) / 1e12 if fm else None
+    ach_b = f_bwd / (bm * 1e-3) / 1e12 if bm else None
+    vol_bytes = 4.0 * N * N * B
+    line = {
+        "metric": "image-pairs/sec trained (3d3d relative-pose regression, bf16 autocast, 360x270)", "value": round(B * args.steps * world / elapsed, 3),
+        "unit": "image-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16 autocast (encoder / head convolutions), f32 (correlation-volume kernel, pose algebra, losses, master weights, Adam)",
+        "data": "synthetic (seeded textured planes under a random relative pose; no Map-free training split offline), random-init weights",
+        "config": {"workload": "configs[4]: 3d3d.yaml (ResUNet 3-3-3 -> CorrelationVolumeWarping -> ProcrustesDeepResBlock), full training step",
+                   "global_batch": B * world, "pairs_per_gpu_per_step": B, "parallelism": f"dp{world} (DDP, one {cfg.TRAINING.DDP_BUCKET_MB} MB gradient bucket, RCCL all-reduce)",
+                   "volume_positions": N, "feature_channels": D, "parameters": n_param, "optimizer": "Adam (fused), eps 1e-6",
+                   "last_losses": [round(float(x.float().sum()), 5) for x in losses]},
+        "roofline": {"kernel": "cw_bwd_q_kernel + cw_bwd_kv_kernel (mfr_corr_warp_bwd: fused correlation-volume warping, backward)", "bound": "mfma",
+                     "achieved": round(ach_b, 2) if ach_b else None, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(ach_b / FP32_MFMA_PEAK_TFLOPS, 4) if ach_b else None, "traffic": None,
+                     "avg_launch_ms": round(bm, 4) if bm else None, "launches_timed": len(bwd_t.events), "flops_per_launch": f_bwd,
+                     "note": f"the [B, N, N] volume ({vol_bytes / 1e9:.2f} GB fp32 at this batch) is never written: it is recomputed tile by tile on the "
+                             "fp32 matrix cores; HBM-side algorithmic bytes are the q/k/v/gradient maps only (a few MB)",
+                     "other_kernels": [{"kernel": "cw_fwd_kernel (mfr_corr_warp_fwd)", "bound": "mfma", "achieved": round(ach_f, 2) if ach_f else None,
+                                        "peak": FP32_MFMA_PEAK_TFLOPS, "frac": round(ach_f / FP32_MFMA_PEAK_TFLOPS, 4) if ach_f else None,
+                                        "avg_launch_ms": round(fm, 4) if fm else None, "launches_timed": len(fwd_t.events), "flops_per_launch": f_fwd}]},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline_subprocess("rpr_train", args.cpu_pairs, args.cpu_threads, "")
+    print(json.dumps(line))
+
+
 def _traffic(tag, B):
     """HBM traffic of the dominant kernel: PMC counters cannot be read inside this process, so the per-launch figure
     comes from the committed rocprofv3 --pmc passes of this same command (2 x FETCH_SIZE + WRITE_SIZE, the guide's
@@ -348,6 +468,12 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)        # backend "nccl" is RCCL on ROCm
         world = dist.get_world_size()                         # what RCCL actually formed
+
+    if args.config == "rpr_train":
+        rpr_train_bench(args, rank, world, dev, use_dist)
+        if use_dist:
+            dist.destroy_process_group()
+        return
 
     import mapfree_reloc_amd as mfr
     from mapfree_reloc_amd import images as IM

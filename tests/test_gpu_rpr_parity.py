@@ -110,3 +110,27 @@ def test_bf16_autocast_training_step_runs_and_tracks_fp32():
     loss.backward()
     assert torch.isfinite(loss.detach()).item()
     assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
+
+
+def test_trainer_steps_on_device_with_fused_aggregator(tmp_path):
+    """regression/train.py on the device: 3d3d configuration (fused correlation-volume kernel in forward AND backward), bf16
+    autocast, fused Adam, gradient clipping; parameters move, losses stay finite, checkpoint -> resume continues (to the
+    round-off of MIOpen's atomically accumulated weight gradients)"""
+    from mapfree_reloc_amd.regression.train import SyntheticPairs, Trainer
+    from oracle.gen_rpr_golden import CASES
+    cfg = get_cfg_defaults()
+    cfg.merge_from_list(CASES["3d3d"][0])
+    cfg.merge_from_list(["TRAINING.LR", 1e-4, "TRAINING.GRAD_CLIP", 1.0, "TRAINING.PRECISION", "bf16"])
+    src = SyntheticPairs(4, 96, 72, DEV, seed=11)
+    batches = [src.batch() for _ in range(4)]
+    tr = Trainer(cfg, DEV, sample=batches[0]).build()
+    p0 = [p.detach().clone() for p in tr.model.parameters()]
+    losses = [tr.train_step(b)[2].item() for b in batches[:3]]
+    assert all(np.isfinite(losses)), losses
+    assert any(not torch.equal(a, b) for a, b in zip(p0, tr.model.parameters()))
+    assert all(p.dtype == torch.float32 and torch.isfinite(p).all() for p in tr.model.parameters())
+    tr.save(str(tmp_path / "last.ckpt"))
+    nxt = tr.train_step(batches[3])[2].item()
+    tr2 = Trainer(cfg, DEV, sample=batches[0])
+    tr2.resume(str(tmp_path / "last.ckpt"))
+    assert tr2.global_step == 3 and abs(tr2.train_step(batches[3])[2].item() - nxt) <= 1e-2 * max(1.0, abs(nxt))
