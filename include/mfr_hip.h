@@ -222,6 +222,12 @@ size_t mfr_loftr_coarse_match_workspace_bytes(int B, int L0, int L1);
 int mfr_loftr_coarse_match(const float *S, int B, int h0, int w0, int h1, int w1, float temperature, float thr, int border,
                            void *workspace, size_t workspace_bytes, int32_t *i_ids, int32_t *j_ids, float *mconf,
                            int32_t *n_match, void *stream);
+/* variant 0 (what mfr_loftr_coarse_match runs): S is swept twice (tiled kernels produce row AND column quantities in the same
+ * sweep); variant 1: the four-sweep row / column kernels of round 1.  Same arithmetic per element; the partial logsumexps are
+ * folded in a different (fixed) order. */
+int mfr_loftr_coarse_match_variant(const float *S, int B, int h0, int w0, int h1, int w1, float temperature, float thr, int border,
+                                   void *workspace, size_t workspace_bytes, int32_t *i_ids, int32_t *j_ids, float *mconf,
+                                   int32_t *n_match, int variant, void *stream);
 int mfr_loftr_gather_windows(const float *feat, int Bimg, int Hf, int Wf, int C, const int32_t *img_ids,
                              const int32_t *cell_ids, int M, int wc, int stride, int win, float *out, void *stream);
 

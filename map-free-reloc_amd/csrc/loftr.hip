@@ -225,6 +225,198 @@ __global__ void __launch_bounds__(1024) dsm_colbest_kernel(const float *__restri
     }
 }
 
+// ---- two-pass variant: ONE sweep over S for both logsumexps, ONE sweep for both arg-max searches ----------------
+// A workgroup owns a tile of DSM_RS rows x DSM_CB columns (a thread owns 4 adjacent columns: 16-byte loads, a row of the
+// tile is 4 KB contiguous).  Row quantities are reduced inside the tile (wave shuffles, then the 4 waves in column order)
+// and written as one partial per (column block, row); column quantities are carried in registers down the tile's rows and
+// written as one partial per (row stripe, column).  Two small kernels fold the partials in a fixed order (deterministic).
+// HBM traffic: S is read twice (the four-pass variant reads it four times); partials add 3 % of S.
+#define DSM_RS 64
+#define DSM_CB 1024
+#define DSM_RU 4
+
+static __device__ __forceinline__ void dsm_load4(const float *__restrict__ row, int j0, int nval, bool vec, float x[4])
+{
+    if (nval == 4 && vec) {
+        const float4 t = *(const float4 *)(row + j0);
+        x[0] = t.x; x[1] = t.y; x[2] = t.z; x[3] = t.w;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) x[k] = k < nval ? row[j0 + k] : 0.f;
+    }
+}
+
+__global__ void __launch_bounds__(256) dsm_stats_tile_kernel(const float *__restrict__ S, int L0, int L1, float temp,
+                                                             float *__restrict__ rpm, float *__restrict__ rps,
+                                                             float *__restrict__ cpm, float *__restrict__ cps)
+{
+    __shared__ float wm[DSM_RS][4], wsum[DSM_RS][4];
+    const int st = blockIdx.x, cb = blockIdx.y, b = blockIdx.z, nst = gridDim.x, ncb = gridDim.y;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int j0 = cb * DSM_CB + 4 * tid, nval = min(4, max(0, L1 - j0));
+    const int i0 = st * DSM_RS, nrows = min(DSM_RS, L0 - i0);
+    const bool vec = (L1 & 3) == 0;
+    const float *base = S + ((size_t)b * L0 + i0) * L1;
+    Lse c[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) c[k] = { -INFINITY, 0.f };
+    for (int r0 = 0; r0 < nrows; r0 += DSM_RU) {
+        float x[DSM_RU][4];
+#pragma unroll
+        for (int u = 0; u < DSM_RU; ++u)
+            if (r0 + u < nrows) dsm_load4(base + (size_t)(r0 + u) * L1, j0, nval, vec, x[u]);
+        Lse a[DSM_RU];
+#pragma unroll
+        for (int u = 0; u < DSM_RU; ++u) {
+            a[u] = { -INFINITY, 0.f };
+            if (r0 + u < nrows) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (k < nval) { const float t = x[u][k] / temp; lse_add(a[u], t); lse_add(c[k], t); }
+            }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+#pragma unroll
+            for (int u = 0; u < DSM_RU; ++u) {
+                const float om = __shfl_xor(a[u].m, off, 64), os = __shfl_xor(a[u].s, off, 64);
+                lse_merge(a[u], om, os);
+            }
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int u = 0; u < DSM_RU; ++u)
+                if (r0 + u < nrows) { wm[r0 + u][wid] = a[u].m; wsum[r0 + u][wid] = a[u].s; }
+        }
+    }
+    __syncthreads();
+    if (tid < nrows) {
+        Lse a = { wm[tid][0], wsum[tid][0] };
+#pragma unroll
+        for (int w = 1; w < 4; ++w) lse_merge(a, wm[tid][w], wsum[tid][w]);
+        const size_t o = ((size_t)b * ncb + cb) * L0 + i0 + tid;
+        rpm[o] = a.m; rps[o] = a.s;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (k < nval) {
+            const size_t o = ((size_t)b * nst + st) * L1 + j0 + k;
+            cpm[o] = c[k].m; cps[o] = c[k].s;
+        }
+}
+
+// fold the partials: rows over the column blocks (ascending), columns over the row stripes (ascending)
+__global__ void __launch_bounds__(256) dsm_stats_fold_kernel(int L0, int L1, int nst, int ncb, const float *__restrict__ rpm,
+                                                             const float *__restrict__ rps, const float *__restrict__ cpm,
+                                                             const float *__restrict__ cps, float *__restrict__ rmax,
+                                                             float *__restrict__ rsum, float *__restrict__ cmax,
+                                                             float *__restrict__ csum)
+{
+    const int b = blockIdx.y, t = blockIdx.x * 256 + threadIdx.x;
+    if (t < L0) {
+        Lse a = { -INFINITY, 0.f };
+        for (int k = 0; k < ncb; ++k) lse_merge(a, rpm[((size_t)b * ncb + k) * L0 + t], rps[((size_t)b * ncb + k) * L0 + t]);
+        rmax[(size_t)b * L0 + t] = a.m; rsum[(size_t)b * L0 + t] = a.s;
+    }
+    if (t < L1) {
+        Lse a = { -INFINITY, 0.f };
+        for (int k = 0; k < nst; ++k) lse_merge(a, cpm[((size_t)b * nst + k) * L1 + t], cps[((size_t)b * nst + k) * L1 + t]);
+        cmax[(size_t)b * L1 + t] = a.m; csum[(size_t)b * L1 + t] = a.s;
+    }
+}
+
+__global__ void __launch_bounds__(256) dsm_best_tile_kernel(const float *__restrict__ S, int L0, int L1, float temp,
+                                                            const float *__restrict__ rmax, const float *__restrict__ rsum,
+                                                            const float *__restrict__ cmax, const float *__restrict__ csum,
+                                                            float *__restrict__ rbp, int *__restrict__ rap,
+                                                            float *__restrict__ cbp)
+{
+    __shared__ float rm_s[DSM_RS], rs_s[DSM_RS], wb[DSM_RS][4];
+    __shared__ int wj[DSM_RS][4];
+    const int st = blockIdx.x, cb = blockIdx.y, b = blockIdx.z, nst = gridDim.x, ncb = gridDim.y;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int j0 = cb * DSM_CB + 4 * tid, nval = min(4, max(0, L1 - j0));
+    const int i0 = st * DSM_RS, nrows = min(DSM_RS, L0 - i0);
+    const bool vec = (L1 & 3) == 0;
+    const float *base = S + ((size_t)b * L0 + i0) * L1;
+    if (tid < nrows) { rm_s[tid] = rmax[(size_t)b * L0 + i0 + tid]; rs_s[tid] = rsum[(size_t)b * L0 + i0 + tid]; }
+    float cm[4], cs[4], cbest[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        cm[k] = k < nval ? cmax[(size_t)b * L1 + j0 + k] : 0.f;
+        cs[k] = k < nval ? csum[(size_t)b * L1 + j0 + k] : 1.f;
+        cbest[k] = -1.f;
+    }
+    __syncthreads();
+    for (int r0 = 0; r0 < nrows; r0 += DSM_RU) {
+        float x[DSM_RU][4];
+#pragma unroll
+        for (int u = 0; u < DSM_RU; ++u)
+            if (r0 + u < nrows) dsm_load4(base + (size_t)(r0 + u) * L1, j0, nval, vec, x[u]);
+        float best[DSM_RU]; int bj[DSM_RU];
+#pragma unroll
+        for (int u = 0; u < DSM_RU; ++u) {
+            best[u] = -1.f; bj[u] = 0x7fffffff;
+            if (r0 + u < nrows) {
+                const float rm = rm_s[r0 + u], rs = rs_s[r0 + u];
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (k < nval) {
+                        const float cf = conf_val(x[u][k] / temp, rm, rs, cm[k], cs[k]);
+                        if (cf > best[u]) { best[u] = cf; bj[u] = j0 + k; }
+                        if (cf > cbest[k]) cbest[k] = cf;
+                    }
+            }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+#pragma unroll
+            for (int u = 0; u < DSM_RU; ++u) {
+                const float ob = __shfl_xor(best[u], off, 64); const int oj = __shfl_xor(bj[u], off, 64);
+                if (ob > best[u] || (ob == best[u] && oj < bj[u])) { best[u] = ob; bj[u] = oj; }
+            }
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int u = 0; u < DSM_RU; ++u)
+                if (r0 + u < nrows) { wb[r0 + u][wid] = best[u]; wj[r0 + u][wid] = bj[u]; }
+        }
+    }
+    __syncthreads();
+    if (tid < nrows) {
+        float best = wb[tid][0]; int bj = wj[tid][0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w)
+            if (wb[tid][w] > best || (wb[tid][w] == best && wj[tid][w] < bj)) { best = wb[tid][w]; bj = wj[tid][w]; }
+        const size_t o = ((size_t)b * ncb + cb) * L0 + i0 + tid;
+        rbp[o] = best; rap[o] = bj;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (k < nval) cbp[((size_t)b * nst + st) * L1 + j0 + k] = cbest[k];
+}
+
+__global__ void __launch_bounds__(256) dsm_best_fold_kernel(int L0, int L1, int nst, int ncb, const float *__restrict__ rbp,
+                                                            const int *__restrict__ rap, const float *__restrict__ cbp,
+                                                            float *__restrict__ rbest, int *__restrict__ rarg,
+                                                            float *__restrict__ cbest)
+{
+    const int b = blockIdx.y, t = blockIdx.x * 256 + threadIdx.x;
+    if (t < L0) {
+        float best = -1.f; int bj = 0x7fffffff;
+        for (int k = 0; k < ncb; ++k) {
+            const float v = rbp[((size_t)b * ncb + k) * L0 + t]; const int j = rap[((size_t)b * ncb + k) * L0 + t];
+            if (v > best || (v == best && j < bj)) { best = v; bj = j; }
+        }
+        rbest[(size_t)b * L0 + t] = best; rarg[(size_t)b * L0 + t] = bj;
+    }
+    if (t < L1) {
+        float best = -1.f;
+        for (int k = 0; k < nst; ++k) best = fmaxf(best, cbp[((size_t)b * nst + k) * L1 + t]);
+        cbest[(size_t)b * L1 + t] = best;
+    }
+}
+
 // one workgroup per pair: threshold, border, mutual max, ordered compaction (upstream get_coarse_match)
 __global__ void __launch_bounds__(256) dsm_match_kernel(int L0, int L1, int h0, int w0, int h1, int w1, float thr, int border,
                                                         const float *__restrict__ rbest, const int *__restrict__ rarg,
@@ -404,13 +596,17 @@ int mfr_loftr_linear_attention(const float *q, int ldq, const float *k, const fl
 size_t mfr_loftr_coarse_match_workspace_bytes(int B, int L0, int L1)
 {
     if (B <= 0 || L0 <= 0 || L1 <= 0) return 0;
-    return align_up((size_t)B * L0 * 4, 256) * 4 + align_up((size_t)B * L1 * 4, 256) * 3;
+    const size_t nst = (size_t)(L0 + DSM_RS - 1) / DSM_RS, ncb = (size_t)(L1 + DSM_CB - 1) / DSM_CB;
+    return align_up((size_t)B * L0 * 4, 256) * 4 + align_up((size_t)B * L1 * 4, 256) * 3 +
+           2 * align_up((size_t)B * ncb * L0 * 4, 256) + 2 * align_up((size_t)B * nst * L1 * 4, 256);
 }
 
 // S [B,L0,L1] = (f0/sqrt(C)) (f1/sqrt(C))^T (temperature applied here) -> matches (i ascending)
-int mfr_loftr_coarse_match(const float *S, int B, int h0, int w0, int h1, int w1, float temperature, float thr, int border,
-                           void *workspace, size_t workspace_bytes, int32_t *i_ids, int32_t *j_ids, float *mconf,
-                           int32_t *n_match, void *stream)
+// variant 0: two sweeps over S (tile kernels + folds); variant 1: the round-1 four sweeps (row / column kernels) -- same
+// definition of every quantity, kept for A/B timing and as a cross-check of the tiled reductions
+int mfr_loftr_coarse_match_variant(const float *S, int B, int h0, int w0, int h1, int w1, float temperature, float thr, int border,
+                                   void *workspace, size_t workspace_bytes, int32_t *i_ids, int32_t *j_ids, float *mconf,
+                                   int32_t *n_match, int variant, void *stream)
 {
     if (!S || !workspace || !i_ids || !j_ids || !mconf || !n_match || B <= 0 || h0 <= 0 || w0 <= 0 || h1 <= 0 || w1 <= 0)
         return MFR_E_ARG;
@@ -422,18 +618,45 @@ int mfr_loftr_coarse_match(const float *S, int B, int h0, int w0, int h1, int w1
     int *rarg = (int *)(ws + 3 * a0);
     float *cmax = (float *)(ws + 4 * a0), *csum = (float *)(ws + 4 * a0 + a1), *cbest = (float *)(ws + 4 * a0 + 2 * a1);
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(dsm_rowstat_kernel, dim3((L0 + 3) / 4, B), dim3(256), 0, s, S, L0, L1, temperature, rmax, rsum);
-    hipLaunchKernelGGL(dsm_colstat_kernel, dim3((L1 + 63) / 64, B), dim3(1024), 0, s, S, L0, L1, temperature, cmax, csum);
-    CHECK_LAUNCH();
-    hipLaunchKernelGGL(dsm_rowbest_kernel, dim3((L0 + 3) / 4, B), dim3(256), 0, s, S, L0, L1, temperature, rmax, rsum, cmax,
-                       csum, rbest, rarg);
-    hipLaunchKernelGGL(dsm_colbest_kernel, dim3((L1 + 63) / 64, B), dim3(1024), 0, s, S, L0, L1, temperature, rmax, rsum,
-                       cmax, csum, cbest);
-    CHECK_LAUNCH();
+    if (variant != 0 && variant != 1) return MFR_E_ARG;
+    if (variant == 1) {
+        hipLaunchKernelGGL(dsm_rowstat_kernel, dim3((L0 + 3) / 4, B), dim3(256), 0, s, S, L0, L1, temperature, rmax, rsum);
+        hipLaunchKernelGGL(dsm_colstat_kernel, dim3((L1 + 63) / 64, B), dim3(1024), 0, s, S, L0, L1, temperature, cmax, csum);
+        CHECK_LAUNCH();
+        hipLaunchKernelGGL(dsm_rowbest_kernel, dim3((L0 + 3) / 4, B), dim3(256), 0, s, S, L0, L1, temperature, rmax, rsum, cmax,
+                           csum, rbest, rarg);
+        hipLaunchKernelGGL(dsm_colbest_kernel, dim3((L1 + 63) / 64, B), dim3(1024), 0, s, S, L0, L1, temperature, rmax, rsum,
+                           cmax, csum, cbest);
+        CHECK_LAUNCH();
+    } else {
+        const int nst = (L0 + DSM_RS - 1) / DSM_RS, ncb = (L1 + DSM_CB - 1) / DSM_CB;
+        if (B > 65535 || ncb > 65535) return MFR_E_ARG;
+        const size_t ar = align_up((size_t)B * ncb * L0 * 4, 256), ac = align_up((size_t)B * nst * L1 * 4, 256);
+        char *pw = ws + 4 * a0 + 3 * a1;
+        float *rp0 = (float *)pw, *rp1 = (float *)(pw + ar), *cp0 = (float *)(pw + 2 * ar), *cp1 = (float *)(pw + 2 * ar + ac);
+        const int nfold = (max(L0, L1) + 255) / 256;
+        hipLaunchKernelGGL(dsm_stats_tile_kernel, dim3(nst, ncb, B), dim3(256), 0, s, S, L0, L1, temperature, rp0, rp1, cp0, cp1);
+        hipLaunchKernelGGL(dsm_stats_fold_kernel, dim3(nfold, B), dim3(256), 0, s, L0, L1, nst, ncb, rp0, rp1, cp0, cp1, rmax, rsum,
+                           cmax, csum);
+        CHECK_LAUNCH();
+        hipLaunchKernelGGL(dsm_best_tile_kernel, dim3(nst, ncb, B), dim3(256), 0, s, S, L0, L1, temperature, rmax, rsum, cmax, csum,
+                           rp0, (int *)rp1, cp0);
+        hipLaunchKernelGGL(dsm_best_fold_kernel, dim3(nfold, B), dim3(256), 0, s, L0, L1, nst, ncb, rp0, (const int *)rp1, cp0, rbest,
+                           rarg, cbest);
+        CHECK_LAUNCH();
+    }
     hipLaunchKernelGGL(dsm_match_kernel, dim3(B), dim3(256), 0, s, L0, L1, h0, w0, h1, w1, thr, border, rbest, rarg, cbest,
                        i_ids, j_ids, mconf, n_match);
     CHECK_LAUNCH();
     return 0;
+}
+
+int mfr_loftr_coarse_match(const float *S, int B, int h0, int w0, int h1, int w1, float temperature, float thr, int border,
+                           void *workspace, size_t workspace_bytes, int32_t *i_ids, int32_t *j_ids, float *mconf,
+                           int32_t *n_match, void *stream)
+{
+    return mfr_loftr_coarse_match_variant(S, B, h0, w0, h1, w1, temperature, thr, border, workspace, workspace_bytes, i_ids, j_ids,
+                                          mconf, n_match, 0, stream);
 }
 
 // feat [Bimg,Hf,Wf,C] NHWC -> out [M, win*win, C] windows centred on coarse cell `cell_ids[m]` of image `img_ids[m]`

@@ -172,7 +172,8 @@ class LoFTRHIP:
                                                 _lib.stream_ptr()), "mfr_loftr_fine_attention")
         return out
 
-    def coarse_match(self, S, hw0, hw1):
+    def coarse_match(self, S, hw0, hw1, variant=0):
+        """variant 0: two sweeps over S (default); 1: the four-sweep kernels of round 1 (A/B, cross-check)"""
         lib = _lib.load()
         B, L0, L1 = S.shape
         need = lib.mfr_loftr_coarse_match_workspace_bytes(B, L0, L1)
@@ -181,9 +182,9 @@ class LoFTRHIP:
         i_ids = torch.empty(B, L0, dtype=torch.int32, device=S.device); j_ids = torch.empty_like(i_ids)
         mconf = torch.empty(B, L0, dtype=torch.float32, device=S.device)
         n = torch.empty(B, dtype=torch.int32, device=S.device)
-        _lib.check(lib.mfr_loftr_coarse_match(_lib.ptr(S.contiguous()), B, hw0[0], hw0[1], hw1[0], hw1[1], self.temp, self.thr,
-                                              self.border, _lib.ptr(self._ws_cm), self._ws_cm.numel(), _lib.ptr(i_ids),
-                                              _lib.ptr(j_ids), _lib.ptr(mconf), _lib.ptr(n), _lib.stream_ptr()),
+        _lib.check(lib.mfr_loftr_coarse_match_variant(_lib.ptr(S.contiguous()), B, hw0[0], hw0[1], hw1[0], hw1[1], self.temp, self.thr,
+                                                      self.border, _lib.ptr(self._ws_cm), self._ws_cm.numel(), _lib.ptr(i_ids),
+                                                      _lib.ptr(j_ids), _lib.ptr(mconf), _lib.ptr(n), variant, _lib.stream_ptr()),
                    "mfr_loftr_coarse_match")
         return i_ids, j_ids, mconf, n
 
@@ -210,8 +211,13 @@ class LoFTRHIP:
     def coarse_match_features(self, f0, f1, hw):
         """coarse features [B,L,256] x2 -> dual-softmax mutual-NN matches (upstream CoarseMatching, dual_softmax)"""
         C = f0.shape[-1]
-        S = torch.bmm(f0, f1.transpose(1, 2))            # strided operands are fine for the batched GEMM
-        S.mul_(1.0 / C)                                  # (f0 / sqrt C) . (f1 / sqrt C)
+        # (f0 / sqrt C) . (f1 / sqrt C): for C a power of two (256) scaling the 6 MB operand is EXACT and commutes with the
+        # contraction bit for bit, so the 150 MB/pair similarity matrix is written once and never rescaled in place
+        if C & (C - 1) == 0:
+            S = torch.bmm(f0 * (1.0 / C), f1.transpose(1, 2))        # strided operands are fine for the batched GEMM
+        else:
+            S = torch.bmm(f0, f1.transpose(1, 2))
+            S.mul_(1.0 / C)
         return self.coarse_match(S, hw, hw)
 
     def gather_windows(self, feat_nhwc, img_ids, cell_ids, wc, stride, out=None):

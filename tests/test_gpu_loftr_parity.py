@@ -87,6 +87,34 @@ def test_coarse_match_vs_oracle(pair):
         np.testing.assert_allclose(gc[safe_g].numpy(), wc[safe_w].numpy(), rtol=2e-4)
 
 
+@pytest.mark.parametrize("h,w,B", [(30, 22, 2), (90, 68, 1), (17, 13, 3)])
+def test_coarse_match_two_sweep_equals_four_sweep(pair, h, w, B):
+    """the tiled two-sweep kernels (default) against the row / column kernels of round 1 on the same S: identical mutual matches
+    and confidences to fp32 round-off of the differently ordered logsumexp folds; sizes: a ragged tile (660 = not a multiple of the
+    64-row stripe / 1024-column block), the Map-free size (6120: 6 column blocks, 96 stripes) and an odd width (221: scalar loads)"""
+    ref, hip = pair
+    g = torch.Generator().manual_seed(11 + h)
+    L = h * w
+    f0 = torch.randn(B, L, 256, generator=g) * 2.2
+    perm = torch.stack([torch.randperm(L, generator=g) for _ in range(B)])
+    f1 = torch.gather(f0, 1, perm[..., None].expand(-1, -1, 256)) + 0.3 * torch.randn(B, L, 256, generator=g)
+    S = torch.bmm(f0.to(DEV) / 16.0, (f1.to(DEV) / 16.0).transpose(1, 2))
+    a = [t.cpu() for t in hip.coarse_match(S, (h, w), (h, w), variant=0)]
+    b = [t.cpu() for t in hip.coarse_match(S, (h, w), (h, w), variant=1)]
+    for k in range(B):
+        na, nb = int(a[3][k]), int(b[3][k])
+        pa = {(int(i), int(j)): float(c) for i, j, c in zip(a[0][k, :na], a[1][k, :na], a[2][k, :na])}
+        pb = {(int(i), int(j)): float(c) for i, j, c in zip(b[0][k, :nb], b[1][k, :nb], b[2][k, :nb])}
+        assert nb > L // 4
+        diff = set(pa) ^ set(pb)
+        # a match can only appear / vanish if its confidence sits on the 0.2 threshold to round-off
+        assert all(abs({**pa, **pb}[m] - 0.2) < 1e-5 for m in diff), (len(diff), na, nb)
+        assert len(diff) <= 2
+        common = set(pa) & set(pb)
+        np.testing.assert_allclose([pa[m] for m in common], [pb[m] for m in common], rtol=2e-5)
+        assert a[0][k, :na].tolist() == sorted(a[0][k, :na].tolist())           # ascending i, like upstream's nonzero order
+
+
 def test_fine_window_gather_vs_unfold(pair):
     ref, hip = pair
     g = torch.Generator().manual_seed(3)
