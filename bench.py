@@ -57,6 +57,8 @@ def parse(argv=None):
     ap.add_argument("--cpu-out", default="", help=argparse.SUPPRESS)
     ap.add_argument("--no-kernel-timer", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--verbose", action="store_true")
+    ap.add_argument("--rpr-opts", default="", help="rpr_train only, comma list: channels_last (NHWC activations / weights), siamese "
+                    "(TRAINING.SIAMESE_BATCH: both images of a pair in one encoder pass), fp32 (TRAINING.PRECISION fp32)")
     a = ap.parse_args(argv)
     if a.batch <= 0:
         a.batch = {"sg_pnp": 32, "loftr_emat": 16, "rpr_train": 10}[a.config]
@@ -290,10 +292,11 @@ RPR_3D3D = ["MODEL", "Regression", "ENCODER.TYPE", "ResUNet", "ENCODER.BLOCK_TYP
             "TRAINING.TRANS_LOSS", "trans_l1_loss", "TRAINING.LAMBDA", 1.0, "DATASET.HEIGHT", RPR_H, "DATASET.WIDTH", RPR_W]
 
 
-def rpr_cfg(precision):
+def rpr_cfg(precision, opts=()):
     from mapfree_reloc_amd.config import get_cfg_defaults
     cfg = get_cfg_defaults()
-    cfg.merge_from_list(RPR_3D3D + ["TRAINING.PRECISION", precision])
+    cfg.merge_from_list(RPR_3D3D + ["TRAINING.PRECISION", "fp32" if "fp32" in opts else precision, "TRAINING.SIAMESE_BATCH", "siamese" in opts,
+                                    "TRAINING.CHANNELS_LAST", "channels_last" in opts])
     return cfg
 
 
@@ -326,7 +329,8 @@ def rpr_train_bench(args, rank, world, dev, use_dist):
     from mapfree_reloc_amd.regression.train import SyntheticPairs, Trainer
     lib = mfr._lib.load(require_gpu=True)
     B = args.batch
-    cfg = rpr_cfg("bf16")
+    opts = tuple(o for o in args.rpr_opts.split(",") if o)
+    cfg = rpr_cfg("bf16", opts)
     src = SyntheticPairs(B, RPR_H, RPR_W, dev, seed=0, rank=rank)
     batches = [src.batch() for _ in range(2)]            # resident in HBM before the timed region, alternated
     torch.cuda.synchronize()
@@ -376,6 +380,7 @@ def rpr_train_bench(args, rank, world, dev, use_dist):
         "data": "synthetic (seeded textured planes under a random relative pose; no Map-free training split offline), random-init weights",
         "config": {"workload": "configs[4]: 3d3d.yaml (ResUNet 3-3-3 -> CorrelationVolumeWarping -> ProcrustesDeepResBlock), full training step",
                    "global_batch": B * world, "pairs_per_gpu_per_step": B, "parallelism": f"dp{world} (DDP, one {cfg.TRAINING.DDP_BUCKET_MB} MB gradient bucket, RCCL all-reduce)",
+                   "precision": cfg.TRAINING.PRECISION, "siamese_batch": bool(cfg.TRAINING.SIAMESE_BATCH), "channels_last": bool(cfg.TRAINING.CHANNELS_LAST),
                    "volume_positions": N, "feature_channels": D, "parameters": n_param, "optimizer": "Adam (fused), eps 1e-6",
                    "last_losses": [round(float(x.float().sum()), 5) for x in losses]},
         "roofline": {"kernel": "cw_bwd_q_kernel + cw_bwd_kv_kernel (mfr_corr_warp_bwd: fused correlation-volume warping, backward)", "bound": "mfma",

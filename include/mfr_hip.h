@@ -269,6 +269,10 @@ int mfr_procrustes_icp_refine(const float *depth0, const float *depth1, int B, i
 int mfr_layernorm(const float *x, int ldx, const float *gamma, const float *beta, const float *residual, int ldr, long long rows, int C,
                   float eps, float *out, int ldo, void *stream);
 int mfr_upsample2x_add(const float *lo, float *y, int planes, int H, int W, void *stream);
+/*   mfr_upsample_bilinear  out [planes,Ho,Wo] = F.interpolate(in [planes,H,W], size=(Ho,Wo), bilinear, align_corners=True) with
+ *                       torch's arithmetic; dtype 0 = float32, 1 = bfloat16 storage (f32 arithmetic).  Reference call site: the
+ *                       regression encoder's `upconv` (lib/models/regression/encoder/resunet.py:30-38, used at :121-126). */
+int mfr_upsample_bilinear(const void *in, void *out, int planes, int H, int W, int Ho, int Wo, int dtype, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * SIFT-descriptor correspondence leg.  Reference call sites:

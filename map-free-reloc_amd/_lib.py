@@ -59,6 +59,7 @@ SIGNATURES = {
     "mfr_conv3x3_wino_variant": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "mfr_layernorm": (_i, [_vp, _i, _vp, _vp, _vp, _i, C.c_longlong, _i, C.c_float, _vp, _i, _vp]),
     "mfr_upsample2x_add": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "mfr_upsample_bilinear": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "mfr_corr_warp_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mfr_corr_warp_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mfr_rootsift": (_i, [_vp, _i, _vp, _vp, _vp]),

@@ -12,6 +12,7 @@ keys this implementation adds (declared here because unknown keys are rejected o
   TRAINING.PRECISION 'bf16' (autocast; the aggregator kernel and the pose algebra stay fp32) | 'fp32'
   TRAINING.SIAMESE_BATCH  encode both images of a pair in one encoder pass (BatchNorm statistics over both)
   TRAINING.DDP_BUCKET_MB  gradient all-reduce bucket size
+  TRAINING.CHANNELS_LAST  keep weights / activations of the regression model NHWC (MIOpen's implicit-GEMM kernels are NHWC)
   SUPERGLUE.*        matcher hyper-parameters of record (matchers.py:65-71) and weight paths
 """
 from .node import CfgNode as CN
@@ -56,7 +57,7 @@ def get_cfg_defaults():
                      SAMPLE_WITH_REPLACEMENT=None, LR=None, LR_STEP_INTERVAL=None, LR_STEP_GAMMA=None,
                      VAL_INTERVAL=None, VAL_BATCHES=None, LOG_INTERVAL=None, EPOCHS=None, GRAD_CLIP=0.,
                      ROT_LOSS='rot_frobenius_loss', TRANS_LOSS='trans_l2_loss', LAMBDA=1.0,
-                     PRECISION='bf16', SIAMESE_BATCH=False, DDP_BUCKET_MB=64).items():
+                     PRECISION='bf16', SIAMESE_BATCH=False, DDP_BUCKET_MB=64, CHANNELS_LAST=False).items():
         c.TRAINING[k] = v
     # ---- additions of this implementation ----
     c.RANSAC = CN(); c.RANSAC.SEED = 0

@@ -57,37 +57,69 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const float *__restrict_
     *(vec *)(out + row * ldo + lane * VEC) = y;
 }
 
-// y [planes, 2H, 2W] += bilinear(lo [planes, H, W]), align_corners = True; each thread makes 4 consecutive outputs of a row
-__global__ void __launch_bounds__(256) upsample2x_add_kernel(const float *__restrict__ lo, float *__restrict__ y, int H, int W, float rh, float rw)
+// Bilinear resampling with align_corners = True, torch's arithmetic (upsample_bilinear2d: ratio = (in - 1) / (out - 1) in f32,
+// source = ratio * dst, the four taps weighted in f32).  One thread makes 4 consecutive outputs of a row; the (plane, row, quad)
+// index space is FLAT, so small maps (a 34-wide row is 17 quads) still fill whole wavefronts -- PyTorch's own kernel assigns
+// one thread per output PIXEL and loops over batch x channels (6256 threads for the regression decoder's 92x68 map: 2.4 ms per
+// call where the data moves in 40 us).
+//   ADD:  y += bilinear(lo)   (LoFTR's FPN merge, in place, f32)
+//   !ADD: y  = bilinear(lo)   (the regression decoder's upconv; f32 or bf16 storage, f32 arithmetic, round-to-nearest-even)
+template <typename T> struct UpIO;
+template <> struct UpIO<float> {
+    static __device__ __forceinline__ float ld(const float *p) { return *p; }
+    static __device__ __forceinline__ void st(float *p, float v) { *p = v; }
+};
+template <> struct UpIO<unsigned short> {                                   // bfloat16 storage
+    static __device__ __forceinline__ float ld(const unsigned short *p) { return __uint_as_float((unsigned)(*p) << 16); }
+    static __device__ __forceinline__ void st(unsigned short *p, float v)
+    {
+        unsigned u = __float_as_uint(v);
+        if ((u & 0x7fffffffu) > 0x7f800000u) { *p = (unsigned short)((u >> 16) | 0x40); return; }   // NaN stays NaN
+        u += 0x7fffu + ((u >> 16) & 1u);
+        *p = (unsigned short)(u >> 16);
+    }
+};
+
+template <typename T, bool ADD>
+__global__ void __launch_bounds__(256) upsample_ac_kernel(const T *__restrict__ lo, T *__restrict__ y, int H, int W, int Ho, int Wo,
+                                                          float rh, float rw, size_t total)
 {
-    const int plane = blockIdx.z, oy = blockIdx.y;
-    const int Wo = 2 * W, Ho = 2 * H;
-    const int ox0 = (blockIdx.x * 256 + threadIdx.x) * 4;
-    if (ox0 >= Wo) return;
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int Q = (Wo + 3) >> 2;
+    const int q = (int)(idx % Q);
+    const size_t t = idx / Q;
+    const int oy = (int)(t % Ho);
+    const size_t plane = t / Ho;
+    const int ox0 = q * 4;
     const float h1r = rh * oy;
-    const int h1 = (int)h1r;
+    const int h1 = min((int)h1r, H - 1);
     const int h1p = (h1 < H - 1) ? 1 : 0;
     const float h1l = h1r - h1, h0l = 1.f - h1l;
-    const float *r0 = lo + ((size_t)plane * H + h1) * W, *r1 = r0 + h1p * W;
-    float *o = y + ((size_t)plane * Ho + oy) * Wo + ox0;
+    const T *r0 = lo + (plane * H + h1) * W, *r1 = r0 + h1p * W;
+    T *o = y + (plane * Ho + oy) * Wo + ox0;
     float acc[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const int ox = ox0 + k;
+        const int ox = min(ox0 + k, Wo - 1);
         const float w1r = rw * ox;
         const int w1 = min((int)w1r, W - 1);
         const int w1p = (w1 < W - 1) ? 1 : 0;
         const float w1l = w1r - w1, w0l = 1.f - w1l;
-        acc[k] = h0l * (w0l * r0[w1] + w1l * r0[w1 + w1p]) + h1l * (w0l * r1[w1] + w1l * r1[w1 + w1p]);
+        acc[k] = h0l * (w0l * UpIO<T>::ld(r0 + w1) + w1l * UpIO<T>::ld(r0 + w1 + w1p)) +
+                 h1l * (w0l * UpIO<T>::ld(r1 + w1) + w1l * UpIO<T>::ld(r1 + w1 + w1p));
     }
-    if (ox0 + 3 < Wo && (((size_t)o & 15) == 0)) {
-        float4 v = *(float4 *)o;
-        v.x += acc[0]; v.y += acc[1]; v.z += acc[2]; v.w += acc[3];
-        *(float4 *)o = v;
-    } else {
+    if constexpr (sizeof(T) == 4) {
+        if (ox0 + 3 < Wo && (((size_t)o & 15) == 0)) {
+            float4 v = ADD ? *(float4 *)o : make_float4(0.f, 0.f, 0.f, 0.f);
+            v.x += acc[0]; v.y += acc[1]; v.z += acc[2]; v.w += acc[3];
+            *(float4 *)o = v;
+            return;
+        }
+    }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) if (ox0 + k < Wo) o[k] += acc[k];
-    }
+    for (int k = 0; k < 4; ++k)
+        if (ox0 + k < Wo) UpIO<T>::st(o + k, ADD ? UpIO<T>::ld(o + k) + acc[k] : acc[k]);
 }
 
 extern "C" {
@@ -106,12 +138,33 @@ int mfr_layernorm(const float *x, int ldx, const float *gamma, const float *beta
     return 0;
 }
 
+static inline float up_ratio(int in, int out) { return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f; }
+
 int mfr_upsample2x_add(const float *lo, float *y, int planes, int H, int W, void *stream)
 {
-    if (!lo || !y || planes <= 0 || H <= 0 || W <= 0 || 2 * H > 65535 || planes > 65535 * 1) return MFR_E_ARG;
-    const float rh = (2 * H > 1) ? (float)(H - 1) / (float)(2 * H - 1) : 0.f, rw = (2 * W > 1) ? (float)(W - 1) / (float)(2 * W - 1) : 0.f;
-    const dim3 grid((2 * W + 1023) / 1024, 2 * H, planes);
-    hipLaunchKernelGGL(upsample2x_add_kernel, grid, dim3(256), 0, (hipStream_t)stream, lo, y, H, W, rh, rw);
+    if (!lo || !y || planes <= 0 || H <= 0 || W <= 0) return MFR_E_ARG;
+    const int Ho = 2 * H, Wo = 2 * W;
+    const size_t total = (size_t)planes * Ho * ((Wo + 3) / 4);
+    if ((total + 255) / 256 > 0x7fffffffull) return MFR_E_ARG;
+    hipLaunchKernelGGL((upsample_ac_kernel<float, true>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, lo, y, H, W,
+                       Ho, Wo, up_ratio(H, Ho), up_ratio(W, Wo), total);
+    CHECK_LAUNCH();
+    return 0;
+}
+
+// out [planes, Ho, Wo] = bilinear(in [planes, H, W]), align_corners = True; dtype 0: float32, 1: bfloat16 (both tensors)
+int mfr_upsample_bilinear(const void *in, void *out, int planes, int H, int W, int Ho, int Wo, int dtype, void *stream)
+{
+    if (!in || !out || planes <= 0 || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0 || (dtype != 0 && dtype != 1)) return MFR_E_ARG;
+    const size_t total = (size_t)planes * Ho * ((Wo + 3) / 4);
+    if ((total + 255) / 256 > 0x7fffffffull) return MFR_E_ARG;
+    const dim3 grid((unsigned)((total + 255) / 256));
+    if (dtype == 0)
+        hipLaunchKernelGGL((upsample_ac_kernel<float, false>), grid, dim3(256), 0, (hipStream_t)stream, (const float *)in, (float *)out, H, W, Ho, Wo,
+                           up_ratio(H, Ho), up_ratio(W, Wo), total);
+    else
+        hipLaunchKernelGGL((upsample_ac_kernel<unsigned short, false>), grid, dim3(256), 0, (hipStream_t)stream, (const unsigned short *)in,
+                           (unsigned short *)out, H, W, Ho, Wo, up_ratio(H, Ho), up_ratio(W, Wo), total);
     CHECK_LAUNCH();
     return 0;
 }

@@ -103,6 +103,38 @@ class conv(nn.Module):
         return F.elu(self.normalize(self.conv(x)))
 
 
+class _UpsampleAC(torch.autograd.Function):
+    """F.interpolate(x, size, mode='bilinear', align_corners=True) for device tensors through csrc/loftr_fused.hip
+    (mfr_upsample_bilinear: same arithmetic, all (plane, row) pairs in flight instead of one thread per output pixel);
+    the backward is ATen's own scatter kernel."""
+
+    @staticmethod
+    def forward(ctx, x, Ho, Wo):
+        from .._lib import check, load, ptr, stream_ptr
+        lib = load(require_gpu=True)
+        x = x.contiguous()
+        B, C, H, W = x.shape
+        out = torch.empty(B, C, Ho, Wo, dtype=x.dtype, device=x.device)
+        check(lib.mfr_upsample_bilinear(ptr(x), ptr(out), B * C, H, W, Ho, Wo, 0 if x.dtype == torch.float32 else 1, stream_ptr()),
+              "mfr_upsample_bilinear")
+        ctx.in_shape = tuple(x.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        B, C, H, W = ctx.in_shape
+        gi = torch.ops.aten.upsample_bilinear2d_backward(g.contiguous(), [g.shape[2], g.shape[3]], [B, C, H, W], True, None, None)
+        return gi, None, None
+
+
+def upsample_bilinear_ac(x, scale):
+    """bilinear, align_corners=True, output size floor(in * scale) like F.interpolate(scale_factor=scale)"""
+    Ho, Wo = int(x.shape[2] * scale), int(x.shape[3] * scale)
+    if x.is_cuda and x.dtype in (torch.float32, torch.bfloat16):
+        return _UpsampleAC.apply(x, Ho, Wo)
+    return F.interpolate(x, scale_factor=scale, mode="bilinear", align_corners=True)
+
+
 class upconv(nn.Module):
     """bilinear (align_corners) upsampling by `scale`, then conv+BN+ELU (resunet.py:30-38)"""
 
@@ -112,7 +144,7 @@ class upconv(nn.Module):
         self.conv1 = conv(cin, cout, kernel_size, 1)
 
     def forward(self, x):
-        return self.conv1(F.interpolate(x, scale_factor=self.scale, mode="bilinear", align_corners=True))
+        return self.conv1(upsample_bilinear_ac(x, self.scale))
 
 
 def _centre_pad_to(x, ref):

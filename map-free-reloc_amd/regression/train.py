@@ -134,6 +134,9 @@ class Trainer:
         torch.manual_seed(0)                                    # pl.seed_everything(0), train.py:25: identical replicas
         cls = {"Regression": RegressionModel, "RegressionMultiFrame": RegressionMultiFrameModel}[cfg.MODEL]
         self.model = cls(cfg).to(self.device)
+        self.channels_last = bool(getattr(cfg.TRAINING, "CHANNELS_LAST", False))
+        if self.channels_last:
+            self.model = self.model.to(memory_format=torch.channels_last)
         self.precision = str(getattr(cfg.TRAINING, "PRECISION", "bf16"))
         if self.precision not in ("bf16", "fp32"):
             raise ValueError(f"TRAINING.PRECISION must be 'bf16' or 'fp32', got {self.precision!r}")
@@ -150,6 +153,8 @@ class Trainer:
         with torch.no_grad(), self.autocast():
             self.model({k: v for k, v in sample.items()})
         self.model.train(was)                                   # (DDP broadcasts rank 0's parameters and buffers when it wraps)
+        if self.channels_last:                                  # the lazily created layers too
+            self.model = self.model.to(memory_format=torch.channels_last)
 
     def autocast(self):
         if self.precision == "bf16":

@@ -134,3 +134,22 @@ def test_trainer_steps_on_device_with_fused_aggregator(tmp_path):
     tr2 = Trainer(cfg, DEV, sample=batches[0])
     tr2.resume(str(tmp_path / "last.ckpt"))
     assert tr2.global_step == 3 and abs(tr2.train_step(batches[3])[2].item() - nxt) <= 1e-2 * max(1.0, abs(nxt))
+
+
+@pytest.mark.parametrize("shape,scale", [((3, 40, 23, 17), 2), ((2, 7, 5, 9), 2), ((1, 3, 1, 1), 2), ((2, 16, 12, 10), 3)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_upsample_bilinear_kernel_vs_aten(shape, scale, dtype):
+    """mfr_upsample_bilinear (the regression decoder's upconv) against ATen's upsample_bilinear2d on the device: same f32
+    arithmetic (fp32: to contraction round-off; bf16: within one bf16 ulp of the rounded result), same gradient"""
+    from mapfree_reloc_amd.regression.encoder import upsample_bilinear_ac
+    torch.manual_seed(3)
+    x = torch.randn(shape, device=DEV).to(dtype).requires_grad_()
+    y = upsample_bilinear_ac(x, scale)
+    x2 = x.detach().clone().requires_grad_()
+    want = torch.nn.functional.interpolate(x2, scale_factor=scale, mode="bilinear", align_corners=True)
+    assert y.shape == want.shape and y.dtype == want.dtype
+    tol = 2e-6 if dtype == torch.float32 else 2 ** -7
+    assert (y.float() - want.float()).abs().max().item() <= tol * max(1.0, want.float().abs().max().item())
+    g = torch.randn_like(want)
+    y.backward(g); want.backward(g)
+    assert torch.allclose(x.grad.float(), x2.grad.float(), rtol=1e-5 if dtype == torch.float32 else 2e-2, atol=1e-5 if dtype == torch.float32 else 2e-2)
