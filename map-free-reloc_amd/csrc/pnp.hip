@@ -22,6 +22,7 @@
 #include <stdint.h>
 
 #include "../../include/mfr_hip.h"
+#include "zero_fill.h"
 #include "geom_dev.h"
 
 using namespace mfr;
@@ -627,7 +628,7 @@ int mfr_pnp_solve_batch(const float *pts0, const float *pts1, const int32_t *n_c
                        inl, R, t, n_inliers, status, inlier_mask ? maskv : nullptr, nullptr, nullptr, s);
     if (rc) return rc;
     if (inlier_mask) {
-        if (hipMemsetAsync(inlier_mask, 0, (size_t)B * maxN, s) != hipSuccess) return MFR_E_LAUNCH;
+        if (mfr_zero_async(inlier_mask, (size_t)B * maxN, s) != hipSuccess) return MFR_E_LAUNCH;
         hipLaunchKernelGGL(pnp_mask_scatter_kernel, dim3((maxN + 255) / 256, B), dim3(256), 0, s, maskv, src, nvalid,
                            status, maxN, inlier_mask);
         CHECK_LAUNCH();

@@ -22,6 +22,7 @@
 #include <stdint.h>
 
 #include "../../include/mfr_hip.h"
+#include "zero_fill.h"
 #include "geom_dev.h"
 
 using namespace mfr;
@@ -292,7 +293,7 @@ int mfr_procrustes_icp_refine(const float *depth0, const float *depth1, int B, i
     double *state = (double *)ws;              ws += icp_align(sizeof(double) * ICP_STATE * B);
     int32_t *cnt = (int32_t *)ws;
     hipStream_t s = (hipStream_t)stream;
-    if (hipMemsetAsync(cnt, 0, sizeof(int32_t) * 2 * B, s) != hipSuccess) return MFR_E_LAUNCH;
+    if (mfr_zero_async(cnt, sizeof(int32_t) * 2 * B, s) != hipSuccess) return MFR_E_LAUNCH;
     hipLaunchKernelGGL(icp_prep_kernel, dim3(nblk, B), dim3(256), 0, s, depth0, depth1, HW, W, K1, R, t, status, Tc, cnt, state);
     CHECK_LAUNCH();
     for (int k = 0; k <= max_iter; ++k) {

@@ -20,6 +20,7 @@
 #include <stdint.h>
 
 #include "../../include/mfr_hip.h"
+#include "zero_fill.h"
 
 #define CHECK_LAUNCH() do { if (hipGetLastError() != hipSuccess) return MFR_E_LAUNCH; } while (0)
 
@@ -282,7 +283,7 @@ int mfr_sg_sinkhorn_match(const float *S, int B, int ldS, const int32_t *n0, con
     float *u = (float *)(ws + w.u), *v = (float *)(ws + w.v), *val0 = (float *)(ws + w.val0);
     int *idx0 = (int *)(ws + w.idx0), *idx1 = (int *)(ws + w.idx1);
     // u = v = 0 (upstream log_sinkhorn_iterations)
-    if (hipMemsetAsync(ws + w.u, 0, w.idx0 - w.u, s) != hipSuccess) return MFR_E_LAUNCH;
+    if (mfr_zero_async(ws + w.u, w.idx0 - w.u, s) != hipSuccess) return MFR_E_LAUNCH;
     const dim3 rgrid((ldS + 1 + 3) / 4, B), cgrid((ldS + 1 + 63) / 64, B);
     for (int it = 0; it < iters; ++it) {
         hipLaunchKernelGGL(sg_row_kernel, rgrid, dim3(256), 0, s, S, ldS, n0, n1, bin_score, v, u);

@@ -21,6 +21,7 @@
 #include <stdint.h>
 
 #include "../../include/mfr_hip.h"
+#include "zero_fill.h"
 
 #define CHECK_LAUNCH() do { if (hipGetLastError() != hipSuccess) return MFR_E_LAUNCH; } while (0)
 
@@ -343,7 +344,7 @@ int mfr_sp_nms_candidates(const float *scores, int B, int H, int W, int nms_radi
     if (!scores || !cand || !cand_count || B <= 0 || H <= 0 || W <= 0 || cand_cap <= 0) return MFR_E_ARG;
     if (nms_radius != NMS_R) return MFR_E_ARG;          // compiled for the reference's radius (matchers.py:65)
     hipStream_t s = (hipStream_t)stream;
-    if (hipMemsetAsync(cand_count, 0, sizeof(int32_t) * (size_t)B, s) != hipSuccess) return MFR_E_LAUNCH;
+    if (mfr_zero_async(cand_count, sizeof(int32_t) * (size_t)B, s) != hipSuccess) return MFR_E_LAUNCH;
     dim3 grid((W + NMS_TW - 1) / NMS_TW, (H + NMS_TH - 1) / NMS_TH, B);
     // 148 KiB of the CU's 160 KiB LDS: above the 64 KiB default dynamic limit
     if (hipFuncSetAttribute((const void *)sp_nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,

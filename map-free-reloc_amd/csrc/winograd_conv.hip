@@ -37,6 +37,7 @@
 #include <stdint.h>
 
 #include "../../include/mfr_hip.h"
+#include "zero_fill.h"
 
 #define CHECK_LAUNCH() do { if (hipGetLastError() != hipSuccess) return MFR_E_LAUNCH; } while (0)
 
@@ -752,7 +753,7 @@ int mfr_wino_filter_transform(const float *w, int Cin, int Cout, float *upk, voi
 {
     if (!w || !upk || Cin <= 0 || Cout <= 0 || (Cin & 3)) return MFR_E_ARG;
     const int nblk = wn_nblk(Cout), CoutP = wn_coutp(Cout, nblk);
-    if (CoutP != Cout && hipMemsetAsync(upk, 0, sizeof(float) * 16 * (size_t)Cin * CoutP, (hipStream_t)stream) != hipSuccess) return MFR_E_LAUNCH;
+    if (CoutP != Cout && mfr_zero_async(upk, sizeof(float) * 16 * (size_t)Cin * CoutP, (hipStream_t)stream) != hipSuccess) return MFR_E_LAUNCH;
     hipLaunchKernelGGL(wino_filter_kernel, dim3((Cin * Cout + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, Cin, Cout, CoutP, nblk, upk);
     CHECK_LAUNCH();
     return 0;

@@ -98,13 +98,14 @@ def read_color_image(path, resize):
 
 
 class MapFreeScene:
-    """val/test reader of one scene directory (lib/datasets/mapfree.py:16-270, the no-overlaps branch):
-    intrinsics.txt / poses.txt parsing (:36-75), pairs = keyframe seq0/frame_00000 x every
-    `sample_factor`-th seq1 frame (:148-165), sample dict (:211-268) incl. pair_id = index *
-    sample_factor (:265, quirk Q4).  Intrinsics are rescaled exactly like correct_intrinsic_scale
-    (float64 result, as upstream)."""
+    """reader of one scene directory (lib/datasets/mapfree.py:16-270, single-frame queries): intrinsics.txt / poses.txt
+    parsing (:36-75); val/test scenes: pairs = keyframe seq0/frame_00000 x every `sample_factor`-th seq1 frame (:148-165);
+    TRAINING scenes (an `overlaps.npz` is present, :85-112): pairs = the pre-computed (seqA, imA, seqB, imB) rows whose
+    overlap score lies strictly inside `overlap_limits`; sample dict (:211-268) incl. pair_id = index * sample_factor
+    (:265, quirk Q4).  Intrinsics are rescaled exactly like correct_intrinsic_scale (float64 result, as upstream).
+    `black_white`: the reference's Grayscale(num_output_channels=3) training transform (datamodules.py:38-40)."""
 
-    def __init__(self, scene_root, resize, sample_factor=5, estimated_depth=None):
+    def __init__(self, scene_root, resize, sample_factor=5, estimated_depth=None, overlap_limits=None, black_white=False):
         import re
         self.scene_root, self.resize = str(scene_root), resize
         self.scene_id = os.path.basename(self.scene_root.rstrip("/"))
@@ -130,8 +131,20 @@ class MapFreeScene:
                     T[1, 1] = resize[1] / H; T[1, 2] = resize[1] / H / 2 - 0.5
                     K = T @ K
                 self.K[parts[0]] = K
-        ids = sorted(int(re.search(r"_(\d+)\..*$", fn).group(1)) for fn in self.poses if "seq0" not in fn)
-        self.pairs = [(0, 0, 1, i) for i in ids][0::sample_factor]
+        self.black_white = bool(black_white)
+        ov = os.path.join(self.scene_root, "overlaps.npz")
+        if os.path.exists(ov):                                  # training scene
+            f = np.load(ov, allow_pickle=False)
+            idxs, overlaps = np.asarray(f["idxs"]), np.asarray(f["overlaps"])
+            if overlap_limits is not None and overlap_limits[0] is not None:
+                lo, hi = overlap_limits
+                idxs = idxs[np.logical_and(lo < overlaps, overlaps < hi)]
+            if sample_factor != 1:
+                raise ValueError("training scenes (overlaps.npz) take sample_factor 1 (mapfree.py:112)")
+            self.pairs = [tuple(int(v) for v in row) for row in idxs]
+        else:
+            ids = sorted(int(re.search(r"_(\d+)\..*$", fn).group(1)) for fn in self.poses if "seq0" not in fn)
+            self.pairs = [(0, 0, 1, i) for i in ids][0::sample_factor]
 
     def __len__(self):
         return len(self.pairs)
@@ -146,6 +159,8 @@ class MapFreeScene:
         p1, p2 = f"seq{sa}/frame_{ia:05}.jpg", f"seq{sb}/frame_{ib:05}.jpg"
         img1 = read_color_image(os.path.join(self.scene_root, p1), self.resize)
         img2 = read_color_image(os.path.join(self.scene_root, p2), self.resize)
+        if self.black_white:                                    # torchvision Grayscale: ITU-R 601-2 luma, replicated
+            img1, img2 = (_luma3(im) for im in (img1, img2))
         if self.estimated_depth is not None:
             d1 = read_depth_image(os.path.join(self.scene_root, p1).replace(".jpg", f".{self.estimated_depth}.png"))
             d2 = read_depth_image(os.path.join(self.scene_root, p2).replace(".jpg", f".{self.estimated_depth}.png"))
@@ -159,6 +174,11 @@ class MapFreeScene:
                 "K_color0": torch.from_numpy(self.K[p1].copy()), "K_color1": torch.from_numpy(self.K[p2].copy()),
                 "dataset_name": "Mapfree", "scene_id": os.path.basename(self.scene_root.rstrip("/")),
                 "scene_root": self.scene_root, "pair_id": index * self.sample_factor, "pair_names": (p1, p2)}
+
+
+def _luma3(img):
+    l = 0.2989 * img[0] + 0.587 * img[1] + 0.114 * img[2]
+    return l[None].expand(3, -1, -1).contiguous()
 
 
 class MissingDataError(FileNotFoundError):
@@ -183,6 +203,10 @@ def list_scenes(cfg, split="val"):
     names = sorted(d for d in os.listdir(os.path.join(str(root), split)) if os.path.isdir(os.path.join(str(root), split, d)))
     if cfg.DATASET.SCENES:
         names = [s for s in names if s in cfg.DATASET.SCENES]
+    if split == "train":                                        # MapFreeDataset.__init__ (mapfree.py:371-400): sample_factor 1, overlap window
+        limits = (cfg.DATASET.MIN_OVERLAP_SCORE, cfg.DATASET.MAX_OVERLAP_SCORE)
+        return [MapFreeScene(os.path.join(str(root), split, s), resize, 1, cfg.DATASET.ESTIMATED_DEPTH, limits, bool(cfg.DATASET.BLACK_WHITE))
+                for s in names]
     return [MapFreeScene(os.path.join(str(root), split, s), resize, 5, cfg.DATASET.ESTIMATED_DEPTH) for s in names]
 
 
@@ -317,3 +341,106 @@ class DevicePrefetcher:
                 if isinstance(v, torch.Tensor):
                     v.record_stream(torch.cuda.current_stream(self.device))
         return db
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# training-side loader (SURVEY.md 8f-4 adjacency): scene-balanced sampling + worker processes + pinned batches
+# ----------------------------------------------------------------------------------------------------------------
+class SceneBalancedSampler:
+    """TRAINING.SAMPLER 'scene_balance' (lib/datasets/sampler.py:6-77, used by datamodules.py:24-33): every epoch draws
+    `n_per_scene` pair indices from EACH scene (with replacement, or a permutation padded with replacement), then shuffles
+    the union.  The generator is seeded once (66 upstream) and runs on across epochs.  One difference by construction: the
+    reference trains on one device; here the epoch's index list is dealt round-robin to the ranks (`rank::world`), so an
+    epoch is the same set of pairs whatever the world size."""
+
+    def __init__(self, scene_sizes, n_per_scene, replacement=True, seed=66, rank=0, world=1, shuffle=True):
+        self.sizes = [int(n) for n in scene_sizes]
+        self.n, self.replacement, self.shuffle = int(n_per_scene), bool(replacement), bool(shuffle)
+        self.rank, self.world = int(rank), int(world)
+        self.gen = torch.Generator().manual_seed(int(seed))
+
+    def __len__(self):
+        total = len(self.sizes) * self.n
+        return (total - self.rank + self.world - 1) // self.world
+
+    def epoch_indices(self):
+        """the whole epoch: global (concatenated) pair indices, identical on every rank"""
+        out, low = [], 0
+        for size in self.sizes:
+            if size <= 0:
+                continue
+            if self.replacement:
+                r = torch.randint(low, low + size, (self.n,), generator=self.gen, dtype=torch.int64)
+            else:
+                r = torch.randperm(size, generator=self.gen) + low
+                r = r[:self.n] if size >= self.n else torch.cat([r, torch.randint(low, low + size, (self.n - size,), generator=self.gen, dtype=torch.int64)])
+            out.append(r)
+            low += size
+        idx = torch.cat(out) if out else torch.zeros(0, dtype=torch.int64)
+        if self.shuffle:
+            idx = idx[torch.randperm(len(idx), generator=self.gen)]
+        return idx
+
+    def __iter__(self):
+        return iter(self.epoch_indices()[self.rank::self.world].tolist())
+
+
+class _ConcatScenes(torch.utils.data.Dataset):
+    """scenes back to back; only what the regression model consumes is collated (strings / empty depth tensors are dropped)"""
+
+    KEYS = ("image0", "image1", "T_0to1", "K_color0", "K_color1")
+
+    def __init__(self, scenes):
+        self.scenes = list(scenes)
+        self.cum = np.cumsum([0] + [len(s) for s in self.scenes])
+
+    def __len__(self):
+        return int(self.cum[-1])
+
+    def __getitem__(self, i):
+        si = int(np.searchsorted(self.cum, i, side="right") - 1)
+        d = self.scenes[si][int(i - self.cum[si])]
+        out = {k: d[k] for k in self.KEYS}
+        for k in ("depth0", "depth1"):
+            if isinstance(d.get(k), torch.Tensor) and d[k].numel():
+                out[k] = d[k]
+        return out
+
+
+class TrainPairLoader:
+    """batches of TRAINING.BATCH_SIZE pairs for regression/train.py: torch DataLoader worker processes decode JPEGs
+    (TRAINING.NUM_WORKERS), batches arrive in pinned memory and are uploaded on a side stream one batch ahead
+    (DevicePrefetcher).  Iterating yields ONE epoch of this rank's share; `forever()` chains epochs."""
+
+    def __init__(self, scenes, batch_size, sampler=None, num_workers=0, device="cpu", drop_last=True):
+        self.ds = _ConcatScenes(scenes)
+        self.device = torch.device(device)
+        self.dl = torch.utils.data.DataLoader(self.ds, batch_size=int(batch_size), sampler=sampler, num_workers=int(num_workers or 0),
+                                              pin_memory=self.device.type == "cuda", drop_last=drop_last,
+                                              persistent_workers=bool(num_workers))
+
+    def __len__(self):
+        return len(self.dl)
+
+    def __iter__(self):
+        return iter(DevicePrefetcher(self.dl, self.device))
+
+    def forever(self):
+        while True:
+            yield from self
+
+
+def make_train_loaders(cfg, device, rank=0, world=1):
+    """(train TrainPairLoader, this rank's validation batches as a list factory) from cfg, like DataModule
+    (lib/datasets/datamodules.py:35-68): scene-balanced sampling for training, drop_last sequential validation"""
+    train = list_scenes(cfg, "train")
+    sampler = None
+    if cfg.TRAINING.SAMPLER == "scene_balance":
+        sampler = SceneBalancedSampler([len(s) for s in train], cfg.TRAINING.N_SAMPLES_SCENE, bool(cfg.TRAINING.SAMPLE_WITH_REPLACEMENT),
+                                       rank=rank, world=world)
+    tl = TrainPairLoader(train, cfg.TRAINING.BATCH_SIZE, sampler, cfg.TRAINING.NUM_WORKERS, device)
+    val = list_scenes(cfg, "val")
+    vds = _ConcatScenes(val)
+    share = list(range(len(vds)))[rank::world]
+    vl = TrainPairLoader(val, cfg.TRAINING.BATCH_SIZE, share, cfg.TRAINING.NUM_WORKERS, device)
+    return tl, vl

@@ -1,24 +1,37 @@
 """HIP-graph replay of a fixed-shape device function (torch.cuda.CUDAGraph = hipGraph on ROCm).
 
 The per-pair plugin API runs the matcher at batch 1 (lib/models/matching/model.py:30 asserts it), where a SuperPoint +
-SuperGlue forward is ~300 kernel launches of a few microseconds each: issued eagerly the pair is host-bound (~40 ms); replayed
+SuperGlue forward is ~300 kernel launches of a few microseconds each: issued eagerly the pair is host-bound (~29 ms); replayed
 from one captured graph it costs the GPU time only (~4 ms; tools/diag_graph.py).  Everything inside the captured function must
-be free of host synchronisation and of library calls that stage arguments through host memory.
+be free of host synchronisation.
 
-Measured limit (ROCm 7.2 / PyTorch 2.10, tools/diag_graph.py): captures with >= 4 pairs fault at replay -- the large-M GEMMs
-select hipBLASLt "UserArgs" kernels whose argument buffers do not survive capture -- so only batches of 1-2 pairs are graphed.
-In a fresh process the batch-1 replay is exact and runs the matcher in 4-5 ms per pair; in processes that had already run other
-GPU work (the solver plugins, a second matcher instance) the same capture faulted at replay twice, so the switch
-(cfg.HIP.GRAPH_BATCH1) is OFF by default until the library-side cause is understood.
+What made replays unreliable in rounds 1-2 (first replay right, later replays wrong or faulting once the inputs changed,
+tools/diag_graph_phase.py): the C-ABI cleared its counters / masks with hipMemsetAsync, which is captured as a MEMSET NODE, and
+on this stack (ROCm 7.2) those nodes did not reliably re-zero the buffers on replay -- the NMS candidate counters kept growing
+across replays.  The library now clears with a kernel (csrc/zero_fill.h); with kernel nodes only, captures of 1, 8 and 32 pairs
+replay bit-identically to eager with changing inputs, with hipBLASLt GEMMs included.
 """
 import torch
 
-MAX_GRAPH_PAIRS = 2
+
+def _clone(x):
+    if isinstance(x, torch.Tensor):
+        return x.clone()
+    if isinstance(x, dict):
+        return {k: _clone(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return type(x)(_clone(v) for v in x)
+    return x
 
 
 class GraphedCall:
-    def __init__(self, fn, example_inputs, warmup=2):
+    """fn(*tensors) captured once for the shapes of `example_inputs`; __call__ copies the new inputs into the static input
+    buffers (device-to-device, part of the call) and replays.  clone_outputs: hand out copies instead of the static output
+    buffers (needed when the caller keeps results across calls)."""
+
+    def __init__(self, fn, example_inputs, warmup=2, clone_outputs=False):
         self.static_in = [t.clone() for t in example_inputs]
+        self.clone_outputs = clone_outputs
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):                      # warm-up off the capture stream: lazy initialisation, workspaces
@@ -34,4 +47,4 @@ class GraphedCall:
         for s, t in zip(self.static_in, inputs):
             s.copy_(t, non_blocking=True)
         self.graph.replay()
-        return self.static_out
+        return _clone(self.static_out) if self.clone_outputs else self.static_out

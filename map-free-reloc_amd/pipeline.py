@@ -20,8 +20,12 @@ from .solver_ops import PnPBatchSolver
 
 class SuperGluePnPPipeline:
     def __init__(self, device="cuda", sp_state=None, sg_state=None, max_keypoints=1024,
-                 pnp_iters=1000, pnp_thr=3.0, pnp_conf=0.9999, seed=0):
+                 pnp_iters=1000, pnp_thr=3.0, pnp_conf=0.9999, seed=0, graph=False):
+        """graph=True: the whole step (SuperPoint x2 -> SuperGlue -> lift -> PnP-RANSAC, ~330 kernel launches) is captured once
+        per batch shape and replayed as ONE HIP graph; inputs are copied into the graph's static buffers on every call and the
+        (small) results are handed out as copies (nets/graph.py)."""
         _lib.load(require_gpu=True)
+        self.graph, self._graphs = bool(graph), {}
         self.device = torch.device(device)
         self.sp = SuperPointHIP(sp_state or WT.superpoint_state_dict(), self.device, max_keypoints=max_keypoints)
         self.sg = SuperGlueHIP(sg_state or WT.superglue_state_dict(), self.device)
@@ -37,8 +41,18 @@ class SuperGluePnPPipeline:
         m["n_kpts"] = sp["n"]
         return m
 
-    @torch.no_grad()
     def __call__(self, images, depth0, K0, K1, pair_ids, want_mask=False):
+        if self.graph and not want_mask:
+            from .nets.graph import GraphedCall
+            args = [images, depth0, K0, K1, pair_ids]
+            key = tuple(tuple(a.shape) for a in args)
+            if key not in self._graphs:
+                self._graphs[key] = GraphedCall(self._run, args, clone_outputs=True)
+            return self._graphs[key](*args)
+        return self._run(images, depth0, K0, K1, pair_ids, want_mask)
+
+    @torch.no_grad()
+    def _run(self, images, depth0, K0, K1, pair_ids, want_mask=False):
         m = self.match(images)
         out = self.pnp(m["pts0"], m["pts1"], m["n_corr"], depth0, K0, K1, pair_ids, want_mask=want_mask)
         out["n_corr"] = m["n_corr"]
@@ -123,7 +137,24 @@ class FusedPosePipeline:
             sg_sd = WT.load_checkpoint(sg.SUPERGLUE_WEIGHTS) if sg.SUPERGLUE_WEIGHTS else WT.synthetic_or_raise("SuperGlue", cfg, WT.superglue_state_dict)
             sp = SuperPointHIP(sp_sd, self.device, sg.NMS_RADIUS, sg.KEYPOINT_THRESHOLD, sg.MAX_KEYPOINTS)
             net = SuperGlueHIP(sg_sd, self.device, sg.SINKHORN_ITERATIONS, sg.MATCH_THRESHOLD)
-            self.match = lambda b: net(sp(b["images"]), tuple(b["images"].shape[-2:]), maxN=sg.MAX_KEYPOINTS)
+            fwd = lambda images: net(sp(images), tuple(images.shape[-2:]), maxN=sg.MAX_KEYPOINTS)
+            if "GRAPH_FUSED" in cfg.HIP and cfg.HIP.GRAPH_FUSED:
+                # the matcher stage (~300 launches) replayed from one HIP graph per batch shape; at most two shapes are captured
+                # (the full batch and one remainder), anything else runs eagerly: every capture pins its intermediates
+                from .nets.graph import GraphedCall
+                graphs = {}
+
+                def match(b):
+                    im = b["images"]
+                    key = tuple(im.shape)
+                    if key not in graphs:
+                        if len(graphs) >= 2 or not im.is_cuda:
+                            return fwd(im)
+                        graphs[key] = GraphedCall(torch.no_grad()(fwd), [im], clone_outputs=True)
+                    return graphs[key](im)
+                self.match = match
+            else:
+                self.match = lambda b: fwd(b["images"])
         elif fm == "LoFTR":
             lw = cfg.LOFTR.WEIGHTS
             sd = WT.strip_prefix(WT.load_checkpoint(lw), "matcher.") if lw else WT.synthetic_or_raise("LoFTR", cfg, WT.loftr_state_dict)

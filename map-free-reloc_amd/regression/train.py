@@ -16,9 +16,10 @@ eps 1e-6 + StepLR stepped per optimiser step).  The reference runs `pl.Trainer(d
 * checkpoints keep the Lightning layout the reference's `--resume` / `build_model(cfg, checkpoint)` read
   ({'state_dict', 'optimizer_states', 'lr_schedulers', 'epoch', 'global_step'}), written atomically by rank 0.
 
-No dataset is reachable offline: `SyntheticPairs` renders seeded image pairs with a known relative pose (the same
-`data` keys the reference's collate produces for this model: image0, image1, T_0to1); a real loader is any iterable of
-such dicts per rank."""
+Data: `datasets.make_train_loaders` reads the Map-free train split (overlaps.npz pair lists, overlap window,
+scene-balanced sampling dealt round-robin to the ranks, DataLoader workers, pinned batches uploaded one step ahead).  No
+dataset is reachable offline, so the bench and the tests use `SyntheticPairs`: seeded image pairs with a known relative
+pose and the same `data` keys (image0, image1, T_0to1)."""
 import argparse
 import contextlib
 import math
@@ -268,9 +269,20 @@ class Trainer:
         return last
 
 
+class _Reiterable:
+    """an iterable that restarts from a factory each time it is iterated (the validation share of a rank)"""
+
+    def __init__(self, factory):
+        self.factory = factory
+
+    def __iter__(self):
+        return iter(self.factory())
+
+
 def main(argv=None):
-    """python -m mapfree_reloc_amd.regression.train <model.yaml> [<dataset.yaml>] --synthetic B H W --steps-per-epoch K
-    (under torch.distributed.run for more than one GPU)"""
+    """python -m mapfree_reloc_amd.regression.train <model.yaml> [<dataset.yaml>] [--synthetic B H W --steps-per-epoch K]
+    (under torch.distributed.run for more than one GPU).  Without --synthetic the Map-free train / val splits under
+    DATASET.DATA_ROOT are read (datasets.make_train_loaders)."""
     from ..config import get_cfg_defaults
     ap = argparse.ArgumentParser()
     ap.add_argument("config")
@@ -286,19 +298,30 @@ def main(argv=None):
     if a.dataset_config:
         cfg.merge_from_file(a.dataset_config)
     cfg.merge_from_file(a.config)
-    if a.synthetic is None:
-        raise SystemExit("regression.train: the Map-free training split reader is not part of this package; pass --synthetic B H W "
-                         "(or drive Trainer.fit with your own iterable of {'image0','image1','T_0to1'} batches)")
-    B, H, W = a.synthetic
     rank, world, device = init_distributed()
-    src = SyntheticPairs(B, H, W, device, seed=0, rank=rank)
-    tr = Trainer(cfg, device, sample=src.batch())
-    tr.build()
-    if a.resume:
-        tr.resume(a.resume)
-    val_src = SyntheticPairs(B, H, W, device, seed=10_007, rank=rank)
-    val = [val_src.batch() for _ in range(max(1, a.val_batches // world))]
-    res = tr.fit(src, a.steps_per_epoch, val, out_dir=os.path.join("weights", a.experiment))
+    if a.synthetic is None:
+        # the Map-free training split (DATASET.DATA_ROOT/train with overlaps.npz, scene-balanced sampling) and the val split
+        import itertools
+        from ..datasets import make_train_loaders
+        tl, vl = make_train_loaders(cfg, device, rank, world)          # raises MissingDataError without a data root
+        first = next(iter(tl))
+        tr = Trainer(cfg, device, sample=first)
+        tr.build()
+        if a.resume:
+            tr.resume(a.resume)
+        nval = int(cfg.TRAINING.VAL_BATCHES or 0)
+        val = _Reiterable(lambda: itertools.islice(iter(vl), max(1, nval // world) if nval else None))
+        res = tr.fit(tl.forever(), len(tl), val, out_dir=os.path.join("weights", a.experiment))
+    else:
+        B, H, W = a.synthetic
+        src = SyntheticPairs(B, H, W, device, seed=0, rank=rank)
+        tr = Trainer(cfg, device, sample=src.batch())
+        tr.build()
+        if a.resume:
+            tr.resume(a.resume)
+        val_src = SyntheticPairs(B, H, W, device, seed=10_007, rank=rank)
+        val = [val_src.batch() for _ in range(max(1, a.val_batches // world))]
+        res = tr.fit(src, a.steps_per_epoch, val, out_dir=os.path.join("weights", a.experiment))
     if rank == 0:
         print({k: round(v, 5) for k, v in res.items()})
     if dist.is_initialized():

@@ -92,7 +92,6 @@ def test_unknown_config_values_raise(tmp_path):
         build_model(cfg)
 
 
-@pytest.mark.skipif(os.environ.get("MFR_TEST_GRAPH") != "1", reason="HIP-graph replay of the batch-1 matcher is opt-in (nets/graph.py); MFR_TEST_GRAPH=1 runs it")
 def test_batch1_graph_replay_equals_eager():
     """the batch-1 online SuperGlue matcher replayed from a captured HIP graph (nets/graph.py) returns exactly the eager result,
     also after the static input buffer has been overwritten with another pair"""
@@ -110,3 +109,27 @@ def test_batch1_graph_replay_equals_eager():
         a0, a1 = eager.get_correspondences(s)
         b0, b1 = graphed.get_correspondences(s)
         assert len(a0) > 100 and np.array_equal(a0, b0) and np.array_equal(a1, b1)
+
+
+@pytest.mark.parametrize("B", [1, 3])
+def test_fused_pipeline_graph_replay_equals_eager(B):
+    """SuperGluePnPPipeline(graph=True): the whole step replayed from one HIP graph returns exactly the eager results, batch after
+    batch with changing inputs (the regression this guards: memset NODES did not re-zero the library's counters on replay)"""
+    from mapfree_reloc_amd import images as IM
+    from mapfree_reloc_amd.pipeline import SuperGluePnPPipeline
+    dev = torch.device("cuda:0")
+    eager, graphed = SuperGluePnPPipeline(dev), SuperGluePnPPipeline(dev, graph=True)
+    keys = ("images", "depth0", "K0", "K1", "pair_ids")
+    kept = []
+    for k in range(3):
+        sb = IM.synthetic_batch([50 * k + i for i in range(B)])
+        d = {key: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for key, v in sb.items()}
+        a = eager(*[d[key] for key in keys])
+        b = graphed(*[d[key] for key in keys])
+        kept.append((a, b))
+    torch.cuda.synchronize()
+    for a, b in kept:                                         # results handed out earlier are copies, not the static buffers
+        assert int(a["n_corr"].min()) > 20
+        for key in ("n_corr", "n_inliers", "status", "pts0", "pts1"):
+            assert torch.equal(a[key], b[key]), key
+        assert torch.equal(torch.nan_to_num(a["R"]), torch.nan_to_num(b["R"])) and torch.equal(torch.nan_to_num(a["t"]), torch.nan_to_num(b["t"]))

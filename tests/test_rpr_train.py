@@ -108,7 +108,7 @@ assert torch.equal(parts[0], parts[1]), "replicas diverged"
 val = tr.validate([src.batch()])
 assert "val_loss/loss" in val
 tr.save(sys.argv[1])
-print("rank", rank, "ok", tr.global_step)
+sys.stdout.write(f"rank {rank} ok {tr.global_step}\n"); sys.stdout.flush()
 dist.destroy_process_group()
 '''
 
@@ -122,3 +122,71 @@ def test_ddp_gloo_world2(tmp_path):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     assert r.stdout.count("ok 3") == 2
     assert os.path.exists(tmp_path / "ddp.ckpt")
+
+
+def _write_train_scene(root, name, n_frames, rng, n_pairs):
+    """a Map-free TRAINING scene: two sequences, poses / intrinsics, overlaps.npz with (seqA, imA, seqB, imB) rows + scores"""
+    import numpy as np
+    from PIL import Image
+    sc = root / name
+    (sc / "seq0").mkdir(parents=True); (sc / "seq1").mkdir()
+    lp, lk = ["# name qw qx qy qz tx ty tz"], ["# name fx fy cx cy W H"]
+    for s in (0, 1):
+        for i in range(n_frames):
+            nme = f"seq{s}/frame_{i:05d}.jpg"
+            Image.fromarray(rng.integers(0, 255, (96, 72, 3), dtype=np.uint8)).save(sc / nme, format="PNG")
+            q = rng.normal(size=4); q /= np.linalg.norm(q)
+            lp.append(nme + " " + " ".join(f"{v:.8f}" for v in np.r_[q, rng.normal(size=3)]))
+            lk.append(nme + " 100.0 110.0 35.5 47.5 72 96")
+    (sc / "poses.txt").write_text("\n".join(lp) + "\n"); (sc / "intrinsics.txt").write_text("\n".join(lk) + "\n")
+    idxs = np.stack([rng.integers(0, 2, n_pairs), rng.integers(0, n_frames, n_pairs), rng.integers(0, 2, n_pairs),
+                     rng.integers(0, n_frames, n_pairs)], 1).astype(np.uint16)
+    overlaps = rng.uniform(0.1, 1.0, n_pairs).astype(np.float32)
+    np.savez(sc / "overlaps.npz", idxs=idxs, overlaps=overlaps)
+    return idxs, overlaps
+
+
+def test_training_split_reader_sampler_and_loader(tmp_path):
+    """lib/datasets/mapfree.py:85-112 (overlaps.npz, overlap window), sampler.py (scene balance), datamodules.py:35-46: the
+    reader on a synthetic training tree, the sampler's epoch dealt to two ranks, and one optimiser step from the loader"""
+    import numpy as np
+    from mapfree_reloc_amd import evaluation as E
+    from mapfree_reloc_amd.datasets import MapFreeScene, SceneBalancedSampler, make_train_loaders
+    ns = _ns()
+    rng = np.random.default_rng(5)
+    idxs, ov = _write_train_scene(tmp_path / "train", "s00001", 6, rng, 40)
+    _write_train_scene(tmp_path / "train", "s00002", 5, rng, 25)
+    # a val scene in the usual layout
+    idv, _ = _write_train_scene(tmp_path / "val", "s00460", 6, rng, 1)
+    os.remove(tmp_path / "val" / "s00460" / "overlaps.npz")
+    sc = MapFreeScene(tmp_path / "train" / "s00001", (36, 48), 1, None, (0.4, 0.8))
+    keep = idxs[(0.4 < ov) & (ov < 0.8)]
+    assert len(sc) == len(keep) and sc.pairs == [tuple(int(v) for v in r) for r in keep]
+    d = sc[3]
+    sa, ia, sb, ib = keep[3]
+    assert d["pair_names"] == (f"seq{sa}/frame_{ia:05d}.jpg", f"seq{sb}/frame_{ib:05d}.jpg") and d["pair_id"] == 3
+    (q1, t1), (q2, t2) = sc.poses[d["pair_names"][0]], sc.poses[d["pair_names"][1]]
+    q12 = E.qmult(q2, E.qinverse(q1))
+    np.testing.assert_allclose(d["T_0to1"][:3, :3].numpy(), E.quat2mat(q12), atol=1e-6)
+    np.testing.assert_allclose(d["T_0to1"][:3, 3].numpy(), t2 - E.rotate_vector(t1, q12), atol=1e-6)
+    bw = MapFreeScene(tmp_path / "train" / "s00001", (36, 48), 1, None, (0.4, 0.8), black_white=True)[0]["image0"]
+    assert torch.equal(bw[0], bw[1]) and torch.equal(bw[1], bw[2])
+    # sampler: n per scene from every scene, identical epoch list on every rank, dealt round-robin
+    s0, s1 = (SceneBalancedSampler([10, 4], 6, True, rank=r, world=2) for r in (0, 1))
+    whole = SceneBalancedSampler([10, 4], 6, True).epoch_indices().tolist()
+    a, b = list(s0), list(s1)
+    assert a == whole[0::2] and b == whole[1::2] and sum(i < 10 for i in whole) == 6 and all(0 <= i < 14 for i in whole)
+    nr = SceneBalancedSampler([10, 4], 6, False).epoch_indices().tolist()
+    assert len(set(i for i in nr if i < 10)) == 6 and set(i for i in nr if i >= 10) == {10, 11, 12, 13}   # permutation, then padding
+    # loader -> one optimiser step
+    cfg = ns["make"]()
+    cfg.merge_from_list(["DATASET.DATA_ROOT", str(tmp_path), "DATASET.HEIGHT", 128, "DATASET.WIDTH", 96, "DATASET.MIN_OVERLAP_SCORE", 0.2,
+                         "DATASET.MAX_OVERLAP_SCORE", 0.9, "TRAINING.BATCH_SIZE", 2, "TRAINING.NUM_WORKERS", 0, "TRAINING.SAMPLER", "scene_balance",
+                         "TRAINING.N_SAMPLES_SCENE", 4, "TRAINING.SAMPLE_WITH_REPLACEMENT", True])
+    tl, vl = make_train_loaders(cfg, "cpu")
+    assert len(tl) == 4                                        # 2 scenes x 4 samples / batch 2
+    batch = next(iter(tl))
+    assert batch["image0"].shape == (2, 3, 128, 96) and batch["T_0to1"].shape == (2, 4, 4) and batch["K_color0"].dtype == torch.float64
+    tr = ns["Trainer"](cfg, "cpu", sample=batch).build()
+    assert all(x == x for x in (v.item() for v in tr.train_step(batch)))
+    assert sum(1 for _ in vl) == 1 and "val_loss/loss" in tr.validate(list(vl))       # 3 val pairs (every 5th of 6... ) -> drop_last
