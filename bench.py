@@ -57,9 +57,10 @@ def parse(argv=None):
     ap.add_argument("--cpu-out", default="", help=argparse.SUPPRESS)
     ap.add_argument("--no-kernel-timer", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--verbose", action="store_true")
-    ap.add_argument("--graph", type=int, default=-1, help="sg_pnp: 1 = replay the whole step from one captured HIP graph (inputs copied into the "
-                    "graph's static buffers every step), 0 = eager launches; default: 1.  The roofline kernels are then timed with HIP "
-                    "events over extra eager steps AFTER the timed region (events cannot be recorded inside a replay).")
+    ap.add_argument("--graph", type=int, default=0, help="sg_pnp: 1 = replay the whole step from one captured HIP graph (inputs copied into the "
+                    "graph's static buffers every step), 0 = eager launches (default: at 8-32 pairs per step the eager step is GPU-bound, "
+                    "measured 699 vs 694 pairs/s).  With 1 the roofline kernels are timed with HIP events over extra eager steps AFTER the "
+                    "timed region (events cannot be recorded inside a replay).")
     ap.add_argument("--rpr-opts", default="", help="rpr_train only, comma list: channels_last (NHWC activations / weights), siamese "
                     "(TRAINING.SIAMESE_BATCH: both images of a pair in one encoder pass), fp32 (TRAINING.PRECISION fp32)")
     a = ap.parse_args(argv)
@@ -495,7 +496,7 @@ def main():
         seeds = [1000 * rank + 100 * k + i for i in range(B)]
         sb = IM.synthetic_batch(seeds, H, W)
         batches.append({key: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for key, v in sb.items()})
-    use_graph = args.config == "sg_pnp" and args.graph != 0
+    use_graph = args.config == "sg_pnp" and args.graph == 1
     wl = SgPnpWorkload(dev, B, not args.no_kernel_timer, graph=use_graph) if args.config == "sg_pnp" else LoftrEmatWorkload(dev, B, not args.no_kernel_timer)
 
     def step(i):

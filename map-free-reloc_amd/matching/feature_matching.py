@@ -71,13 +71,19 @@ class SuperGlueMatching:
         import torch
         im0, im1 = _to_gray(data['image0'][0]), _to_gray(data['image1'][0])
         ims = torch.stack([im0, im1])[:, None].to(torch.float32)
+        flat = None
         if self.use_graph:                                   # batch 1 is launch-bound: replay the whole forward from one HIP graph
-            from ..nets.graph import GraphedCall
+            from ..nets.graph import GraphCaptureError, GraphedCall
             key = tuple(ims.shape)
-            if key not in self._graphs:
-                self._graphs[key] = GraphedCall(self._forward, [ims.to(self.device)])
-            flat = self._graphs[key](ims).cpu().numpy()
-        else:
+            try:
+                if key not in self._graphs:
+                    self._graphs[key] = GraphedCall(self._forward, [ims.to(self.device)])
+                flat = self._graphs[key](ims).cpu().numpy()
+            except GraphCaptureError as e:
+                import warnings
+                warnings.warn(f"SuperGlueMatching: {e}; running eagerly from now on")
+                self.use_graph = False
+        if flat is None:
             flat = self._forward(ims.to(self.device).contiguous()).cpu().numpy()
         n = int(flat[0])
         if n == 0:

@@ -24,6 +24,10 @@ def _clone(x):
     return x
 
 
+class GraphCaptureError(RuntimeError):
+    """capture of the function failed; the caller should run it eagerly (the process stays usable)"""
+
+
 class GraphedCall:
     """fn(*tensors) captured once for the shapes of `example_inputs`; __call__ copies the new inputs into the static input
     buffers (device-to-device, part of the call) and replays.  clone_outputs: hand out copies instead of the static output
@@ -40,8 +44,21 @@ class GraphedCall:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.static_out = fn(*self.static_in)
+        before = torch.cuda.current_stream()
+        try:
+            # thread_local: other threads (a prefetching loader pinning memory / issuing H2D copies) must not invalidate the capture
+            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+                self.static_out = fn(*self.static_in)
+        except Exception as e:
+            # torch's context manager does not restore the stream when ending an invalidated capture raises: without this every
+            # later launch of the process would go to the dead capture stream
+            torch.cuda.set_stream(before)
+            self.graph = None
+            try:
+                torch.cuda.synchronize()
+            except Exception:
+                pass
+            raise GraphCaptureError(f"HIP-graph capture failed ({type(e).__name__}: {str(e).splitlines()[0] if str(e) else ''})") from e
 
     def __call__(self, *inputs):
         for s, t in zip(self.static_in, inputs):

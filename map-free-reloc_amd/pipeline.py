@@ -43,12 +43,17 @@ class SuperGluePnPPipeline:
 
     def __call__(self, images, depth0, K0, K1, pair_ids, want_mask=False):
         if self.graph and not want_mask:
-            from .nets.graph import GraphedCall
+            from .nets.graph import GraphCaptureError, GraphedCall
             args = [images, depth0, K0, K1, pair_ids]
             key = tuple(tuple(a.shape) for a in args)
-            if key not in self._graphs:
-                self._graphs[key] = GraphedCall(self._run, args, clone_outputs=True)
-            return self._graphs[key](*args)
+            try:
+                if key not in self._graphs:
+                    self._graphs[key] = GraphedCall(self._run, args, clone_outputs=True)
+                return self._graphs[key](*args)
+            except GraphCaptureError as e:
+                import warnings
+                warnings.warn(f"SuperGluePnPPipeline: {e}; running eagerly from now on")
+                self.graph = False
         return self._run(images, depth0, K0, K1, pair_ids, want_mask)
 
     @torch.no_grad()
@@ -141,16 +146,22 @@ class FusedPosePipeline:
             if "GRAPH_FUSED" in cfg.HIP and cfg.HIP.GRAPH_FUSED:
                 # the matcher stage (~300 launches) replayed from one HIP graph per batch shape; at most two shapes are captured
                 # (the full batch and one remainder), anything else runs eagerly: every capture pins its intermediates
-                from .nets.graph import GraphedCall
+                from .nets.graph import GraphCaptureError, GraphedCall
                 graphs = {}
 
                 def match(b):
                     im = b["images"]
                     key = tuple(im.shape)
                     if key not in graphs:
-                        if len(graphs) >= 2 or not im.is_cuda:
+                        if len(graphs) >= 2 or not im.is_cuda or graphs.get("failed"):
                             return fwd(im)
-                        graphs[key] = GraphedCall(torch.no_grad()(fwd), [im], clone_outputs=True)
+                        try:
+                            graphs[key] = GraphedCall(torch.no_grad()(fwd), [im], clone_outputs=True)
+                        except GraphCaptureError as e:
+                            import warnings
+                            warnings.warn(f"FusedPosePipeline: {e}; the matcher stage runs eagerly")
+                            graphs["failed"] = True
+                            return fwd(im)
                     return graphs[key](im)
                 self.match = match
             else:

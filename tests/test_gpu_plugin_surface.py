@@ -133,3 +133,35 @@ def test_fused_pipeline_graph_replay_equals_eager(B):
         for key in ("n_corr", "n_inliers", "status", "pts0", "pts1"):
             assert torch.equal(a[key], b[key]), key
         assert torch.equal(torch.nan_to_num(a["R"]), torch.nan_to_num(b["R"])) and torch.equal(torch.nan_to_num(a["t"]), torch.nan_to_num(b["t"]))
+
+
+_CAPTURE_FAIL = r"""
+import sys
+sys.path.insert(0, %r)
+import torch
+from mapfree_reloc_amd.nets.graph import GraphCaptureError, GraphedCall
+dev = torch.device("cuda:0")
+x = torch.arange(1024, device=dev, dtype=torch.float32)
+before = torch.cuda.current_stream()
+try:
+    GraphedCall(lambda t: t * float(t.sum().item()), [x])          # .item() synchronises: illegal while capturing
+    print("NO ERROR")
+except GraphCaptureError as e:
+    print("raised", type(e).__name__)
+assert torch.cuda.current_stream() == before
+assert float((x * 2).sum().item()) == 2.0 * 1023 * 512             # the process still launches and synchronises
+g = GraphedCall(lambda t: t * 3 + 1, [x])
+assert torch.equal(g(x + 1), (x + 1) * 3 + 1)
+print("usable")
+"""
+
+
+def test_failed_graph_capture_falls_back_and_leaves_the_process_usable(tmp_path):
+    """a function that cannot be captured (host synchronisation inside) raises GraphCaptureError, the current stream is restored
+    and later work -- eager and captured -- runs normally.  Runs in a child process: a capture that cannot be unwound must not
+    take the test session with it."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _CAPTURE_FAIL % root], capture_output=True, text=True, timeout=300)
+    assert "raised GraphCaptureError" in r.stdout and "usable" in r.stdout, r.stdout[-1500:] + r.stderr[-2500:]

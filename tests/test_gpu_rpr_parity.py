@@ -153,3 +153,29 @@ def test_upsample_bilinear_kernel_vs_aten(shape, scale, dtype):
     g = torch.randn_like(want)
     y.backward(g); want.backward(g)
     assert torch.allclose(x.grad.float(), x2.grad.float(), rtol=1e-5 if dtype == torch.float32 else 2e-2, atol=1e-5 if dtype == torch.float32 else 2e-2)
+
+
+def test_train_loader_feeds_the_device_trainer(tmp_path):
+    """datasets.make_train_loaders on a synthetic Map-free training tree: worker process + pinned batches + side-stream upload,
+    then optimiser steps of the fused-aggregator model straight from the loader"""
+    from mapfree_reloc_amd.datasets import make_train_loaders
+    from mapfree_reloc_amd.regression.train import Trainer
+    from oracle.gen_rpr_golden import CASES
+    from tests.test_rpr_train import _write_train_scene
+    rng = np.random.default_rng(9)
+    _write_train_scene(tmp_path / "train", "s00001", 5, rng, 30)
+    _write_train_scene(tmp_path / "train", "s00002", 5, rng, 30)
+    _write_train_scene(tmp_path / "val", "s00460", 6, rng, 1)
+    os.remove(tmp_path / "val" / "s00460" / "overlaps.npz")
+    cfg = get_cfg_defaults()
+    cfg.merge_from_list(CASES["3d3d"][0])
+    cfg.merge_from_list(["DATASET.DATA_ROOT", str(tmp_path), "DATASET.HEIGHT", 96, "DATASET.WIDTH", 72, "DATASET.MIN_OVERLAP_SCORE", 0.1,
+                         "DATASET.MAX_OVERLAP_SCORE", 1.1, "TRAINING.BATCH_SIZE", 4, "TRAINING.NUM_WORKERS", 1, "TRAINING.SAMPLER", "scene_balance",
+                         "TRAINING.N_SAMPLES_SCENE", 8, "TRAINING.SAMPLE_WITH_REPLACEMENT", True, "TRAINING.LR", 1e-4, "TRAINING.GRAD_CLIP", 1.0])
+    tl, vl = make_train_loaders(cfg, DEV)
+    it = iter(tl)
+    first = next(it)
+    assert first["image0"].is_cuda and first["image0"].shape == (4, 3, 96, 72) and first["T_0to1"].shape == (4, 4, 4)
+    tr = Trainer(cfg, DEV, sample=first).build()
+    losses = [tr.train_step(first)[2].item()] + [tr.train_step(b)[2].item() for b in it]
+    assert len(losses) == len(tl) == 4 and all(np.isfinite(losses)), losses
