@@ -43,6 +43,37 @@ class PrecomputedMatching:
 from ..datasets import to_gray as _to_gray   # BT.601 luma, what cv2.imread(GRAYSCALE) / COLOR_RGB2GRAY compute
 
 
+class _GrayPairStage:
+    """data['image0'], data['image1'] ([1,3,H,W] or [1,1,H,W] in [0,1]) -> ONE host array [2,1,H,W] f32 of BT.601 luma, written with
+    numpy on the calling thread into a persistent buffer.  No torch CPU kernel touches the images: on the GPU boxes' 256-core hosts
+    a torch elementwise op / stack over a 1.5 MB image fans out over every core and costs ~20 ms in thread wake-ups per call
+    (tools/diag_plugin_prof2.py), more than the whole matcher on the GPU."""
+
+    def __init__(self):
+        self.buf = self.np = None
+
+    def __call__(self, data):
+        import torch
+        ims = [data['image0'][0], data['image1'][0]]
+        if any(isinstance(im, torch.Tensor) and im.is_cuda for im in ims):      # device-resident inputs: torch ops on the device
+            return torch.stack([_to_gray(im) for im in ims])[:, None].to(torch.float32)
+        H, W = ims[0].shape[-2:]
+        if self.np is None or self.np.shape[-2:] != (H, W):
+            self.np = np.empty((2, 1, H, W), np.float32)
+            self.buf = torch.from_numpy(self.np)
+        for k, im in enumerate(ims):
+            a = im.numpy() if isinstance(im, torch.Tensor) else np.asarray(im)
+            g = self.np[k, 0]
+            if a.shape[0] == 1:
+                g[...] = a[0]
+            else:                                               # same products and order as datasets.to_gray
+                a = a.astype(np.float32, copy=False)
+                np.multiply(a[0], np.float32(0.299), out=g)
+                g += np.float32(0.587) * a[1]
+                g += np.float32(0.114) * a[2]
+        return self.buf
+
+
 class SuperGlueMatching:
     """online matcher: data['image0'], data['image1'] ([1,3,H,W] in [0,1]) -> correspondences"""
 
@@ -60,6 +91,7 @@ class SuperGlueMatching:
         self.sg = SuperGlueHIP(sg_sd, self.device, sg.SINKHORN_ITERATIONS, sg.MATCH_THRESHOLD)
         self.use_graph = bool(cfg.HIP.GRAPH_BATCH1)
         self._graphs = {}
+        self._gray = _GrayPairStage()
 
     def _forward(self, ims):
         out = self.sg(self.sp(ims), tuple(ims.shape[-2:]))
@@ -69,8 +101,7 @@ class SuperGlueMatching:
 
     def get_correspondences(self, data):
         import torch
-        im0, im1 = _to_gray(data['image0'][0]), _to_gray(data['image1'][0])
-        ims = torch.stack([im0, im1])[:, None].to(torch.float32)
+        ims = self._gray(data)
         flat = None
         if self.use_graph:                                   # batch 1 is launch-bound: replay the whole forward from one HIP graph
             from ..nets.graph import GraphCaptureError, GraphedCall
@@ -105,11 +136,11 @@ class LoFTRMatching:
         sd = WT.strip_prefix(WT.load_checkpoint(lw), "matcher.") if lw else WT.synthetic_or_raise("LoFTR", cfg, WT.loftr_state_dict)
         self.device = torch.device("cuda")
         self.net = LoFTRHIP(sd, self.device)
+        self._gray = _GrayPairStage()
 
     def get_correspondences(self, data):
         import torch
-        im0, im1 = _to_gray(data['image0'][0]), _to_gray(data['image1'][0])
-        ims = torch.stack([im0, im1])[:, None].to(self.device, torch.float32)
+        ims = self._gray(data).to(self.device)
         H, W = ims.shape[-2:]
         ims = torch.nn.functional.pad(ims, (0, (-W) % 8, 0, (-H) % 8)).contiguous()
         out = self.net(ims)
