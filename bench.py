@@ -389,7 +389,7 @@ def rpr_train_bench(args, rank, world, dev, use_dist):
                    "last_losses": [round(float(x.float().sum()), 5) for x in losses]},
         "roofline": {"kernel": "cw_bwd_q_kernel + cw_bwd_kv_kernel (mfr_corr_warp_bwd: fused correlation-volume warping, backward)", "bound": "mfma",
                      "achieved": round(ach_b, 2) if ach_b else None, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(ach_b / FP32_MFMA_PEAK_TFLOPS, 4) if ach_b else None, "traffic": None,
+                     "frac": round(ach_b / FP32_MFMA_PEAK_TFLOPS, 4) if ach_b else None, "traffic": _traffic("cw_bwd_kv", B),
                      "avg_launch_ms": round(bm, 4) if bm else None, "launches_timed": len(bwd_t.events), "flops_per_launch": f_bwd,
                      "note": f"the [B, N, N] volume ({vol_bytes / 1e9:.2f} GB fp32 at this batch) is never written: it is recomputed tile by tile on the "
                              "fp32 matrix cores; HBM-side algorithmic bytes are the q/k/v/gradient maps only (a few MB)",

@@ -137,18 +137,42 @@ class LoFTRMatching:
         self.device = torch.device("cuda")
         self.net = LoFTRHIP(sd, self.device)
         self._gray = _GrayPairStage()
+        self.use_graph = bool(cfg.HIP.GRAPH_BATCH1)
+        self._graphs = {}
+
+    def _coarse(self, ims):
+        import torch
+        H, W = ims.shape[-2:]
+        with torch.no_grad():
+            return self.net.coarse_stage(torch.nn.functional.pad(ims, (0, (-W) % 8, 0, (-H) % 8)).contiguous())
 
     def get_correspondences(self, data):
         import torch
-        ims = self._gray(data).to(self.device)
-        H, W = ims.shape[-2:]
-        ims = torch.nn.functional.pad(ims, (0, (-W) % 8, 0, (-H) % 8)).contiguous()
-        out = self.net(ims)
-        n = int(out["n_corr"][0])
+        ims = self._gray(data)
+        c = None
+        if self.use_graph:          # everything before the match count is known: ~350 launches replayed as one HIP graph
+            from ..nets.graph import GraphCaptureError, GraphedCall
+            key = tuple(ims.shape)
+            try:
+                if key not in self._graphs:
+                    self._graphs[key] = GraphedCall(self._coarse, [ims.to(self.device)])
+                c = self._graphs[key](ims)
+            except GraphCaptureError as e:
+                import warnings
+                warnings.warn(f"LoFTRMatching: {e}; running eagerly from now on")
+                self.use_graph = False
+        if c is None:
+            c = self._coarse(ims.to(self.device))
+        with torch.no_grad():
+            out = self.net.fine_stage(c)                       # reads the graph's static buffers before the next replay
+            n_t = out["n_corr"][:1].to(torch.float32)
+            flat = torch.cat([n_t, out["pts0"][0].reshape(-1), out["pts1"][0].reshape(-1)]).cpu().numpy()      # one D2H copy
+        n = int(flat[0])
         if n == 0:
             e = np.array([])
             return e, e
-        return out["pts0"][0, :n].cpu().numpy(), out["pts1"][0, :n].cpu().numpy()
+        L = (len(flat) - 1) // 4
+        return flat[1:1 + 2 * L].reshape(L, 2)[:n].copy(), flat[1 + 2 * L:].reshape(L, 2)[:n].copy()
 
 
 def _cv_sift_detector(num_features):

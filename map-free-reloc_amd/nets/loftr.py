@@ -280,6 +280,11 @@ class LoFTRHIP:
     def __call__(self, images):
         """images [2B,1,H,W] (interleaved pairs; H, W multiples of 8) -> dict(pts0, pts1 [B,L0,2],
         n_corr [B], mconf [B,L0]) in the matcher's pixel frame (mkpts0_f / mkpts1_f)."""
+        return self.fine_stage(self.coarse_stage(images))
+
+    def coarse_stage(self, images):
+        """backbone -> coarse transformer -> dual-softmax matching: everything BEFORE the match count is known.  Fixed shapes and
+        no host synchronisation, so the batch-1 plugin path replays this stage from one captured HIP graph (nets/graph.py)."""
         B2, _, H, W = images.shape
         B = B2 // 2
         fc, ff = self.backbone(images)
@@ -300,31 +305,44 @@ class LoFTRHIP:
         valid = torch.arange(L0, device=images.device)[None] < n[:, None]
         k0 = torch.stack([ii % wc, ii // wc], -1).float() * scale
         k1 = torch.stack([jj % wc, jj // wc], -1).float() * scale
+        ff_nhwc = ff.permute(0, 2, 3, 1).contiguous()                                   # [2B, Hf, Wf, 128]
+        return dict(xm=xm, ff_nhwc=ff_nhwc, i_ids=i_ids, j_ids=j_ids, ii=ii, jj=jj, mconf=mconf, n=n, valid=valid, k0=k0, k1=k1,
+                    hc=hc, wc=wc, H=H)
+
+    def fine_stage(self, c):
+        """the matched cells' 5x5 windows -> fine transformer -> sub-pixel expectation (data-dependent sizes: one host
+        synchronisation for the match count)"""
+        xm, ff_nhwc, i_ids, j_ids, ii, jj, mconf, n, valid, k0, k1 = (c[k] for k in ("xm", "ff_nhwc", "i_ids", "j_ids", "ii", "jj", "mconf",
+                                                                                     "n", "valid", "k0", "k1"))
+        hc, wc, H = c["hc"], c["wc"], c["H"]
+        B, L0 = valid.shape
+        dev = valid.device
+        f0, f1 = xm[0].view(B, L0, 512)[..., :256], xm[1].view(B, L0, 512)[..., :256]
         b_ids, slot = torch.where(valid)                                            # (host sync: match count)
         M = b_ids.numel()
         pts1 = k1.clone()
         if M > 0:
             mi, mj = ii[b_ids, slot], jj[b_ids, slot]
-            ff_nhwc = ff.permute(0, 2, 3, 1).contiguous()                           # [2B, Hf, Wf, 128]
-            stride = ff.shape[2] // hc
+            Hf = ff_nhwc.shape[1]
+            stride = Hf // hc
             WW = self.W * self.W
-            win = torch.empty(2 * M, WW, 128, dtype=torch.float32, device=images.device)
+            win = torch.empty(2 * M, WW, 128, dtype=torch.float32, device=dev)
             self.gather_windows(ff_nhwc, (2 * b_ids).int(), mi.int(), wc, stride, out=win[:M])
             self.gather_windows(ff_nhwc, (2 * b_ids + 1).int(), mj.int(), wc, stride, out=win[M:])
             fcw = F.linear(torch.cat([f0[b_ids, mi], f1[b_ids, mj]], 0), *self.down_proj)
             # merge_feat(cat[window, coarse]) = window Wa^T + (coarse Wb^T + b): the coarse half is constant over the 25 taps
             wmf, bmf = self.merge_feat
             cw = torch.addmm(bmf, fcw, wmf[:, 128:].t())
-            xf = torch.empty(2, M * WW, 256, dtype=torch.float32, device=images.device)
+            xf = torch.empty(2, M * WW, 256, dtype=torch.float32, device=dev)
             torch.add(torch.mm(win.view(2 * M * WW, 128), wmf[:, :128].t()).view(2 * M, WW, 128), cw[:, None, :],
                       out=xf.view(2 * M, WW, 256)[..., :128])
             self._transformer(self.fine, xf, self.fine_attention if self.W == 5 else self._torch_linear_attention(8), M, WW)
             g0, g1 = xf[0].view(M, WW, 256)[..., :128], xf[1].view(M, WW, 256)[..., :128]
             picked = g0[:, WW // 2]
             heat = torch.softmax(torch.einsum('mc,mrc->mr', picked, g1) / g0.shape[-1] ** .5, dim=1).view(-1, self.W, self.W)
-            lin = torch.linspace(-1, 1, self.W, device=images.device)
+            lin = torch.linspace(-1, 1, self.W, device=dev)
             coords = torch.stack([(heat * lin[None, None, :]).sum((1, 2)), (heat * lin[None, :, None]).sum((1, 2))], 1)
-            scale1 = H // ff.shape[2]
+            scale1 = H // Hf
             pts1[b_ids, slot] = k1[b_ids, slot] + coords * (self.W // 2) * scale1
         zero = torch.zeros_like(k0)
         return dict(pts0=torch.where(valid[..., None], k0, zero).contiguous(), pts1=torch.where(valid[..., None], pts1, zero).contiguous(),

@@ -111,6 +111,27 @@ def test_batch1_graph_replay_equals_eager():
         assert len(a0) > 100 and np.array_equal(a0, b0) and np.array_equal(a1, b1)
 
 
+def test_batch1_loftr_graph_replay_equals_eager():
+    """LoFTRMatching: the stage before the match count (backbone incl. the library's stride-2 convolutions, coarse transformer,
+    dual-softmax matching) replayed from a HIP graph, the fine stage eager on the graph's static buffers -- identical to the fully
+    eager matcher, pair after pair with changing inputs and when a pair comes back"""
+    from mapfree_reloc_amd.datasets import SyntheticScene, collate_batch1
+    from mapfree_reloc_amd.matching.feature_matching import LoFTRMatching
+    cfg = _cfg("EssentialMatrixMetric", "", matcher="LoFTR")
+    cfg.ALLOW_SYNTHETIC_WEIGHTS = True
+    sc = SyntheticScene(5, frames=3)
+    samples = [collate_batch1(sc[i]) for i in range(3)]
+    cfg.HIP.GRAPH_BATCH1 = False
+    eager = LoFTRMatching(cfg)
+    cfg.HIP.GRAPH_BATCH1 = True
+    graphed = LoFTRMatching(cfg)
+    for s in samples + samples[:2]:
+        a0, a1 = eager.get_correspondences(s)
+        b0, b1 = graphed.get_correspondences(s)
+        assert len(a0) > 100 and np.array_equal(a0, b0) and np.array_equal(a1, b1)
+    assert graphed.use_graph and len(graphed._graphs) == 1
+
+
 @pytest.mark.parametrize("B", [1, 3])
 def test_fused_pipeline_graph_replay_equals_eager(B):
     """SuperGluePnPPipeline(graph=True): the whole step replayed from one HIP graph returns exactly the eager results, batch after

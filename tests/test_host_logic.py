@@ -286,3 +286,19 @@ def test_descriptor_matcher_packs_ragged_inputs():
     # all-empty batch still yields a valid (1-row) stride
     kp, de, n = DescriptorRatioMatcher(0.8, "cpu")._pack([(np.zeros((0, 2), np.float32), np.zeros((0, 128), np.float32))])
     assert kp.shape == (1, 1, 2) and n.tolist() == [0]
+
+
+def test_plugin_image_staging_equals_the_torch_path():
+    """matching/feature_matching._GrayPairStage (numpy on the calling thread, persistent buffer) produces bit for bit what
+    datasets.to_gray + torch.stack produced, for colour and single-channel inputs, and reuses its buffer across pairs"""
+    from mapfree_reloc_amd.datasets import to_gray
+    from mapfree_reloc_amd.matching.feature_matching import _GrayPairStage
+    st = _GrayPairStage()
+    g = torch.Generator().manual_seed(0)
+    for C in (3, 1, 3):
+        d = {"image0": torch.rand(1, C, 48, 36, generator=g), "image1": torch.rand(1, C, 48, 36, generator=g)}
+        out = st(d)
+        ref = torch.stack([to_gray(d["image0"][0]), to_gray(d["image1"][0])])[:, None].to(torch.float32)
+        assert out.shape == (2, 1, 48, 36) and out.dtype == torch.float32 and torch.equal(out, ref)
+    assert st(d) is out                                        # same persistent buffer
+    assert st({"image0": torch.rand(1, 3, 24, 20), "image1": torch.rand(1, 3, 24, 20)}).shape == (2, 1, 24, 20)
