@@ -62,7 +62,7 @@ def parse(argv=None):
                     "measured 699 vs 694 pairs/s).  With 1 the roofline kernels are timed with HIP events over extra eager steps AFTER the "
                     "timed region (events cannot be recorded inside a replay).")
     ap.add_argument("--rpr-opts", default="", help="rpr_train only, comma list: channels_last (NHWC activations / weights), siamese "
-                    "(TRAINING.SIAMESE_BATCH: both images of a pair in one encoder pass), fp32 (TRAINING.PRECISION fp32)")
+                    "(TRAINING.SIAMESE_BATCH: both images of a pair in one encoder pass), fp32 (TRAINING.PRECISION fp32), graph (TRAINING.GRAPH_STEP)")
     a = ap.parse_args(argv)
     if a.batch <= 0:
         a.batch = {"sg_pnp": 32, "loftr_emat": 16, "rpr_train": 10}[a.config]
@@ -300,7 +300,7 @@ def rpr_cfg(precision, opts=()):
     from mapfree_reloc_amd.config import get_cfg_defaults
     cfg = get_cfg_defaults()
     cfg.merge_from_list(RPR_3D3D + ["TRAINING.PRECISION", "fp32" if "fp32" in opts else precision, "TRAINING.SIAMESE_BATCH", "siamese" in opts,
-                                    "TRAINING.CHANNELS_LAST", "channels_last" in opts])
+                                    "TRAINING.CHANNELS_LAST", "channels_last" in opts, "TRAINING.GRAPH_STEP", "graph" in opts])
     return cfg
 
 
@@ -358,6 +358,14 @@ def rpr_train_bench(args, rank, world, dev, use_dist):
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    if tr.graph_step and tr._gstep is not None:
+        # HIP events cannot be recorded inside a replay: time the correlation-volume kernels over eager steps right after the region
+        saved = (tr._gstep, tr._gkeys)
+        tr._gstep, tr._gkeys = None, ()
+        for i in range(3):
+            tr.train_step(batches[i & 1])
+        torch.cuda.synchronize()
+        tr._gstep, tr._gkeys = saved
     fwd_t.enabled = bwd_t.enabled = False
     if use_dist:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -383,8 +391,8 @@ def rpr_train_bench(args, rank, world, dev, use_dist):
         "dtype": "bf16 autocast (encoder / head convolutions), f32 (correlation-volume kernel, pose algebra, losses, master weights, Adam)",
         "data": "synthetic (seeded textured planes under a random relative pose; no Map-free training split offline), random-init weights",
         "config": {"workload": "configs[4]: 3d3d.yaml (ResUNet 3-3-3 -> CorrelationVolumeWarping -> ProcrustesDeepResBlock), full training step",
-                   "global_batch": B * world, "pairs_per_gpu_per_step": B, "parallelism": f"dp{world} (DDP, one {cfg.TRAINING.DDP_BUCKET_MB} MB gradient bucket, RCCL all-reduce)",
-                   "precision": cfg.TRAINING.PRECISION, "siamese_batch": bool(cfg.TRAINING.SIAMESE_BATCH), "channels_last": bool(cfg.TRAINING.CHANNELS_LAST),
+                   "global_batch": B * world, "pairs_per_gpu_per_step": B, "parallelism": f"dp{world} (" + ("one flat-gradient RCCL all-reduce per step after the graph replay" if tr.graph_step else f"DDP, {cfg.TRAINING.DDP_BUCKET_MB} MB gradient buckets, RCCL all-reduce") + ")",
+                   "precision": cfg.TRAINING.PRECISION, "siamese_batch": bool(cfg.TRAINING.SIAMESE_BATCH), "channels_last": bool(cfg.TRAINING.CHANNELS_LAST), "graph_step": bool(tr.graph_step),
                    "volume_positions": N, "feature_channels": D, "parameters": n_param, "optimizer": "Adam (fused), eps 1e-6",
                    "last_losses": [round(float(x.float().sum()), 5) for x in losses]},
         "roofline": {"kernel": "cw_bwd_q_kernel + cw_bwd_kv_kernel (mfr_corr_warp_bwd: fused correlation-volume warping, backward)", "bound": "mfma",

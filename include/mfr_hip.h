@@ -275,6 +275,16 @@ int mfr_upsample2x_add(const float *lo, float *y, int planes, int H, int W, void
 int mfr_upsample_bilinear(const void *in, void *out, int planes, int H, int W, int Ho, int Wo, int dtype, void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Differentiable batched Kabsch rotation of the regression heads (csrc/kabsch.hip, csrc/kabsch_math.h).  Reference: `procrustes`,
+ * lib/utils/solver.py:4-37 (torch.svd + reflection fix), called from lib/models/regression/head.py:55-163.  No host
+ * synchronisation (torch.linalg.svd reads the solver's status back), so the training step can be captured as a HIP graph.
+ *   mfr_kabsch_fwd   H [B,3,3] = A_c^T B_c -> R [B,3,3], the proper rotation with B_c ~ A_c R^T (Horn quaternion + Jacobi)
+ *   mfr_kabsch_bwd   gR = dL/dR -> gH = dL/dH (closed form through the polar factor, see kabsch.hip)
+ * ------------------------------------------------------------------------------------------ */
+int mfr_kabsch_fwd(const float *H, int B, float *R, void *stream);
+int mfr_kabsch_bwd(const float *H, const float *gR, int B, float *gH, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * SIFT-descriptor correspondence leg.  Reference call sites:
  * SIFTMatching.get_correspondences (lib/models/matching/feature_matching.py:75-118) and
  * SIFT_matcher.match (etc/feature_matching_baselines/matchers.py:135-188), everything AFTER

@@ -62,6 +62,8 @@ SIGNATURES = {
     "mfr_upsample_bilinear": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "mfr_corr_warp_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mfr_corr_warp_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mfr_kabsch_fwd": (_i, [_vp, _i, _vp, _vp]),
+    "mfr_kabsch_bwd": (_i, [_vp, _vp, _i, _vp, _vp]),
     "mfr_rootsift": (_i, [_vp, _i, _vp, _vp, _vp]),
     "mfr_desc_ratio_match": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _d, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "mfr_scale_workspace_bytes": (_sz, [_i, _i]),

@@ -13,6 +13,8 @@ keys this implementation adds (declared here because unknown keys are rejected o
   TRAINING.PRECISION 'bf16' (autocast; the aggregator kernel and the pose algebra stay fp32) | 'fp32'
   TRAINING.SIAMESE_BATCH  encode both images of a pair in one encoder pass (BatchNorm statistics over both)
   TRAINING.DDP_BUCKET_MB  gradient all-reduce bucket size
+  TRAINING.GRAPH_STEP     forward + loss + backward of the training step replayed from one captured HIP graph; gradients in one flat
+                          buffer, one all-reduce per step instead of DDP's bucket hooks (regression/train.py)
   TRAINING.CHANNELS_LAST  keep weights / activations of the regression model NHWC (MIOpen's implicit-GEMM kernels are NHWC)
   SUPERGLUE.*        matcher hyper-parameters of record (matchers.py:65-71) and weight paths
 """
@@ -58,7 +60,7 @@ def get_cfg_defaults():
                      SAMPLE_WITH_REPLACEMENT=None, LR=None, LR_STEP_INTERVAL=None, LR_STEP_GAMMA=None,
                      VAL_INTERVAL=None, VAL_BATCHES=None, LOG_INTERVAL=None, EPOCHS=None, GRAD_CLIP=0.,
                      ROT_LOSS='rot_frobenius_loss', TRANS_LOSS='trans_l2_loss', LAMBDA=1.0,
-                     PRECISION='bf16', SIAMESE_BATCH=False, DDP_BUCKET_MB=64, CHANNELS_LAST=False).items():
+                     PRECISION='bf16', SIAMESE_BATCH=False, DDP_BUCKET_MB=64, CHANNELS_LAST=False, GRAPH_STEP=False).items():
         c.TRAINING[k] = v
     # ---- additions of this implementation ----
     c.RANSAC = CN(); c.RANSAC.SEED = 0

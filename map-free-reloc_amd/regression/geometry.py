@@ -6,9 +6,39 @@ import torch
 import torch.nn.functional as F
 
 
+class _KabschRotation(torch.autograd.Function):
+    """H [b,3,3] (= A_c^T B_c) -> the reflection-corrected Kabsch rotation, forward and backward through csrc/kabsch.hip: Horn's
+    quaternion form + Jacobi sweeps instead of an SVD, the gradient in closed form through the polar factor.  Same rotation and
+    same gradient as the SVD route (tests/test_kabsch_host.py: 1e-13 in binary64), but with no host synchronisation --
+    torch.linalg.svd reads the solver status back, which stalls the launch queue every step and forbids HIP-graph capture."""
+
+    @staticmethod
+    def forward(ctx, H):
+        from .._lib import check, load, ptr, stream_ptr
+        lib = load(require_gpu=True)
+        H = H.detach().float().contiguous()
+        R = torch.empty_like(H)
+        check(lib.mfr_kabsch_fwd(ptr(H), H.shape[0], ptr(R), stream_ptr()), "mfr_kabsch_fwd")
+        ctx.save_for_backward(H)
+        return R
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gR):
+        from .._lib import check, load, ptr, stream_ptr
+        (H,) = ctx.saved_tensors
+        gR = gR.float().contiguous()
+        gH = torch.empty_like(H)
+        check(load(require_gpu=True).mfr_kabsch_bwd(ptr(H), ptr(gR), H.shape[0], ptr(gH), stream_ptr()), "mfr_kabsch_bwd")
+        return gH
+
+
+SYNC_FREE_KABSCH = True        # device tensors: csrc/kabsch.hip; False: torch.linalg.svd everywhere (A/B switch)
+
+
 def procrustes(A, B):
     """least-squares rigid registration of point sets with known correspondences (Kabsch): R, t with B ~ A R^T + t.
-    A, B [b, n, 3] -> R [b, 3, 3], t [b, 1, 3].  fp32/fp64 only (SVD)."""
+    A, B [b, n, 3] -> R [b, 3, 3], t [b, 1, 3].  fp32 on the device (kernel), fp32/fp64 on the host (SVD)."""
     if A.dim() != 3 or B.dim() != 3:
         raise AssertionError("three dimensions are required")
     if A.shape != B.shape:
@@ -17,6 +47,9 @@ def procrustes(A, B):
         raise AssertionError("number of spatial dimensions must be 3")
     a0, b0 = A.mean(dim=1, keepdim=True), B.mean(dim=1, keepdim=True)
     H = (A - a0).transpose(1, 2) @ (B - b0)
+    if SYNC_FREE_KABSCH and H.is_cuda and H.dtype == torch.float32:
+        R = _KabschRotation.apply(H)
+        return R, b0 - a0 @ R.transpose(1, 2)
     U, _, Vh = torch.linalg.svd(H)
     V = Vh.transpose(1, 2)
     # proper rotation: flip the last singular direction when det(V U^T) < 0

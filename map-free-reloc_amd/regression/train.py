@@ -145,6 +145,12 @@ class Trainer:
             self.materialise(sample)
         self.step_mod = self.opt = self.sched = None
         self.global_step, self.epoch = 0, 0
+        # TRAINING.GRAPH_STEP: forward + loss + backward of a step replayed from ONE captured HIP graph (the step is ~1900 kernel
+        # launches for ~33 ms of GPU time at batch 10: launch-bound).  Gradients then live in one flat buffer that is all-reduced
+        # with a single RCCL call after the replay (no DDP wrapper: its hooks cannot run inside a replay), clipped and handed to Adam.
+        # (On a CPU device the same flat-gradient / single-all-reduce step runs with eager launches: that is what the gloo tests drive.)
+        self.graph_step = bool(getattr(cfg.TRAINING, "GRAPH_STEP", False)) and not self.channels_last
+        self._flat = self._gstep = self._gkeys = None
 
     # lazy layers (the heads size their first linear layer from the feature volume) must exist before the optimiser and
     # the gradient buckets are built
@@ -167,7 +173,12 @@ class Trainer:
             raise RuntimeError("lazy layers are not materialised: pass a sample batch to Trainer(...) or call materialise()")
         self.opt, self.sched = self.model.configure_optimizers()
         step = _Step(self.model)
-        if self.world > 1:
+        if self.graph_step:
+            self._flatten_grads()
+            if self.world > 1:                                  # what DDP does when it wraps: replicas start from rank 0's state
+                for t in list(self.model.parameters()) + list(self.model.buffers()):
+                    dist.broadcast(t.data, 0)
+        elif self.world > 1:
             mb = int(getattr(self.cfg.TRAINING, "DDP_BUCKET_MB", 64))
             step = nn.parallel.DistributedDataParallel(
                 step, device_ids=[self.device.index] if self.device.type == "cuda" else None,
@@ -175,12 +186,76 @@ class Trainer:
         self.step_mod = step
         return self
 
+    # ---- graph-step mode ----
+    def _flatten_grads(self):
+        """every parameter's .grad becomes a view into ONE fp32 buffer: one zero kernel, one all-reduce, one norm"""
+        params = [p for p in self.model.parameters() if p.requires_grad]
+        self._flat = torch.zeros(sum(p.numel() for p in params), dtype=torch.float32, device=self.device)
+        o = 0
+        for p in params:
+            p.grad = self._flat[o:o + p.numel()].view_as(p)
+            o += p.numel()
+
+    def _fwd_bwd(self, data):
+        self._flat.zero_()
+        with self.autocast():
+            R_loss, t_loss, loss = self.step_mod(data)
+        loss = loss.float().sum()
+        loss.backward()                                         # accumulates in place into the flat views
+        return R_loss.detach(), t_loss.detach(), loss.detach()
+
+    def _graph_train_step(self, data):
+        from ..nets.graph import GraphCaptureError, GraphedCall
+        keys = sorted(k for k, v in data.items() if isinstance(v, torch.Tensor))
+        shapes = tuple((k, tuple(data[k].shape)) for k in keys)
+        if self._gstep is None and self._gkeys is None and self.device.type != "cuda":
+            self._gkeys = ()
+        if self._gstep is None and self._gkeys is None:
+            try:
+                self._gstep = GraphedCall(lambda *ts: self._fwd_bwd(dict(zip(keys, ts))), [data[k] for k in keys], warmup=3, clone_outputs=True)
+                self._gkeys = shapes
+            except GraphCaptureError as e:
+                import warnings
+                warnings.warn(f"regression.train: {e}; forward / backward run eagerly from now on")
+                self._gkeys = ()
+        if self._gstep is not None and shapes == self._gkeys:
+            losses = self._gstep(*[data[k] for k in keys])
+        else:                                                   # another batch shape (or capture failed): same arithmetic, eager launches
+            losses = self._fwd_bwd(data)
+        if self.world > 1:
+            if dist.get_backend() == "nccl":
+                dist.all_reduce(self._flat, op=dist.ReduceOp.AVG)
+            else:
+                dist.all_reduce(self._flat)
+                self._flat.div_(self.world)
+        clip = float(self.cfg.TRAINING.GRAD_CLIP or 0.0)
+        if clip > 0:                                            # clip_grad_norm_'s formula on the flat buffer, no host read
+            total = torch.linalg.vector_norm(self._flat, dtype=torch.float64)       # binary64 accumulation: 20 M terms in one reduction
+            self._flat.mul_((clip / (total + 1e-6)).clamp(max=1.0).float())
+        self.opt.step()
+        if self.sched is not None:
+            self.sched.step()
+        self.global_step += 1
+        return losses
+
+    @torch.no_grad()
+    def sync_buffers(self):
+        """graph-step mode has no DDP wrapper broadcasting BatchNorm statistics: average the floating-point buffers over the ranks
+        (before validation / checkpoints)"""
+        if self.world > 1 and self.graph_step:
+            for b in self.model.buffers():
+                if b.dtype.is_floating_point:
+                    dist.all_reduce(b)
+                    b.div_(self.world)
+
     def train_step(self, data):
         """model.py:84-97 + Lightning's optimiser step: zero, forward, loss, backward (gradient all-reduce overlapped),
         clip, Adam, StepLR.  Returns the three loss tensors (device, no sync)."""
         if self.step_mod is None:
             self.build()
         self.model.train()
+        if self.graph_step:
+            return self._graph_train_step(data)
         self.opt.zero_grad(set_to_none=True)
         with self.autocast():
             R_loss, t_loss, loss = self.step_mod(data)
@@ -198,6 +273,7 @@ class Trainer:
     @torch.no_grad()
     def validate(self, batches):
         """validation_step / on_validation_epoch_end: `batches` is THIS rank's share; the summary is computed from all ranks'"""
+        self.sync_buffers()
         self.model.eval()
         outs = []
         for data in batches:
@@ -217,6 +293,7 @@ class Trainer:
                 "lr_schedulers": [self.sched.state_dict()] if self.sched else [], "epoch": self.epoch, "global_step": self.global_step}
 
     def save(self, path):
+        self.sync_buffers()
         if self.rank == 0:
             os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
             tmp = f"{path}.tmp{os.getpid()}"

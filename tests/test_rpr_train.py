@@ -76,6 +76,30 @@ def test_bf16_autocast_step_and_fit(tmp_path):
     assert "val_loss/loss" in res and any("validation" in l for l in logs)
 
 
+def test_flat_gradient_step_equals_the_standard_step():
+    """TRAINING.GRAPH_STEP on a CPU device = the same step with gradients in one flat buffer and the clip on that buffer (the graph
+    capture itself needs a GPU): same loss, same clipped gradients as the standard zero_grad / backward / clip_grad_norm_ step.
+    (Parameters after Adam are not compared element by element: Adam turns a last-bit difference of a near-zero gradient into a
+    +-lr step.)"""
+    ns = _ns()
+    src = ns["SyntheticPairs"](2, 128, 96, "cpu", seed=6)
+    batches = [src.batch() for _ in range(2)]
+    out = []
+    for flat in (False, True):
+        cfg = ns["make"]()
+        cfg.TRAINING.GRAPH_STEP = flat
+        tr = ns["Trainer"](cfg, "cpu", sample=batches[0]).build()
+        assert tr.graph_step == flat
+        loss = tr.train_step(batches[0])[2].item()
+        out.append((loss, [p.grad.detach().clone() for p in tr.model.parameters()], tr))
+    assert out[0][0] == out[1][0]
+    gmax = max(float(g.abs().max()) for g in out[0][1])
+    for a, b in zip(out[0][1], out[1][1]):
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-6 * gmax)
+    assert all(p.grad.data_ptr() >= out[1][2]._flat.data_ptr() for p in out[1][2].model.parameters())       # still views of the flat buffer
+    assert abs(out[1][2].train_step(batches[1])[2].item() - out[0][2].train_step(batches[1])[2].item()) < 1e-2
+
+
 _WORKER = _SETUP + r'''
 import torch.distributed as dist
 cfg = make()
@@ -108,6 +132,23 @@ assert torch.equal(parts[0], parts[1]), "replicas diverged"
 val = tr.validate([src.batch()])
 assert "val_loss/loss" in val
 tr.save(sys.argv[1])
+# the flat-gradient mode (what TRAINING.GRAPH_STEP runs between replays): ONE all-reduce of one buffer instead of DDP's hooks
+cfg2 = make(); cfg2.TRAINING.GRAPH_STEP = True
+tr2 = Trainer(cfg2, "cpu", sample=SyntheticPairs(2, 64, 48, "cpu", seed=0, rank=0).batch()).build()
+cfg3 = make()
+tr3 = Trainer(cfg3, "cpu", sample=SyntheticPairs(2, 64, 48, "cpu", seed=0, rank=0).batch()).build()
+src2 = SyntheticPairs(2, 64, 48, "cpu", seed=9, rank=rank)
+bb = src2.batch()
+tr2.train_step(bb); tr3.train_step(bb)
+gm = max(float(p.grad.abs().max()) for p in tr3.model.parameters())
+for a, c in zip(tr2.model.parameters(), tr3.model.parameters()):       # rank-averaged, clipped gradients of the two routes
+    assert torch.allclose(a.grad, c.grad, rtol=1e-4, atol=1e-6 * gm), "flat-gradient step differs from DDP"
+tr2.train_step(src2.batch())
+f2 = torch.cat([p.detach().reshape(-1) for p in tr2.model.parameters()])
+pp = [torch.zeros_like(f2) for _ in range(2)]
+dist.all_gather(pp, f2)
+assert torch.equal(pp[0], pp[1]), "flat-gradient replicas diverged"
+tr2.validate([src2.batch()])
 sys.stdout.write(f"rank {rank} ok {tr.global_step}\n"); sys.stdout.flush()
 dist.destroy_process_group()
 '''
