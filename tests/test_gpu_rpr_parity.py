@@ -213,38 +213,46 @@ import torch
 from mapfree_reloc_amd.config import get_cfg_defaults
 from mapfree_reloc_amd.regression.train import SyntheticPairs, Trainer
 from oracle.gen_rpr_golden import CASES
-res = {}
-for mode in (False, True):
-    cfg = get_cfg_defaults()
-    cfg.merge_from_list(CASES["3d3d"][0])
-    cfg.merge_from_list(["TRAINING.LR", 1e-4, "TRAINING.GRAD_CLIP", 1.0, "TRAINING.PRECISION", "fp32", "TRAINING.GRAPH_STEP", mode])
-    src = SyntheticPairs(4, 96, 72, "cuda:0", seed=21)
-    batches = [src.batch() for _ in range(3)]
-    tr = Trainer(cfg, "cuda:0", sample=batches[0]).build()
-    losses = [tr.train_step(b)[2].item() for b in batches]
-    g = torch.cat([p.grad.reshape(-1).float() for p in tr.model.parameters() if p.grad is not None])
-    res[mode] = (losses, g.clone(), tr)
-print("captured", res[True][2]._gstep is not None)
-l0, l1 = res[False][0], res[True][0]
-print("loss0 equal", abs(l0[0] - l1[0]) <= 1e-4 * max(1.0, abs(l0[0])), l0, l1)
-g0, g1 = res[False][1], res[True][1]
-print("grad rel diff", float((g0 - g1).norm() / g0.norm()))
-print("finite", all(torch.isfinite(p).all().item() for p in res[True][2].model.parameters()))
+cfg = get_cfg_defaults()
+cfg.merge_from_list(CASES["3d3d"][0])
+cfg.merge_from_list(["TRAINING.LR", 1e-4, "TRAINING.GRAD_CLIP", 1.0, "TRAINING.PRECISION", "fp32", "TRAINING.GRAPH_STEP", True])
+src = SyntheticPairs(4, 96, 72, "cuda:0", seed=21)
+b0, b1, b2 = src.batch(), src.batch(), src.batch()
+tr = Trainer(cfg, "cuda:0", sample=b0).build()
+tr.model.train()
+rel = lambda a, b: float((a - b).norm() / a.norm())
+eager = lambda b: (tr._fwd_bwd(b), tr._flat.clone())
+# same parameters, no optimiser step in between: eager twice (run-to-run noise of MIOpen's atomically accumulated weight gradients),
+# then the captured graph on the same batches
+(l0, e0), (_, e0b), (l1, e1), (_, e1b) = eager(b0), eager(b0), eager(b1), eager(b1)
+from mapfree_reloc_amd.nets.graph import GraphedCall
+keys = sorted(b0)
+g = GraphedCall(lambda *ts: tr._fwd_bwd(dict(zip(keys, ts))), [b0[k] for k in keys], warmup=3, clone_outputs=True)
+for name, b, e, eb, l in (("b0", b0, e0, e0b, l0), ("b1", b1, e1, e1b, l1)):
+    lr_ = g(*[b[k] for k in keys]); r = tr._flat.clone()
+    print(name, "faithful", rel(e, r) <= 1e-2, "tight", rel(e, r) <= 1e-4, rel(e, r), rel(e, eb), abs(lr_[2].item() - l[2].item()) <= 1e-4 * max(1.0, abs(l[2].item())))
+# and the trainer's own path: capture at the first step, replays afterwards, parameters move and stay finite
+p0 = torch.cat([p.detach().reshape(-1) for p in tr.model.parameters()]).clone()
+losses = [tr.train_step(b)[2].item() for b in (b0, b1, b2)]
+print("captured", tr._gstep is not None, "finite", all(torch.isfinite(p).all().item() for p in tr.model.parameters()) and all(x == x for x in losses),
+      "moved", not torch.equal(p0, torch.cat([p.detach().reshape(-1) for p in tr.model.parameters()])))
 print("done")
 """
 
 
 def test_graph_step_trainer_in_a_child_process():
     """TRAINING.GRAPH_STEP on the device: forward + loss + backward replayed from one HIP graph (possible because nothing in the step
-    synchronises the host any more), gradients in one flat buffer.  First-step loss equal to the eager trainer's; later losses and
-    the last gradients agree to the run-to-run noise of MIOpen's atomically accumulated weight gradients.  Child process: a capture
-    problem must not take the test session with it."""
+    synchronises the host any more), gradients in one flat buffer.  With the SAME parameters and batch the replay's gradients equal
+    the eager ones -- to 1e-5 relative for a well-conditioned batch; an ill-conditioned batch shows the 0.4 %% spread that MIOpen's
+    per-handle (= per-stream) solver selection also produces between two eager runs (tools/diag_graph_step.py) -- for the capture batch
+    and for a new one; the trainer captures at its first step and keeps training.  Child process: a capture problem must not take the
+    test session with it."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", _GRAPH_STEP % root], capture_output=True, text=True, timeout=600)
     out = r.stdout
     assert "done" in out, out[-1500:] + r.stderr[-2500:]
-    assert "captured True" in out and "loss0 equal True" in out and "finite True" in out, out[-1500:]
-    rel = float(out.split("grad rel diff")[1].split()[0])
-    assert rel < 0.05, out[-1500:]
+    assert "b0 faithful True" in out and "b1 faithful True" in out and "tight True" in out, out[-1500:]
+    assert "captured True finite True moved True" in out, out[-1500:]
+    assert all(line.split()[-1] == "True" for line in out.splitlines() if line.startswith(("b0 ", "b1 "))), out[-1500:]     # losses equal
