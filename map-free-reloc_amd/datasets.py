@@ -176,6 +176,71 @@ class MapFreeScene:
                 "scene_root": self.scene_root, "pair_id": index * self.sample_factor, "pair_names": (p1, p2)}
 
 
+class MapFreeSceneMultiFrame(MapFreeScene):
+    """multi-frame queries (lib/datasets/mapfree.py:273-368 with load_pairs' sample_offset branches :89-141, :166-205; used by
+    RegressionMultiFrameModel): `image1` is the stack of the `query_frames` consecutive VALID frames that end at the query frame
+    [T,3,H,W] (depth1 [T,H,W]), poses / intrinsics are those of the LAST frame.
+      val / test: queries = every (query_frames + 1)-th seq1 frame starting at index query_frames of the sorted frame list;
+      train (overlaps.npz): every overlap row whose query frame has query_frames - 1 valid predecessors in its sequence and whose
+      map frame does not fall inside that window (different sequence, or before the window, or after the query frame) -- the valid
+      frame lists are taken BEFORE the overlap window is applied, like upstream.
+    The device-tracking poses (poses_device.txt) only feed upstream's debug plot and are not read."""
+
+    def __init__(self, scene_root, resize, query_frames=9, estimated_depth=None, overlap_limits=None, black_white=False):
+        import re
+        T = int(query_frames)
+        if T < 2:
+            raise ValueError("query_frames must be >= 2 (use MapFreeScene for single-frame queries)")
+        super().__init__(scene_root, resize, 1, estimated_depth, None, black_white)
+        self.query_frames, self.sample_factor = T, T + 1
+        ov = os.path.join(self.scene_root, "overlaps.npz")
+        if os.path.exists(ov):
+            f = np.load(ov, allow_pickle=False)
+            idxs, overlaps = np.asarray(f["idxs"]).astype(np.int64), np.asarray(f["overlaps"])
+            valid = {q: sorted(set(idxs[idxs[:, 0] == q, 1].tolist()) | set(idxs[idxs[:, 2] == q, 3].tolist())) for q in (0, 1)}
+            where = {q: {im: k for k, im in enumerate(valid[q])} for q in (0, 1)}
+            if overlap_limits is not None and overlap_limits[0] is not None:
+                idxs = idxs[np.logical_and(overlap_limits[0] < overlaps, overlaps < overlap_limits[1])]
+            pairs = []
+            for sa, ia, sb, ib in idxs.tolist():
+                k = where[sb][ib] - T + 1
+                if k < 0:
+                    continue
+                window = valid[sb][k:k + T]
+                if sa != sb or ia < window[0] or ib < ia:
+                    pairs.append((sa, ia, sb, tuple(window)))
+            self.pairs = pairs
+        else:
+            ids = sorted(int(re.search(r"_(\d+)\..*$", fn).group(1)) for fn in self.poses if "seq0" not in fn)
+            self.pairs = [(0, 0, 1, tuple(ids[k - T + 1:k + 1])) for k in range(T, len(ids), T + 1)]
+
+    def pair_name(self, index):
+        sa, ia, sb, ibs = self.pairs[index]
+        return f"seq{sb}/frame_{ibs[-1]:05}.jpg"
+
+    def __getitem__(self, index):
+        from . import evaluation as E
+        sa, ia, sb, ibs = self.pairs[index]
+        p1, p2s = f"seq{sa}/frame_{ia:05}.jpg", tuple(f"seq{sb}/frame_{ib:05}.jpg" for ib in ibs)
+        rd = lambda p: read_color_image(os.path.join(self.scene_root, p), self.resize)
+        img1, img2 = rd(p1), torch.stack([rd(p) for p in p2s])
+        if self.black_white:
+            img1, img2 = _luma3(img1), torch.stack([_luma3(im) for im in img2])
+        if self.estimated_depth is not None:
+            dp = lambda p: read_depth_image(os.path.join(self.scene_root, p).replace(".jpg", f".{self.estimated_depth}.png"))
+            d1, d2 = dp(p1), torch.stack([dp(p) for p in p2s])
+        else:
+            d1 = d2 = torch.tensor([])
+        (q1, t1), (q2, t2) = self.poses[p1], self.poses[p2s[-1]]
+        q12 = E.qmult(q2, E.qinverse(q1))
+        t12 = t2 - E.rotate_vector(t1, q12)
+        T = np.eye(4, dtype=np.float32); T[:3, :3] = E.quat2mat(q12); T[:3, -1] = t12
+        return {"image0": img1, "depth0": d1, "image1": img2, "depth1": d2, "T_0to1": torch.from_numpy(T),
+                "K_color0": torch.from_numpy(self.K[p1].copy()), "K_color1": torch.from_numpy(self.K[p2s[-1]].copy()),
+                "dataset_name": "Mapfree", "scene_id": os.path.basename(self.scene_root.rstrip("/")),
+                "scene_root": self.scene_root, "pair_id": index * self.sample_factor, "pair_names": (p1, p2s)}
+
+
 def _luma3(img):
     l = 0.2989 * img[0] + 0.587 * img[1] + 0.114 * img[2]
     return l[None].expand(3, -1, -1).contiguous()
@@ -203,6 +268,11 @@ def list_scenes(cfg, split="val"):
     names = sorted(d for d in os.listdir(os.path.join(str(root), split)) if os.path.isdir(os.path.join(str(root), split, d)))
     if cfg.DATASET.SCENES:
         names = [s for s in names if s in cfg.DATASET.SCENES]
+    qf = int(cfg.DATASET.QUERY_FRAME_COUNT or 1)
+    if qf > 1:                                                  # mapfree.py:383-396: RegressionMultiFrame data
+        limits = (cfg.DATASET.MIN_OVERLAP_SCORE, cfg.DATASET.MAX_OVERLAP_SCORE) if split == "train" else None
+        return [MapFreeSceneMultiFrame(os.path.join(str(root), split, s), resize, qf, cfg.DATASET.ESTIMATED_DEPTH, limits,
+                                       bool(cfg.DATASET.BLACK_WHITE) and split == "train") for s in names]
     if split == "train":                                        # MapFreeDataset.__init__ (mapfree.py:371-400): sample_factor 1, overlap window
         limits = (cfg.DATASET.MIN_OVERLAP_SCORE, cfg.DATASET.MAX_OVERLAP_SCORE)
         return [MapFreeScene(os.path.join(str(root), split, s), resize, 1, cfg.DATASET.ESTIMATED_DEPTH, limits, bool(cfg.DATASET.BLACK_WHITE))

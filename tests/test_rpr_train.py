@@ -231,3 +231,40 @@ def test_training_split_reader_sampler_and_loader(tmp_path):
     tr = ns["Trainer"](cfg, "cpu", sample=batch).build()
     assert all(x == x for x in (v.item() for v in tr.train_step(batch)))
     assert sum(1 for _ in vl) == 1 and "val_loss/loss" in tr.validate(list(vl))       # 3 val pairs (every 5th of 6... ) -> drop_last
+
+
+def test_multi_frame_query_reader(tmp_path):
+    """lib/datasets/mapfree.py:273-368 + load_pairs' sample_offset branches: val/test windows of T consecutive frames every T+1, train
+    rows filtered by window availability / map-frame-outside-window on the UNFILTERED valid-frame lists; image1 [T,3,H,W]"""
+    import numpy as np
+    from mapfree_reloc_amd.datasets import MapFreeSceneMultiFrame, list_scenes
+    ns = _ns()
+    rng = np.random.default_rng(8)
+    T = 3
+    idxs, ov = _write_train_scene(tmp_path / "train", "s00001", 8, rng, 60)
+    sc = MapFreeSceneMultiFrame(tmp_path / "train" / "s00001", (36, 48), T, None, (0.3, 0.9))
+    # brute-force restatement of the upstream comprehension
+    idx64 = idxs.astype(np.int64)
+    valid = {q: sorted(set(idx64[idx64[:, 0] == q, 1]) | set(idx64[idx64[:, 2] == q, 3])) for q in (0, 1)}
+    want = []
+    for (sa, ia, sb, ib), o in zip(idx64.tolist(), ov.tolist()):
+        if not (0.3 < o < 0.9):
+            continue
+        k = valid[sb].index(ib) - T + 1
+        if k < 0:
+            continue
+        w = tuple(int(v) for v in valid[sb][k:k + T])
+        if sa != sb or ia < w[0] or ib < ia:
+            want.append((sa, ia, sb, w))
+    assert sc.pairs == want and len(want) > 5
+    d = sc[2]
+    assert d["image1"].shape == (T, 3, 48, 36) and d["image0"].shape == (3, 48, 36) and d["pair_id"] == 2 * (T + 1)
+    assert d["pair_names"][1][-1] == f"seq{want[2][2]}/frame_{want[2][3][-1]:05d}.jpg" and len(d["pair_names"][1]) == T
+    # val layout: windows end at positions T, 2T+1, ... of the sorted seq1 frames
+    _write_train_scene(tmp_path / "val", "s00460", 9, rng, 1)
+    os.remove(tmp_path / "val" / "s00460" / "overlaps.npz")
+    cfg = ns["make"]()
+    cfg.merge_from_list(["DATASET.DATA_ROOT", str(tmp_path), "DATASET.HEIGHT", 48, "DATASET.WIDTH", 36, "DATASET.QUERY_FRAME_COUNT", T])
+    (val,) = list_scenes(cfg, "val")
+    assert isinstance(val, MapFreeSceneMultiFrame) and [p[3] for p in val.pairs] == [(1, 2, 3), (5, 6, 7)]
+    assert val.pair_name(1) == "seq1/frame_00007.jpg" and val[0]["image1"].shape == (T, 3, 48, 36)
