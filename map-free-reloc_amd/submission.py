@@ -49,10 +49,24 @@ def _has_pose(R, t):
     return not (np.isnan(R).any() or np.isnan(t).any() or np.isinf(t).any())       # submission.py:48-49
 
 
+def data_to_model_device(data, model):
+    """lib/utils/data.py:4-17: tensors follow the model's parameters; a model without parameters (the matching baselines: their
+    solvers take host arrays) keeps the batch on the host"""
+    try:
+        device = next(model.parameters()).device
+    except (StopIteration, AttributeError):
+        device = torch.device('cpu')
+    for k, v in data.items():
+        if torch.is_tensor(v):
+            data[k] = v.to(device)
+    return data
+
+
 def predict(loader, model):
     """scene -> [Pose] over a batch-1 loader; pairs without an estimate are left out"""
     results = defaultdict(list)
     for data in loader:
+        data = data_to_model_device(data, model)                # submission.py:39
         with torch.no_grad():
             R, t = model(data)
         R, t = R.detach().cpu().numpy(), t.detach().cpu().numpy().reshape(-1)

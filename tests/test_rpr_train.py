@@ -268,3 +268,26 @@ def test_multi_frame_query_reader(tmp_path):
     (val,) = list_scenes(cfg, "val")
     assert isinstance(val, MapFreeSceneMultiFrame) and [p[3] for p in val.pairs] == [(1, 2, 3), (5, 6, 7)]
     assert val.pair_name(1) == "seq1/frame_00007.jpg" and val[0]["image1"].shape == (T, 3, 48, 36)
+
+
+def test_regression_model_through_the_submission_loop(tmp_path):
+    """build_model(cfg) for MODEL 'Regression' + submission.predict / save_submission (submission.py:33-65 with data_to_model_device,
+    lib/utils/data.py:4-17): every pair gets a finite pose line with confidence 0"""
+    from mapfree_reloc_amd import submission
+    from mapfree_reloc_amd.builder import build_model
+    from mapfree_reloc_amd.datasets import make_loader
+    ns = _ns()
+    cfg = ns["make"]()
+    cfg.merge_from_list(["DATASET.SYNTHETIC", [2, 3], "DATASET.HEIGHT", 256, "DATASET.WIDTH", 192])
+    torch.manual_seed(0)
+    model = build_model(cfg)
+    assert not model.training
+    res = submission.predict(make_loader(cfg, "val"), model)
+    assert sorted(res) == ["s00000", "s00001"] and all(len(v) == 3 for v in res.values())
+    z = tmp_path / "submission.zip"
+    submission.save_submission(res, z)
+    import zipfile
+    with zipfile.ZipFile(z) as zf:
+        lines = zf.read("pose_s00000.txt").decode().strip().splitlines()
+    assert len(lines) == 3 and all(len(l.split()) == 9 and l.split()[-1] == "0" for l in lines)
+    assert abs(sum(float(v) ** 2 for v in lines[0].split()[1:5]) - 1.0) < 1e-4          # unit quaternion
