@@ -302,3 +302,38 @@ def test_plugin_image_staging_equals_the_torch_path():
         assert out.shape == (2, 1, 48, 36) and out.dtype == torch.float32 and torch.equal(out, ref)
     assert st(d) is out                                        # same persistent buffer
     assert st({"image0": torch.rand(1, 3, 24, 20), "image1": torch.rand(1, 3, 24, 20)}).shape == (2, 1, 24, 20)
+
+
+def test_sharding_and_sampler_properties():
+    """size-independent properties: shard_range partitions [0, n) in order for any world size; shard_scenes keeps scenes whole, in order
+    and balanced to within one scene's weight; the scene-balanced sampler's epoch is the same multiset whatever the world size"""
+    from hypothesis import given, settings, strategies as st
+    from mapfree_reloc_amd.datasets import SceneBalancedSampler
+    from mapfree_reloc_amd.parallel import shard_range, shard_scenes
+
+    @settings(max_examples=60, deadline=None)
+    @given(st.integers(0, 5000), st.integers(1, 16))
+    def ranges(n, world):
+        parts = [shard_range(n, world, r) for r in range(world)]
+        flat = [i for lo, hi in parts for i in range(lo, hi)]
+        assert flat == list(range(n)) and max(hi - lo for lo, hi in parts) - min(hi - lo for lo, hi in parts) <= 1
+    ranges()
+
+    @settings(max_examples=60, deadline=None)
+    @given(st.lists(st.integers(1, 600), min_size=1, max_size=40), st.integers(1, 8))
+    def scenes(sizes, world):
+        blocks = shard_scenes(sizes, world)
+        assert len(blocks) == world
+        flat = [i for b in blocks for i in (range(*b) if isinstance(b, tuple) else b)]
+        assert flat == list(range(len(sizes)))                  # every scene exactly once, in order, contiguous blocks
+    scenes()
+
+    @settings(max_examples=30, deadline=None)
+    @given(st.lists(st.integers(1, 50), min_size=1, max_size=8), st.integers(1, 12), st.booleans(), st.integers(1, 5))
+    def sampler(sizes, n, repl, world):
+        whole = sorted(SceneBalancedSampler(sizes, n, repl).epoch_indices().tolist())
+        dealt = sorted(i for r in range(world) for i in SceneBalancedSampler(sizes, n, repl, rank=r, world=world))
+        assert whole == dealt and len(whole) == n * len(sizes)
+        bounds = np.cumsum([0] + sizes)
+        assert all(sum(bounds[k] <= i < bounds[k + 1] for i in whole) == n for k in range(len(sizes)))
+    sampler()
