@@ -346,11 +346,16 @@ class PairBatchLoader:
         has_depth = samples[0]["depth0"].numel() > 0
         depth0 = mk(b, Hh, Ww) if has_depth else None
         depth1 = mk(b, Hh, Ww) if has_depth else None
+        # packing through the buffers' numpy views: plain memcpy on this thread (a torch copy_ of a 1.5 MB plane is dispatched to
+        # the intra-op thread pool)
+        npv = lambda t: t.numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
+        im_np = images.numpy()
+        d0_np, d1_np = (depth0.numpy(), depth1.numpy()) if has_depth else (None, None)
         for p, smp in enumerate(samples):
-            images[2 * p, 0] = to_gray(smp["image0"]); images[2 * p + 1, 0] = to_gray(smp["image1"])
+            im_np[2 * p, 0] = npv(to_gray(smp["image0"])); im_np[2 * p + 1, 0] = npv(to_gray(smp["image1"]))
             K0[p] = smp["K_color0"].to(torch.float32); K1[p] = smp["K_color1"].to(torch.float32)
             if has_depth:
-                depth0[p] = smp["depth0"]; depth1[p] = smp["depth1"]
+                d0_np[p] = npv(smp["depth0"]); d1_np[p] = npv(smp["depth1"])
         return dict(images=images, depth0=depth0, depth1=depth1, K0=K0, K1=K1,
                     seed_ids=torch.tensor([int(smp["pair_id"]) for smp in samples], dtype=torch.int64),
                     global_ids=torch.arange(self.offsets[si] + lo, self.offsets[si] + hi, dtype=torch.int64),

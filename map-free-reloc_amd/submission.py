@@ -138,8 +138,12 @@ def predict_fused(cfg, split, output_root, pipeline=None, batch_pairs=None, resu
     B = int(batch_pairs or cfg.HIP.BATCH_PAIRS)
 
     todo = [i for i in range(lo, hi) if not (resume and (out_dir / f'pose_{scenes[i].scene_id}.txt').exists())]
+    # decode threads: a pair costs ~45 ms of JPEG / PNG decode on one core (2 images + depth maps), the pipeline consumes 100-700 pairs/s
+    # per GPU: the host's cores are split between the ranks of this node
+    local_world = int(os.environ.get('LOCAL_WORLD_SIZE', world)) if world > 1 else 1
+    workers = max(4, min(32, (os.cpu_count() or 8) // max(1, local_world)))
     loader = PairBatchLoader([scenes[i] for i in todo], B, prefetch=prefetch, pin=device.type == 'cuda',
-                             global_offsets=[int(offsets[i]) for i in todo])
+                             global_offsets=[int(offsets[i]) for i in todo], workers=workers)
     recs, names, acc = [], {}, []
     for batch in DevicePrefetcher(loader, device):
         out = pipeline(batch)
