@@ -1,0 +1,43 @@
+"""CPU: this package's Map-free pair lists (training overlap window, val/test sub-sampling, multi-frame windows), the rescaled
+float64 intrinsics and the scene-balanced sampler against outputs of the REFERENCE'S OWN lib/datasets/{mapfree,sampler}.py executed in
+the build container (tests/golden/ref_data_pairs.npz, written by oracle/gen_data_golden.py)."""
+import os
+
+import numpy as np
+import pytest
+
+from mapfree_reloc_amd.datasets import MapFreeScene, MapFreeSceneMultiFrame, SceneBalancedSampler
+from oracle.gen_data_golden import write_tree
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "ref_data_pairs.npz")
+
+
+@pytest.fixture(scope="module")
+def g():
+    return np.load(GOLD)
+
+
+def test_training_and_val_pair_lists_equal_the_reference(g, tmp_path):
+    T, n_frames = int(g["T"]), int(g["n_frames"])
+    lim = tuple(float(v) for v in g["limits"])
+    write_tree(tmp_path / "train", n_frames, g["idxs"], g["overlaps"], train=True)
+    write_tree(tmp_path / "val", n_frames, g["idxs"], g["overlaps"], train=False)
+    sc = MapFreeScene(tmp_path / "train", (270, 360), 1, None, lim)
+    assert np.array_equal(np.asarray(sc.pairs, np.int64), g["train_single"])
+    K = sc.K["seq0/frame_00000.jpg"]
+    assert K.dtype == np.float64 and np.array_equal(K, g["K_first"])                      # bit-equal rescaled intrinsics
+    mf = MapFreeSceneMultiFrame(tmp_path / "train", (270, 360), T, None, lim)
+    assert np.array_equal(np.asarray([p[:3] for p in mf.pairs], np.int64).reshape(-1, 3), g["train_multi_head"])
+    assert np.array_equal(np.asarray([p[3] for p in mf.pairs], np.int64).reshape(-1, T), g["train_multi_window"])
+    vs = MapFreeScene(tmp_path / "val", (540, 720), 5)
+    assert np.array_equal(np.asarray(vs.pairs, np.int64), g["val_single"])
+    vm = MapFreeSceneMultiFrame(tmp_path / "val", (540, 720), T)
+    assert np.array_equal(np.asarray([p[3] for p in vm.pairs], np.int64).reshape(-1, T), g["val_multi_window"])
+
+
+@pytest.mark.parametrize("tag,repl", [("repl", True), ("norepl", False)])
+def test_scene_balanced_sampler_equals_the_reference_stream(g, tag, repl):
+    """same generator seed (66), same draw order: the epoch index lists are IDENTICAL to RandomConcatSampler's, epoch after epoch"""
+    s = SceneBalancedSampler([int(v) for v in g["sampler_sizes"]], 6, repl)
+    assert np.array_equal(np.asarray(list(s), np.int64), g[f"sampler_{tag}_e0"])
+    assert np.array_equal(np.asarray(list(s), np.int64), g[f"sampler_{tag}_e1"])
