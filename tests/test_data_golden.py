@@ -41,3 +41,20 @@ def test_scene_balanced_sampler_equals_the_reference_stream(g, tag, repl):
     s = SceneBalancedSampler([int(v) for v in g["sampler_sizes"]], 6, repl)
     assert np.array_equal(np.asarray(list(s), np.int64), g[f"sampler_{tag}_e0"])
     assert np.array_equal(np.asarray(list(s), np.int64), g[f"sampler_{tag}_e1"])
+
+
+def test_pose_lines_and_zip_members_equal_the_reference(tmp_path):
+    """submission.Pose.__str__ / save_submission against the reference's own submission.py executed on the same seeded poses
+    (tests/golden/ref_submission_format.npz, oracle/gen_submission_golden.py): every line byte for byte (float32 and float64 inputs,
+    negative zero, tiny / large magnitudes, int / float / numpy confidences), member names, order and contents of the archive"""
+    import zipfile
+    from mapfree_reloc_amd.submission import Pose, save_submission
+    from oracle.gen_submission_golden import cases
+    gz = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_submission_format.npz"))
+    cs = cases()
+    assert [str(Pose(n, q, t, c)) for n, q, t, c in cs] == gz["lines"].tolist()
+    res = {"s00460": [Pose(*c) for c in cs[:10]], "s00461": [], "s00462": [Pose(*c) for c in cs[10:]]}
+    save_submission(res, tmp_path / "s.zip")
+    with zipfile.ZipFile(tmp_path / "s.zip") as zf:
+        assert zf.namelist() == gz["members"].tolist()
+        assert [zf.read(m).decode("utf-8") for m in zf.namelist()] == gz["texts"].tolist()
