@@ -58,3 +58,15 @@ def test_pose_lines_and_zip_members_equal_the_reference(tmp_path):
     with zipfile.ZipFile(tmp_path / "s.zip") as zf:
         assert zf.namelist() == gz["members"].tolist()
         assert [zf.read(m).decode("utf-8") for m in zf.namelist()] == gz["texts"].tolist()
+
+
+def test_config_schema_holds_every_reference_key_with_its_default():
+    """config/default.py of the reference, executed (oracle/gen_config_golden.py): all 69 keys exist here with the same default, so
+    every yaml the reference accepts merges and behaves the same; this package's additions are extra keys only"""
+    import json
+    from mapfree_reloc_amd.config import get_cfg_defaults
+    from oracle.gen_config_golden import flat
+    ref = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ref_config_defaults.json")))
+    ours = flat(get_cfg_defaults())
+    assert len(ref) == 69 and not [k for k in ref if k not in ours]
+    assert {k: (ref[k], ours[k]) for k in ref if ref[k] != ours[k]} == {}
