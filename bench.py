@@ -41,6 +41,8 @@ H, W = 720, 540                      # config/mapfree.yaml:7-8, compute.py:42
 FP32_MFMA_PEAK_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md (v_mfma_f32_32x32x2_f32 / 16x16x4_f32)
 HBM_PEAK_GBS = 8000.0                # same guide: 8.0 TB/s spec (6.3 TB/s achievable)
 CONFIGS = ("sg_pnp", "loftr_emat", "rpr_train")
+# v_exp_f32 is a quarter-rate VALU op: 256 CUs x 4 SIMDs x 16 lanes / 4 per clock at the 2.4 GHz peak engine clock
+EXP_PEAK_GOPS = 256 * 4 * 16 / 4 * 2.4
 
 
 def parse(argv=None):
@@ -57,6 +59,9 @@ def parse(argv=None):
     ap.add_argument("--cpu-out", default="", help=argparse.SUPPRESS)
     ap.add_argument("--no-kernel-timer", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--verbose", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="default run (sg_pnp, 1 GPU): do not append the loftr_emat and rpr_train "
+                    "bench lines under \"secondary\"")
+    ap.add_argument("--secondary-budget", type=float, default=110.0, help="seconds each secondary config may take (child process)")
     ap.add_argument("--graph", type=int, default=0, help="sg_pnp: 1 = replay the whole step from one captured HIP graph (inputs copied into the "
                     "graph's static buffers every step), 0 = eager launches (default: at 8-32 pairs per step the eager step is GPU-bound, "
                     "measured 699 vs 694 pairs/s).  With 1 the roofline kernels are timed with HIP events over extra eager steps AFTER the "
@@ -191,15 +196,16 @@ class SgPnpWorkload:
         from mapfree_reloc_amd.pipeline import SuperGluePnPPipeline
         self.B = B
         self.pipe = SuperGluePnPPipeline(dev, seed=0, graph=graph)
-        self.att_timer, self.conv_timer = KernelTimer(every=9), KernelTimer(every=1)
+        self.att_timer, self.conv_timer, self.sk_timer = KernelTimer(every=9), KernelTimer(every=1), KernelTimer(every=1)
         if timers:
             self.pipe.sg.attention = self.att_timer.wrap(self.pipe.sg.attention)
+            self.pipe.sg.sinkhorn_match = self.sk_timer.wrap(self.pipe.sg.sinkhorn_match)
             sp_conv, timed_conv = self.pipe.sp._conv, self.conv_timer.wrap(self.pipe.sp._conv)
             self.pipe.sp._conv = lambda x, name, **kw: (timed_conv if name == "conv1b" else sp_conv)(x, name, **kw)
         self.kp_sum, self.kp_cnt = 0.0, 0
 
     def timers(self):
-        return [self.att_timer, self.conv_timer]
+        return [self.att_timer, self.conv_timer, self.sk_timer]
 
     def run(self, d):
         return self.pipe(d["images"], d["depth0"], d["K0"], d["K1"], d["pair_ids"])
@@ -233,7 +239,27 @@ class SgPnpWorkload:
                 "other_kernels": [{"kernel": "sg_attention_kernel", "bound": "mfma", "achieved": round(att_tf, 2) if att_tf else None,
                                    "peak": FP32_MFMA_PEAK_TFLOPS, "frac": round(att_tf / FP32_MFMA_PEAK_TFLOPS, 4) if att_tf else None,
                                    "avg_launch_ms": round(att_ms, 4) if att_ms else None, "launches_timed": len(self.att_timer.events),
-                                   "mean_keypoints_per_image": round(nk, 1)}]}
+                                   "mean_keypoints_per_image": round(nk, 1)},
+                                  self._sinkhorn_line(out)]}
+
+    def _sinkhorn_line(self, out):
+        """log-Sinkhorn + mutual arg-max stage.  Its binding resource is the transcendental ALU, not HBM: 2 x iters x (n+1)^2
+        exp per pair against 4.2 MB of algorithmic reads -- so the line carries the exp rate against the quarter-rate VALU peak
+        and, for reference, the algorithmic-bytes rate (which no schedule can bring near the HBM roofline)."""
+        sk_ms = self.sk_timer.mean_ms()
+        iters = 20
+        n0 = out["n_kpts"][0::2].double() + 1 if "n_kpts" in out else torch.full((self.B,), 1025.0)
+        n1 = out["n_kpts"][1::2].double() + 1 if "n_kpts" in out else torch.full((self.B,), 1025.0)
+        n_exp = float((2.0 * iters * n0 * n1).sum())
+        alg_bytes = float((4.0 * (n0 - 1) * (n1 - 1)).sum())
+        g = n_exp / (sk_ms * 1e-3) / 1e9 if sk_ms else None
+        return {"kernel": "sg_row/col_kernel x 2*iters + sg_match (mfr_sg_sinkhorn_match: log-Sinkhorn, mutual arg-max, threshold, compaction)",
+                "bound": "alu (v_exp_f32, quarter rate)", "achieved": round(g, 1) if g else None, "peak": EXP_PEAK_GOPS, "unit": "Gexp/s",
+                "frac": round(g / EXP_PEAK_GOPS, 4) if g else None, "avg_launch_ms": round(sk_ms, 4) if sk_ms else None,
+                "launches_timed": len(self.sk_timer.events), "exp_per_launch": n_exp,
+                "hbm_view": {"algorithmic_bytes_per_launch": alg_bytes, "achieved_gbs": round(alg_bytes / (sk_ms * 1e-3) / 1e9, 1) if sk_ms else None,
+                             "frac_of_hbm_peak": round(alg_bytes / (sk_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if sk_ms else None,
+                             "note": "S is read once algorithmically; the implementation streams the MALL-resident matrix 42 times"}}
 
 
 class LoftrEmatWorkload:
@@ -273,16 +299,26 @@ class LoftrEmatWorkload:
         L = 90 * 68
         cm_bytes = 2.0 * L * 256 * 4 * B
         cm_gbs = cm_bytes / (cm_ms * 1e-3) / 1e9 if cm_ms else None
+        cm_flops = 2.0 * L * L * 256 * B                      # the similarity contraction (19.2 GFLOP/pair)
+        cm_tf = cm_flops / (cm_ms * 1e-3) / 1e12 if cm_ms else None
+        cm_impl_bytes = (3.0 * L * L * 4 + 2.0 * L * 256 * 4) * B   # as implemented: S written once, swept twice, features in
+        cm_impl_gbs = cm_impl_bytes / (cm_ms * 1e-3) / 1e9 if cm_ms else None
         return {"kernel": "wino_conv3x3 layer1_outconv2.0 launch, 196->196 ch at 360x272 (dominant kernel: fused Winograd F(2x2,3x3) convolutions of the ResNet-FPN backbone)",
                 "bound": "mfma", "achieved": round(achieved, 2) if achieved else None, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4) if achieved else None, "traffic": _traffic("loftr_l1out2", B),
                 "avg_launch_ms": round(conv_ms, 4) if conv_ms else None, "launches_timed": len(self.conv_timer.events), "flops_per_launch": conv_flops,
                 "other_kernels": [{"kernel": "dual-softmax coarse matching (similarity + row/col softmax statistics + mutual-NN selection)",
-                                   "bound": "hbm", "achieved": round(cm_gbs, 1) if cm_gbs else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                   "frac": round(cm_gbs / HBM_PEAK_GBS, 5) if cm_gbs else None, "avg_launch_ms": round(cm_ms, 4) if cm_ms else None,
-                                   "algorithmic_bytes_per_launch": cm_bytes,
-                                   "note": "algorithmic bytes = coarse features in (12.5 MB/pair, SURVEY 8d); the stage is a 19 GFLOP/pair "
-                                           "contraction evaluated on the fp32 matrix cores, so its floor is MFMA time, not HBM time"}]}
+                                   "bound": "mfma + hbm (fp32 similarity GEMM, then two streaming sweeps over the materialised S)",
+                                   "achieved": round(cm_tf, 2) if cm_tf else None, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                   "frac": round(cm_tf / FP32_MFMA_PEAK_TFLOPS, 4) if cm_tf else None,
+                                   "avg_launch_ms": round(cm_ms, 4) if cm_ms else None, "flops_per_launch": cm_flops,
+                                   "hbm_view": {"implemented_bytes_per_launch": cm_impl_bytes,
+                                                "implemented_gbs": round(cm_impl_gbs, 1) if cm_impl_gbs else None,
+                                                "implemented_frac_of_hbm_peak": round(cm_impl_gbs / HBM_PEAK_GBS, 4) if cm_impl_gbs else None,
+                                                "algorithmic_bytes_per_launch": cm_bytes,
+                                                "algorithmic_frac_of_hbm_peak": round(cm_gbs / HBM_PEAK_GBS, 5) if cm_gbs else None},
+                                   "note": "time = contraction on the fp32 matrix cores + 3 passes over S (150 MB/pair); algorithmic bytes "
+                                           "(features in, 12.5 MB/pair) are not what bounds it -- both fractions are given"}]}
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -408,6 +444,24 @@ def rpr_train_bench(args, rank, world, dev, use_dist):
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline_subprocess("rpr_train", args.cpu_pairs, args.cpu_threads, "")
     print(json.dumps(line))
+
+
+def secondary_line(config, extra, budget_s):
+    """python bench.py --config <config> in a child process -> its parsed JSON line (or an error record, never an exception)"""
+    import subprocess
+    t0 = time.perf_counter()
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--gpus", "1", "--config", config, "--no-secondary"] + extra,
+                           capture_output=True, text=True, timeout=budget_s, env=env)
+        for ln in reversed(r.stdout.strip().splitlines()):
+            if ln.startswith("{"):
+                out = json.loads(ln)
+                out["wall_s"] = round(time.perf_counter() - t0, 1)
+                return out
+        return {"config": {"workload": config}, "value": None, "error": (r.stderr or "no output")[-400:]}
+    except subprocess.TimeoutExpired:
+        return {"config": {"workload": config}, "value": None, "error": f"exceeded its {budget_s:.0f}s budget"}
 
 
 def _traffic(tag, B):
@@ -587,6 +641,12 @@ def main():
                         cfg["parity"] = parity_leg(wl, npz, dev)
                     except Exception as e:        # never lose the bench line over the parity side-note
                         cfg["parity"] = {"error": str(e)[:300]}
+        if world == 1 and args.config == "sg_pnp" and not args.no_secondary:
+            # the other two single-GPU configurations BASELINE.json names, each with its OWN timed region, roofline, cpu_baseline
+            # and parity, measured by this same script in a child process right after the headline (the driver runs only the
+            # default command): configs[2] LoFTR + E-mat and configs[4] the bf16 regression training step
+            line["secondary"] = [secondary_line("loftr_emat", ["--steps", "8", "--warmup", "2", "--cpu-pairs", "2"], args.secondary_budget),
+                                 secondary_line("rpr_train", ["--steps", "20", "--warmup", "3", "--cpu-pairs", "4"], args.secondary_budget)]
         print(json.dumps(line))
     if use_dist:
         dist.destroy_process_group()

@@ -17,8 +17,18 @@
  *   - batches: leading dim B = image pairs; correspondences are fixed-stride
  *     [B, maxN, 2] float32 with a count n_corr[B] (the device-side twin of the
  *     NaN-padded [Npairs, maxN, 4] npz wire format, utils.py:59-69).
- *   - images are H x W row-major float32, intrinsics K are 3x3 row-major float32
- *     with zero skew and bottom row [0,0,1] (lib/datasets/utils.py:117-130).
+ *   - images are H x W row-major float32.  Intrinsics K are [B,3,3] row-major with zero skew and
+ *     bottom row [0,0,1], handed over IN THE DTYPE THE `data` DICT HOLDS THEM, tagged by `k_dtype`
+ *     (one tag for K0 and K1):
+ *       MFR_K_F64  float64 -- the Map-free loader's flow: correct_intrinsic_scale multiplies a
+ *                  float64 np.eye(3) into K (lib/datasets/utils.py:117-130; always called,
+ *                  lib/datasets/mapfree.py:50-52, config/mapfree.yaml:7-8), so np.linalg.inv(K)
+ *                  (pose_solver.py:16), the K-normalisation (:39-40) and the threshold mean (:43)
+ *                  are float64 arithmetic in the reference, and so they are here;
+ *       MFR_K_F32  float32 -- resize=None datasets (K stays as parsed): the same three steps are
+ *                  float32 arithmetic and only their results are promoted (quirk Q5).
+ *     Both flows are pinned bit-for-bit against the reference's own Python
+ *     (tests/golden/ref_k64.npz, ref_backproject.npz, ref_pnp_lift.npz, ref_emat_metric.npz).
  *
  * Every entry point names the reference interface it replaces (file:line under
  * the upstream repository).
@@ -32,7 +42,11 @@
 extern "C" {
 #endif
 
-#define MFR_ABI_VERSION 1
+#define MFR_ABI_VERSION 2   /* 2: intrinsics as (const void *K, int k_dtype) instead of const float * */
+
+/* intrinsics dtype tags */
+#define MFR_K_F32 0
+#define MFR_K_F64 1
 
 /* library-level error codes (negative) */
 #define MFR_E_ARG      (-1)
@@ -70,7 +84,7 @@ int mfr_test_sample(uint64_t seed, const int64_t *pair_ids, int B, int iters, in
 size_t mfr_pnp_workspace_bytes(int B, int maxN, int max_iters);
 int mfr_pnp_solve_batch(const float *pts0, const float *pts1, const int32_t *n_corr, int B, int maxN,
                         const float *depth0, int H, int W,
-                        const float *K0, const float *K1,
+                        const void *K0, const void *K1, int k_dtype,
                         int max_iters, double reproj_thr, double confidence,
                         uint64_t seed, const int64_t *pair_ids,
                         void *workspace, size_t workspace_bytes,
@@ -82,10 +96,10 @@ int mfr_pnp_solve_batch(const float *pts0, const float *pts1, const int32_t *n_c
  * src_idx [B,maxN] i32, n_valid [B] i32. */
 int mfr_depth_min(const float *depth, int B, int H, int W, float *partial_min /*[B,16]*/, void *stream);
 int mfr_pnp_lift(const float *pts0, const float *pts1, const int32_t *n_corr, int B, int maxN,
-                 const float *depth0, const float *partial_min, int H, int W, const float *K0,
+                 const float *depth0, const float *partial_min, int H, int W, const void *K0, int k_dtype,
                  double *xyz, double *obs, int32_t *src_idx, int32_t *n_valid, void *stream);
 int mfr_pnp_ransac(const double *xyz, const double *obs, const int32_t *n_valid, int B, int maxN,
-                   const float *K1, int max_iters, double reproj_thr, double confidence,
+                   const void *K1, int k_dtype, int max_iters, double reproj_thr, double confidence,
                    uint64_t seed, const int64_t *pair_ids,
                    int32_t *counts /*[B,max_iters] workspace*/, int32_t *inl_idx /*[B,maxN] workspace*/,
                    double *R, double *t, int32_t *n_inliers, int32_t *status,
@@ -109,7 +123,7 @@ size_t mfr_scale_workspace_bytes(int B, int maxN);
 int mfr_scale_from_depth_batch(const float *pts0, const float *pts1, const uint8_t *emat_mask,
                                const int32_t *n_corr, int B, int maxN,
                                const float *depth0, const float *depth1, int H, int W,
-                               const float *K0, const float *K1,
+                               const void *K0, const void *K1, int k_dtype,
                                const double *R, const double *t,
                                const int32_t *in_status /* [B] status of the E-mat stage, may be NULL */,
                                double scale_thr,
@@ -119,7 +133,7 @@ int mfr_scale_from_depth_batch(const float *pts0, const float *pts1, const uint8
 
 /* ------------------------------------------------------------------------------------------
  * Essential-matrix path: EssentialMatrixSolver.estimate_pose, lib/models/matching/pose_solver.py:29-61
- *   K-normalise in f32 (:39-40) -> thr = pix_thr / mean(fx0, fy1, fy0, fx1) (:43, Q8)
+ *   K-normalise in K's dtype (:39-40) -> thr = pix_thr / mean(fx0, fy1, fy0, fx1) (:43, Q8)
  *   -> cv.findEssentialMat(USAC_MAGSAC, prob) (:46-48): 5-point RANSAC, max_iters (OpenCV default
  *      1000; the reference does not override it), adaptive iteration cap, Sampson inliers
  *   -> cv.recoverPose per E (:56-60): 4 decompositions, cheirality vote -> LM polish of (R,t).
@@ -130,15 +144,15 @@ int mfr_scale_from_depth_batch(const float *pts0, const float *pts1, const uint8
  * ------------------------------------------------------------------------------------------ */
 size_t mfr_emat_workspace_bytes(int B, int maxN, int max_iters);
 int mfr_emat_solve_batch(const float *pts0, const float *pts1, const int32_t *n_corr, int B, int maxN,
-                         const float *K0, const float *K1, double pix_thr, double confidence, int max_iters,
+                         const void *K0, const void *K1, int k_dtype, double pix_thr, double confidence, int max_iters,
                          uint64_t seed, const int64_t *pair_ids, void *workspace, size_t workspace_bytes,
                          double *R, double *t, int32_t *n_inliers, int32_t *status, uint8_t *inlier_mask,
                          int32_t *best_iter, int32_t *iters_run, int32_t *counts_out, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Procrustes path: ProcrustesSolver.estimate_pose, lib/models/matching/pose_solver.py:238-320 with
- * PROCRUSTES.REFINE False (config/matching/mapfree/sg_procrustes_dptkitti.yaml; ICP refinement is
- * not built).  int-truncate both views (:248-249) -> depth gather (:256-258) -> valid vs each map's
+ * PROCRUSTES.REFINE False (config/matching/mapfree/sg_procrustes_dptkitti.yaml; the optional ICP
+ * refinement is mfr_procrustes_icp_refine below).  int-truncate both views (:248-249) -> depth gather (:256-258) -> valid vs each map's
  * minimum (:261, Q6) -> back-project both (:273-274) -> o3d registration_ransac_based_on_correspondence
  * (3-point Kabsch RANSAC, max_corr_dist, confidence 0.999, best = fitness then RMSE, final re-fit)
  * (:286-287) -> inliers = int(fitness * N) (:288).  max_iters caps Open3D's 100000.
@@ -146,7 +160,7 @@ int mfr_emat_solve_batch(const float *pts0, const float *pts1, const int32_t *n_
  * ------------------------------------------------------------------------------------------ */
 size_t mfr_procrustes_workspace_bytes(int B, int maxN, int max_iters);
 int mfr_procrustes_solve_batch(const float *pts0, const float *pts1, const int32_t *n_corr, int B, int maxN,
-                               const float *depth0, const float *depth1, int H, int W, const float *K0, const float *K1,
+                               const float *depth0, const float *depth1, int H, int W, const void *K0, const void *K1, int k_dtype,
                                double max_corr_dist, double confidence, int max_iters, uint64_t seed, const int64_t *pair_ids,
                                void *workspace, size_t workspace_bytes, double *R, double *t, int32_t *n_inliers,
                                int32_t *status, int32_t *best_iter, int32_t *iters_run, int32_t *counts_out, void *stream);
@@ -252,7 +266,7 @@ int mfr_bias_pool2_relu_nchw(const float *x, const float *bias, int B, int C, in
  * `status` (may be NULL) is not MFR_ST_OK are left untouched with 0 inliers; n_inliers = int(fitness * |target cloud|) (:319).
  */
 size_t mfr_procrustes_icp_workspace_bytes(int B, int H, int W);
-int mfr_procrustes_icp_refine(const float *depth0, const float *depth1, int B, int H, int W, const float *K0, const float *K1,
+int mfr_procrustes_icp_refine(const float *depth0, const float *depth1, int B, int H, int W, const void *K0, const void *K1, int k_dtype,
                               double max_corr_dist, double rel_fitness, double rel_rmse, int max_iter, const int32_t *status,
                               void *workspace, size_t workspace_bytes, double *R, double *t, int32_t *n_inliers, double *fitness,
                               double *rmse, int32_t *iters, void *stream);

@@ -21,20 +21,20 @@ SIGNATURES = {
     "mfr_test_f64_ops": (_i, [_vp, _vp, _vp, _i, _vp, _vp]),
     "mfr_test_sample": (_i, [_u64, _vp, _i, _i, _i, _i, _vp, _vp]),
     "mfr_pnp_workspace_bytes": (_sz, [_i, _i, _i]),
-    "mfr_pnp_solve_batch": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _i, _d, _d, _u64, _vp,
+    "mfr_pnp_solve_batch": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _i, _i, _d, _d, _u64, _vp,
                                  _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mfr_depth_min": (_i, [_vp, _i, _i, _i, _vp, _vp]),
-    "mfr_pnp_lift": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "mfr_pnp_ransac": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _d, _d, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+    "mfr_pnp_lift": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
+    "mfr_pnp_ransac": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _i, _d, _d, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                             _vp, _vp, _vp, _vp]),
     "mfr_emat_workspace_bytes": (_sz, [_i, _i, _i]),
-    "mfr_emat_solve_batch": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _d, _d, _i, _u64, _vp, _vp, _sz, _vp, _vp, _vp, _vp,
+    "mfr_emat_solve_batch": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _i, _d, _d, _i, _u64, _vp, _vp, _sz, _vp, _vp, _vp, _vp,
                                   _vp, _vp, _vp, _vp, _vp]),
     "mfr_procrustes_workspace_bytes": (_sz, [_i, _i, _i]),
-    "mfr_procrustes_solve_batch": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _d, _d, _i, _u64, _vp, _vp, _sz,
+    "mfr_procrustes_solve_batch": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _i, _d, _d, _i, _u64, _vp, _vp, _sz,
                                         _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mfr_procrustes_icp_workspace_bytes": (_sz, [_i, _i, _i]),
-    "mfr_procrustes_icp_refine": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _d, _d, _d, _i, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mfr_procrustes_icp_refine": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _i, _d, _d, _d, _i, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mfr_sp_scoremap": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "mfr_sp_nms_candidates": (_i, [_vp, _i, _i, _i, _i, C.c_float, _i, _vp, _vp, _i, _vp, _vp]),
     "mfr_sp_select_topk": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
@@ -67,7 +67,7 @@ SIGNATURES = {
     "mfr_rootsift": (_i, [_vp, _i, _vp, _vp, _vp]),
     "mfr_desc_ratio_match": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _d, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "mfr_scale_workspace_bytes": (_sz, [_i, _i]),
-    "mfr_scale_from_depth_batch": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp,
+    "mfr_scale_from_depth_batch": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _i, _vp, _vp, _vp,
                                         _d, _vp, _sz, _vp, _vp, _vp, _vp, _vp]),
 }
 

@@ -29,22 +29,36 @@ using namespace mfr;
 
 __global__ void __launch_bounds__(256) emat_prep_kernel(
     const float *__restrict__ pts0, const float *__restrict__ pts1, const int32_t *__restrict__ n_corr, int maxN,
-    const float *__restrict__ K0, const float *__restrict__ K1, double pix_thr,
+    const void *__restrict__ K0, const void *__restrict__ K1, int k_dtype, double pix_thr,
     double *__restrict__ x0, double *__restrict__ x1, double *__restrict__ thr2)
 {
+    // pose_solver.py:39-43 in the dtype K arrives in: numpy float32 arithmetic for a float32 K, float64 (keypoints widened) for
+    // the Map-free loader's float64 K; the threshold mean likewise
     const int b = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
-    const float *k0 = K0 + 9 * b, *k1 = K1 + 9 * b;
-    if (i == 0) {
-        const float m = (((k0[0] + k1[4]) + k0[4]) + k1[0]) / 4.0f;       // np.mean([fx0, fy1, fy0, fx1]) in f32
-        const double thr = pix_thr / (double)m;
-        thr2[b] = thr * thr;
-    }
     int n = n_corr[b];
     if (n > maxN) n = maxN;
-    if (i >= n) return;
     const size_t o = ((size_t)b * maxN + i) * 2;
-    x0[o] = (double)((pts0[o] - k0[2]) / k0[0]); x0[o + 1] = (double)((pts0[o + 1] - k0[5]) / k0[4]);
-    x1[o] = (double)((pts1[o] - k1[2]) / k1[0]); x1[o + 1] = (double)((pts1[o + 1] - k1[5]) / k1[4]);
+    if (k_dtype == MFR_K_F32) {
+        const float *k0 = (const float *)K0 + 9 * b, *k1 = (const float *)K1 + 9 * b;
+        if (i == 0) {
+            const float m = (((k0[0] + k1[4]) + k0[4]) + k1[0]) / 4.0f;       // np.mean([fx0, fy1, fy0, fx1]) in f32
+            const double thr = pix_thr / (double)m;
+            thr2[b] = thr * thr;
+        }
+        if (i >= n) return;
+        x0[o] = (double)((pts0[o] - k0[2]) / k0[0]); x0[o + 1] = (double)((pts0[o + 1] - k0[5]) / k0[4]);
+        x1[o] = (double)((pts1[o] - k1[2]) / k1[0]); x1[o + 1] = (double)((pts1[o + 1] - k1[5]) / k1[4]);
+    } else {
+        const double *k0 = (const double *)K0 + 9 * b, *k1 = (const double *)K1 + 9 * b;
+        if (i == 0) {
+            const double m = (((k0[0] + k1[4]) + k0[4]) + k1[0]) / 4.0;
+            const double thr = pix_thr / m;
+            thr2[b] = thr * thr;
+        }
+        if (i >= n) return;
+        x0[o] = ((double)pts0[o] - k0[2]) / k0[0]; x0[o + 1] = ((double)pts0[o + 1] - k0[5]) / k0[4];
+        x1[o] = ((double)pts1[o] - k1[2]) / k1[0]; x1[o + 1] = ((double)pts1[o + 1] - k1[5]) / k1[4];
+    }
 }
 
 // grid (ceil(iters/64), B), one lane per hypothesis
@@ -464,13 +478,13 @@ size_t mfr_emat_workspace_bytes(int B, int maxN, int max_iters)
 }
 
 int mfr_emat_solve_batch(const float *pts0, const float *pts1, const int32_t *n_corr, int B, int maxN,
-                         const float *K0, const float *K1, double pix_thr, double confidence, int max_iters,
+                         const void *K0, const void *K1, int k_dtype, double pix_thr, double confidence, int max_iters,
                          uint64_t seed, const int64_t *pair_ids, void *workspace, size_t workspace_bytes,
                          double *R, double *t, int32_t *n_inliers, int32_t *status, uint8_t *inlier_mask,
                          int32_t *best_iter, int32_t *iters_run, int32_t *counts_out, void *stream)
 {
     if (!pts0 || !pts1 || !n_corr || !K0 || !K1 || !pair_ids || !workspace || !R || !t || !n_inliers || !status ||
-        B <= 0 || maxN <= 0) return MFR_E_ARG;
+        B <= 0 || maxN <= 0 || !k_dtype_ok(k_dtype)) return MFR_E_ARG;
     if (max_iters < 1) max_iters = 1;
     const EmWs w = em_ws_layout(B, maxN, max_iters);
     if (workspace_bytes < w.total) return MFR_E_WORKSPACE;
@@ -481,7 +495,7 @@ int mfr_emat_solve_batch(const float *pts0, const float *pts1, const int32_t *n_
     int32_t *nsol = (int32_t *)(ws + w.nsol), *counts = (int32_t *)(ws + w.counts), *bestm = (int32_t *)(ws + w.bestm);
     int32_t *idx = (int32_t *)(ws + w.idx);
     uint8_t *rm = (uint8_t *)(ws + w.rm);
-    hipLaunchKernelGGL(emat_prep_kernel, dim3((maxN + 255) / 256, B), dim3(256), 0, s, pts0, pts1, n_corr, maxN, K0, K1,
+    hipLaunchKernelGGL(emat_prep_kernel, dim3((maxN + 255) / 256, B), dim3(256), 0, s, pts0, pts1, n_corr, maxN, K0, K1, k_dtype,
                        pix_thr, x0, x1, thr2);
     CHECK_LAUNCH();
     const dim3 hgrid((max_iters + 63) / 64, B);

@@ -14,6 +14,13 @@
 
 namespace mfr {
 
+// intrinsics dtype tags (values of include/mfr_hip.h MFR_K_F32 / MFR_K_F64; this header is also used without it)
+#ifndef MFR_K_F32
+#define MFR_K_F32 0
+#define MFR_K_F64 1
+#endif
+static inline bool k_dtype_ok(int k_dtype) { return k_dtype == MFR_K_F32 || k_dtype == MFR_K_F64; }
+
 // ---------------------------------------------------------------- Philox4x32-10
 MFR_DEV void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                            uint32_t k0, uint32_t k1, uint32_t out[4])
@@ -212,19 +219,42 @@ MFR_DEV double reproj_err2(const double *R, const double *t, const double *X, co
     return du * du + dv * dv;
 }
 
-// pose_solver.py:6-17 with the f32 inverse of the pinhole K (quirk Q5): returns ray so that
-// xyz = depth * ray.  Ki = {1/fx, -(cx/fx), 1/fy, -(cy/fy)} in f32 (LAPACK sgesv
-// back-substitution form, bit-identical to np.linalg.inv on the f32 matrix).
-MFR_DEV void kinv_f32(const float *K, float Ki[4])
+// Intrinsics cross the C-ABI in the dtype the `data` dict holds them (include/mfr_hip.h MFR_K_F32 / MFR_K_F64); pair b's matrix
+// is the b-th block of 9 values.
+// kparams: {fx, fy, cx, cy} as stored (float32 widens exactly: what K.numpy() handed to OpenCV becomes, pose_solver.py:209-213).
+MFR_DEV void kparams(const void *K, int k_dtype, int b, double Kd[4])
 {
-    Ki[0] = 1.0f / K[0]; Ki[1] = -(K[2] / K[0]);
-    Ki[2] = 1.0f / K[4]; Ki[3] = -(K[5] / K[4]);
+    if (k_dtype == MFR_K_F32) {
+        const float *k = (const float *)K + 9 * (size_t)b;
+        Kd[0] = (double)k[0]; Kd[1] = (double)k[4]; Kd[2] = (double)k[2]; Kd[3] = (double)k[5];
+    } else {
+        const double *k = (const double *)K + 9 * (size_t)b;
+        Kd[0] = k[0]; Kd[1] = k[4]; Kd[2] = k[2]; Kd[3] = k[5];
+    }
 }
-MFR_DEV void backproject(int u, int v, float depth, const float Ki[4], double *xyz)
+// kinv: np.linalg.inv(K) of the pinhole matrix, evaluated in K's OWN dtype (pose_solver.py:16), widened to double:
+// Ki = {inv[0,0], inv[0,2], inv[1,1], inv[1,2]}.  float32 (quirk Q5, resize=None datasets): {1/fx, -(cx/fx), ..} (LAPACK sgesv
+// back-substitution divides); float64 (the Map-free loader: lib/datasets/utils.py:117-130): {1/fx, -(cx*(1/fx)), ..} (dgesv's
+// triangular solve multiplies by the reciprocal pivot).  Both forms are pinned bit-for-bit by the reference-executed fixtures
+// (tests/golden/ref_backproject.npz, ref_k64.npz) through oracle/mfr_oracle.c:mfr_ref_load_intr, which this mirrors.
+MFR_DEV void kinv(const void *K, int k_dtype, int b, double Ki[4])
+{
+    if (k_dtype == MFR_K_F32) {
+        const float *k = (const float *)K + 9 * (size_t)b;
+        const float ifx = 1.0f / k[0], icx = -(k[2] / k[0]), ify = 1.0f / k[4], icy = -(k[5] / k[4]);
+        Ki[0] = (double)ifx; Ki[1] = (double)icx; Ki[2] = (double)ify; Ki[3] = (double)icy;
+    } else {
+        const double *k = (const double *)K + 9 * (size_t)b;
+        Ki[0] = 1.0 / k[0]; Ki[2] = 1.0 / k[4];
+        Ki[1] = -(k[2] * Ki[0]); Ki[3] = -(k[5] * Ki[2]);
+    }
+}
+// pose_solver.py:6-17: ray = inv(K) @ [u, v, 1] as the float64 matrix product evaluates it, xyz = depth * ray
+MFR_DEV void backproject(int u, int v, float depth, const double Ki[4], double *xyz)
 {
     const double du = (double)u, dv = (double)v, d = (double)depth;
-    const double rx = ((double)Ki[0] * du + 0.0 * dv) + (double)Ki[1];
-    const double ry = (0.0 * du + (double)Ki[2] * dv) + (double)Ki[3];
+    const double rx = (Ki[0] * du + 0.0 * dv) + Ki[1];
+    const double ry = (0.0 * du + Ki[2] * dv) + Ki[3];
     const double rz = (0.0 * du + 0.0 * dv) + 1.0;
     xyz[0] = d * rx; xyz[1] = d * ry; xyz[2] = d * rz;
 }

@@ -64,7 +64,7 @@ __global__ void __launch_bounds__(256) depth_min_kernel(const float *__restrict_
 __global__ void __launch_bounds__(256) pnp_lift_kernel(
     const float *__restrict__ pts0, const float *__restrict__ pts1, const int32_t *__restrict__ n_corr, int maxN,
     const float *__restrict__ depth0, const float *__restrict__ partial_min, int H, int W,
-    const float *__restrict__ K0, double *__restrict__ xyz, double *__restrict__ obs,
+    const void *__restrict__ K0, int k_dtype, double *__restrict__ xyz, double *__restrict__ obs,
     int32_t *__restrict__ src_idx, int32_t *__restrict__ n_valid)
 {
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -74,8 +74,8 @@ __global__ void __launch_bounds__(256) pnp_lift_kernel(
     __shared__ int base_s;
     float dmin = partial_min[b * MFR_NSEG];
     for (int s = 1; s < MFR_NSEG; ++s) { const float v = partial_min[b * MFR_NSEG + s]; if (v < dmin) dmin = v; }
-    float Ki[4];
-    kinv_f32(K0 + 9 * b, Ki);
+    double Ki[4];
+    kinv(K0, k_dtype, b, Ki);
     const float *p0 = pts0 + (size_t)b * maxN * 2, *p1 = pts1 + (size_t)b * maxN * 2;
     const float *dm = depth0 + (size_t)b * H * W;
     double *oxyz = xyz + (size_t)b * maxN * 3, *oobs = obs + (size_t)b * maxN * 2;
@@ -121,7 +121,7 @@ __global__ void __launch_bounds__(256) pnp_lift_kernel(
 // LDS-staged points, ballot/popcount inlier counting.
 __global__ void __launch_bounds__(HYP_BLOCK) pnp_hyp_score_kernel(
     const double *__restrict__ xyz, const double *__restrict__ obs, const int32_t *__restrict__ n_valid,
-    int maxN, const float *__restrict__ K1, int max_iters, double thr2, uint64_t seed,
+    int maxN, const void *__restrict__ K1, int k_dtype, int max_iters, double thr2, uint64_t seed,
     const int64_t *__restrict__ pair_ids, int32_t *__restrict__ counts)
 {
     const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -140,8 +140,8 @@ __global__ void __launch_bounds__(HYP_BLOCK) pnp_hyp_score_kernel(
     int *cnt = mvalid + HYP_BLOCK;                            // [HYP_BLOCK]
 
     const double *X = xyz + (size_t)b * maxN * 3, *O = obs + (size_t)b * maxN * 2;
-    const float *Kf = K1 + 9 * b;
-    const double Kd[4] = { (double)Kf[0], (double)Kf[4], (double)Kf[2], (double)Kf[5] };
+    double Kd[4];
+    kparams(K1, k_dtype, b, Kd);
 
     {   // phase 1
         double R[9], t[3];
@@ -344,7 +344,7 @@ static __device__ __noinline__ int pnp_lm(const double *X, const double *O, cons
 // iteration-cap logic over the precomputed counts, inlier set, refit + refinement, checks.
 __global__ void __launch_bounds__(64) pnp_select_kernel(
     const double *__restrict__ xyz, const double *__restrict__ obs, const int32_t *__restrict__ n_valid,
-    const int32_t *__restrict__ pre_status, int maxN, const float *__restrict__ K1, int max_iters,
+    const int32_t *__restrict__ pre_status, int maxN, const void *__restrict__ K1, int k_dtype, int max_iters,
     double thr2, double conf, uint64_t seed, const int64_t *__restrict__ pair_ids,
     const int32_t *__restrict__ counts, int32_t *__restrict__ inl_idx,
     double *__restrict__ Rout, double *__restrict__ tout, int32_t *__restrict__ n_inliers,
@@ -354,8 +354,8 @@ __global__ void __launch_bounds__(64) pnp_select_kernel(
     const int b = blockIdx.x, lane = threadIdx.x;
     const int n = n_valid[b];
     const double *X = xyz + (size_t)b * maxN * 3, *O = obs + (size_t)b * maxN * 2;
-    const float *Kf = K1 + 9 * b;
-    const double Kd[4] = { (double)Kf[0], (double)Kf[4], (double)Kf[2], (double)Kf[5] };
+    double Kd[4];
+    kparams(K1, k_dtype, b, Kd);
     int32_t *idx = inl_idx + (size_t)b * maxN;
     const double qnan = __longlong_as_double(0x7ff8000000000000LL);
 
@@ -528,13 +528,13 @@ int mfr_depth_min(const float *depth, int B, int H, int W, float *partial_min, v
 }
 
 int mfr_pnp_lift(const float *pts0, const float *pts1, const int32_t *n_corr, int B, int maxN,
-                 const float *depth0, const float *partial_min, int H, int W, const float *K0,
+                 const float *depth0, const float *partial_min, int H, int W, const void *K0, int k_dtype,
                  double *xyz, double *obs, int32_t *src_idx, int32_t *n_valid, void *stream)
 {
     if (!pts0 || !pts1 || !n_corr || !depth0 || !partial_min || !K0 || !xyz || !obs || !src_idx || !n_valid ||
-        B <= 0 || maxN <= 0 || H <= 0 || W <= 0) return MFR_E_ARG;
+        B <= 0 || maxN <= 0 || H <= 0 || W <= 0 || !k_dtype_ok(k_dtype)) return MFR_E_ARG;
     hipLaunchKernelGGL(pnp_lift_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, pts0, pts1, n_corr, maxN,
-                       depth0, partial_min, H, W, K0, xyz, obs, src_idx, n_valid);
+                       depth0, partial_min, H, W, K0, k_dtype, xyz, obs, src_idx, n_valid);
     CHECK_LAUNCH();
     return 0;
 }
@@ -545,16 +545,16 @@ static size_t hyp_smem_bytes(void)
 }
 
 static int launch_ransac(const double *xyz, const double *obs, const int32_t *n_valid, const int32_t *pre_status,
-                         int B, int maxN, const float *K1, int max_iters, double thr, double conf, uint64_t seed,
+                         int B, int maxN, const void *K1, int k_dtype, int max_iters, double thr, double conf, uint64_t seed,
                          const int64_t *pair_ids, int32_t *counts, int32_t *inl_idx, double *R, double *t,
                          int32_t *n_inliers, int32_t *status, uint8_t *mask_valid, int32_t *best_iter,
                          int32_t *iters_run, hipStream_t s)
 {
     const double thr2 = thr * thr;
     hipLaunchKernelGGL(pnp_hyp_score_kernel, dim3((max_iters + HYP_BLOCK - 1) / HYP_BLOCK, B), dim3(HYP_BLOCK),
-                       hyp_smem_bytes(), s, xyz, obs, n_valid, maxN, K1, max_iters, thr2, seed, pair_ids, counts);
+                       hyp_smem_bytes(), s, xyz, obs, n_valid, maxN, K1, k_dtype, max_iters, thr2, seed, pair_ids, counts);
     CHECK_LAUNCH();
-    hipLaunchKernelGGL(pnp_select_kernel, dim3(B), dim3(64), 0, s, xyz, obs, n_valid, pre_status, maxN, K1, max_iters,
+    hipLaunchKernelGGL(pnp_select_kernel, dim3(B), dim3(64), 0, s, xyz, obs, n_valid, pre_status, maxN, K1, k_dtype, max_iters,
                        thr2, conf, seed, pair_ids, counts, inl_idx, R, t, n_inliers, status, mask_valid, best_iter,
                        iters_run);
     CHECK_LAUNCH();
@@ -562,15 +562,15 @@ static int launch_ransac(const double *xyz, const double *obs, const int32_t *n_
 }
 
 int mfr_pnp_ransac(const double *xyz, const double *obs, const int32_t *n_valid, int B, int maxN,
-                   const float *K1, int max_iters, double reproj_thr, double confidence,
+                   const void *K1, int k_dtype, int max_iters, double reproj_thr, double confidence,
                    uint64_t seed, const int64_t *pair_ids, int32_t *counts, int32_t *inl_idx,
                    double *R, double *t, int32_t *n_inliers, int32_t *status, uint8_t *mask_valid,
                    int32_t *best_iter, int32_t *iters_run, void *stream)
 {
     if (!xyz || !obs || !n_valid || !K1 || !pair_ids || !counts || !inl_idx || !R || !t || !n_inliers || !status ||
-        B <= 0 || maxN <= 0) return MFR_E_ARG;
+        B <= 0 || maxN <= 0 || !k_dtype_ok(k_dtype)) return MFR_E_ARG;
     if (max_iters < 1) max_iters = 1;
-    return launch_ransac(xyz, obs, n_valid, nullptr, B, maxN, K1, max_iters, reproj_thr, confidence, seed, pair_ids,
+    return launch_ransac(xyz, obs, n_valid, nullptr, B, maxN, K1, k_dtype, max_iters, reproj_thr, confidence, seed, pair_ids,
                          counts, inl_idx, R, t, n_inliers, status, mask_valid, best_iter, iters_run, (hipStream_t)stream);
 }
 
@@ -600,13 +600,13 @@ size_t mfr_pnp_workspace_bytes(int B, int maxN, int max_iters)
 }
 
 int mfr_pnp_solve_batch(const float *pts0, const float *pts1, const int32_t *n_corr, int B, int maxN,
-                        const float *depth0, int H, int W, const float *K0, const float *K1,
+                        const float *depth0, int H, int W, const void *K0, const void *K1, int k_dtype,
                         int max_iters, double reproj_thr, double confidence, uint64_t seed, const int64_t *pair_ids,
                         void *workspace, size_t workspace_bytes,
                         double *R, double *t, int32_t *n_inliers, int32_t *status, uint8_t *inlier_mask, void *stream)
 {
     if (!pts0 || !pts1 || !n_corr || !depth0 || !K0 || !K1 || !pair_ids || !workspace || !R || !t || !n_inliers ||
-        !status || B <= 0 || maxN <= 0 || H <= 0 || W <= 0) return MFR_E_ARG;
+        !status || B <= 0 || maxN <= 0 || H <= 0 || W <= 0 || !k_dtype_ok(k_dtype)) return MFR_E_ARG;
     if (max_iters < 1) max_iters = 1;
     const PnpWs w = pnp_ws_layout(B, maxN, max_iters);
     if (workspace_bytes < w.total) return MFR_E_WORKSPACE;
@@ -620,11 +620,11 @@ int mfr_pnp_solve_batch(const float *pts0, const float *pts1, const int32_t *n_c
 
     int rc = mfr_depth_min(depth0, B, H, W, partial, stream);
     if (rc) return rc;
-    rc = mfr_pnp_lift(pts0, pts1, n_corr, B, maxN, depth0, partial, H, W, K0, xyz, obs, src, nvalid, stream);
+    rc = mfr_pnp_lift(pts0, pts1, n_corr, B, maxN, depth0, partial, H, W, K0, k_dtype, xyz, obs, src, nvalid, stream);
     if (rc) return rc;
     hipLaunchKernelGGL(pnp_prestatus_kernel, dim3((B + 63) / 64), dim3(64), 0, s, n_corr, nvalid, B, pre);
     CHECK_LAUNCH();
-    rc = launch_ransac(xyz, obs, nvalid, pre, B, maxN, K1, max_iters, reproj_thr, confidence, seed, pair_ids, counts,
+    rc = launch_ransac(xyz, obs, nvalid, pre, B, maxN, K1, k_dtype, max_iters, reproj_thr, confidence, seed, pair_ids, counts,
                        inl, R, t, n_inliers, status, inlier_mask ? maskv : nullptr, nullptr, nullptr, s);
     if (rc) return rc;
     if (inlier_mask) {

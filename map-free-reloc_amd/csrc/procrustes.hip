@@ -93,7 +93,7 @@ MFR_DEV void sample3_model(const double *P, const double *Q, int n, uint64_t see
 __global__ void __launch_bounds__(256) proc_lift_kernel(
     const float *__restrict__ pts0, const float *__restrict__ pts1, const int32_t *__restrict__ n_corr, int maxN,
     const float *__restrict__ depth0, const float *__restrict__ depth1, const float *__restrict__ pmin0,
-    const float *__restrict__ pmin1, int H, int W, const float *__restrict__ K0, const float *__restrict__ K1,
+    const float *__restrict__ pmin1, int H, int W, const void *__restrict__ K0, const void *__restrict__ K1, int k_dtype,
     double *__restrict__ P, double *__restrict__ Q, int32_t *__restrict__ n_valid)
 {
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -107,8 +107,8 @@ __global__ void __launch_bounds__(256) proc_lift_kernel(
         if (a < m0) m0 = a;
         if (c < m1) m1 = c;
     }
-    float Ki0[4], Ki1[4];
-    kinv_f32(K0 + 9 * b, Ki0); kinv_f32(K1 + 9 * b, Ki1);
+    double Ki0[4], Ki1[4];
+    kinv(K0, k_dtype, b, Ki0); kinv(K1, k_dtype, b, Ki1);
     const float *p0 = pts0 + (size_t)b * maxN * 2, *p1 = pts1 + (size_t)b * maxN * 2;
     const float *d0m = depth0 + (size_t)b * H * W, *d1m = depth1 + (size_t)b * H * W;
     double *oP = P + (size_t)b * maxN * 3, *oQ = Q + (size_t)b * maxN * 3;
@@ -330,13 +330,13 @@ size_t mfr_procrustes_workspace_bytes(int B, int maxN, int max_iters)
 }
 
 int mfr_procrustes_solve_batch(const float *pts0, const float *pts1, const int32_t *n_corr, int B, int maxN,
-                               const float *depth0, const float *depth1, int H, int W, const float *K0, const float *K1,
+                               const float *depth0, const float *depth1, int H, int W, const void *K0, const void *K1, int k_dtype,
                                double max_corr_dist, double confidence, int max_iters, uint64_t seed, const int64_t *pair_ids,
                                void *workspace, size_t workspace_bytes, double *R, double *t, int32_t *n_inliers,
                                int32_t *status, int32_t *best_iter, int32_t *iters_run, int32_t *counts_out, void *stream)
 {
     if (!pts0 || !pts1 || !n_corr || !depth0 || !depth1 || !K0 || !K1 || !pair_ids || !workspace || !R || !t || !n_inliers ||
-        !status || B <= 0 || maxN <= 0 || H <= 0 || W <= 0 || !(max_corr_dist > 0.0)) return MFR_E_ARG;
+        !status || B <= 0 || maxN <= 0 || H <= 0 || W <= 0 || !(max_corr_dist > 0.0) || !k_dtype_ok(k_dtype)) return MFR_E_ARG;
     if (max_iters < 1) max_iters = 1;
     const PrWs w = pr_ws_layout(B, maxN, max_iters);
     if (workspace_bytes < w.total) return MFR_E_WORKSPACE;
@@ -350,7 +350,7 @@ int mfr_procrustes_solve_batch(const float *pts0, const float *pts1, const int32
     rc = mfr_depth_min(depth1, B, H, W, pm1, stream);
     if (rc) return rc;
     hipLaunchKernelGGL(proc_lift_kernel, dim3(B), dim3(256), 0, s, pts0, pts1, n_corr, maxN, depth0, depth1, pm0, pm1, H, W, K0,
-                       K1, P, Q, nvalid);
+                       K1, k_dtype, P, Q, nvalid);
     CHECK_LAUNCH();
     const double thr2 = max_corr_dist * max_corr_dist;
     const size_t smem = (size_t)(12 * 256 + 6 * PR_TILE) * sizeof(double) + 256 * sizeof(int) + 256 * sizeof(double);

@@ -78,7 +78,7 @@ MFR_DEV_NOINLINE void icp_kabsch_from_moments(const double *s, double *R, double
 
 // grid (ceil(HW/256), B)
 __global__ void __launch_bounds__(256) icp_prep_kernel(const float *__restrict__ depth0, const float *__restrict__ depth1, int HW, int W,
-                                                       const float *__restrict__ K1, const double *__restrict__ Rin, const double *__restrict__ tin,
+                                                       const void *__restrict__ K1, int k_dtype, const double *__restrict__ Rin, const double *__restrict__ tin,
                                                        const int32_t *__restrict__ status, double *__restrict__ Tc, int32_t *__restrict__ cnt,
                                                        double *__restrict__ state)
 {
@@ -98,8 +98,8 @@ __global__ void __launch_bounds__(256) icp_prep_kernel(const float *__restrict__
         t = d > 0.f;
         double q[3] = { 0.0, 0.0, 0.0 };
         if (t) {
-            float Ki[4];
-            kinv_f32(K1 + 9 * b, Ki);
+            double Ki[4];
+            kinv(K1, k_dtype, b, Ki);
             backproject(i % W, i / W, d, Ki, q);
         }
         double *o = Tc + ((size_t)b * HW + i) * 3;
@@ -114,8 +114,8 @@ __global__ void __launch_bounds__(256) icp_prep_kernel(const float *__restrict__
 
 // grid (ceil(HW/256), B)
 __global__ void __launch_bounds__(256) icp_assoc_kernel(const float *__restrict__ depth0, const float *__restrict__ depth1,
-                                                        const double *__restrict__ Tc, int H, int W, const float *__restrict__ K0,
-                                                        const float *__restrict__ K1, double r, const double *__restrict__ state,
+                                                        const double *__restrict__ Tc, int H, int W, const void *__restrict__ K0,
+                                                        const void *__restrict__ K1, int k_dtype, double r, const double *__restrict__ state,
                                                         double *__restrict__ partial)
 {
     __shared__ double ws[4][ICP_NACC];
@@ -136,12 +136,13 @@ __global__ void __launch_bounds__(256) icp_assoc_kernel(const float *__restrict_
         for (int k = 0; k < 9; ++k) R[k] = st[k];
 #pragma unroll
         for (int k = 0; k < 3; ++k) t[k] = st[9 + k];
-        float Ki[4];
-        kinv_f32(K0 + 9 * b, Ki);
+        double Ki[4];
+        kinv(K0, k_dtype, b, Ki);
         backproject(i % W, i / W, d, Ki, X);
         rot_apply(R, t, X, Y);
-        const float *k1 = K1 + 9 * b;
-        const double fx = (double)k1[0], fy = (double)k1[4], cx = (double)k1[2], cy = (double)k1[5];
+        double Kd1[4];
+        kparams(K1, k_dtype, b, Kd1);
+        const double fx = Kd1[0], fy = Kd1[1], cx = Kd1[2], cy = Kd1[3];
         const double Z = Y[2];
         int u0 = 0, u1 = W - 1, v0 = 0, v1 = H - 1;
         bool search = true;
@@ -278,13 +279,13 @@ size_t mfr_procrustes_icp_workspace_bytes(int B, int H, int W)
            icp_align(sizeof(int32_t) * 2 * B);
 }
 
-int mfr_procrustes_icp_refine(const float *depth0, const float *depth1, int B, int H, int W, const float *K0, const float *K1,
+int mfr_procrustes_icp_refine(const float *depth0, const float *depth1, int B, int H, int W, const void *K0, const void *K1, int k_dtype,
                               double max_corr_dist, double rel_fitness, double rel_rmse, int max_iter, const int32_t *status,
                               void *workspace, size_t workspace_bytes, double *R, double *t, int32_t *n_inliers, double *fitness,
                               double *rmse, int32_t *iters, void *stream)
 {
     if (!depth0 || !depth1 || !K0 || !K1 || !workspace || !R || !t || !n_inliers || B <= 0 || H <= 0 || W <= 0 || !(max_corr_dist > 0.0) ||
-        max_iter < 0 || (size_t)H * W > 0x3fffffffu) return MFR_E_ARG;
+        max_iter < 0 || (size_t)H * W > 0x3fffffffu || !k_dtype_ok(k_dtype)) return MFR_E_ARG;
     if (workspace_bytes < mfr_procrustes_icp_workspace_bytes(B, H, W)) return MFR_E_WORKSPACE;
     const int HW = H * W, nblk = (HW + 255) / 256;
     char *ws = (char *)workspace;
@@ -294,10 +295,10 @@ int mfr_procrustes_icp_refine(const float *depth0, const float *depth1, int B, i
     int32_t *cnt = (int32_t *)ws;
     hipStream_t s = (hipStream_t)stream;
     if (mfr_zero_async(cnt, sizeof(int32_t) * 2 * B, s) != hipSuccess) return MFR_E_LAUNCH;
-    hipLaunchKernelGGL(icp_prep_kernel, dim3(nblk, B), dim3(256), 0, s, depth0, depth1, HW, W, K1, R, t, status, Tc, cnt, state);
+    hipLaunchKernelGGL(icp_prep_kernel, dim3(nblk, B), dim3(256), 0, s, depth0, depth1, HW, W, K1, k_dtype, R, t, status, Tc, cnt, state);
     CHECK_LAUNCH();
     for (int k = 0; k <= max_iter; ++k) {
-        hipLaunchKernelGGL(icp_assoc_kernel, dim3(nblk, B), dim3(256), 0, s, depth0, depth1, Tc, H, W, K0, K1, max_corr_dist, state, partial);
+        hipLaunchKernelGGL(icp_assoc_kernel, dim3(nblk, B), dim3(256), 0, s, depth0, depth1, Tc, H, W, K0, K1, k_dtype, max_corr_dist, state, partial);
         CHECK_LAUNCH();
         hipLaunchKernelGGL(icp_update_kernel, dim3(B), dim3(64), 0, s, partial, nblk, cnt, k, max_iter, rel_fitness, rel_rmse, state);
         CHECK_LAUNCH();

@@ -27,7 +27,7 @@ using namespace mfr;
 __global__ void __launch_bounds__(256) scale_lift_kernel(
     const float *__restrict__ pts0, const float *__restrict__ pts1, const uint8_t *__restrict__ emat_mask,
     const int32_t *__restrict__ n_corr, int maxN, const float *__restrict__ depth0,
-    const float *__restrict__ depth1, int H, int W, const float *__restrict__ K0, const float *__restrict__ K1,
+    const float *__restrict__ depth1, int H, int W, const void *__restrict__ K0, const void *__restrict__ K1, int k_dtype,
     const double *__restrict__ Rin, const double *__restrict__ tin, const int32_t *__restrict__ in_status,
     double *__restrict__ scale, int32_t *__restrict__ n_scale)
 {
@@ -37,9 +37,9 @@ __global__ void __launch_bounds__(256) scale_lift_kernel(
     if (in_status && in_status[b] != MFR_ST_OK) n = 0;
     __shared__ int wave_cnt[4];
     __shared__ int base_s;
-    float Ki0[4], Ki1[4];
-    kinv_f32(K0 + 9 * b, Ki0);
-    kinv_f32(K1 + 9 * b, Ki1);
+    double Ki0[4], Ki1[4];
+    kinv(K0, k_dtype, b, Ki0);
+    kinv(K1, k_dtype, b, Ki1);
     double R[9], t[3];
     for (int k = 0; k < 9; ++k) R[k] = Rin[9 * b + k];
     for (int k = 0; k < 3; ++k) t[k] = tin[3 * b + k];
@@ -192,13 +192,13 @@ size_t mfr_scale_workspace_bytes(int B, int maxN)
 int mfr_scale_from_depth_batch(const float *pts0, const float *pts1, const uint8_t *emat_mask,
                                const int32_t *n_corr, int B, int maxN,
                                const float *depth0, const float *depth1, int H, int W,
-                               const float *K0, const float *K1, const double *R, const double *t,
+                               const void *K0, const void *K1, int k_dtype, const double *R, const double *t,
                                const int32_t *in_status, double scale_thr,
                                void *workspace, size_t workspace_bytes,
                                double *t_metric, double *best_scale, int32_t *n_inliers, int32_t *status, void *stream)
 {
     if (!pts0 || !pts1 || !n_corr || !depth0 || !depth1 || !K0 || !K1 || !R || !t || !workspace || !t_metric ||
-        !best_scale || !n_inliers || !status || B <= 0 || maxN <= 0 || H <= 0 || W <= 0) return MFR_E_ARG;
+        !best_scale || !n_inliers || !status || B <= 0 || maxN <= 0 || H <= 0 || W <= 0 || !k_dtype_ok(k_dtype)) return MFR_E_ARG;
     const ScaleWs w = scale_ws_layout(B, maxN);
     if (workspace_bytes < w.total) return MFR_E_WORKSPACE;
     char *ws = (char *)workspace;
@@ -206,7 +206,7 @@ int mfr_scale_from_depth_batch(const float *pts0, const float *pts1, const uint8
     double *scale = (double *)(ws + w.scale);
     int32_t *nscale = (int32_t *)(ws + w.nscale), *pcnt = (int32_t *)(ws + w.pcnt), *pidx = (int32_t *)(ws + w.pidx);
     hipLaunchKernelGGL(scale_lift_kernel, dim3(B), dim3(256), 0, s, pts0, pts1, emat_mask, n_corr, maxN, depth0,
-                       depth1, H, W, K0, K1, R, t, in_status, scale, nscale);
+                       depth1, H, W, K0, K1, k_dtype, R, t, in_status, scale, nscale);
     CHECK_LAUNCH();
     hipLaunchKernelGGL(scale_ransac_kernel, dim3(w.nchunks, B), dim3(SC_BLOCK), 0, s, scale, nscale, maxN, scale_thr,
                        pcnt, pidx, w.nchunks);

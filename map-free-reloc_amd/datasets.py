@@ -1,7 +1,7 @@
 """Input contract of the hot path: the per-pair `data` dict of MapFreeScene.__getitem__
 (lib/datasets/mapfree.py:250-268) -- image0/1 f32 [1,3,H,W] in [0,1], depth0/1 f32
-[1,H,W] metres (uint16 PNG / 1000, lib/datasets/utils.py:77-81), K_color0/1 f32 [1,3,3] rescaled
-like correct_intrinsic_scale (utils.py:117-130), T_0to1, pair_id (= index * 5, mapfree.py:265),
+[1,H,W] metres (uint16 PNG / 1000, lib/datasets/utils.py:77-81), K_color0/1 [1,3,3] rescaled
+like correct_intrinsic_scale (utils.py:117-130: FLOAT64 whenever the dataset resizes, i.e. always on Map-free), T_0to1, pair_id (= index * 5, mapfree.py:265),
 scene_id, scene_root, pair_names.
 
 No Map-free data exists offline, so the loader that ships is SYNTHETIC (same schema, known
@@ -52,7 +52,8 @@ class SyntheticScene:
         return {
             "image0": rgb(p["img0"]), "image1": rgb(p["img1"]),
             "depth0": torch.from_numpy(p["depth0"]), "depth1": torch.from_numpy(p["depth1"]),
-            "K_color0": torch.from_numpy(p["K"]), "K_color1": torch.from_numpy(p["K"]),
+            # float64, like every sample of the Map-free loader it stands in for (correct_intrinsic_scale, utils.py:117-130)
+            "K_color0": torch.from_numpy(p["K"].copy()), "K_color1": torch.from_numpy(p["K"].copy()),
             "T_0to1": torch.from_numpy(T), "pair_id": f * self.sample_factor,
             "scene_id": self.scene_id, "scene_root": self.scene_root,
             "pair_names": ("seq0/frame_00000.jpg", f"seq1/frame_{f * self.sample_factor:05d}.jpg"),
@@ -309,7 +310,7 @@ class PairBatchLoader:
     thread decodes the next batches into PINNED host buffers (queue depth `prefetch`), so JPEG/PNG decode and
     the H2D copy of batch i+1 overlap the kernels of batch i (DevicePrefetcher below issues the copies on a
     side stream).  Yields dict(images [2b,1,H,W] f32 gray interleaved (2p = reference view), depth0/depth1 [b,H,W],
-    K0/K1 [b,3,3] f32, seed_ids [b] i64 (= data['pair_id'], the RANSAC stream id the per-pair plugin uses),
+    K0/K1 [b,3,3] in the loader's dtype (float64 on Map-free), seed_ids [b] i64 (= data['pair_id'], the RANSAC stream id the per-pair plugin uses),
     global_ids [b] i64, names [b], scene_id)."""
 
     def __init__(self, scenes, batch_pairs=32, prefetch=2, pin=None, global_offsets=None, workers=8):
@@ -342,7 +343,11 @@ class PairBatchLoader:
         Hh, Ww = samples[0]["image0"].shape[-2:]
         mk = (lambda *shape, dtype=torch.float32: torch.empty(*shape, dtype=dtype, pin_memory=True)) if self.pin else \
              (lambda *shape, dtype=torch.float32: torch.empty(*shape, dtype=dtype))
-        images = mk(2 * b, 1, Hh, Ww); K0 = mk(b, 3, 3); K1 = mk(b, 3, 3)
+        # intrinsics keep the loader's dtype (float64 on Map-free, float32 on resize=None datasets): the solvers evaluate
+        # inv(K) / the K-normalisation in that dtype, as the reference does (include/mfr_hip.h k_dtype)
+        kdt = torch.float64 if any(torch.as_tensor(smp[k]).dtype == torch.float64 for smp in samples for k in ("K_color0", "K_color1")) \
+            else torch.float32
+        images = mk(2 * b, 1, Hh, Ww); K0 = mk(b, 3, 3, dtype=kdt); K1 = mk(b, 3, 3, dtype=kdt)
         has_depth = samples[0]["depth0"].numel() > 0
         depth0 = mk(b, Hh, Ww) if has_depth else None
         depth1 = mk(b, Hh, Ww) if has_depth else None
@@ -353,7 +358,7 @@ class PairBatchLoader:
         d0_np, d1_np = (depth0.numpy(), depth1.numpy()) if has_depth else (None, None)
         for p, smp in enumerate(samples):
             im_np[2 * p, 0] = npv(to_gray(smp["image0"])); im_np[2 * p + 1, 0] = npv(to_gray(smp["image1"]))
-            K0[p] = smp["K_color0"].to(torch.float32); K1[p] = smp["K_color1"].to(torch.float32)
+            K0[p] = torch.as_tensor(smp["K_color0"]); K1[p] = torch.as_tensor(smp["K_color1"])
             if has_depth:
                 d0_np[p] = npv(smp["depth0"]); d1_np[p] = npv(smp["depth1"])
         return dict(images=images, depth0=depth0, depth1=depth1, K0=K0, K1=K1,

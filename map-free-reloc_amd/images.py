@@ -29,7 +29,7 @@ def synthetic_pair(seed, H=720, W=540, f=590.0):
     of true correspondences and the pose has a known answer.
 
     returns dict(img0, img1 [H,W] f32 in [0,1], depth0, depth1 [H,W] f32 metres (uint16-mm
-    quantised like lib/datasets/utils.py:77-81), K [3,3] f32, R_gt, t_gt)."""
+    quantised like lib/datasets/utils.py:77-81), K [3,3] f64, R_gt, t_gt)."""
     rng = np.random.default_rng(seed)
     pad = 32
     base = _texture(rng, H, W + 2 * pad)
@@ -44,7 +44,9 @@ def synthetic_pair(seed, H=720, W=540, f=590.0):
         img1[y0:y1] = base[y0:y1, pad - sft:pad - sft + W]      # x1 = x0 + shift
         depth[y0:y1] = f * tx / sft
     depth = (np.round(depth * 1000).astype(np.uint16) / 1000.0).astype(np.float32)
-    K = np.array([[f, 0, W / 2 - 0.5], [0, f, H / 2 - 0.5], [0, 0, 1]], dtype=np.float32)
+    # float64, the dtype every Map-free sample carries (correct_intrinsic_scale multiplies a float64 eye(3) into K:
+    # lib/datasets/utils.py:117-130, lib/datasets/mapfree.py:50-52) -- the solvers evaluate inv(K) / the K-normalisation in it
+    K = np.array([[f, 0, W / 2 - 0.5], [0, f, H / 2 - 0.5], [0, 0, 1]], dtype=np.float64)
     return dict(img0=img0, img1=img1, depth0=depth, depth1=depth.copy(), K=K,
                 R_gt=np.eye(3), t_gt=np.array([tx, 0.0, 0.0]))
 

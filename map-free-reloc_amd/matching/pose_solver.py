@@ -17,7 +17,7 @@ def backproject_3d(uv, depth, K):
     """pose_solver.py:6-17 (host restatement kept for API completeness; the device path fuses this
     into the lift kernels)"""
     uv1 = np.concatenate([uv, np.ones((uv.shape[0], 1))], axis=1)
-    Ki = np.linalg.inv(np.asarray(K, dtype=np.float32))
+    Ki = np.linalg.inv(np.asarray(K))            # in K's own dtype (float64 from the Map-free loader, float32 otherwise)
     return np.asarray(depth, dtype=np.float32).reshape(-1, 1) * (Ki @ uv1.T).T
 
 
@@ -32,57 +32,76 @@ def _pair_id(data):
 
 class _PairStage:
     """Host->device hand-over of ONE pair for the per-pair plugin API (batch 1): everything the solver needs
-    -- correspondences, both depth maps, both intrinsics, count and RANSAC stream id -- is packed into one pinned host
-    buffer and crosses PCIe as ONE asynchronous copy into a persistent device buffer (the reference's flow hands numpy
-    arrays to OpenCV; the first version of this class issued 6-8 small synchronous copies per pair).  The device tensors
-    handed to the kernels are views into that buffer; results come back as one packed D2H copy (`fetch`)."""
-    CAP = 8192                                       # correspondences per pair (LoFTR yields <= 6120)
+    -- count and RANSAC stream id, both intrinsics IN THE DTYPE `data` HOLDS THEM (float64 from the Map-free loader,
+    lib/datasets/utils.py:117-130; float32 from resize=None datasets), the correspondences -- is packed into one pinned host
+    buffer and crosses PCIe as ONE asynchronous copy of the used prefix into a persistent device buffer (the reference's flow
+    hands numpy arrays to OpenCV; the first version of this class issued 6-8 small synchronous copies per pair).  The device
+    tensors handed to the kernels are views into that buffer; results come back as one packed D2H copy (`fetch`).
+    Pack layout in 4-byte words: meta [0,8) = n (i32) | pad | pair id (i64 in words 2-3) ; K0 | K1 [8,48) (2 x 9 float32 or
+    2 x 9 float64) ; pts0 [48, 48+2m) ; pts1 [48+2m, 48+4m) ; then, at fixed offsets, the two depth maps."""
+    O_META, O_K, O_P = 0, 8, 48
 
     def __init__(self):
         self.hw = None
+        self.cap = 8192                              # correspondences per pair; grows on demand (LoFTR yields <= 6120)
         self.host = self.dev = None
 
-    def _alloc(self, H, W):
-        self.hw = (H, W)
-        self.o_p0, self.o_p1 = 0, self.CAP * 2
-        self.o_k = self.CAP * 4                      # K0 (9) | K1 (9) | pad to 32
-        self.o_meta = self.o_k + 32                  # n (as i32 bits) | pad | pair id (i64 bits in 2 words) ; 8 words
-        self.o_d0 = self.o_meta + 8
+    def _alloc(self, H, W, cap):
+        self.hw, self.cap = (H, W), cap
+        self.o_d0 = self.O_P + 4 * cap
         self.o_d1 = self.o_d0 + H * W
         n = self.o_d1 + H * W
-        self.host = torch.empty(n, dtype=torch.float32, pin_memory=True)
+        self.host = torch.empty(self.o_d0, dtype=torch.float32, pin_memory=True)
         self.dev = torch.empty(n, dtype=torch.float32, device='cuda')
         self.host_i32 = self.host.view(torch.int32)
-        self.host_i64 = self.host[self.o_meta + 2:self.o_meta + 4].view(torch.int64)
+        self.host_i64 = self.host[self.O_META + 2:self.O_META + 4].view(torch.int64)
+        self.host_k64 = self.host[self.O_K:self.O_K + 36].view(torch.float64)
 
-    def put(self, kpts0, kpts1, data, need_depth1):
-        """-> dict of device views (pts0/pts1 [1,m,2], n [1] i32, depth0/depth1 [1,H,W], K0/K1 [1,3,3], pid [1] i64)"""
-        H, W = data['depth0'].shape[-2:]
-        if self.hw != (H, W):
-            self._alloc(H, W)
+    def put(self, kpts0, kpts1, data, need_depth0=True, need_depth1=False):
+        """-> dict of device views (pts0/pts1 [1,m,2], n [1] i32, depth0/depth1 [1,H,W], K0/K1 [1,3,3] f32 or f64, pid [1] i64)"""
         k0 = np.asarray(kpts0, dtype=np.float32).reshape(-1, 2)
         k1 = np.asarray(kpts1, dtype=np.float32).reshape(-1, 2)
-        n = min(len(k0), self.CAP)
+        n = len(k0)
+        # the depth-free solver (EssentialMatrixSolver) must not touch data['depth*'] (an uncollated empty tensor when the
+        # dataset has no depth, lib/datasets/mapfree.py:233-234)
+        H, W = data['depth0'].shape[-2:] if (need_depth0 or need_depth1) else (self.hw or (0, 0))
+        cap = self.cap
+        while n > cap:
+            cap *= 2                                 # every correspondence is used, as in the reference (no truncation)
+        if self.hw != (H, W) or cap != self.cap or self.host is None:
+            self._alloc(H, W, cap)
         m = max(n, 1)
         h = self.host
-        h[self.o_p0:self.o_p0 + 2 * n] = torch.from_numpy(k0[:n].reshape(-1))
-        h[self.o_p1:self.o_p1 + 2 * n] = torch.from_numpy(k1[:n].reshape(-1))
-        h[self.o_k:self.o_k + 9] = data['K_color0'].reshape(9).to(torch.float32)
-        h[self.o_k + 9:self.o_k + 18] = data['K_color1'].reshape(9).to(torch.float32)
-        self.host_i32[self.o_meta] = n
+        o_p1 = self.O_P + 2 * m
+        h[self.O_P:self.O_P + 2 * n] = torch.from_numpy(k0.reshape(-1))
+        h[o_p1:o_p1 + 2 * n] = torch.from_numpy(k1.reshape(-1))
+        K0, K1 = data['K_color0'], data['K_color1']
+        k64 = (K0.dtype == torch.float64) or (K1.dtype == torch.float64)
+        if k64:
+            self.host_k64[:9] = K0.reshape(9); self.host_k64[9:18] = K1.reshape(9)
+        else:
+            h[self.O_K:self.O_K + 9] = K0.reshape(9); h[self.O_K + 9:self.O_K + 18] = K1.reshape(9)
+        self.host_i32[self.O_META] = n
         self.host_i64[0] = _pair_id(data)
-        # the small operands cross in ONE async copy from the pinned pack; the depth maps (1.5 MB each) go straight from the
-        # loader's pageable tensors into their slots of the persistent device buffer (CPU stores into pinned, uncached
-        # host memory were measured slower than the driver's own staging for MB-sized pieces)
+        # the small operands cross in ONE async copy from the pinned pack (only the used prefix); the depth maps (1.5 MB each)
+        # go straight from the loader's pageable tensors into their slots of the persistent device buffer (CPU stores into
+        # pinned, uncached host memory were measured slower than the driver's own staging for MB-sized pieces)
         d = self.dev
-        d[:self.o_d0].copy_(h[:self.o_d0], non_blocking=True)
-        d[self.o_d0:self.o_d0 + H * W].copy_(data['depth0'].reshape(-1), non_blocking=True)
+        used = self.O_P + 4 * m
+        d[:used].copy_(h[:used], non_blocking=True)
+        if need_depth0:
+            d[self.o_d0:self.o_d0 + H * W].copy_(data['depth0'].reshape(-1), non_blocking=True)
         if need_depth1:
             d[self.o_d1:self.o_d1 + H * W].copy_(data['depth1'].reshape(-1), non_blocking=True)
         di32 = d.view(torch.int32)
-        return dict(pts0=d[self.o_p0:self.o_p0 + 2 * m].view(1, m, 2), pts1=d[self.o_p1:self.o_p1 + 2 * m].view(1, m, 2),
-                    n=di32[self.o_meta:self.o_meta + 1], K0=d[self.o_k:self.o_k + 9].view(1, 3, 3),
-                    K1=d[self.o_k + 9:self.o_k + 18].view(1, 3, 3), pid=d[self.o_meta + 2:self.o_meta + 4].view(torch.int64),
+        if k64:
+            kk = d[self.O_K:self.O_K + 36].view(torch.float64)
+            Kd0, Kd1 = kk[:9].view(1, 3, 3), kk[9:18].view(1, 3, 3)
+        else:
+            Kd0, Kd1 = d[self.O_K:self.O_K + 9].view(1, 3, 3), d[self.O_K + 9:self.O_K + 18].view(1, 3, 3)
+        return dict(pts0=d[self.O_P:self.O_P + 2 * m].view(1, m, 2), pts1=d[o_p1:o_p1 + 2 * m].view(1, m, 2),
+                    n=di32[self.O_META:self.O_META + 1], K0=Kd0, K1=Kd1,
+                    pid=d[self.O_META + 2:self.O_META + 4].view(torch.int64),
                     depth0=d[self.o_d0:self.o_d0 + H * W].view(1, H, W), depth1=d[self.o_d1:self.o_d1 + H * W].view(1, H, W), n_host=n)
 
     @staticmethod
@@ -137,7 +156,7 @@ class EssentialMatrixSolver(_Base):
         self.mask = None
 
     def _run(self, kpts0, kpts1, data, need_depth):
-        d = self._stage.put(kpts0, kpts1, data, need_depth1=need_depth)
+        d = self._stage.put(kpts0, kpts1, data, need_depth0=need_depth, need_depth1=need_depth)
         out = self._emat(d["pts0"], d["pts1"], d["n"], d["K0"], d["K1"], d["pid"])
         return d, out
 

@@ -21,6 +21,24 @@ def _chk(t, dtype, name):
     return t.contiguous()
 
 
+K_F32, K_F64 = 0, 1        # include/mfr_hip.h MFR_K_F32 / MFR_K_F64
+
+
+def _chk_K(K0, K1=None):
+    """Intrinsics go to the library in the dtype the `data` dict holds them: float64 from the Map-free loader
+    (lib/datasets/utils.py:117-130 multiplies a float64 eye(3) into K), float32 from resize=None datasets.  -> (K0, K1, tag);
+    a mixed pair is promoted to float64, as numpy would promote the reference's arithmetic."""
+    Ks = [K for K in (K0, K1) if K is not None]
+    for K in Ks:
+        if not (isinstance(K, torch.Tensor) and K.is_cuda):
+            raise _lib.MfrLibraryError("K must be a CUDA(HIP) tensor: the HIP path has no CPU fallback")
+        if K.dtype not in (torch.float32, torch.float64):
+            raise TypeError(f"K: expected float32 or float64, got {K.dtype}")
+    dt = torch.float64 if any(K.dtype == torch.float64 for K in Ks) else torch.float32
+    out = [None if K is None else K.to(dt).contiguous() for K in (K0, K1)]
+    return out[0], out[1], (K_F64 if dt == torch.float64 else K_F32)
+
+
 def _ws(nbytes, device):
     return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
 
@@ -40,7 +58,7 @@ def pnp_lift(pts0, pts1, n_corr, depth0, K0):
     lib = _lib.load(require_gpu=True)
     pts0 = _chk(pts0, torch.float32, "pts0"); pts1 = _chk(pts1, torch.float32, "pts1")
     n_corr = _chk(n_corr, torch.int32, "n_corr"); depth0 = _chk(depth0, torch.float32, "depth0")
-    K0 = _chk(K0, torch.float32, "K0")
+    K0, _, kdt = _chk_K(K0)
     B, maxN, _ = pts0.shape
     _, H, W = depth0.shape
     dev = pts0.device
@@ -50,7 +68,7 @@ def pnp_lift(pts0, pts1, n_corr, depth0, K0):
     src = torch.zeros(B, maxN, dtype=torch.int32, device=dev)
     nv = torch.zeros(B, dtype=torch.int32, device=dev)
     _lib.check(lib.mfr_pnp_lift(_lib.ptr(pts0), _lib.ptr(pts1), _lib.ptr(n_corr), B, maxN, _lib.ptr(depth0),
-                                _lib.ptr(part), H, W, _lib.ptr(K0), _lib.ptr(xyz), _lib.ptr(obs), _lib.ptr(src),
+                                _lib.ptr(part), H, W, _lib.ptr(K0), kdt, _lib.ptr(xyz), _lib.ptr(obs), _lib.ptr(src),
                                 _lib.ptr(nv), _lib.stream_ptr()), "mfr_pnp_lift")
     return xyz, obs, src, nv
 
@@ -60,7 +78,7 @@ def pnp_ransac(xyz, obs, n_valid, K1, pair_ids, max_iters=1000, thr=3.0, conf=0.
     on already lifted points.  Returns dict(R, t, n_inliers, status, mask, best_iter, iters_run, counts)."""
     lib = _lib.load(require_gpu=True)
     xyz = _chk(xyz, torch.float64, "xyz"); obs = _chk(obs, torch.float64, "obs")
-    n_valid = _chk(n_valid, torch.int32, "n_valid"); K1 = _chk(K1, torch.float32, "K1")
+    n_valid = _chk(n_valid, torch.int32, "n_valid"); K1, _, kdt = _chk_K(K1)
     pair_ids = _chk(pair_ids, torch.int64, "pair_ids")
     B, maxN, _ = xyz.shape
     dev = xyz.device
@@ -74,7 +92,7 @@ def pnp_ransac(xyz, obs, n_valid, K1, pair_ids, max_iters=1000, thr=3.0, conf=0.
     mask = torch.empty(B, maxN, dtype=torch.uint8, device=dev)
     bi = torch.empty(B, dtype=torch.int32, device=dev)
     ir = torch.empty(B, dtype=torch.int32, device=dev)
-    _lib.check(lib.mfr_pnp_ransac(_lib.ptr(xyz), _lib.ptr(obs), _lib.ptr(n_valid), B, maxN, _lib.ptr(K1), max_iters,
+    _lib.check(lib.mfr_pnp_ransac(_lib.ptr(xyz), _lib.ptr(obs), _lib.ptr(n_valid), B, maxN, _lib.ptr(K1), kdt, max_iters,
                                   float(thr), float(conf), int(seed), _lib.ptr(pair_ids), _lib.ptr(counts),
                                   _lib.ptr(inl), _lib.ptr(R), _lib.ptr(t), _lib.ptr(ni), _lib.ptr(st), _lib.ptr(mask),
                                   _lib.ptr(bi), _lib.ptr(ir), _lib.stream_ptr()), "mfr_pnp_ransac")
@@ -95,7 +113,7 @@ class PnPBatchSolver:
         lib = _lib.load(require_gpu=True)
         pts0 = _chk(pts0, torch.float32, "pts0"); pts1 = _chk(pts1, torch.float32, "pts1")
         n_corr = _chk(n_corr, torch.int32, "n_corr"); depth0 = _chk(depth0, torch.float32, "depth0")
-        K0 = _chk(K0, torch.float32, "K0"); K1 = _chk(K1, torch.float32, "K1")
+        K0, K1, kdt = _chk_K(K0, K1)
         pair_ids = _chk(pair_ids, torch.int64, "pair_ids")
         B, maxN, _ = pts0.shape
         _, H, W = depth0.shape
@@ -110,7 +128,7 @@ class PnPBatchSolver:
         mask = torch.empty(B, maxN, dtype=torch.uint8, device=dev) if want_mask else None
         _lib.check(lib.mfr_pnp_solve_batch(
             _lib.ptr(pts0), _lib.ptr(pts1), _lib.ptr(n_corr), B, maxN, _lib.ptr(depth0), H, W, _lib.ptr(K0),
-            _lib.ptr(K1), self.max_iters, self.reproj_thr, self.confidence, self.seed, _lib.ptr(pair_ids),
+            _lib.ptr(K1), kdt, self.max_iters, self.reproj_thr, self.confidence, self.seed, _lib.ptr(pair_ids),
             _lib.ptr(self._ws), self._ws.numel(), _lib.ptr(R), _lib.ptr(t), _lib.ptr(ni), _lib.ptr(st),
             _lib.ptr(mask), _lib.stream_ptr()), "mfr_pnp_solve_batch")
         out = dict(R=R, t=t, n_inliers=ni, status=st)
@@ -131,7 +149,7 @@ class EssentialBatchSolver:
         lib = _lib.load(require_gpu=True)
         pts0 = _chk(pts0, torch.float32, "pts0"); pts1 = _chk(pts1, torch.float32, "pts1")
         n_corr = _chk(n_corr, torch.int32, "n_corr")
-        K0 = _chk(K0, torch.float32, "K0"); K1 = _chk(K1, torch.float32, "K1")
+        K0, K1, kdt = _chk_K(K0, K1)
         pair_ids = _chk(pair_ids, torch.int64, "pair_ids")
         B, maxN, _ = pts0.shape
         dev = pts0.device
@@ -148,7 +166,7 @@ class EssentialBatchSolver:
             bi = torch.empty(B, dtype=torch.int32, device=dev); ir = torch.empty(B, dtype=torch.int32, device=dev)
             cnt = torch.empty(B, self.max_iters, dtype=torch.int32, device=dev)
         _lib.check(lib.mfr_emat_solve_batch(
-            _lib.ptr(pts0), _lib.ptr(pts1), _lib.ptr(n_corr), B, maxN, _lib.ptr(K0), _lib.ptr(K1), self.pix_thr,
+            _lib.ptr(pts0), _lib.ptr(pts1), _lib.ptr(n_corr), B, maxN, _lib.ptr(K0), _lib.ptr(K1), kdt, self.pix_thr,
             self.confidence, self.max_iters, self.seed, _lib.ptr(pair_ids), _lib.ptr(self._ws), self._ws.numel(),
             _lib.ptr(R), _lib.ptr(t), _lib.ptr(ni), _lib.ptr(st), _lib.ptr(mask), _lib.ptr(bi), _lib.ptr(ir),
             _lib.ptr(cnt), _lib.stream_ptr()), "mfr_emat_solve_batch")
@@ -171,7 +189,7 @@ class ProcrustesBatchSolver:
         pts0 = _chk(pts0, torch.float32, "pts0"); pts1 = _chk(pts1, torch.float32, "pts1")
         n_corr = _chk(n_corr, torch.int32, "n_corr")
         depth0 = _chk(depth0, torch.float32, "depth0"); depth1 = _chk(depth1, torch.float32, "depth1")
-        K0 = _chk(K0, torch.float32, "K0"); K1 = _chk(K1, torch.float32, "K1")
+        K0, K1, kdt = _chk_K(K0, K1)
         pair_ids = _chk(pair_ids, torch.int64, "pair_ids")
         B, maxN, _ = pts0.shape
         _, H, W = depth0.shape
@@ -189,7 +207,7 @@ class ProcrustesBatchSolver:
             cnt = torch.empty(B, self.max_iters, dtype=torch.int32, device=dev)
         _lib.check(lib.mfr_procrustes_solve_batch(
             _lib.ptr(pts0), _lib.ptr(pts1), _lib.ptr(n_corr), B, maxN, _lib.ptr(depth0), _lib.ptr(depth1), H, W, _lib.ptr(K0),
-            _lib.ptr(K1), self.max_corr_dist, self.confidence, self.max_iters, self.seed, _lib.ptr(pair_ids),
+            _lib.ptr(K1), kdt, self.max_corr_dist, self.confidence, self.max_iters, self.seed, _lib.ptr(pair_ids),
             _lib.ptr(self._ws), self._ws.numel(), _lib.ptr(R), _lib.ptr(t), _lib.ptr(ni), _lib.ptr(st), _lib.ptr(bi),
             _lib.ptr(ir), _lib.ptr(cnt), _lib.stream_ptr()), "mfr_procrustes_solve_batch")
         out = dict(R=R, t=t, n_inliers=ni, status=st)
@@ -210,7 +228,7 @@ class ProcrustesIcpRefine:
     def __call__(self, depth0, depth1, K0, K1, R, t, status=None):
         lib = _lib.load(require_gpu=True)
         depth0 = _chk(depth0, torch.float32, "depth0"); depth1 = _chk(depth1, torch.float32, "depth1")
-        K0 = _chk(K0, torch.float32, "K0"); K1 = _chk(K1, torch.float32, "K1")
+        K0, K1, kdt = _chk_K(K0, K1)
         R = _chk(R, torch.float64, "R"); t = _chk(t, torch.float64, "t")
         if status is not None:
             status = _chk(status, torch.int32, "status")
@@ -222,7 +240,7 @@ class ProcrustesIcpRefine:
         ni = torch.empty(B, dtype=torch.int32, device=dev)
         fit = torch.empty(B, dtype=torch.float64, device=dev); rm = torch.empty(B, dtype=torch.float64, device=dev)
         it = torch.empty(B, dtype=torch.int32, device=dev)
-        _lib.check(lib.mfr_procrustes_icp_refine(_lib.ptr(depth0), _lib.ptr(depth1), B, H, W, _lib.ptr(K0), _lib.ptr(K1), self.max_corr_dist,
+        _lib.check(lib.mfr_procrustes_icp_refine(_lib.ptr(depth0), _lib.ptr(depth1), B, H, W, _lib.ptr(K0), _lib.ptr(K1), kdt, self.max_corr_dist,
                                                  self.rel_fitness, self.rel_rmse, self.max_iter, _lib.ptr(status), _lib.ptr(self._ws),
                                                  self._ws.numel(), _lib.ptr(R), _lib.ptr(t), _lib.ptr(ni), _lib.ptr(fit), _lib.ptr(rm),
                                                  _lib.ptr(it), _lib.stream_ptr()), "mfr_procrustes_icp_refine")
@@ -241,7 +259,7 @@ class ScaleFromDepthBatch:
         pts0 = _chk(pts0, torch.float32, "pts0"); pts1 = _chk(pts1, torch.float32, "pts1")
         n_corr = _chk(n_corr, torch.int32, "n_corr")
         depth0 = _chk(depth0, torch.float32, "depth0"); depth1 = _chk(depth1, torch.float32, "depth1")
-        K0 = _chk(K0, torch.float32, "K0"); K1 = _chk(K1, torch.float32, "K1")
+        K0, K1, kdt = _chk_K(K0, K1)
         R = _chk(R, torch.float64, "R"); t = _chk(t, torch.float64, "t")
         if emat_mask is not None:
             emat_mask = _chk(emat_mask, torch.uint8, "emat_mask")
@@ -259,7 +277,7 @@ class ScaleFromDepthBatch:
         st = torch.empty(B, dtype=torch.int32, device=dev)
         _lib.check(lib.mfr_scale_from_depth_batch(
             _lib.ptr(pts0), _lib.ptr(pts1), _lib.ptr(emat_mask), _lib.ptr(n_corr), B, maxN, _lib.ptr(depth0),
-            _lib.ptr(depth1), H, W, _lib.ptr(K0), _lib.ptr(K1), _lib.ptr(R), _lib.ptr(t), _lib.ptr(in_status),
+            _lib.ptr(depth1), H, W, _lib.ptr(K0), _lib.ptr(K1), kdt, _lib.ptr(R), _lib.ptr(t), _lib.ptr(in_status),
             self.scale_thr, _lib.ptr(self._ws), self._ws.numel(), _lib.ptr(tm), _lib.ptr(bs), _lib.ptr(ni),
             _lib.ptr(st), _lib.stream_ptr()), "mfr_scale_from_depth_batch")
         return dict(t_metric=tm, best_scale=bs, n_inliers=ni, status=st)

@@ -181,31 +181,50 @@ int mfr_ref_poly_real_roots(const double *c_in, int deg, double *roots)
 /* ------------------------------------------------------------------------ */
 /* pose_solver.py:6-17 backproject_3d                                        */
 /* ------------------------------------------------------------------------ */
-static int kinv_f32(const float K[9], float Ki[9])
+/* np.linalg.inv on the pinhole matrix [[fx,0,cx],[0,fy,cy],[0,0,1]] in K's own dtype (zero skew / unit bottom row only).
+ * The off-diagonal entries are what the LAPACK gesv back-substitution of the numpy build in the reference container gives,
+ * pinned by the reference-executed fixtures (oracle/gen_golden.py, 5000 random K each, zero mismatches):
+ *   float32 (sgesv): -(cx / fx)          -- a division
+ *   float64 (dgesv): -(cx * (1.0 / fx))  -- the triangular solve multiplies by the reciprocal of the pivot */
+int mfr_ref_load_intr(const void *K, int k_dtype, mfr_intr *o)
 {
-    /* np.linalg.inv on the f32 pinhole matrix [[fx,0,cx],[0,fy,cy],[0,0,1]]
-     * (quirk Q5: inverse evaluated in f32).  Zero skew / unit bottom row only. */
-    if (K[1] != 0.f || K[3] != 0.f || K[6] != 0.f || K[7] != 0.f || K[8] != 1.f) return -1;
-    if (K[0] == 0.f || K[4] == 0.f) return -1;
-    float ifx = 1.0f / K[0], ify = 1.0f / K[4];
-    /* LAPACK sgesv back-substitution form (matches np.linalg.inv bit-for-bit on 2000 random K) */
-    Ki[0] = ifx; Ki[1] = 0.f; Ki[2] = -(K[2] / K[0]);
-    Ki[3] = 0.f; Ki[4] = ify; Ki[5] = -(K[5] / K[4]);
-    Ki[6] = 0.f; Ki[7] = 0.f; Ki[8] = 1.f;
+    if (k_dtype == MFR_K_F32) {
+        const float *k = (const float *)K;
+        if (k[1] != 0.f || k[3] != 0.f || k[6] != 0.f || k[7] != 0.f || k[8] != 1.f) return -1;
+        if (k[0] == 0.f || k[4] == 0.f) return -1;
+        const float ifx = 1.0f / k[0], ify = 1.0f / k[4];
+        const float icx = -(k[2] / k[0]), icy = -(k[5] / k[4]);
+        o->fx = (double)k[0]; o->fy = (double)k[4]; o->cx = (double)k[2]; o->cy = (double)k[5];
+        o->ifx = (double)ifx; o->ify = (double)ify; o->icx = (double)icx; o->icy = (double)icy;
+        o->f32 = 1;
+        return 0;
+    }
+    if (k_dtype != MFR_K_F64) return -1;
+    const double *k = (const double *)K;
+    if (k[1] != 0.0 || k[3] != 0.0 || k[6] != 0.0 || k[7] != 0.0 || k[8] != 1.0) return -1;
+    if (k[0] == 0.0 || k[4] == 0.0) return -1;
+    o->fx = k[0]; o->fy = k[4]; o->cx = k[2]; o->cy = k[5];
+    o->ifx = 1.0 / k[0]; o->ify = 1.0 / k[4];
+    o->icx = -(k[2] * o->ifx); o->icy = -(k[5] * o->ify);
+    o->f32 = 0;
     return 0;
 }
 
-int mfr_ref_backproject(const int32_t *uv, const float *depth, int n, const float K[9], double *xyz)
+static inline void backproject_intr(const mfr_intr *ki, int32_t ui, int32_t vi, float depth, double *xyz)
 {
-    float Ki[9];
-    if (kinv_f32(K, Ki)) return -1;
-    for (int i = 0; i < n; ++i) {
-        double u = (double)uv[2 * i], v = (double)uv[2 * i + 1], d = (double)depth[i];
-        double rx = ((double)Ki[0] * u + (double)Ki[1] * v) + (double)Ki[2];
-        double ry = ((double)Ki[3] * u + (double)Ki[4] * v) + (double)Ki[5];
-        double rz = ((double)Ki[6] * u + (double)Ki[7] * v) + (double)Ki[8];
-        xyz[3 * i] = d * rx; xyz[3 * i + 1] = d * ry; xyz[3 * i + 2] = d * rz;
-    }
+    /* (inv(K) @ [u, v, 1]) as the f64 matrix product evaluates it (zero entries included), then depth * ray */
+    const double u = (double)ui, v = (double)vi, d = (double)depth;
+    const double rx = (ki->ifx * u + 0.0 * v) + ki->icx;
+    const double ry = (0.0 * u + ki->ify * v) + ki->icy;
+    const double rz = (0.0 * u + 0.0 * v) + 1.0;
+    xyz[0] = d * rx; xyz[1] = d * ry; xyz[2] = d * rz;
+}
+
+int mfr_ref_backproject(const int32_t *uv, const float *depth, int n, const void *K, int k_dtype, double *xyz)
+{
+    mfr_intr ki;
+    if (mfr_ref_load_intr(K, k_dtype, &ki)) return -1;
+    for (int i = 0; i < n; ++i) backproject_intr(&ki, uv[2 * i], uv[2 * i + 1], depth[i], xyz + 3 * i);
     return 0;
 }
 
@@ -222,17 +241,18 @@ static inline int32_t trunc_i32(float x) { return (int32_t)x; }
 /* pose_solver.py:186-206.  Out-of-image pixels (numpy would raise IndexError,
  * or wrap for negatives) are treated as invalid -- documented deviation. */
 int mfr_ref_pnp_lift(const float *pts0, const float *pts1, int n, const float *depth0, int H, int W,
-                     const float K0[9], double *xyz, double *obs, int32_t *src_idx)
+                     const void *K0, int k_dtype, double *xyz, double *obs, int32_t *src_idx)
 {
     float dmin = mfr_ref_depth_min(depth0, H * W);
+    mfr_intr ki;
+    if (mfr_ref_load_intr(K0, k_dtype, &ki)) return -1;
     int m = 0;
     for (int i = 0; i < n; ++i) {
         int32_t u = trunc_i32(pts0[2 * i]), v = trunc_i32(pts0[2 * i + 1]);
         if (u < 0 || u >= W || v < 0 || v >= H) continue;
         float d = depth0[v * W + u];
         if (!(d > dmin)) continue;
-        int32_t uv[2] = { u, v };
-        if (mfr_ref_backproject(uv, &d, 1, K0, xyz + 3 * m)) return -1;
+        backproject_intr(&ki, u, v, d, xyz + 3 * m);
         obs[2 * m] = (double)pts1[2 * i]; obs[2 * m + 1] = (double)pts1[2 * i + 1];
         src_idx[m] = i;
         ++m;
@@ -538,12 +558,15 @@ int mfr_ref_pnp_lm(const double *xyz, const double *obs, const int32_t *idx, int
 /* cap.  All max_iters hypotheses are a pure function of (seed,pair,iter), so */
 /* the device evaluates them in parallel and replays this loop as a scan.    */
 /* ------------------------------------------------------------------------ */
-int mfr_ref_pnp_ransac(const double *xyz, const double *obs, int n, const float K1[9],
+int mfr_ref_pnp_ransac(const double *xyz, const double *obs, int n, const void *K1, int k_dtype,
                        int max_iters, double thr, double conf, uint64_t seed, uint64_t pair_id,
                        double R[9], double t[3], uint8_t *mask, int *n_inl,
                        int *best_iter, int *iters_run, int32_t *counts)
 {
-    const double Kd[4] = { (double)K1[0], (double)K1[4], (double)K1[2], (double)K1[5] };
+    /* K1.numpy() handed to OpenCV, which works in double: exact widening for float32 (pose_solver.py:209-213) */
+    mfr_intr k1;
+    if (mfr_ref_load_intr(K1, k_dtype, &k1)) return MFR_ST_NO_MODEL;
+    const double Kd[4] = { k1.fx, k1.fy, k1.cx, k1.cy };
     const double thr2 = thr * thr;
     for (int i = 0; i < 9; ++i) R[i] = NAN;
     for (int i = 0; i < 3; ++i) t[i] = NAN;
@@ -611,7 +634,7 @@ int mfr_ref_pnp_ransac(const double *xyz, const double *obs, int n, const float 
 }
 
 int mfr_ref_pnp_solve(const float *pts0, const float *pts1, int n, const float *depth0, int H, int W,
-                      const float K0[9], const float K1[9], int max_iters, double thr, double conf,
+                      const void *K0, const void *K1, int k_dtype, int max_iters, double thr, double conf,
                       uint64_t seed, uint64_t pair_id, double R[9], double t[3], int *n_inl)
 {
     for (int i = 0; i < 9; ++i) R[i] = NAN;
@@ -621,10 +644,10 @@ int mfr_ref_pnp_solve(const float *pts0, const float *pts1, int n, const float *
     double *xyz = (double *)malloc(sizeof(double) * 3 * (size_t)n);
     double *obs = (double *)malloc(sizeof(double) * 2 * (size_t)n);
     int32_t *src = (int32_t *)malloc(sizeof(int32_t) * (size_t)n);
-    int m = mfr_ref_pnp_lift(pts0, pts1, n, depth0, H, W, K0, xyz, obs, src);
+    int m = mfr_ref_pnp_lift(pts0, pts1, n, depth0, H, W, K0, k_dtype, xyz, obs, src);
     int st;
     if (m < 4) st = MFR_ST_BAD_DEPTH;                  /* pose_solver.py:197-198 */
-    else st = mfr_ref_pnp_ransac(xyz, obs, m, K1, max_iters, thr, conf, seed, pair_id, R, t, NULL, n_inl,
+    else st = mfr_ref_pnp_ransac(xyz, obs, m, K1, k_dtype, max_iters, thr, conf, seed, pair_id, R, t, NULL, n_inl,
                                  NULL, NULL, NULL);
     free(xyz); free(obs); free(src);
     return st;
@@ -635,10 +658,12 @@ int mfr_ref_pnp_solve(const float *pts0, const float *pts1, int n, const float *
 /* ------------------------------------------------------------------------ */
 int mfr_ref_scale_lift(const float *pts0, const float *pts1, const uint8_t *mask, int n,
                        const float *depth0, const float *depth1, int H, int W,
-                       const float K0[9], const float K1[9], const double R[9], const double t[3],
+                       const void *K0, const void *K1, int k_dtype, const double R[9], const double t[3],
                        double *scale)
 {
     int m = 0;
+    mfr_intr ki0, ki1;
+    if (mfr_ref_load_intr(K0, k_dtype, &ki0) || mfr_ref_load_intr(K1, k_dtype, &ki1)) return -1;
     for (int i = 0; i < n; ++i) {
         if (mask && mask[i] != 1) continue;                                 /* :137 mask == 1 */
         int32_t u0 = trunc_i32(pts0[2 * i]), v0 = trunc_i32(pts0[2 * i + 1]);   /* :138 */
@@ -646,10 +671,9 @@ int mfr_ref_scale_lift(const float *pts0, const float *pts1, const uint8_t *mask
         if (u0 < 0 || u0 >= W || v0 < 0 || v0 >= H || u1 < 0 || u1 >= W || v1 < 0 || v1 >= H) continue;
         float d0 = depth0[v0 * W + u0], d1 = depth1[v1 * W + u1];           /* :140-141 */
         if (!(d0 > 0.f) || !(d1 > 0.f)) continue;                           /* :144 */
-        int32_t uv0[2] = { u0, v0 }, uv1[2] = { u1, v1 };
         double p0[3], p1[3], rp0[3];
-        if (mfr_ref_backproject(uv0, &d0, 1, K0, p0)) return -1;            /* :150 */
-        if (mfr_ref_backproject(uv1, &d1, 1, K1, p1)) return -1;            /* :151 */
+        backproject_intr(&ki0, u0, v0, d0, p0);                             /* :150 */
+        backproject_intr(&ki1, u1, v1, d1, p1);                             /* :151 */
         rp0[0] = (R[0] * p0[0] + R[1] * p0[1]) + R[2] * p0[2];              /* :154 */
         rp0[1] = (R[3] * p0[0] + R[4] * p0[1]) + R[5] * p0[2];
         rp0[2] = (R[6] * p0[0] + R[7] * p0[1]) + R[8] * p0[2];

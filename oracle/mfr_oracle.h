@@ -38,33 +38,50 @@ enum {
     MFR_ST_DEGENERATE = 4    /* |t| > 1000 (pose_solver.py:223-225)           */
 };
 
+/* Intrinsics cross every boundary as 9 row-major values of the dtype the `data` dict holds (same tags as include/mfr_hip.h):
+ *   MFR_K_F64  the Map-free loader's flow: correct_intrinsic_scale multiplies a float64 np.eye(3) into K
+ *              (lib/datasets/utils.py:117-130, always called: lib/datasets/mapfree.py:50-52), so data['K_color*'] is
+ *              float64 and np.linalg.inv(K) (pose_solver.py:16), the K-normalisation (:39-40) and the threshold mean
+ *              (:43) are float64 arithmetic;
+ *   MFR_K_F32  resize=None datasets: K stays float32, the inverse / normalisation / mean are float32 arithmetic
+ *              (quirk Q5) and only the products are promoted to float64. */
+#define MFR_K_F32 0
+#define MFR_K_F64 1
+typedef struct {
+    double fx, fy, cx, cy;        /* as stored (f32 values widen exactly)                                  */
+    double ifx, icx, ify, icy;    /* np.linalg.inv(K)[0,0], [0,2], [1,1], [1,2] evaluated in K's own dtype  */
+    int f32;
+} mfr_intr;
+/* -1 if K is not a zero-skew pinhole matrix with bottom row [0,0,1] */
+int mfr_ref_load_intr(const void *K, int k_dtype, mfr_intr *out);
+
 void mfr_ref_philox4x32_10(const uint32_t ctr[4], uint32_t k0, uint32_t k1, uint32_t out[4]);
 void mfr_ref_sample_distinct(uint64_t seed, uint64_t pair_id, uint32_t iter, int n, int k, int *out);
 double mfr_ref_det_log(double x);
 int mfr_ref_update_num_iters(double p, double ep, int model_points, int max_iters);
 int mfr_ref_poly_real_roots(const double *c, int deg, double *roots);
 
-/* pose_solver.py:6-17 -- xyz[N,3] = depth * (inv(K) @ [u,v,1]); K is the f32
- * 3x3 pinhole matrix (zero skew), inverse evaluated in f32 (quirk Q5). */
-int mfr_ref_backproject(const int32_t *uv, const float *depth, int n, const float K[9], double *xyz);
+/* pose_solver.py:6-17 -- xyz[N,3] = depth * (inv(K) @ [u,v,1]); K is the 3x3 pinhole matrix (zero skew) in
+ * float32 or float64; the inverse is evaluated in K's dtype exactly as np.linalg.inv does (see mfr_ref_load_intr). */
+int mfr_ref_backproject(const int32_t *uv, const float *depth, int n, const void *K, int k_dtype, double *xyz);
 
 float mfr_ref_depth_min(const float *depth, int hw);
 
 /* pose_solver.py:186-206 (PnP input prep): int-truncate pts0, gather depth0,
  * valid = d > depth_min, compact, back-project with K0.  obs = pts1 (f64). */
 int mfr_ref_pnp_lift(const float *pts0, const float *pts1, int n, const float *depth0, int H, int W,
-                     const float K0[9], double *xyz, double *obs, int32_t *src_idx);
+                     const void *K0, int k_dtype, double *xyz, double *obs, int32_t *src_idx);
 
 /* cv.solvePnPRansac(P3P) + refit + cv.solvePnPGeneric(ITERATIVE) restatement
  * (pose_solver.py:209-235).  Returns per-pair status. */
-int mfr_ref_pnp_ransac(const double *xyz, const double *obs, int n, const float K1[9],
+int mfr_ref_pnp_ransac(const double *xyz, const double *obs, int n, const void *K1, int k_dtype,
                        int max_iters, double thr, double conf, uint64_t seed, uint64_t pair_id,
                        double R[9], double t[3], uint8_t *mask, int *n_inl,
                        int *best_iter, int *iters_run, int32_t *counts /* [max_iters] or NULL */);
 
 /* full PnPSolver.estimate_pose (pose_solver.py:184-235) */
 int mfr_ref_pnp_solve(const float *pts0, const float *pts1, int n, const float *depth0, int H, int W,
-                      const float K0[9], const float K1[9], int max_iters, double thr, double conf,
+                      const void *K0, const void *K1, int k_dtype, int max_iters, double thr, double conf,
                       uint64_t seed, uint64_t pair_id, double R[9], double t[3], int *n_inl);
 
 int mfr_ref_p3p(const double X[9], const double f[9], double Rs[36], double ts[12]);
@@ -72,7 +89,7 @@ int mfr_ref_p3p(const double X[9], const double f[9], double Rs[36], double ts[1
 /* pose_solver.py:137-172 -- depth lift of E-mat inliers + exhaustive 1-D scale RANSAC */
 int mfr_ref_scale_lift(const float *pts0, const float *pts1, const uint8_t *mask, int n,
                        const float *depth0, const float *depth1, int H, int W,
-                       const float K0[9], const float K1[9], const double R[9], const double t[3],
+                       const void *K0, const void *K1, int k_dtype, const double R[9], const double t[3],
                        double *scale /* [n] */);
 int mfr_ref_scale_ransac(const double *scale, int n, double thr, double *best_scale, int *best_idx);
 

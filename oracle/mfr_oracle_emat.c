@@ -365,20 +365,36 @@ int mfr_ref_emat_refine(const double *x0, const double *x1, const int32_t *idx, 
     return 0;
 }
 
-/* K-normalisation in f32 exactly as pose_solver.py:39-40 (numpy float32 arithmetic) */
-void mfr_ref_normalize_points(const float *pts, int n, const float K[9], double *out)
+/* K-normalisation exactly as pose_solver.py:39-40: float32 keypoints minus / over K's entries -- numpy float32 arithmetic
+ * for a float32 K, float64 arithmetic (keypoints widened) for the Map-free loader's float64 K */
+void mfr_ref_normalize_points(const float *pts, int n, const void *K, int k_dtype, double *out)
 {
-    for (int i = 0; i < n; ++i) {
-        float x = (pts[2 * i] - K[2]) / K[0], y = (pts[2 * i + 1] - K[5]) / K[4];
-        out[2 * i] = (double)x; out[2 * i + 1] = (double)y;
+    if (k_dtype == MFR_K_F32) {
+        const float *k = (const float *)K;
+        for (int i = 0; i < n; ++i) {
+            float x = (pts[2 * i] - k[2]) / k[0], y = (pts[2 * i + 1] - k[5]) / k[4];
+            out[2 * i] = (double)x; out[2 * i + 1] = (double)y;
+        }
+    } else {
+        const double *k = (const double *)K;
+        for (int i = 0; i < n; ++i) {
+            out[2 * i] = ((double)pts[2 * i] - k[2]) / k[0];
+            out[2 * i + 1] = ((double)pts[2 * i + 1] - k[5]) / k[4];
+        }
     }
 }
 
-/* pose_solver.py:43: thr = PIX_THRESHOLD / np.mean([fx0, fy1, fy0, fx1]) (f32 mean, f64 divide) */
-double mfr_ref_emat_threshold(double pix_thr, const float K0[9], const float K1[9])
+/* pose_solver.py:43: thr = PIX_THRESHOLD / np.mean([fx0, fy1, fy0, fx1]); the mean is taken in K's dtype */
+double mfr_ref_emat_threshold(double pix_thr, const void *K0, const void *K1, int k_dtype)
 {
-    float m = (((K0[0] + K1[4]) + K0[4]) + K1[0]) / 4.0f;
-    return pix_thr / (double)m;
+    if (k_dtype == MFR_K_F32) {
+        const float *a = (const float *)K0, *b = (const float *)K1;
+        float m = (((a[0] + b[4]) + a[4]) + b[0]) / 4.0f;
+        return pix_thr / (double)m;
+    }
+    const double *a = (const double *)K0, *b = (const double *)K1;
+    double m = (((a[0] + b[4]) + a[4]) + b[0]) / 4.0;
+    return pix_thr / m;
 }
 
 /* one hypothesis: best (most inliers, first on ties) of the <= 10 five-point models */
@@ -399,7 +415,7 @@ static int emat_hypothesis(const double *x0, const double *x1, int n, const int 
 
 /* EssentialMatrixSolver.estimate_pose (pose_solver.py:29-61).  mask_out = cheirality-filtered
  * inliers (what self.mask holds after the recoverPose loop, quirk Q7), n_inl = their count. */
-int mfr_ref_emat_solve(const float *pts0, const float *pts1, int n, const float K0[9], const float K1[9],
+int mfr_ref_emat_solve(const float *pts0, const float *pts1, int n, const void *K0, const void *K1, int k_dtype,
                        double pix_thr, double conf, int max_iters, uint64_t seed, uint64_t pair_id,
                        double R[9], double t[3], uint8_t *mask_out, int *n_inl,
                        int *best_iter, int *iters_run, int32_t *counts, uint8_t *ransac_mask)
@@ -412,9 +428,9 @@ int mfr_ref_emat_solve(const float *pts0, const float *pts1, int n, const float 
     if (n < 5) return MFR_ST_TOO_FEW;                                        /* :32-33 */
     if (max_iters < 1) max_iters = 1;
     double *x0 = (double *)malloc(sizeof(double) * 2 * (size_t)n), *x1 = (double *)malloc(sizeof(double) * 2 * (size_t)n);
-    mfr_ref_normalize_points(pts0, n, K0, x0);                               /* :39 */
-    mfr_ref_normalize_points(pts1, n, K1, x1);                               /* :40 */
-    double thr = mfr_ref_emat_threshold(pix_thr, K0, K1), thr2 = thr * thr;  /* :43 */
+    mfr_ref_normalize_points(pts0, n, K0, k_dtype, x0);                      /* :39 */
+    mfr_ref_normalize_points(pts1, n, K1, k_dtype, x1);                      /* :40 */
+    double thr = mfr_ref_emat_threshold(pix_thr, K0, K1, k_dtype), thr2 = thr * thr;  /* :43 */
     double Eb[9], Eh[9];
     int best = 4, bit = -1, niters = max_iters, it = 0;
     if (n == 5) {

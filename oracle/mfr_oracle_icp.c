@@ -23,7 +23,7 @@
 #include <string.h>
 #include <stdlib.h>
 
-int mfr_ref_backproject(const int32_t *uv, const float *depth, int n, const float K[9], double *xyz);
+/* (prototype in mfr_oracle.h) */
 void mfr_ref_kabsch_from_moments(const double *s, double *R, double *t);
 
 #define NACC 17
@@ -36,9 +36,9 @@ static void rot_apply(const double *R, const double *t, const double *X, double 
 }
 
 /* nearest target point of Y within radius r (strictly): returns pixel index or -1, *bd2 = squared distance */
-static int nearest(const double *Y, const float *depth1, const double *Tc, int H, int W, const float K1[9], double r, double *bd2)
+static int nearest(const double *Y, const float *depth1, const double *Tc, int H, int W, const mfr_intr *k1, double r, double *bd2)
 {
-    const double fx = (double)K1[0], fy = (double)K1[4], cx = (double)K1[2], cy = (double)K1[5];
+    const double fx = k1->fx, fy = k1->fy, cx = k1->cx, cy = k1->cy;
     const double Z = Y[2];
     int u0 = 0, u1 = W - 1, v0 = 0, v1 = H - 1;
     if (Z > 2.0 * r) {
@@ -76,9 +76,11 @@ static int nearest(const double *Y, const float *depth1, const double *Tc, int H
     return best;
 }
 
-static void evaluate(const float *depth0, const float *depth1, const double *Tc, int H, int W, const float K0[9], const float K1[9],
-                     const double *R, const double *t, double r, double *tot)
+static void evaluate(const float *depth0, const float *depth1, const double *Tc, int H, int W, const void *K0, const void *K1,
+                     int k_dtype, const double *R, const double *t, double r, double *tot)
 {
+    mfr_intr k1;
+    mfr_ref_load_intr(K1, k_dtype, &k1);
     const int hw = H * W, nblk = (hw + 255) / 256;
     for (int k = 0; k < NACC; ++k) tot[k] = 0.0;
     for (int blk = 0; blk < nblk; ++blk) {
@@ -93,9 +95,9 @@ static void evaluate(const float *depth0, const float *depth1, const double *Tc,
                 if (!(d > 0.f)) continue;
                 int32_t uv[2] = { i % W, i / W };
                 double X[3], Y[3], bd2 = 0.0;
-                mfr_ref_backproject(uv, &d, 1, K0, X);
+                mfr_ref_backproject(uv, &d, 1, K0, k_dtype, X);
                 rot_apply(R, t, X, Y);
-                const int j = nearest(Y, depth1, Tc, H, W, K1, r, &bd2);
+                const int j = nearest(Y, depth1, Tc, H, W, &k1, r, &bd2);
                 if (j < 0) continue;
                 const double *q = Tc + 3 * (size_t)j;
                 double *c = a[l];
@@ -116,7 +118,7 @@ static void evaluate(const float *depth0, const float *depth1, const double *Tc,
 }
 
 /* R, t: in = initial transform (RANSAC result), out = refined.  Returns number of update steps taken. */
-int mfr_ref_procrustes_icp(const float *depth0, const float *depth1, int H, int W, const float K0[9], const float K1[9],
+int mfr_ref_procrustes_icp(const float *depth0, const float *depth1, int H, int W, const void *K0, const void *K1, int k_dtype,
                            double max_dist, double rel_fitness, double rel_rmse, int max_iter, double R[9], double t[3],
                            int *n_inliers, double *fitness_out, double *rmse_out)
 {
@@ -129,13 +131,13 @@ int mfr_ref_procrustes_icp(const float *depth0, const float *depth1, int H, int 
         if (depth1[i] > 0.f) {
             ++nT;
             int32_t uv[2] = { i % W, i / W };
-            mfr_ref_backproject(uv, depth1 + i, 1, K1, Tc + 3 * i);
+            mfr_ref_backproject(uv, depth1 + i, 1, K1, k_dtype, Tc + 3 * i);
         }
     }
     double tot[NACC], fit_prev = 0.0, rmse_prev = 0.0, fit = 0.0, rmse = 0.0;
     int k;
     for (k = 0; ; ++k) {
-        evaluate(depth0, depth1, Tc, H, W, K0, K1, R, t, max_dist, tot);
+        evaluate(depth0, depth1, Tc, H, W, K0, K1, k_dtype, R, t, max_dist, tot);
         const double n = tot[0];
         fit = (nS > 0) ? n / (double)nS : 0.0;
         rmse = (n > 0.0) ? sqrt(tot[16] / n) : 0.0;

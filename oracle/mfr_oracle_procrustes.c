@@ -22,7 +22,7 @@
 
 void mfr_ref_sample_distinct(uint64_t seed, uint64_t pair_id, uint32_t iter, int n, int k, int *out);
 double mfr_ref_det_log(double x);
-int mfr_ref_backproject(const int32_t *uv, const float *depth, int n, const float K[9], double *xyz);
+/* (prototype in mfr_oracle.h) */
 float mfr_ref_depth_min(const float *depth, int hw);
 
 /* symmetric 4x4 eigen-decomposition, cyclic Jacobi, fixed 10 sweeps; returns unit eigenvector of
@@ -137,7 +137,7 @@ static void moments3(const double *P, const double *Q, const int *s, double *m)
 
 /* lift: both views int-truncated, validity vs each map's minimum (Q6), ordered compaction */
 int mfr_ref_procrustes_lift(const float *pts0, const float *pts1, int n, const float *depth0, const float *depth1, int H, int W,
-                            const float K0[9], const float K1[9], double *P, double *Q)
+                            const void *K0, const void *K1, int k_dtype, double *P, double *Q)
 {
     float m0 = mfr_ref_depth_min(depth0, H * W), m1 = mfr_ref_depth_min(depth1, H * W);
     int m = 0;
@@ -147,8 +147,8 @@ int mfr_ref_procrustes_lift(const float *pts0, const float *pts1, int n, const f
         float d0 = depth0[v0 * W + u0], d1 = depth1[v1 * W + u1];
         if (!(d0 > m0) || !(d1 > m1)) continue;                              /* :261 */
         int32_t a[2] = { u0, v0 }, b[2] = { u1, v1 };
-        if (mfr_ref_backproject(a, &d0, 1, K0, P + 3 * m)) return -1;
-        if (mfr_ref_backproject(b, &d1, 1, K1, Q + 3 * m)) return -1;
+        if (mfr_ref_backproject(a, &d0, 1, K0, k_dtype, P + 3 * m)) return -1;
+        if (mfr_ref_backproject(b, &d1, 1, K1, k_dtype, Q + 3 * m)) return -1;
         ++m;
     }
     return m;
@@ -218,7 +218,7 @@ int mfr_ref_procrustes_ransac(const double *P, const double *Q, int n, double ma
 }
 
 int mfr_ref_procrustes_solve(const float *pts0, const float *pts1, int n, const float *depth0, const float *depth1, int H, int W,
-                             const float K0[9], const float K1[9], double max_dist, double conf, int max_iters,
+                             const void *K0, const void *K1, int k_dtype, double max_dist, double conf, int max_iters,
                              uint64_t seed, uint64_t pair_id, double R[9], double t[3], int *n_inl)
 {
     for (int i = 0; i < 9; ++i) R[i] = NAN;
@@ -226,7 +226,7 @@ int mfr_ref_procrustes_solve(const float *pts0, const float *pts1, int n, const 
     *n_inl = 0;
     if (n < 3) return MFR_ST_TOO_FEW;                                        /* :252-253 */
     double *P = (double *)malloc(sizeof(double) * 3 * (size_t)n), *Q = (double *)malloc(sizeof(double) * 3 * (size_t)n);
-    int m = mfr_ref_procrustes_lift(pts0, pts1, n, depth0, depth1, H, W, K0, K1, P, Q);
+    int m = mfr_ref_procrustes_lift(pts0, pts1, n, depth0, depth1, H, W, K0, K1, k_dtype, P, Q);
     int st;
     if (m < 3) st = MFR_ST_BAD_DEPTH;                                        /* :262-263 */
     else st = mfr_ref_procrustes_ransac(P, Q, m, max_dist, conf, max_iters, seed, pair_id, R, t, n_inl, NULL, NULL, NULL);

@@ -50,6 +50,27 @@ def _f64(a):
     return np.ascontiguousarray(a, dtype=np.float64)
 
 
+K_F32, K_F64 = 0, 1
+
+
+def _K(K):
+    """intrinsics in the dtype the caller holds them (float64 = the Map-free loader's flow, anything else float32) -> (array, tag)"""
+    K = np.asarray(K)
+    if K.dtype == np.float64:
+        return np.ascontiguousarray(K).reshape(9), K_F64
+    return np.ascontiguousarray(K, dtype=np.float32).reshape(9), K_F32
+
+
+def _K2(K0, K1):
+    """a pair of intrinsics in ONE dtype (float64 as soon as either is float64, as numpy promotion would)"""
+    K0, K1 = np.asarray(K0), np.asarray(K1)
+    if K0.dtype == np.float64 or K1.dtype == np.float64:
+        K0, K1 = K0.astype(np.float64), K1.astype(np.float64)
+    a, tag = _K(K0)
+    b, _ = _K(K1)
+    return a, b, tag
+
+
 def philox(ctr, k0, k1):
     c = np.asarray(ctr, dtype=np.uint32)
     out = np.zeros(4, dtype=np.uint32)
@@ -81,9 +102,9 @@ def poly_real_roots(c):
 def backproject(uv, depth, K):
     uv = np.ascontiguousarray(uv, dtype=np.int32)
     depth = _f32(depth)
-    K = _f32(K).reshape(9)
+    K, kdt = _K(K)
     xyz = np.zeros((len(uv), 3), dtype=np.float64)
-    rc = lib().mfr_ref_backproject(_p(uv), _p(depth), C.c_int(len(uv)), _p(K), _p(xyz))
+    rc = lib().mfr_ref_backproject(_p(uv), _p(depth), C.c_int(len(uv)), _p(K), C.c_int(kdt), _p(xyz))
     if rc:
         raise ValueError("unsupported K")
     return xyz
@@ -94,8 +115,9 @@ def pnp_lift(pts0, pts1, depth0, K0):
     n = len(pts0)
     H, W = depth0.shape
     xyz = np.zeros((max(n, 1), 3)); obs = np.zeros((max(n, 1), 2)); src = np.zeros(max(n, 1), dtype=np.int32)
+    K0, kdt = _K(K0)
     m = lib().mfr_ref_pnp_lift(_p(pts0), _p(pts1), C.c_int(n), _p(depth0), C.c_int(H), C.c_int(W),
-                               _p(_f32(K0).reshape(9)), _p(xyz), _p(obs), _p(src))
+                               _p(K0), C.c_int(kdt), _p(xyz), _p(obs), _p(src))
     if m < 0:
         raise ValueError("unsupported K")
     return xyz[:m].copy(), obs[:m].copy(), src[:m].copy()
@@ -115,7 +137,8 @@ def pnp_ransac(xyz, obs, K1, max_iters=1000, thr=3.0, conf=0.9999, seed=0, pair_
     mask = np.zeros(max(n, 1), dtype=np.uint8)
     n_inl = C.c_int(0); best_it = C.c_int(0); iters_run = C.c_int(0)
     counts = np.zeros(max_iters, dtype=np.int32) if want_counts else None
-    st = lib().mfr_ref_pnp_ransac(_p(xyz), _p(obs), C.c_int(n), _p(_f32(K1).reshape(9)),
+    K1, kdt = _K(K1)
+    st = lib().mfr_ref_pnp_ransac(_p(xyz), _p(obs), C.c_int(n), _p(K1), C.c_int(kdt),
                                   C.c_int(max_iters), C.c_double(thr), C.c_double(conf),
                                   C.c_uint64(seed), C.c_uint64(pair_id), _p(R), _p(t), _p(mask),
                                   C.byref(n_inl), C.byref(best_it), C.byref(iters_run),
@@ -131,8 +154,9 @@ def pnp_solve(pts0, pts1, depth0, K0, K1, max_iters=1000, thr=3.0, conf=0.9999, 
     pts0, pts1, depth0 = _f32(pts0).reshape(-1, 2), _f32(pts1).reshape(-1, 2), _f32(depth0)
     H, W = depth0.shape
     R = np.zeros((3, 3)); t = np.zeros(3); n_inl = C.c_int(0)
+    K0, K1, kdt = _K2(K0, K1)
     st = lib().mfr_ref_pnp_solve(_p(pts0), _p(pts1), C.c_int(len(pts0)), _p(depth0), C.c_int(H), C.c_int(W),
-                                 _p(_f32(K0).reshape(9)), _p(_f32(K1).reshape(9)), C.c_int(max_iters),
+                                 _p(K0), _p(K1), C.c_int(kdt), C.c_int(max_iters),
                                  C.c_double(thr), C.c_double(conf), C.c_uint64(seed), C.c_uint64(pair_id),
                                  _p(R), _p(t), C.byref(n_inl))
     return st, R, t.reshape(3, 1), n_inl.value
@@ -141,7 +165,7 @@ def pnp_solve(pts0, pts1, depth0, K0, K1, max_iters=1000, thr=3.0, conf=0.9999, 
 def pnp_lm(xyz, obs, idx, K1, R, t, max_iter=20):
     xyz, obs = _f64(xyz), _f64(obs)
     idx = np.ascontiguousarray(idx, dtype=np.int32)
-    K1 = _f32(K1).reshape(9)
+    K1 = np.asarray(K1).reshape(9)
     Kd = np.array([K1[0], K1[4], K1[2], K1[5]], dtype=np.float64)
     R = _f64(R).copy(); t = _f64(t).reshape(3).copy()
     rc = lib().mfr_ref_pnp_lm(_p(xyz), _p(obs), _p(idx), C.c_int(len(idx)), _p(Kd), C.c_int(max_iter), _p(R), _p(t))
@@ -158,8 +182,9 @@ def scale_lift(pts0, pts1, mask, depth0, depth1, K0, K1, R, t):
         mask = np.ascontiguousarray(mask, dtype=np.uint8)
         mask_p = _p(mask)
     scale = np.zeros(max(n, 1))
+    K0, K1, kdt = _K2(K0, K1)
     m = lib().mfr_ref_scale_lift(_p(pts0), _p(pts1), mask_p, C.c_int(n), _p(depth0), _p(depth1),
-                                 C.c_int(H), C.c_int(W), _p(_f32(K0).reshape(9)), _p(_f32(K1).reshape(9)),
+                                 C.c_int(H), C.c_int(W), _p(K0), _p(K1), C.c_int(kdt),
                                  _p(_f64(R).reshape(9)), _p(_f64(t).reshape(3)), _p(scale))
     if m < 0:
         raise ValueError("unsupported K")
@@ -189,13 +214,15 @@ def emat_decompose(E):
 
 def emat_threshold(pix_thr, K0, K1):
     lib().mfr_ref_emat_threshold.restype = C.c_double
-    return lib().mfr_ref_emat_threshold(C.c_double(pix_thr), _p(_f32(K0).reshape(9)), _p(_f32(K1).reshape(9)))
+    K0, K1, kdt = _K2(K0, K1)
+    return lib().mfr_ref_emat_threshold(C.c_double(pix_thr), _p(K0), _p(K1), C.c_int(kdt))
 
 
 def normalize_points(pts, K):
     pts = _f32(pts).reshape(-1, 2)
     out = np.zeros((len(pts), 2))
-    lib().mfr_ref_normalize_points(_p(pts), C.c_int(len(pts)), _p(_f32(K).reshape(9)), _p(out))
+    K, kdt = _K(K)
+    lib().mfr_ref_normalize_points(_p(pts), C.c_int(len(pts)), _p(K), C.c_int(kdt), _p(out))
     return out
 
 
@@ -206,7 +233,8 @@ def emat_solve(pts0, pts1, K0, K1, pix_thr=2.0, conf=0.9999, max_iters=1000, see
     mask = np.zeros(max(n, 1), np.uint8); rmask = np.zeros(max(n, 1), np.uint8)
     n_inl = C.c_int(0); bi = C.c_int(0); ir = C.c_int(0)
     counts = np.zeros(max_iters, np.int32) if want_counts else None
-    st = lib().mfr_ref_emat_solve(_p(pts0), _p(pts1), C.c_int(n), _p(_f32(K0).reshape(9)), _p(_f32(K1).reshape(9)),
+    K0, K1, kdt = _K2(K0, K1)
+    st = lib().mfr_ref_emat_solve(_p(pts0), _p(pts1), C.c_int(n), _p(K0), _p(K1), C.c_int(kdt),
                                   C.c_double(pix_thr), C.c_double(conf), C.c_int(max_iters), C.c_uint64(seed),
                                   C.c_uint64(pair_id), _p(R), _p(t), _p(mask), C.byref(n_inl), C.byref(bi), C.byref(ir),
                                   _p(counts) if want_counts else None, _p(rmask))
@@ -223,8 +251,9 @@ def procrustes_lift(pts0, pts1, depth0, depth1, K0, K1):
     H, W = depth0.shape
     n = len(pts0)
     P = np.zeros((max(n, 1), 3)); Q = np.zeros((max(n, 1), 3))
+    K0, K1, kdt = _K2(K0, K1)
     m = lib().mfr_ref_procrustes_lift(_p(pts0), _p(pts1), C.c_int(n), _p(depth0), _p(depth1), C.c_int(H), C.c_int(W),
-                                      _p(_f32(K0).reshape(9)), _p(_f32(K1).reshape(9)), _p(P), _p(Q))
+                                      _p(K0), _p(K1), C.c_int(kdt), _p(P), _p(Q))
     return P[:m].copy(), Q[:m].copy()
 
 
@@ -247,8 +276,9 @@ def procrustes_solve(pts0, pts1, depth0, depth1, K0, K1, max_dist=0.05, conf=0.9
     depth0, depth1 = _f32(depth0), _f32(depth1)
     H, W = depth0.shape
     R = np.zeros((3, 3)); t = np.zeros(3); n_inl = C.c_int(0)
+    K0, K1, kdt = _K2(K0, K1)
     st = lib().mfr_ref_procrustes_solve(_p(pts0), _p(pts1), C.c_int(len(pts0)), _p(depth0), _p(depth1), C.c_int(H), C.c_int(W),
-                                        _p(_f32(K0).reshape(9)), _p(_f32(K1).reshape(9)), C.c_double(max_dist), C.c_double(conf),
+                                        _p(K0), _p(K1), C.c_int(kdt), C.c_double(max_dist), C.c_double(conf),
                                         C.c_int(max_iters), C.c_uint64(seed), C.c_uint64(pair_id), _p(R), _p(t), C.byref(n_inl))
     return st, R, t.reshape(3, 1), n_inl.value
 
@@ -259,7 +289,8 @@ def procrustes_icp(depth0, depth1, K0, K1, R, t, max_dist=0.05, rel_fitness=1e-4
     H, W = depth0.shape
     R = _f64(R).reshape(9).copy(); t = _f64(t).reshape(3).copy()
     n_inl = C.c_int(0); fit = C.c_double(0); rmse = C.c_double(0)
-    it = lib().mfr_ref_procrustes_icp(_p(depth0), _p(depth1), C.c_int(H), C.c_int(W), _p(_f32(K0).reshape(9)), _p(_f32(K1).reshape(9)),
+    K0, K1, kdt = _K2(K0, K1)
+    it = lib().mfr_ref_procrustes_icp(_p(depth0), _p(depth1), C.c_int(H), C.c_int(W), _p(K0), _p(K1), C.c_int(kdt),
                                       C.c_double(max_dist), C.c_double(rel_fitness), C.c_double(rel_rmse), C.c_int(max_iter), _p(R), _p(t),
                                       C.byref(n_inl), C.byref(fit), C.byref(rmse))
     return dict(R=R.reshape(3, 3), t=t, n_inliers=n_inl.value, fitness=fit.value, rmse=rmse.value, iters=it)
