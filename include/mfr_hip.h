@@ -189,8 +189,12 @@ int mfr_sp_sample_descriptors(const float *dense_nhwc, int B, int Hc, int Wc, co
 
 /* ------------------------------------------------------------------------------------------
  * SuperGlue kernels (same call site; upstream algorithm per SURVEY.md Appendix A.3).
- *   mfr_sg_attention       softmax(q k^T / 8) v, `heads` heads x 64, exact fp32 on the f32 matrix
- *                          cores, scores never materialised.  q,k,v [B2,N,ld] (head h = channels
+ *   mfr_sg_attention       softmax(q k^T / 8) v, `heads` heads x 64, fp32 in / fp32 out, scores never materialised.
+ *                          Both contractions run on the bf16 matrix cores at fp32 accuracy: every fp32 operand is split
+ *                          exactly into three bf16 terms and a product is the six leading partial products accumulated
+ *                          in fp32 (csrc/attention.hip; error vs fp64 = that of the exact-fp32 MFMA, measured in
+ *                          profiles/r03_bf16x3_probe.jsonl).  mfr_sg_attention_variant: 0 = that kernel, 1 = the
+ *                          exact-fp32 matrix-core kernel of rounds 1-2 (v_mfma_f32_32x32x2_f32), kept for A/B and tests.  q,k,v [B2,N,ld] (head h = channels
  *                          [64h, 64h+64) from each base pointer), out [B2,N,ldo]; keys/queries
  *                          >= n_tok[image] are masked; cross != 0 -> image b reads K/V of image b^1.
  *   mfr_sg_sinkhorn_match  log_optimal_transport(S, bin_score, iters) without materialising the
@@ -202,6 +206,8 @@ int mfr_sp_sample_descriptors(const float *dense_nhwc, int B, int Hc, int Wc, co
  * ------------------------------------------------------------------------------------------ */
 int mfr_sg_attention(const float *q, const float *k, const float *v, int ld, int B2, int N, int heads,
                      const int32_t *n_tok, int cross, float *out, int ldo, void *stream);
+int mfr_sg_attention_variant(const float *q, const float *k, const float *v, int ld, int B2, int N, int heads,
+                             const int32_t *n_tok, int cross, float *out, int ldo, int variant, void *stream);
 size_t mfr_sg_match_workspace_bytes(int B, int ldS);
 int mfr_sg_sinkhorn_match(const float *S, int B, int ldS, const int32_t *n0, const int32_t *n1,
                           float bin_score, int iters, float match_thr,

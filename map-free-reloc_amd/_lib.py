@@ -40,6 +40,7 @@ SIGNATURES = {
     "mfr_sp_select_topk": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "mfr_sp_sample_descriptors": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp]),
     "mfr_sg_attention": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp]),
+    "mfr_sg_attention_variant": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _i, _vp]),
     "mfr_sg_match_workspace_bytes": (_sz, [_i, _i]),
     "mfr_sg_sinkhorn_match": (_i, [_vp, _i, _i, _vp, _vp, C.c_float, _i, C.c_float, _vp, _vp, _i, _vp, _sz,
                                    _vp, _vp, _vp, _vp, _i, _vp, _vp]),

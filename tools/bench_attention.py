@@ -1,0 +1,34 @@
+"""A/B timing of the SuperGlue attention kernel variants on the bench shape (2B = 64 images x 4 heads x 1024 keypoints):
+variant 0 = bf16x3 matrix-core kernel, 1 = exact-fp32 matrix-core kernel.  python tools/bench_attention.py [out.json]"""
+import json
+import sys
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import mapfree_reloc_amd as mfr
+from mapfree_reloc_amd.nets.superglue import SuperGlueHIP
+from mapfree_reloc_amd.nets import weights as WT
+
+dev = "cuda:0"
+sg = SuperGlueHIP(WT.superglue_state_dict(), dev)
+B2, K = 64, 1024
+qkv = torch.randn(B2, K, 768, device=dev)
+n = torch.full((B2,), K, dtype=torch.int32, device=dev)
+out = torch.empty(B2, K, 256, device=dev)
+res = {}
+for variant in (1, 0, 1, 0):
+    for cross in (False, True):
+        for _ in range(3):
+            sg.attention(qkv, n, cross, out=out, variant=variant)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            sg.attention(qkv, n, cross, out=out, variant=variant)
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 20
+        flops = 2 * 2.0 * K * K * 64 * 4 * B2
+        res[f"variant{variant}_{'cross' if cross else 'self'}"] = dict(ms=round(ms, 4), fp32_equiv_tflops=round(flops / ms / 1e9, 1))
+print(json.dumps(res, indent=1))
+if len(sys.argv) > 1:
+    json.dump(res, open(sys.argv[1], "w"), indent=1)
