@@ -342,6 +342,22 @@ int mfr_desc_ratio_match(const float *des0, const float *des1, const float *norm
  *                              convolutions of LoFTR's ResNet-FPN backbone (BatchNorm folded into w / bias).
  * f32 Winograd arithmetic: agrees with a direct f32 convolution to ~1e-6 relative (not bit-identical).
  * ------------------------------------------------------------------------------------------ */
+/* The same layer (same arguments, same epilogue) on the BF16 matrix cores at fp32 accuracy (csrc/winograd_bf16x3.hip): U = G g G^T
+ * and V = B^T d B are formed in fp32 as above, then every operand is split exactly into three bf16 terms and a product is the six
+ * leading partial products accumulated in fp32 (error vs fp64 = that of the exact-fp32 matrix instruction, profiles/
+ * r03_bf16x3_probe.jsonl).  Any Cin, Cout (padded to multiples of 16 / 64 inside the packed filter).
+ *   mfr_wino_bf16x3_filter_bytes      size of the packed, split filter (ceil(Cout/64) * ceil(Cin/16) * 96 KiB)
+ *   mfr_wino_bf16x3_filter_transform  w [Cout,Cin,3,3] f32 -> upk; once per weight set
+ *   mfr_conv3x3_wino_bf16x3           as mfr_conv3x3_wino */
+size_t mfr_wino_bf16x3_filter_bytes(int Cin, int Cout);
+int mfr_wino_bf16x3_filter_transform(const float *w, int Cin, int Cout, void *upk, void *stream);
+int mfr_conv3x3_wino_bf16x3(const float *x, const void *upk, const float *bias, const float *residual, int B, int Cin, int Cout,
+                            int H, int W, int act, int pool, float *y, void *stream);
+/* variant 0 = the kernel; other values = timing ablations of tools/bench_conv.py (pooled layers only; results are wrong) */
+int mfr_conv3x3_wino_bf16x3_variant(const float *x, const void *upk, const float *bias, const float *residual, int B, int Cin, int Cout,
+                                    int H, int W, int act, int pool, int variant, float *y, void *stream);
+/* debug hook of tools/ablate_conv_bf16x3.py: s_memtime stamps (4 wavefronts x 64) of one workgroup of the last variant-16 launch */
+int mfr_wino_bf16x3_profile(unsigned long long *out_host);
 size_t mfr_wino_filter_bytes(int Cin, int Cout);
 int mfr_wino_filter_transform(const float *w, int Cin, int Cout, float *upk, void *stream);
 int mfr_conv3x3_wino(const float *x, const float *upk, const float *bias, const float *residual, int B, int Cin, int Cout,
