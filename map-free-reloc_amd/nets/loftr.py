@@ -67,16 +67,11 @@ class LoFTRHIP:
         self.upk = {}
         lib = _lib.load()
         if os.environ.get("MFR_CONV", "wino") == "wino":
-            for name, (cw, _) in w.items():
+            from .conv import WinoConv3x3
+            for name, (cw, cb) in w.items():
                 if tuple(cw.shape[2:]) != (3, 3) or name.endswith(".ds") or name == "conv1":
                     continue
-                co, ci = int(cw.shape[0]), int(cw.shape[1])
-                nbytes = lib.mfr_wino_filter_bytes(ci, co)
-                if nbytes == 0:
-                    continue
-                u = torch.empty(nbytes // 4, dtype=torch.float32, device=self.device)
-                _lib.check(lib.mfr_wino_filter_transform(_lib.ptr(cw), ci, co, _lib.ptr(u), _lib.stream_ptr()), "mfr_wino_filter_transform")
-                self.upk[name] = u
+                self.upk[name] = WinoConv3x3(cw, cb)                     # both packed filter forms; kernel chosen per shape (nets/conv.py)
 
         def encoder(prefix, n):
             layers = []
@@ -100,15 +95,7 @@ class LoFTRHIP:
         """conv (+folded BN) [+ residual] [+ activation]; stride-1 3x3 layers: one fused Winograd launch"""
         cw, cb = self.w[name]
         if stride == 1 and name in self.upk:
-            lib = _lib.load()
-            x = x.contiguous()
-            B, C, H, W = x.shape
-            co = int(cw.shape[0])
-            y = torch.empty(B, co, H, W, dtype=torch.float32, device=x.device)
-            code = {None: 0, "relu": 1, "leaky": 2}[act]
-            _lib.check(lib.mfr_conv3x3_wino(_lib.ptr(x), _lib.ptr(self.upk[name]), _lib.ptr(cb), _lib.ptr(residual.contiguous()) if residual is not None else None,
-                                            B, C, co, H, W, code, 0, _lib.ptr(y), _lib.stream_ptr()), "mfr_conv3x3_wino")
-            return y
+            return self.upk[name](x, act={None: 0, "relu": 1, "leaky": 2}[act], residual=residual)
         if cw.shape[-1] == 1:
             # 1x1 convolutions (FPN lateral / output convs, the stride-2 downsample of a BasicBlock) are plain matrix products:
             # one batched library GEMM [Cout,Cin] x [Cin,HW] per image; stride 2 = the same on the even-pixel sub-grid

@@ -12,6 +12,7 @@ import torch
 import torch.nn.functional as F
 
 from .. import _lib
+from .conv import WinoConv3x3
 
 CAND_CAP = 32768
 
@@ -33,16 +34,11 @@ class SuperPointHIP:
         self.w["convDb.mat"] = self.w["convDb.weight"].reshape(256, 256).contiguous()
         # Winograd-transformed 3x3 filters, packed in MFMA operand order (csrc/winograd_conv.hip), once per weight set
         self.upk = {}
-        lib = _lib.load()
         for name in ("conv1b", "conv2a", "conv2b", "conv3a", "conv3b", "conv4a", "conv4b", "convPa", "convDa"):
             w = self.w[name + ".weight"]
-            co, ci = int(w.shape[0]), int(w.shape[1])
-            nbytes = lib.mfr_wino_filter_bytes(ci, co)
-            if tuple(w.shape[2:]) != (3, 3) or nbytes == 0:
+            if tuple(w.shape[2:]) != (3, 3):
                 continue
-            u = torch.empty(nbytes // 4, dtype=torch.float32, device=self.device)
-            _lib.check(lib.mfr_wino_filter_transform(_lib.ptr(w), ci, co, _lib.ptr(u), _lib.stream_ptr()), "mfr_wino_filter_transform")
-            self.upk[name] = u
+            self.upk[name] = WinoConv3x3(w, self.w[name + ".bias"])      # both packed filter forms; kernel chosen per shape (nets/conv.py)
 
     def _conv(self, x, name, relu=True, pool=False):
         """3x3 layer = ONE launch of the fused Winograd/MFMA kernel (conv + bias + ReLU [+ 2x2 max-pool],
@@ -52,13 +48,7 @@ class SuperPointHIP:
         w, b = self.w[name + ".weight"], self.w[name + ".bias"]
         pad = w.shape[-1] // 2
         if self.use_wino and relu and name in self.upk:
-            x = x.contiguous()
-            B, C, H, W = x.shape
-            co = int(w.shape[0])
-            y = torch.empty((B, co, H // 2, W // 2) if pool else (B, co, H, W), dtype=torch.float32, device=x.device)
-            _lib.check(lib.mfr_conv3x3_wino(_lib.ptr(x), _lib.ptr(self.upk[name]), _lib.ptr(b), None, B, C, co, H, W, 1, int(pool),
-                                            _lib.ptr(y), _lib.stream_ptr()), "mfr_conv3x3_wino")
-            return y
+            return self.upk[name](x, act=1, pool=pool)
         if not relu:
             if w.shape[-1] == 1:            # 1x1 head (convPb): one batched library GEMM [Cout,Cin] x [Cin,HW] per image, no MIOpen
                 B, C, H, W = x.shape
