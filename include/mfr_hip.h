@@ -204,6 +204,14 @@ int mfr_sp_sample_descriptors(const float *dense_nhwc, int B, int Hc, int Wc, co
  *                          S [B,ldS,ldS] = mdesc0^T mdesc1 / 16, n0/n1 [B] true keypoint counts,
  *                          kpts0/kpts1 [B,K,2]; also matches0 [B,ldS] (-1 = none), mscores0 [B,ldS].
  * ------------------------------------------------------------------------------------------ */
+/*   mfr_gemm_bf16x3        the transformers' linear layers, y [M, ldy] (+)= act(x [M, ldx] W [N, K]^T + bias), fp32 in / fp32 out, on the
+ *                          bf16 matrix cores at fp32 accuracy (csrc/gemm_bf16x3.hip: exact 3-way bf16 operand split, six partial products,
+ *                          fp32 accumulate; rounds 1-2 called the library's fp32 GEMM here).  W is split and packed once per weight set
+ *                          (mfr_gemm_bf16x3_pack, size from mfr_gemm_bf16x3_pack_bytes; 0 if K % 32 != 0).  flags: 1 = ReLU, 2 = accumulate
+ *                          into y (y += x W^T + bias).  x 16-byte aligned, ldx % 4 == 0; bias may be NULL. */
+size_t mfr_gemm_bf16x3_pack_bytes(int N, int K);
+int mfr_gemm_bf16x3_pack(const float *w, int N, int K, void *packed, void *stream);
+int mfr_gemm_bf16x3(const float *x, int ldx, const void *packed_w, const float *bias, float *y, int ldy, int M, int N, int K, int flags, void *stream);
 int mfr_sg_attention(const float *q, const float *k, const float *v, int ld, int B2, int N, int heads,
                      const int32_t *n_tok, int cross, float *out, int ldo, void *stream);
 int mfr_sg_attention_variant(const float *q, const float *k, const float *v, int ld, int B2, int N, int heads,

@@ -39,6 +39,9 @@ SIGNATURES = {
     "mfr_sp_nms_candidates": (_i, [_vp, _i, _i, _i, _i, C.c_float, _i, _vp, _vp, _i, _vp, _vp]),
     "mfr_sp_select_topk": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "mfr_sp_sample_descriptors": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp]),
+    "mfr_gemm_bf16x3_pack_bytes": (_sz, [_i, _i]),
+    "mfr_gemm_bf16x3_pack": (_i, [_vp, _i, _i, _vp, _vp]),
+    "mfr_gemm_bf16x3": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "mfr_sg_attention": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp]),
     "mfr_sg_attention_variant": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _i, _vp]),
     "mfr_sg_match_workspace_bytes": (_sz, [_i, _i]),

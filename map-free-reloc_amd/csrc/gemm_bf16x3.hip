@@ -1,0 +1,213 @@
+// gemm_bf16x3.hip -- Y[M, N] (+)= act(X[M, K] W[N, K]^T + bias): the linear layers of the SuperGlue / LoFTR transformers (fp32 in,
+// fp32 out) on the gfx950 BF16 matrix cores at fp32 accuracy ("bf16x3").
+//
+// Reference call site: SuperGlue_matcher / LoFTR_matcher (etc/feature_matching_baselines/matchers.py:12-120) -> the un-vendored
+// networks' Conv1d(k=1) / Linear layers; rounds 1-2 ran them as library (hipBLASLt) fp32 GEMMs.
+//
+// Arithmetic: every fp32 operand is split EXACTLY into three bf16 terms x = h + m + l (truncation, 8 + 8 + 8 significand bits); a
+// product is the six partial products hh + hm + mh + hl + lh + mm (each exact in fp32) accumulated in fp32 by
+// v_mfma_f32_32x32x16_bf16.  Error against an fp64 product = that of the exact-fp32 matrix instruction (tools/ubench/
+// bf16x3_probe.hip, profiles/r03_bf16x3_probe.jsonl: rms 2.4e-8 vs 2.8e-8 of sum|x||w| at K = 64 .. 2304).
+//
+// Mapping: workgroup = 128 rows x 128 output features, 4 wavefronts as 2 x 2, each 64 x 64 = 2 x 2 MFMA tiles (64 accumulator
+// registers); K in steps of 32.  W is split and packed ONCE per weight set in the exact image the workgroup stages (three terms x
+// [k group of 8][feature][8 bf16]); X is read as fp32 (coalesced 128-byte row pieces), split by the staging threads -- each
+// element once per workgroup -- and written to LDS in the same fragment order, so every MFMA operand is one conflict-free
+// ds_read_b128.  The next K step's global loads are in flight while the current one is multiplied (register staging, one LDS
+// stage of 48 KB: three workgroups per CU hide each other's barriers).  Output features run along the lanes: 128-byte stores.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/mfr_hip.h"
+
+#define CHECK_LAUNCH() do { if (hipGetLastError() != hipSuccess) return MFR_E_LAUNCH; } while (0)
+
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define GB_BM 128
+#define GB_BN 128
+#define GB_BK 32
+#define GB_KG_STRIDE 129                  // 16-byte units per k group (128 rows + 1 pad: conflict-free stores)
+#define GB_TERM_UNITS (4 * GB_KG_STRIDE)  // units per term image
+#define GB_W_TILE_UNITS 1536              // packed W tile: 3 terms x 4 k groups x 128 features, 16 bytes each
+
+union GbFrag { bf16x8 v; unsigned u[4]; uint4 q; };
+
+__device__ __forceinline__ void gb_split3(float x, unsigned &h, unsigned &m, unsigned &l)
+{
+    h = __float_as_uint(x);
+    const float r = x - __uint_as_float(h & 0xffff0000u);
+    m = __float_as_uint(r);
+    l = __float_as_uint(r - __uint_as_float(m & 0xffff0000u));
+}
+__device__ __forceinline__ unsigned gb_pack(unsigned lo, unsigned hi) { return __builtin_amdgcn_perm(hi, lo, 0x07060302u); }
+
+// W [N, K] f32 row-major -> packed [n block][k block][term][k group][feature (128)][8 bf16]; one thread per 16-byte unit
+__global__ void __launch_bounds__(256) gb_pack_kernel(const float *__restrict__ w, int N, int K, long long total, uint4 *__restrict__ out)
+{
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    const int u = (int)(t % GB_W_TILE_UNITS);
+    const long long tile = t / GB_W_TILE_UNITS;
+    const int nkb = K / GB_BK;
+    const int kb = (int)(tile % nkb), nb = (int)(tile / nkb);
+    const int term = u / 512, kg = (u % 512) / 128, f = u % 128;
+    const int n = nb * GB_BN + f, k0 = kb * GB_BK + 8 * kg;
+    unsigned word[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float x = (n < N) ? w[(size_t)n * K + k0 + e] : 0.f;
+        unsigned h, m, l;
+        gb_split3(x, h, m, l);
+        word[e] = term == 0 ? h : term == 1 ? m : l;
+    }
+    out[t] = make_uint4(gb_pack(word[0], word[1]), gb_pack(word[2], word[3]), gb_pack(word[4], word[5]), gb_pack(word[6], word[7]));
+}
+
+#define GB_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+
+// FLAGS: 1 = ReLU, 2 = accumulate into Y (Y += ...)
+template <int FLAGS>
+__global__ void __launch_bounds__(256, 2) gemm_bf16x3_kernel(const float *__restrict__ X, int ldx, const uint4 *__restrict__ Wp, const float *__restrict__ bias,
+                                                             float *__restrict__ Y, int ldy, int M, int N, int K, int nnb)
+{
+    __shared__ uint4 lds[6 * GB_TERM_UNITS];             // X terms 0..2, W terms 0..2 (49.5 KB)
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    // feature blocks innermost: the workgroups that share an X row block run back to back (its tiles stay in L2)
+    const int nb = blockIdx.x % nnb, mb = blockIdx.x / nnb;
+    const int m0 = mb * GB_BM;
+    const int nkb = K / GB_BK;
+
+    // staging assignment.  X: unit u = tid + 256 i -> (row = u >> 2, k group = u & 3), 8 floats = two 16-byte loads.
+    // W: unit u = tid + 256 i, i = 0..5 -> straight copy of the packed tile image.
+    const float *xrow[2];
+    int xdst[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int u = tid + 256 * i, row = u >> 2, kg = u & 3;
+        const int m = min(m0 + row, M - 1);               // rows beyond M: a valid row is read and its results are never stored
+        xrow[i] = X + (size_t)m * ldx + 8 * kg;
+        xdst[i] = kg * GB_KG_STRIDE + row;
+    }
+    int wdst[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int u = tid + 256 * i, term = u / 512, kg = (u % 512) / 128, f = u % 128;
+        wdst[i] = (3 + term) * GB_TERM_UNITS + kg * GB_KG_STRIDE + f;
+    }
+    const uint4 *wtile = Wp + (size_t)nb * nkb * GB_W_TILE_UNITS + tid;
+
+    // (named registers, not arrays: hipcc keeps a lambda-captured array that is written under a condition in scratch memory)
+    float4 xa0, xa1, xb0, xb1;
+    uint4 w0, w1, w2, w3, w4, w5;
+#define GB_GLOAD(kb) do { \
+        xa0 = *(const float4 *)(xrow[0] + (kb) * GB_BK); xa1 = *(const float4 *)(xrow[0] + (kb) * GB_BK + 4); \
+        xb0 = *(const float4 *)(xrow[1] + (kb) * GB_BK); xb1 = *(const float4 *)(xrow[1] + (kb) * GB_BK + 4); \
+        const uint4 *wt_ = wtile + (size_t)(kb) * GB_W_TILE_UNITS; \
+        w0 = wt_[0]; w1 = wt_[256]; w2 = wt_[512]; w3 = wt_[768]; w4 = wt_[1024]; w5 = wt_[1280]; } while (0)
+    auto xsplit_store = [&](const float4 &p, const float4 &q, int dst) {
+        const float x[8] = { p.x, p.y, p.z, p.w, q.x, q.y, q.z, q.w };
+        unsigned h[8], m[8], l[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) gb_split3(x[e], h[e], m[e], l[e]);
+        lds[0 * GB_TERM_UNITS + dst] = make_uint4(gb_pack(h[0], h[1]), gb_pack(h[2], h[3]), gb_pack(h[4], h[5]), gb_pack(h[6], h[7]));
+        lds[1 * GB_TERM_UNITS + dst] = make_uint4(gb_pack(m[0], m[1]), gb_pack(m[2], m[3]), gb_pack(m[4], m[5]), gb_pack(m[6], m[7]));
+        lds[2 * GB_TERM_UNITS + dst] = make_uint4(gb_pack(l[0], l[1]), gb_pack(l[2], l[3]), gb_pack(l[4], l[5]), gb_pack(l[6], l[7]));
+    };
+#define GB_LSTORE() do { xsplit_store(xa0, xa1, xdst[0]); xsplit_store(xb0, xb1, xdst[1]); \
+        lds[wdst[0]] = w0; lds[wdst[1]] = w1; lds[wdst[2]] = w2; lds[wdst[3]] = w3; lds[wdst[4]] = w4; lds[wdst[5]] = w5; } while (0)
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // fragment addresses: operand row (token / feature) = 64 w + 32 t + (lane & 31), k group = 2 ks + (lane >> 5)
+    const int arow = (lane >> 5) * GB_KG_STRIDE + 64 * wm + (lane & 31);
+    const int brow = (lane >> 5) * GB_KG_STRIDE + 64 * wn + (lane & 31);
+
+    GB_GLOAD(0);
+    for (int kb = 0; kb < nkb; ++kb) {
+        __syncthreads();                                  // the previous step's fragment reads are done
+        GB_LSTORE();
+        __syncthreads();
+        { const int kn = min(kb + 1, nkb - 1); GB_GLOAD(kn); }   // in flight during the MFMAs below (the last step re-reads its own tile)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            GbFrag a[2][3], b[2][3];
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    a[i][t].q = lds[t * GB_TERM_UNITS + 2 * ks * GB_KG_STRIDE + arow + 32 * i];
+                    b[i][t].q = lds[(3 + t) * GB_TERM_UNITS + 2 * ks * GB_KG_STRIDE + brow + 32 * i];
+                }
+            // six partial products, small terms first; the four accumulators alternate
+#define GB_PROD(ta, tb) do { \
+                acc[0][0] = GB_MFMA(a[0][ta].v, b[0][tb].v, acc[0][0]); acc[0][1] = GB_MFMA(a[0][ta].v, b[1][tb].v, acc[0][1]); \
+                acc[1][0] = GB_MFMA(a[1][ta].v, b[0][tb].v, acc[1][0]); acc[1][1] = GB_MFMA(a[1][ta].v, b[1][tb].v, acc[1][1]); } while (0)
+            GB_PROD(1, 1); GB_PROD(0, 2); GB_PROD(2, 0); GB_PROD(0, 1); GB_PROD(1, 0); GB_PROD(0, 0);
+#undef GB_PROD
+        }
+    }
+
+    // epilogue: accumulator register r of tile (i, j): token row 64 wm + 32 i + (r & 3) + 8 (r >> 2) + 4 (lane >> 5), feature 64 wn + 32 j + (lane & 31)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = nb * GB_BN + 64 * wn + 32 * j + (lane & 31);
+        if (n >= N) continue;
+        const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + 64 * wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (m >= M) continue;
+                float *yp = Y + (size_t)m * ldy + n;
+                float v = acc[i][j][r] + bv;
+                if (FLAGS & 1) v = fmaxf(v, 0.f);
+                if (FLAGS & 2) v += *yp;
+                *yp = v;
+            }
+        }
+    }
+}
+
+extern "C" {
+
+size_t mfr_gemm_bf16x3_pack_bytes(int N, int K)
+{
+    if (N <= 0 || K <= 0 || (K % GB_BK)) return 0;
+    return (size_t)((N + GB_BN - 1) / GB_BN) * (K / GB_BK) * GB_W_TILE_UNITS * 16;
+}
+
+int mfr_gemm_bf16x3_pack(const float *w, int N, int K, void *packed, void *stream)
+{
+    if (!w || !packed || N <= 0 || K <= 0 || (K % GB_BK)) return MFR_E_ARG;
+    const long long total = (long long)(mfr_gemm_bf16x3_pack_bytes(N, K) / 16);
+    hipLaunchKernelGGL(gb_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, N, K, total, (uint4 *)packed);
+    CHECK_LAUNCH();
+    return 0;
+}
+
+int mfr_gemm_bf16x3(const float *x, int ldx, const void *packed_w, const float *bias, float *y, int ldy, int M, int N, int K, int flags, void *stream)
+{
+    if (!x || !packed_w || !y || M <= 0 || N <= 0 || K <= 0 || (K % GB_BK) || (ldx & 3) || ldx < K || ldy < N || flags < 0 || flags > 3) return MFR_E_ARG;
+    if (((uintptr_t)x & 15)) return MFR_E_ARG;
+    const int nnb = (N + GB_BN - 1) / GB_BN;
+    const long long grid = (long long)((M + GB_BM - 1) / GB_BM) * nnb;
+    if (grid > 0x7fffffffll) return MFR_E_ARG;
+    hipStream_t st = (hipStream_t)stream;
+#define GB_GO(F) hipLaunchKernelGGL((gemm_bf16x3_kernel<F>), dim3((unsigned)grid), dim3(256), 0, st, x, ldx, (const uint4 *)packed_w, bias, y, ldy, M, N, K, nnb)
+    switch (flags) { case 0: GB_GO(0); break; case 1: GB_GO(1); break; case 2: GB_GO(2); break; default: GB_GO(3); break; }
+#undef GB_GO
+    CHECK_LAUNCH();
+    return 0;
+}
+
+}  // extern "C"

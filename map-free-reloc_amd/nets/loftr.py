@@ -226,14 +226,16 @@ class LoFTRHIP:
         n, C2 = xm.shape
         C = C2 // 2
         x = xm[:, :C]
-        q = torch.mm(x, Lw["wq"].t())
-        kv = torch.mm(src, Lw["wkv"].t())
+        if "lq" not in Lw:        # the five bias-free projections through csrc/gemm_bf16x3.hip, weights split / packed once per layer
+            from .linear import SplitLinear
+            Lw["lq"], Lw["lkv"], Lw["lm"] = SplitLinear(Lw["wq"]), SplitLinear(Lw["wkv"]), SplitLinear(Lw["wm"])
+            Lw["l1"], Lw["l2"] = SplitLinear(Lw["w1"]), SplitLinear(Lw["w2"])
+        q = Lw["lq"](x)
+        kv = Lw["lkv"](src)
         msg = attn(q.view(nb, L, C), kv.view(nb, L, 2 * C))
-        self.layernorm(torch.mm(msg.view(n, C), Lw["wm"].t()), Lw["n1"], xm[:, C:])
-        if "zb" not in Lw:
-            Lw["zb"] = torch.zeros(C2, dtype=torch.float32, device=xm.device)
-        hid = torch._addmm_activation(Lw["zb"], xm, Lw["w1"].t())                  # relu([x | message] W1^T) in the GEMM epilogue
-        self.layernorm(torch.mm(hid, Lw["w2"].t()), Lw["n2"], x, residual=x)        # x += norm2(mlp)
+        self.layernorm(Lw["lm"](msg.view(n, C)), Lw["n1"], xm[:, C:])
+        hid = Lw["l1"](xm, relu=True)                                              # relu([x | message] W1^T) in the GEMM epilogue
+        self.layernorm(Lw["l2"](hid), Lw["n2"], x, residual=x)                     # x += norm2(mlp)
         return xm
 
     @staticmethod

@@ -13,6 +13,7 @@ import torch
 import torch.nn.functional as F
 
 from .. import _lib
+from .linear import SplitLinear
 
 
 def _fold_bn(w, b, sd, bn):
@@ -71,7 +72,14 @@ class SuperGlueHIP:
         self.kenc = [(dev(w), dev(b)) for w, b in fw["kenc"]]
         self.layers = [dict(wqkv=dev(L["wqkv"]), bqkv=dev(L["bqkv"]), w1t=dev(L["w1"]).t(), b1=dev(L["b1"]), w2t=dev(L["w2"]).t(),
                             cross=L["cross"]) for L in fw["layers"]]
+        # the three GEMMs of a layer through csrc/gemm_bf16x3.hip (weights split / packed once here); the plain tensors above stay for
+        # the stage-level parity tests
+        for L in self.layers:
+            L["lin_qkv"] = SplitLinear(L["wqkv"], L["bqkv"])
+            L["lin1"] = SplitLinear(L["w1t"].t(), L["b1"])
+            L["lin2"] = SplitLinear(L["w2t"].t())
         self.wf, self.bf = dev(fw["wf"]), dev(fw["bf"])
+        self.lin_final = SplitLinear(self.wf, self.bf)
         self.bin_score = fw["bin_score"]
         self._ws = None
         self._size = {}
@@ -127,12 +135,14 @@ class SuperGlueHIP:
         xa = torch.empty(B2 * K, 512, dtype=torch.float32, device=kpts.device)
         xv, av = xa[:, :256], xa[:, 256:]
         torch.add(desc.reshape(B2 * K, 256), h.reshape(B2 * K, 256), out=xv)
+        qkv = torch.empty(B2 * K, 768, dtype=torch.float32, device=kpts.device)
+        hid = torch.empty(B2 * K, 512, dtype=torch.float32, device=kpts.device)
         for L in self.layers:
-            qkv = torch.addmm(L["bqkv"], xv, L["wqkv"].t()).view(B2, K, 768)
-            self.attention(qkv, n, L["cross"], out=av, ldo=512)
-            hid = torch._addmm_activation(L["b1"], xa, L["w1t"])          # relu(W1' [x~ ; a] + b1') in the GEMM epilogue
-            xv.addmm_(hid, L["w2t"])                                      # x~ += W2 hid, in place
-        return torch.addmm(self.bf, xv, self.wf.t()).view(B2, K, 256)
+            L["lin_qkv"](xv, out=qkv)
+            self.attention(qkv.view(B2, K, 768), n, L["cross"], out=av, ldo=512)
+            L["lin1"](xa, out=hid, relu=True)                             # relu(W1' [x~ ; a] + b1') in the GEMM epilogue
+            L["lin2"](hid, out=xv, accumulate=True)                       # x~ += W2 hid, in place
+        return self.lin_final(xv).view(B2, K, 256)
 
     @torch.no_grad()
     def __call__(self, sp_out, image_hw, maxN=None):

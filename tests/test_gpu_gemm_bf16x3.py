@@ -1,0 +1,68 @@
+"""-m gpu: linear layers on the bf16 matrix cores at fp32 accuracy (csrc/gemm_bf16x3.hip) vs a float64 product: the transformer
+shapes, strided in-place operands, ReLU / accumulate epilogues, ragged M and N, and the error class against the library's fp32 GEMM."""
+import pytest
+import torch
+
+from mapfree_reloc_amd.nets.linear import SplitLinear
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.mark.parametrize("M,K,N,relu,acc,bias", [
+    (4096, 256, 768, 0, 0, 1), (4096, 512, 512, 1, 0, 1), (4096, 512, 256, 0, 1, 0), (1000, 256, 256, 0, 0, 1), (77, 32, 40, 1, 0, 1),
+    (129, 64, 130, 0, 1, 1), (6120, 256, 512, 1, 0, 0), (1, 32, 1, 0, 0, 1), (300, 128, 128, 0, 0, 1)])
+def test_split_linear_vs_float64(M, K, N, relu, acc, bias):
+    g = torch.Generator().manual_seed(M + K + N)
+    x = torch.randn(M, K, generator=g).to(DEV)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(DEV)
+    b = torch.randn(N, generator=g).to(DEV) if bias else None
+    y0 = torch.randn(M, N, generator=g).to(DEV)
+    lin = SplitLinear(w, b)
+    y = lin(x, out=y0.clone() if acc else None, relu=bool(relu), accumulate=bool(acc))
+    want = x.double() @ w.double().t()
+    if bias:
+        want = want + b.double()
+    if relu:
+        want = want.relu()
+    if acc:
+        want = want + y0.double()
+    assert y.shape == (M, N) and torch.isfinite(y).all()
+    assert (y.double() - want).abs().max().item() < 2e-5
+
+
+def test_split_linear_strided_in_place():
+    """the SuperGlue layer's operands: x~ = left half of the [x~ | a] buffer (row stride 512), the MLP reads all 512 columns and
+    its second layer accumulates into the left half in place"""
+    g = torch.Generator().manual_seed(3)
+    M = 2048
+    xa = torch.randn(M, 512, generator=g).to(DEV)
+    xv = xa[:, :256]
+    wq = (torch.randn(768, 256, generator=g) / 16).to(DEV); w1 = (torch.randn(512, 512, generator=g) / 22).to(DEV)
+    w2 = (torch.randn(256, 512, generator=g) / 22).to(DEV); bq = torch.randn(768, generator=g).to(DEV); b1 = torch.randn(512, generator=g).to(DEV)
+    ref_q = xv.double() @ wq.double().t() + bq.double()
+    ref_h = (xa.double() @ w1.double().t() + b1.double()).relu()
+    ref_x = xv.double() + ref_h @ w2.double().t()
+    q = SplitLinear(wq, bq)(xv)
+    h = SplitLinear(w1, b1)(xa, relu=True)
+    SplitLinear(w2)(h, out=xv, accumulate=True)
+    assert (q.double() - ref_q).abs().max() < 2e-5 and (h.double() - ref_h).abs().max() < 2e-5
+    assert (xv.double() - ref_x).abs().max() < 3e-5
+    assert torch.equal(xa[:, 256:], xa[:, 256:])          # right half untouched (no NaN introduced)
+
+
+def test_split_linear_error_class_vs_library_fp32():
+    g = torch.Generator().manual_seed(5)
+    for scale in (1.0, 1e-3, 1e3):
+        x = (torch.randn(8192, 512, generator=g) * scale).to(DEV)
+        w = (torch.randn(512, 512, generator=g) / 22).to(DEV)
+        want = x.double() @ w.double().t()
+        e3 = (SplitLinear(w)(x).double() - want) / scale
+        e1 = ((x @ w.t()).double() - want) / scale
+        assert e3.abs().max() <= 1.5 * e1.abs().max() and e3.pow(2).mean().sqrt() <= 1.5 * e1.pow(2).mean().sqrt(), \
+            (scale, float(e3.abs().max()), float(e1.abs().max()))
+
+
+def test_split_linear_rejects():
+    with pytest.raises(ValueError):
+        SplitLinear(torch.zeros(8, 48, device=DEV))
