@@ -55,7 +55,13 @@ def sg_pnp_pair(img0, img1, depth0, K0, K1, pair_id, pnp_iters=1000, pnp_thr=3.0
     st, R, t, ninl = O.pnp_solve(pts[:, :2], pts[:, 2:], depth0, K0, K1, pnp_iters, pnp_thr, pnp_conf, seed=seed, pair_id=int(pair_id))
     if st != 0:
         return _nan_result(pts, dict(status=int(st)))
-    return dict(pts=pts, status=0, R=R, t=t.reshape(3), n_inliers=int(ninl))
+    # the inlier INDEX set (over the correspondences handed to the solver): the same solve, stage by stage, to get at the mask
+    xyz, obs, src = O.pnp_lift(pts[:, :2], pts[:, 2:], depth0, K0)
+    rr = O.pnp_ransac(xyz, obs, K1, pnp_iters, pnp_thr, pnp_conf, seed=seed, pair_id=int(pair_id))
+    mask = np.zeros(len(pts), bool)
+    mask[src[rr["mask"].astype(bool)]] = True
+    assert int(mask.sum()) == int(ninl) and np.array_equal(rr["R"], R)
+    return dict(pts=pts, status=0, R=R, t=t.reshape(3), n_inliers=int(ninl), mask=mask)
 
 
 @torch.no_grad()
@@ -75,7 +81,27 @@ def loftr_emat_pair(img0, img1, depth0, depth1, K0, K1, pair_id, pix_thr=2.0, sc
     return dict(pts=pts, status=0, R=e["R"], t=bs * e["t"], n_inliers=int(cnt), emat_inliers=int(e["n_inl"]), mask=e["mask"])
 
 
-def compare_pair(ref, hip_pts, hip_R, hip_t, hip_ninl, hip_status):
+@torch.no_grad()
+def sg_procrustes_pair(img0, img1, depth0, depth1, K0, K1, pair_id, max_dist=0.05, seed=0):
+    """SuperGlue matches -> ProcrustesSolver.estimate_pose, PROCRUSTES.REFINE False (pose_solver.py:238-320;
+    config/matching/mapfree/sg_procrustes_dptkitti.yaml)"""
+    sp, sg = _nets("sg")
+    pts = NR.superglue_match_pair(sp, sg, _t(img0), _t(img1))
+    if np.isnan(pts).any():
+        return _nan_result(pts)
+    st, R, t, ninl = O.procrustes_solve(pts[:, :2], pts[:, 2:], depth0, depth1, K0, K1, max_dist, 0.999, 4096, seed=seed, pair_id=int(pair_id))
+    if st != 0:
+        return _nan_result(pts, dict(status=int(st)))
+    return dict(pts=pts, status=0, R=R, t=t.reshape(3), n_inliers=int(ninl))
+
+
+def inlier_rows(pts, mask):
+    """canonical form of an inlier index set: the sorted (x0, y0, x1, y1) rows of the inliers (independent of match order)"""
+    p = np.asarray(pts, np.float32).reshape(-1, 4)[np.asarray(mask, bool)[:len(pts)]]
+    return p[np.lexsort(p.T[::-1])] if len(p) else p
+
+
+def compare_pair(ref, hip_pts, hip_R, hip_t, hip_ninl, hip_status, hip_mask=None):
     """per-pair census record: is the match set identical (bit-equal coordinates, same order), what fraction of
     the oracle's matches the HIP path also has, the pose delta (rad / m) and the inlier-count delta"""
     rp = ref["pts"]
@@ -91,6 +117,12 @@ def compare_pair(ref, hip_pts, hip_R, hip_t, hip_ninl, hip_status):
     hq = {tuple(np.round(np.asarray(r) * 64).astype(np.int64).tolist()) for r in hs}
     rec = dict(n_ref=rn, n_hip=len(hp), identical_matches=bool(same), identical_set=bool(rs == hs), common_exact=both, common_q64=len(rq & hq),
                status_ref=int(ref["status"]), status_hip=int(hip_status), inliers_ref=int(ref["n_inliers"]), inliers_hip=int(hip_ninl))
+    if hip_mask is not None and "mask" in ref and ref["status"] == 0 and hip_status == 0:
+        a, b2 = inlier_rows(rp, ref["mask"]), inlier_rows(hp, hip_mask)
+        rec["inlier_set_identical"] = bool(a.shape == b2.shape and np.array_equal(a, b2))
+        sa, sb = {tuple(r) for r in a.tolist()}, {tuple(r) for r in b2.tolist()}
+        rec["inlier_set_jaccard"] = float(len(sa & sb) / max(len(sa | sb), 1))
+        rec["inlier_fraction_ref"] = float(len(a) / max(rn, 1))
     if ref["status"] == 0 and hip_status == 0:
         Rr, Rh = np.asarray(ref["R"], dtype=np.float64), np.asarray(hip_R, dtype=np.float64).reshape(3, 3)
         c = np.clip((np.trace(Rr.T @ Rh) - 1) / 2, -1, 1)
@@ -115,6 +147,12 @@ def summarize(records):
                    median_rot_rad=float(np.median([r["rot_rad"] for r in posed])), median_trans_m=float(np.median([r["trans_m"] for r in posed])),
                    pose_within_bar=sum(r["rot_rad"] <= 1e-4 and r["trans_m"] <= 1e-4 for r in posed), posed_pairs=len(posed),
                    pose_bit_equal=sum(r.get("pose_bit_equal", False) for r in posed))
+    ins = [r for r in records if "inlier_set_identical" in r]
+    if ins:
+        out.update(inlier_index_sets_compared=len(ins), inlier_index_sets_identical=sum(r["inlier_set_identical"] for r in ins),
+                   min_inlier_set_jaccard=round(float(min(r["inlier_set_jaccard"] for r in ins)), 5),
+                   median_inlier_fraction=round(float(np.median([r["inlier_fraction_ref"] for r in ins])), 4),
+                   min_inlier_fraction=round(float(min(r["inlier_fraction_ref"] for r in ins)), 4))
     pi = [r for r in ident if "rot_rad" in r]
     if pi:
         out.update(identical_max_rot_rad=float(max(r["rot_rad"] for r in pi)), identical_max_trans_m=float(max(r["trans_m"] for r in pi)))

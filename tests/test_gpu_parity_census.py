@@ -40,6 +40,36 @@ def test_census_loftr_emat_8_pairs():
     assert s["max_rot_rad"] < 2e-2 and s["max_trans_m"] < 2e-2, s
 
 
+def test_census_hard_scenes_inlier_index_sets():
+    """hard scenes (moving objects + occluder): 30-60 % of the correspondences are outliers, the RANSACs run hundreds of hypotheses.
+    Wherever the matcher reproduces the oracle's match set, the inlier INDEX SET (canonical order) is the oracle's, bit for bit."""
+    recs = census("sg_pnp", [5000 + i for i in range(16)], hard=True)
+    s = PR.summarize(recs)
+    print(json.dumps(s))
+    assert s["status_agree"] == s["pairs"]
+    assert s["inlier_index_sets_compared"] >= 14 and s["median_inlier_fraction"] < 0.75, s          # the scenes really are hard
+    for r in recs:
+        if r["identical_set"] and "inlier_set_identical" in r:
+            assert r["inlier_set_identical"] and r["rot_rad"] <= 1e-4 and r["trans_m"] <= 1e-4, r
+    assert s["pose_within_bar"] >= 13, s
+    recs = census("loftr_emat", [5000 + i for i in range(4)], chunk=4, hard=True)
+    s = PR.summarize(recs)
+    print(json.dumps(s))
+    assert s["status_agree"] == s["pairs"] and s["median_inlier_fraction"] < 0.8, s
+    assert s["min_inlier_set_jaccard"] > 0.97, s
+
+
+def test_census_procrustes_and_sift_leg():
+    """f-1 (SuperGlue -> Procrustes RANSAC) and configs[0] (descriptor leg -> E-mat RANSAC): whole HIP path vs whole oracle path"""
+    s = PR.summarize(census("sg_procrustes", [5000 + i for i in range(8)], hard=True))
+    print(json.dumps(s))
+    assert s["status_agree"] == s["pairs"] and s["pose_within_bar"] >= 6 and s["inlier_count_equal"] >= 6, s
+    recs = census("sift_emat", list(range(8)))
+    s = PR.summarize(recs)
+    print(json.dumps(s))
+    assert s["identical_match_sets"] == 8 and s["inlier_index_sets_identical"] == 8 and s["pose_bit_equal"] == 8, s
+
+
 # lower bounds on the fraction of pairs whose whole match set is bit-identical to the oracle's (measured:
 # profiles/r02_parity_census.json); LoFTR's fine stage is a sub-pixel fp32 expectation, so exact equality of every
 # coordinate is not expected there and the common-fraction (1/64 px quantised) carries the check
