@@ -90,11 +90,36 @@ def collate_batch1(sample):
     return out
 
 
+def resize_bilinear_u8(a, wh):
+    """cv2.resize(img, (w, h)) with its default INTER_LINEAR on a uint8 [H,W,C] image: half-pixel-centre bilinear sampling WITHOUT
+    antialiasing (source coordinate (x + 0.5) * scale - 0.5, edge-clamped), result rounded back to uint8.  At an exact 2x downscale
+    (720x540 -> 360x270, the regression configs) every sample falls midway between two pixels: a 2x2 box average.  PIL's
+    Image.BILINEAR is NOT this: it widens the triangle filter when shrinking ([1/8, 3/8, 3/8, 1/8] at 2x) and blurs the input.
+    (OpenCV evaluates the same interpolation in 11-bit fixed point: the two can differ by one grey level on a rounding tie; cv2 is not
+    installed offline, so that last bit is unpinned.)"""
+    H, W = a.shape[:2]
+    w, h = int(wh[0]), int(wh[1])
+    if (w, h) == (W, H):
+        return a
+
+    def taps(n_out, n_in):
+        s = (np.arange(n_out, dtype=np.float64) + 0.5) * (n_in / n_out) - 0.5
+        i0 = np.floor(s).astype(np.int64)
+        f = (s - i0).astype(np.float32)
+        return np.clip(i0, 0, n_in - 1), np.clip(i0 + 1, 0, n_in - 1), f
+    y0, y1, fy = taps(h, H)
+    x0, x1, fx = taps(w, W)
+    af = a.astype(np.float32)
+    top = af[y0][:, x0] * (1 - fx)[None, :, None] + af[y0][:, x1] * fx[None, :, None]
+    bot = af[y1][:, x0] * (1 - fx)[None, :, None] + af[y1][:, x1] * fx[None, :, None]
+    out = top * (1 - fy)[:, None, None] + bot * fy[:, None, None]
+    return np.clip(np.floor(out + 0.5), 0, 255).astype(np.uint8)
+
+
 def read_color_image(path, resize):
-    """lib/datasets/utils.py:58-74: RGB, resized to (w, h), float /255, [3,h,w].  PIL bilinear stands in
-    for cv2.resize (INTER_LINEAR); sub-grey-level differences (cv2 is not installed offline)."""
+    """lib/datasets/utils.py:58-74: RGB, cv2.resize to (w, h) (INTER_LINEAR: resize_bilinear_u8 above), float /255, [3,h,w]."""
     from PIL import Image
-    im = Image.open(path).convert("RGB").resize((int(resize[0]), int(resize[1])), Image.BILINEAR)
+    im = resize_bilinear_u8(np.asarray(Image.open(path).convert("RGB")), resize) if resize is not None else np.asarray(Image.open(path).convert("RGB"))
     # the /255 in numpy on the calling thread (same IEEE fp32 quotient as torch's): a torch CPU op over a 1.2 M-element image fans out over
     # every host core (256 on the GPU boxes) and costs ~20 ms in thread wake-ups, several times the JPEG decode
     a = np.ascontiguousarray(np.asarray(im, dtype=np.float32).transpose(2, 0, 1))

@@ -313,6 +313,22 @@ class Trainer:
             self.sched.load_state_dict(ck["lr_schedulers"][0])
         self.epoch, self.global_step = int(ck.get("epoch", 0)), int(ck.get("global_step", 0))
 
+    def check_finite(self, loss):
+        """Stop the run -- on EVERY rank, before the next optimizer step can be checkpointed -- when a head flagged NaN / Inf anchors
+        (the reference's check, lib/models/regression/head.py:88-101, is a per-step sys.exit; here the heads raise a device flag and
+        it is read at the log cadence together with the loss that is read anyway) or the loss is not finite."""
+        bad = torch.zeros(1, device=self.device)
+        flag = getattr(getattr(self.model, "head", None), "invalid", None)
+        if flag is not None:
+            bad += flag.to(bad.dtype).reshape(-1)[0]
+        bad += (~torch.isfinite(loss.detach().float().sum())).to(bad.dtype)
+        if self.world > 1 and dist.is_initialized():
+            dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+        if float(bad.item()) > 0:
+            if self.rank == 0:
+                print("Invalid anchors / non-finite loss!")
+            raise SystemExit("Stopped")
+
     def fit(self, train_iter, steps_per_epoch, val_batches=None, out_dir=None, log=print):
         """epochs x steps with the reference's cadence: LOG_INTERVAL, validation at VAL_INTERVAL (fraction of an epoch
         or a step count), `last.ckpt` after every validation and `e{epoch}-last.ckpt` at every epoch end"""
@@ -329,6 +345,8 @@ class Trainer:
             for s in range(steps_per_epoch):
                 t0 = time.perf_counter()
                 R_loss, t_loss, loss = self.train_step(next(it))
+                if self.global_step % log_every == 0:
+                    self.check_finite(loss)                     # the reference stops on NaN / Inf (head.py:88-101 sys.exit('Stopped'))
                 if self.global_step % log_every == 0 and self.rank == 0:
                     log(f"epoch {self.epoch} step {self.global_step}: loss {loss.item():.5f} R {R_loss.float().sum().item():.5f} "
                         f"t {t_loss.float().sum().item():.5f} ({1e3 * (time.perf_counter() - t0):.1f} ms)")
@@ -388,7 +406,11 @@ def main(argv=None):
             tr.resume(a.resume)
         nval = int(cfg.TRAINING.VAL_BATCHES or 0)
         val = _Reiterable(lambda: itertools.islice(iter(vl), max(1, nval // world) if nval else None))
-        res = tr.fit(tl.forever(), len(tl), val, out_dir=os.path.join("weights", a.experiment))
+        # every rank must run the SAME number of steps per epoch (DDP collectives, the sharded validation gather): agree on the minimum
+        spe = torch.tensor([len(tl)], device=device)
+        if world > 1:
+            dist.all_reduce(spe, op=dist.ReduceOp.MIN)
+        res = tr.fit(tl.forever(), int(spe.item()), val, out_dir=os.path.join("weights", a.experiment))
     else:
         B, H, W = a.synthetic
         src = SyntheticPairs(B, H, W, device, seed=0, rank=rank)

@@ -12,6 +12,7 @@ Output format (README.md:182-212, submission.py:18-30,60-65): zip of `pose_{scen
 mat2quat is restated (transforms3d is not installed offline): w >= 0 convention.
 """
 import argparse
+import json
 import os
 from collections import defaultdict
 from dataclasses import dataclass
@@ -109,6 +110,19 @@ def _atomic_write(path: Path, text: str):
     os.replace(tmp, path)
 
 
+def _run_signature(cfg, split):
+    """hash of everything that determines the poses of a run: the merged configuration (dict order independent) and the split"""
+    import hashlib
+
+    def plain(v):
+        if isinstance(v, dict):
+            return {k: plain(v[k]) for k in sorted(v)}
+        if isinstance(v, (list, tuple)):
+            return [plain(x) for x in v]
+        return v if isinstance(v, (int, float, str, bool, type(None))) else repr(v)
+    return hashlib.sha256(json.dumps({'cfg': plain(cfg), 'split': str(split)}, sort_keys=True).encode()).hexdigest()
+
+
 def predict_fused(cfg, split, output_root, pipeline=None, batch_pairs=None, resume=True, scenes=None, prefetch=2):
     """Scene-sharded, batched replacement of the reference's serial loop (submission.py:33-58) -> path of the zip
     (rank 0) or None (other ranks).  Works with or without an initialised torch.distributed process group
@@ -137,6 +151,24 @@ def predict_fused(cfg, split, output_root, pipeline=None, batch_pairs=None, resu
     device = torch.device(pipeline.device)
     B = int(batch_pairs or cfg.HIP.BATCH_PAIRS)
 
+    # Resume is tied to WHAT produced the files: a manifest beside them holds a hash of the configuration (matcher, solver, thresholds,
+    # weights paths, RANSAC seed, ...) and the split.  Pose files left by a different configuration -- or by a run that wrote no
+    # manifest -- are stale: they are removed and recomputed, never mixed into the archive (the reference always recomputes).
+    sig = _run_signature(cfg, split)
+    mf = out_dir / 'manifest.json'
+    if rank == 0:
+        old = None
+        if mf.exists():
+            try:
+                old = json.loads(mf.read_text()).get('signature')
+            except (ValueError, OSError):
+                old = None
+        if not resume or old != sig:
+            for f in out_dir.glob('pose_*.txt'):
+                f.unlink()
+        _atomic_write(mf, json.dumps({'signature': sig, 'split': split}))
+    if world > 1:
+        dist.barrier()
     todo = [i for i in range(lo, hi) if not (resume and (out_dir / f'pose_{scenes[i].scene_id}.txt').exists())]
     # decode threads: a pair costs ~45 ms of JPEG / PNG decode on one core (2 images + depth maps), the pipeline consumes 100-700 pairs/s
     # per GPU: the host's cores are split between the ranks of this node

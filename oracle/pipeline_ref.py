@@ -122,6 +122,11 @@ def compare_pair(ref, hip_pts, hip_R, hip_t, hip_ninl, hip_status, hip_mask=None
         rec["inlier_set_identical"] = bool(a.shape == b2.shape and np.array_equal(a, b2))
         sa, sb = {tuple(r) for r in a.tolist()}, {tuple(r) for r in b2.tolist()}
         rec["inlier_set_jaccard"] = float(len(sa & sb) / max(len(sa | sb), 1))
+        # the same at 1/64 px (LoFTR's fine level is a sub-pixel fp32 expectation: coordinates agree to ~1e-5 px, not bit for bit)
+        qa = {tuple(np.round(np.asarray(r) * 64).astype(np.int64).tolist()) for r in sa}
+        qb = {tuple(np.round(np.asarray(r) * 64).astype(np.int64).tolist()) for r in sb}
+        rec["inlier_set_identical_q64"] = bool(qa == qb)
+        rec["inlier_set_jaccard_q64"] = float(len(qa & qb) / max(len(qa | qb), 1))
         rec["inlier_fraction_ref"] = float(len(a) / max(rn, 1))
     if ref["status"] == 0 and hip_status == 0:
         Rr, Rh = np.asarray(ref["R"], dtype=np.float64), np.asarray(hip_R, dtype=np.float64).reshape(3, 3)
@@ -151,6 +156,8 @@ def summarize(records):
     if ins:
         out.update(inlier_index_sets_compared=len(ins), inlier_index_sets_identical=sum(r["inlier_set_identical"] for r in ins),
                    min_inlier_set_jaccard=round(float(min(r["inlier_set_jaccard"] for r in ins)), 5),
+                   inlier_index_sets_identical_q64=sum(r["inlier_set_identical_q64"] for r in ins),
+                   min_inlier_set_jaccard_q64=round(float(min(r["inlier_set_jaccard_q64"] for r in ins)), 5),
                    median_inlier_fraction=round(float(np.median([r["inlier_fraction_ref"] for r in ins])), 4),
                    min_inlier_fraction=round(float(min(r["inlier_fraction_ref"] for r in ins)), 4))
     pi = [r for r in ident if "rot_rad" in r]

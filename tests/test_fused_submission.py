@@ -97,6 +97,13 @@ def test_predict_fused_world1_zip_layout_and_resume(tmp_path):
     submission.predict_fused(_cfg(), "test", tmp_path / "a", pipeline=pipe3, batch_pairs=4, prefetch=2)
     assert [c[0] for c in pipe3.calls] == ["s00003"]
     assert open(tmp_path / "a" / "submission.zip", "rb").read() == open(z, "rb").read()
+    # ... but only for the SAME configuration: pose files left by another solver / matcher / threshold are stale and recomputed
+    # (the manifest beside them carries a hash of the merged configuration and the split), never mixed into the new archive
+    cfg2 = _cfg()
+    cfg2.PNP.REPROJECTION_INLIER_THRESHOLD = 5
+    pipe4 = _stub()
+    submission.predict_fused(cfg2, "test", tmp_path / "a", pipeline=pipe4, batch_pairs=4, prefetch=0)
+    assert sorted({c[0] for c in pipe4.calls}) == ["s00000", "s00001", "s00002", "s00003", "s00004"]
 
 
 def test_predict_fused_gloo_world2_equals_world1(tmp_path):

@@ -337,3 +337,32 @@ def test_sharding_and_sampler_properties():
         bounds = np.cumsum([0] + sizes)
         assert all(sum(bounds[k] <= i < bounds[k + 1] for i in whole) == n for k in range(len(sizes)))
     sampler()
+
+
+def test_resize_is_cv2_inter_linear_not_pil_bilinear():
+    """cv2.resize(INTER_LINEAR) = half-pixel bilinear without antialiasing; at the exact 2x downscale of the regression
+    configs (720x540 -> 360x270) that is the 2x2 box average, which PIL's Image.BILINEAR (widened triangle filter) is not"""
+    from mapfree_reloc_amd.datasets import resize_bilinear_u8
+    rng = np.random.default_rng(0)
+    a = rng.integers(0, 256, (72, 54, 3), dtype=np.uint8)
+    got = resize_bilinear_u8(a, (27, 36))
+    box = np.floor(a.reshape(36, 2, 27, 2, 3).astype(np.float32).mean((1, 3)) + 0.5).astype(np.uint8)
+    assert np.array_equal(got, box)
+    # identity and an up-scale: corners map with edge clamping, interior is the 4-tap interpolation
+    assert resize_bilinear_u8(a, (54, 72)) is a
+    up = resize_bilinear_u8(a, (108, 144))
+    assert up.shape == (144, 108, 3) and np.array_equal(up[0, 0], a[0, 0]) and np.array_equal(up[-1, -1], a[-1, -1])
+    # against torch's half-pixel bilinear (antialias off) at a non-integer factor: same arithmetic up to the final rounding
+    import torch.nn.functional as F
+    t = torch.from_numpy(a).permute(2, 0, 1)[None].float()
+    ref = F.interpolate(t, size=(50, 31), mode="bilinear", align_corners=False, antialias=False)[0].permute(1, 2, 0).numpy()
+    assert np.abs(resize_bilinear_u8(a, (31, 50)).astype(np.float32) - ref).max() <= 0.5 + 1e-3
+
+
+def test_run_signature_ties_resume_to_the_configuration():
+    from mapfree_reloc_amd.config import get_cfg_defaults
+    from mapfree_reloc_amd.submission import _run_signature
+    a, b = get_cfg_defaults(), get_cfg_defaults()
+    assert _run_signature(a, "val") == _run_signature(b, "val") != _run_signature(a, "test")
+    b.POSE_SOLVER = "EssentialMatrixMetric"
+    assert _run_signature(a, "val") != _run_signature(b, "val")
