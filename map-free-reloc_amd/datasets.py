@@ -331,14 +331,16 @@ def to_gray(img):
 class PairBatchLoader:
     """Loader adjacency of the fused path (replaces the batch-1 DataLoader of
     lib/datasets/datamodules.py:42-46 + lib/datasets/utils.py:58-81 on the hot path): `items` = [(scene, index)]
-    in submission order, grouped into batches of <= B pairs that never cross a scene boundary.  A background
+    in submission order, grouped into batches of B pairs that SPAN scene boundaries (a 116-pair scene is not 3 full batches + a
+    20-pair one: only the very last batch of a rank is short; `span_scenes=False` restores per-scene batches).  A background
     thread decodes the next batches into PINNED host buffers (queue depth `prefetch`), so JPEG/PNG decode and
     the H2D copy of batch i+1 overlap the kernels of batch i (DevicePrefetcher below issues the copies on a
     side stream).  Yields dict(images [2b,1,H,W] f32 gray interleaved (2p = reference view), depth0/depth1 [b,H,W],
     K0/K1 [b,3,3] in the loader's dtype (float64 on Map-free), seed_ids [b] i64 (= data['pair_id'], the RANSAC stream id the per-pair plugin uses),
-    global_ids [b] i64, names [b], scene_id)."""
+    global_ids [b] i64, names [b], scene_ids [b] / scene_roots [b] (per pair), scenes_done (ids of the scenes whose LAST pair is in
+    this batch), scene_id / scene_root / last_of_scene (of the batch's last pair, kept for single-scene consumers))."""
 
-    def __init__(self, scenes, batch_pairs=32, prefetch=2, pin=None, global_offsets=None, workers=8):
+    def __init__(self, scenes, batch_pairs=32, prefetch=2, pin=None, global_offsets=None, workers=8, span_scenes=True):
         """workers: decode threads per batch (PIL / zlib / numpy release the GIL): a pair is two JPEGs + one or two 16-bit PNGs,
         ~12 ms of decode on one core, so one thread feeds ~80 pairs/s where the fused pipeline consumes ~700"""
         self.scenes, self.B, self.prefetch = list(scenes), int(batch_pairs), int(prefetch)
@@ -350,20 +352,24 @@ class PairBatchLoader:
             self.offsets, acc = [], 0
             for sc in self.scenes:
                 self.offsets.append(acc); acc += len(sc)
-        self.batches = [(si, lo, min(lo + self.B, len(sc))) for si, sc in enumerate(self.scenes) for lo in range(0, len(sc), self.B)]
+        if span_scenes:
+            items = [(si, i) for si, sc in enumerate(self.scenes) for i in range(len(sc))]
+            self.batches = [items[lo:lo + self.B] for lo in range(0, len(items), self.B)]
+        else:
+            self.batches = [[(si, i) for i in range(lo, min(lo + self.B, len(sc)))] for si, sc in enumerate(self.scenes) for lo in range(0, len(sc), self.B)]
 
     def __len__(self):
         return len(self.batches)
 
-    def _load(self, si, lo, hi):
-        sc = self.scenes[si]
-        if self.workers > 1 and hi - lo > 1:
+    def _load(self, items):
+        get = lambda it: self.scenes[it[0]][it[1]]
+        if self.workers > 1 and len(items) > 1:
             if self._pool is None:
                 import concurrent.futures
                 self._pool = concurrent.futures.ThreadPoolExecutor(max_workers=self.workers, thread_name_prefix="mfr-decode")
-            samples = list(self._pool.map(sc.__getitem__, range(lo, hi)))      # order preserved
+            samples = list(self._pool.map(get, items))                         # order preserved
         else:
-            samples = [sc[i] for i in range(lo, hi)]
+            samples = [get(it) for it in items]
         b = len(samples)
         Hh, Ww = samples[0]["image0"].shape[-2:]
         mk = (lambda *shape, dtype=torch.float32: torch.empty(*shape, dtype=dtype, pin_memory=True)) if self.pin else \
@@ -386,16 +392,19 @@ class PairBatchLoader:
             K0[p] = torch.as_tensor(smp["K_color0"]); K1[p] = torch.as_tensor(smp["K_color1"])
             if has_depth:
                 d0_np[p] = npv(smp["depth0"]); d1_np[p] = npv(smp["depth1"])
+        sc = self.scenes[items[-1][0]]
+        done = [self.scenes[si].scene_id for si, i in items if i == len(self.scenes[si]) - 1]
         return dict(images=images, depth0=depth0, depth1=depth1, K0=K0, K1=K1,
                     seed_ids=torch.tensor([int(smp["pair_id"]) for smp in samples], dtype=torch.int64),
-                    global_ids=torch.arange(self.offsets[si] + lo, self.offsets[si] + hi, dtype=torch.int64),
-                    names=[smp["pair_names"][1] for smp in samples], scene_id=sc.scene_id, scene_root=sc.scene_root, scene_index=si,
-                    last_of_scene=hi == len(sc))
+                    global_ids=torch.tensor([self.offsets[si] + i for si, i in items], dtype=torch.int64),
+                    names=[smp["pair_names"][1] for smp in samples], scene_ids=[self.scenes[si].scene_id for si, _ in items],
+                    scene_roots=[self.scenes[si].scene_root for si, _ in items], scenes_done=done,
+                    scene_id=sc.scene_id, scene_root=sc.scene_root, scene_index=items[-1][0], last_of_scene=bool(done and done[-1] == sc.scene_id))
 
     def __iter__(self):
         if self.prefetch <= 0:
             for b in self.batches:
-                yield self._load(*b)
+                yield self._load(b)
             return
         import queue
         import threading
@@ -407,7 +416,7 @@ class PairBatchLoader:
                 for b in self.batches:
                     if stop.is_set():
                         return
-                    q.put(self._load(*b))
+                    q.put(self._load(b))
                 q.put(None)
             except BaseException as e:          # surface loader errors in the consumer
                 q.put(e)

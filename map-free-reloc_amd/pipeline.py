@@ -114,8 +114,11 @@ class _PrecomputedStage:
         import numpy as np
         from . import wire
         rows = []
-        for pid in batch["seed_ids"].tolist():
-            p1, p2 = self.pm.get_correspondences({"scene_id": [batch["scene_id"]], "scene_root": [batch.get("scene_root", "")], "pair_id": pid})
+        pids = batch["seed_ids"].tolist()
+        sids = batch.get("scene_ids") or [batch["scene_id"]] * len(pids)           # batches may span scenes (PairBatchLoader)
+        roots = batch.get("scene_roots") or [batch.get("scene_root", "")] * len(pids)
+        for pid, sid, root in zip(pids, sids, roots):
+            p1, p2 = self.pm.get_correspondences({"scene_id": [sid], "scene_root": [root], "pair_id": pid})
             rows.append(np.concatenate([p1, p2], 1) if len(p1) else np.zeros((0, 4), np.float32))
         p0, p1, n = wire.pts_rows_to_device_batch(rows)
         d = lambda a: torch.from_numpy(a).to(self.device)

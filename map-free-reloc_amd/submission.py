@@ -14,6 +14,7 @@ mat2quat is restated (transforms3d is not installed offline): w >= 0 convention.
 import argparse
 import json
 import os
+import time
 from collections import defaultdict
 from dataclasses import dataclass
 from pathlib import Path
@@ -110,6 +111,9 @@ def _atomic_write(path: Path, text: str):
     os.replace(tmp, path)
 
 
+LAST_RUN_STATS = {}          # predict_fused's timing of the last call in this process (pairs, seconds, loader_wait_s, ...)
+
+
 def _run_signature(cfg, split):
     """hash of everything that determines the poses of a run: the merged configuration (dict order independent) and the split"""
     import hashlib
@@ -177,17 +181,37 @@ def predict_fused(cfg, split, output_root, pipeline=None, batch_pairs=None, resu
     loader = PairBatchLoader([scenes[i] for i in todo], B, prefetch=prefetch, pin=device.type == 'cuda',
                              global_offsets=[int(offsets[i]) for i in todo], workers=workers)
     recs, names, acc = [], {}, []
-    for batch in DevicePrefetcher(loader, device):
+    stats = dict(pairs=0, batches=0, loader_wait_s=0.0, t0=time.perf_counter())
+    it = iter(DevicePrefetcher(loader, device))
+    while True:
+        tw = time.perf_counter()
+        batch = next(it, None)                          # time blocked here = the GPU waiting for decode / H2D ("loader stall")
+        stats['loader_wait_s'] += time.perf_counter() - tw
+        if batch is None:
+            break
         out = pipeline(batch)
         rec = parallel.pose_records(batch['global_ids'].to(out['R'].device), out)
         acc.append(rec)
-        for gid, nm in zip(batch['global_ids'].tolist(), batch['names']):
-            names[gid] = (batch['scene_id'], nm)
-        if batch['last_of_scene']:                      # scene complete -> its file (one D2H copy per scene)
-            srec = torch.cat(acc).cpu().numpy(); acc = []
+        sids = batch.get('scene_ids') or [batch['scene_id']] * len(batch['names'])
+        for gid, sid, nm in zip(batch['global_ids'].tolist(), sids, batch['names']):
+            names[gid] = (sid, nm)
+        stats['pairs'] += len(batch['names']); stats['batches'] += 1
+        done = batch.get('scenes_done')
+        if done is None:
+            done = [batch['scene_id']] if batch['last_of_scene'] else []
+        if done:                                        # >= 1 scene complete -> their files (one D2H copy; batches may span scenes)
+            srec = torch.cat(acc).cpu().numpy()
             res = records_to_results(srec, names)
-            _atomic_write(out_dir / f'pose_{batch["scene_id"]}.txt', scene_text(res.get(batch['scene_id'], [])))
-            recs.append(srec)
+            for sid in done:
+                _atomic_write(out_dir / f'pose_{sid}.txt', scene_text(res.get(sid, [])))
+            doneset = set(done)
+            keep = np.array([names[int(g)][0] not in doneset for g in srec[:, 0]], bool)
+            recs.append(srec[~keep])
+            acc = [torch.from_numpy(srec[keep]).to(rec.device)] if keep.any() else []
+    if acc:                                             # (cannot happen: the last pair of the rank's last scene ends a scene)
+        recs.append(torch.cat(acc).cpu().numpy())
+    stats['seconds'] = time.perf_counter() - stats.pop('t0')
+    LAST_RUN_STATS.clear(); LAST_RUN_STATS.update(stats, rank=rank, world=world, scenes_computed=len(todo), decode_workers=workers, batch_pairs=B)
     mine = torch.from_numpy(np.concatenate(recs) if recs else np.zeros((0, parallel.REC_W))).to(device)
     allrec = parallel.gather_records(mine, world).cpu().numpy()
     if rank != 0:

@@ -76,8 +76,9 @@ def test_predict_fused_world1_zip_layout_and_resume(tmp_path):
     from mapfree_reloc_amd import submission
     pipe = _stub()
     z = submission.predict_fused(_cfg(), "test", tmp_path / "a", pipeline=pipe, batch_pairs=2, prefetch=0)
-    # batches never cross a scene boundary: 3 pairs per scene at B=2 -> (2, 1) per scene
-    assert [c[1] for c in pipe.calls] == [2, 1] * 5
+    # batches span scene boundaries (5 scenes x 3 pairs at B=2: seven full batches + the rank's last one), no per-scene tail batch
+    assert [c[1] for c in pipe.calls] == [2] * 7 + [1]
+    assert submission.LAST_RUN_STATS["pairs"] == 15 and submission.LAST_RUN_STATS["batches"] == 8
     with zipfile.ZipFile(z) as zf:
         assert zf.namelist() == [f"pose_s{i:05d}.txt" for i in range(5)]
         lines = zf.read("pose_s00001.txt").decode().split("\n")
@@ -103,7 +104,7 @@ def test_predict_fused_world1_zip_layout_and_resume(tmp_path):
     cfg2.PNP.REPROJECTION_INLIER_THRESHOLD = 5
     pipe4 = _stub()
     submission.predict_fused(cfg2, "test", tmp_path / "a", pipeline=pipe4, batch_pairs=4, prefetch=0)
-    assert sorted({c[0] for c in pipe4.calls}) == ["s00000", "s00001", "s00002", "s00003", "s00004"]
+    assert sum(c[1] for c in pipe4.calls) == 15 and submission.LAST_RUN_STATS["scenes_computed"] == 5
 
 
 def test_predict_fused_gloo_world2_equals_world1(tmp_path):
@@ -181,10 +182,15 @@ def test_pair_batch_loader_threads_and_order(tmp_path):
     scenes = list_scenes(_cfg(3, 5), "test")
     a = list(PairBatchLoader(scenes, 2, prefetch=0, pin=False))
     b = list(DevicePrefetcher(PairBatchLoader(scenes, 2, prefetch=3, pin=False), "cpu"))
-    assert len(a) == len(b) == 9 and [x["global_ids"].tolist() for x in a] == [x["global_ids"].tolist() for x in b]
+    # 3 scenes x 5 pairs at B=2, batches span scenes: 7 full batches + 1; scene ends are reported per batch
+    assert len(a) == len(b) == 8 and [x["global_ids"].tolist() for x in a] == [x["global_ids"].tolist() for x in b]
     assert torch.cat([x["global_ids"] for x in a]).tolist() == list(range(15))
     assert all(torch.equal(x["images"], y["images"]) and x["names"] == y["names"] for x, y in zip(a, b))
-    assert a[2]["last_of_scene"] and not a[1]["last_of_scene"] and a[2]["seed_ids"].tolist() == [20]
+    assert a[2]["scenes_done"] == ["s00000"] and a[2]["scene_ids"] == ["s00000", "s00001"] and a[2]["seed_ids"].tolist() == [20, 0]
+    assert a[1]["scenes_done"] == [] and a[7]["scenes_done"] == ["s00002"] and [len(x["names"]) for x in a] == [2] * 7 + [1]
+    # per-scene batches on request (the pre-round-3 behaviour)
+    c = list(PairBatchLoader(scenes, 2, prefetch=0, pin=False, span_scenes=False))
+    assert len(c) == 9 and c[2]["last_of_scene"] and not c[1]["last_of_scene"] and c[2]["seed_ids"].tolist() == [20]
     assert a[0]["images"].shape == (4, 1, 48, 40) and a[0]["images"].dtype == torch.float32
 
 
