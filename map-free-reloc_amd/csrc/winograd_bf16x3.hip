@@ -424,14 +424,29 @@ __global__ void __launch_bounds__(256, 1) wino_bf16x3_kernel(
     float *yb = y + ((size_t)b * Cout + co0) * cstride;
     const bool allco = cg * 64 + 64 <= Cout;                          // wave-uniform: no padded output channels in this group
     if (POOL) {
+        // wave-uniform decisions (activation code, "no padded channels in this group") are taken ONCE around straight-line loops:
+        // a branch per store serialises sixteen store issues behind sixteen waits
+        float m[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) m[r] = fmaxf(fmaxf(Y[r][0], Y[r][1]), fmaxf(Y[r][2], Y[r][3]));   // the activations are monotone: act(max) = max(act)
+        if (act == 1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) m[r] = fmaxf(m[r], 0.f);
+        } else if (act == 2) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) m[r] = m[r] > 0.f ? m[r] : 0.01f * m[r];
+        }
         if (ty < Ho && tx < Wo) {
             float *yo = yb + (size_t)ty * Wo + tx;
+            if (allco) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float m = fmaxf(fmaxf(Y[r][0], Y[r][1]), fmaxf(Y[r][2], Y[r][3]));      // the activations are monotone: act(max) = max(act)
-                m = (act == 1) ? fmaxf(m, 0.f) : (act == 2) ? (m > 0.f ? m : 0.01f * m) : m;
-                const int dc = (r & 3) + 8 * (r >> 2);
-                if (allco || co0 + dc < Cout) yo[(size_t)dc * cstride] = m;
+                for (int r = 0; r < 16; ++r) yo[(size_t)((r & 3) + 8 * (r >> 2)) * cstride] = m[r];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int dc = (r & 3) + 8 * (r >> 2);
+                    if (co0 + dc < Cout) yo[(size_t)dc * cstride] = m[r];
+                }
             }
         }
     } else {
@@ -452,14 +467,29 @@ __global__ void __launch_bounds__(256, 1) wino_bf16x3_kernel(
             }
         }
         float *yo0 = yb + (size_t)oy * W + ox;
+        if (act == 1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) Y[r][k] = fmaxf(Y[r][k], 0.f);
+        } else if (act == 2) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) Y[r][k] = Y[r][k] > 0.f ? Y[r][k] : 0.01f * Y[r][k];
+        }
+        const bool interior = allco && r0 && r1 && c1 && !(W & 1);       // per lane; the common case: two float2 stores per channel
+        if (interior) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float *yo = yo0 + (size_t)((r & 3) + 8 * (r >> 2)) * cstride;
+                *(float2 *)yo = make_float2(Y[r][0], Y[r][1]);
+                *(float2 *)(yo + W) = make_float2(Y[r][2], Y[r][3]);
+            }
+        } else
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            float y00 = Y[r][0], y01 = Y[r][1], y10 = Y[r][2], y11 = Y[r][3];
-            if (act == 1) { y00 = fmaxf(y00, 0.f); y01 = fmaxf(y01, 0.f); y10 = fmaxf(y10, 0.f); y11 = fmaxf(y11, 0.f); }
-            else if (act == 2) {
-                y00 = y00 > 0.f ? y00 : 0.01f * y00; y01 = y01 > 0.f ? y01 : 0.01f * y01;
-                y10 = y10 > 0.f ? y10 : 0.01f * y10; y11 = y11 > 0.f ? y11 : 0.01f * y11;
-            }
+            const float y00 = Y[r][0], y01 = Y[r][1], y10 = Y[r][2], y11 = Y[r][3];
             const int dc = (r & 3) + 8 * (r >> 2);
             if (!(allco || co0 + dc < Cout)) continue;
             float *yo = yo0 + (size_t)dc * cstride;

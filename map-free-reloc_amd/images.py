@@ -34,6 +34,11 @@ def synthetic_pair(seed, H=720, W=540, f=590.0, hard=False):
     epipolar geometry / the depth of the static scene: 30-60 % OUTLIERS for the E-matrix and PnP RANSACs, which then need
     hundreds of hypotheses and exercise the adaptive termination, the polish and the cheirality vote -- plus an occluder
     strip of unrelated texture in the second view (no matches, a depth discontinuity).  `outlier_area` = moving-object area.
+    hard=2 additionally corrupts the DEPTH maps the way a monocular depth estimate is wrong (the reference lifts matches through
+    DPT / KITTI-finetuned depth, lib/datasets/mapfree.py:150-163): 36-px blocks covering 35-55 % of each map are scaled by a
+    factor in [1.2, 1.8] or its inverse, independently per view.  The images do not change, so the matchers return the same
+    correspondences -- but 35-55 % of the lifted 3-D points are now wrong: outliers for PnP, Procrustes and the scale RANSAC
+    whatever the matcher does.  `depth_outlier_frac` = corrupted fraction of depth0.
 
     returns dict(img0, img1 [H,W] f32 in [0,1], depth0, depth1 [H,W] f32 metres (uint16-mm
     quantised like lib/datasets/utils.py:77-81), K [3,3] f64, R_gt, t_gt)."""
@@ -71,13 +76,26 @@ def synthetic_pair(seed, H=720, W=540, f=590.0, hard=False):
             depth1[y0 + dy:y0 + dy + hh, x0 + dx:x0 + dx + ww] = zo
             area += hh * ww
         outlier_area = float(min(area, H * W) / (H * W))
+    depth_outlier_frac = 0.0
+    if int(hard) >= 2:
+        r2 = np.random.default_rng(seed + 77777)       # own stream: hard=1 scenes are unchanged
+        blk = 36
+        gh, gw = H // blk, W // blk
+        for k, dm in enumerate((depth, depth1)):
+            sel = r2.random((gh, gw)) < r2.uniform(0.35, 0.55)
+            fac = r2.uniform(1.2, 1.8, (gh, gw))
+            fac = np.where(r2.random((gh, gw)) < 0.5, fac, 1.0 / fac)
+            m = np.where(sel, fac, 1.0)
+            dm[:gh * blk, :gw * blk] *= np.kron(m, np.ones((blk, blk)))
+            if k == 0:
+                depth_outlier_frac = float(sel.mean() * gh * gw * blk * blk / (H * W))
     depth1 = (np.round(depth1 * 1000).astype(np.uint16) / 1000.0).astype(np.float32)
     depth = (np.round(depth * 1000).astype(np.uint16) / 1000.0).astype(np.float32)
     # float64, the dtype every Map-free sample carries (correct_intrinsic_scale multiplies a float64 eye(3) into K:
     # lib/datasets/utils.py:117-130, lib/datasets/mapfree.py:50-52) -- the solvers evaluate inv(K) / the K-normalisation in it
     K = np.array([[f, 0, W / 2 - 0.5], [0, f, H / 2 - 0.5], [0, 0, 1]], dtype=np.float64)
     return dict(img0=img0, img1=img1, depth0=depth, depth1=depth1, K=K,
-                R_gt=np.eye(3), t_gt=np.array([tx, 0.0, 0.0]), outlier_area=outlier_area)
+                R_gt=np.eye(3), t_gt=np.array([tx, 0.0, 0.0]), outlier_area=outlier_area, depth_outlier_frac=depth_outlier_frac)
 
 
 def synthetic_batch(seeds, H=720, W=540, hard=False):

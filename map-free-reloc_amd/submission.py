@@ -181,16 +181,24 @@ def predict_fused(cfg, split, output_root, pipeline=None, batch_pairs=None, resu
     loader = PairBatchLoader([scenes[i] for i in todo], B, prefetch=prefetch, pin=device.type == 'cuda',
                              global_offsets=[int(offsets[i]) for i in todo], workers=workers)
     recs, names, acc = [], {}, []
-    stats = dict(pairs=0, batches=0, loader_wait_s=0.0, t0=time.perf_counter())
+    stats = dict(pairs=0, batches=0, loader_wait_s=0.0, issue_s=0.0, gpu_busy_s=0.0, t0=time.perf_counter())
     it = iter(DevicePrefetcher(loader, device))
+    evs = []                                            # (start, end) event pairs around every step: GPU time of the steps, read at the end
     while True:
         tw = time.perf_counter()
         batch = next(it, None)                          # time blocked here = the GPU waiting for decode / H2D ("loader stall")
         stats['loader_wait_s'] += time.perf_counter() - tw
         if batch is None:
             break
+        ti = time.perf_counter()
+        if device.type == 'cuda':
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         out = pipeline(batch)
         rec = parallel.pose_records(batch['global_ids'].to(out['R'].device), out)
+        if device.type == 'cuda':
+            e1.record(); evs.append((e0, e1))
+        stats['issue_s'] += time.perf_counter() - ti    # host time to ISSUE the step (launches; any hidden synchronisation shows up here)
         acc.append(rec)
         sids = batch.get('scene_ids') or [batch['scene_id']] * len(batch['names'])
         for gid, sid, nm in zip(batch['global_ids'].tolist(), sids, batch['names']):
@@ -210,6 +218,9 @@ def predict_fused(cfg, split, output_root, pipeline=None, batch_pairs=None, resu
             acc = [torch.from_numpy(srec[keep]).to(rec.device)] if keep.any() else []
     if acc:                                             # (cannot happen: the last pair of the rank's last scene ends a scene)
         recs.append(torch.cat(acc).cpu().numpy())
+    if evs:
+        torch.cuda.synchronize(device)
+        stats['gpu_busy_s'] = sum(a.elapsed_time(b) for a, b in evs) * 1e-3
     stats['seconds'] = time.perf_counter() - stats.pop('t0')
     LAST_RUN_STATS.clear(); LAST_RUN_STATS.update(stats, rank=rank, world=world, scenes_computed=len(todo), decode_workers=workers, batch_pairs=B)
     mine = torch.from_numpy(np.concatenate(recs) if recs else np.zeros((0, parallel.REC_W))).to(device)

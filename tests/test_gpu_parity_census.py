@@ -41,13 +41,13 @@ def test_census_loftr_emat_8_pairs():
 
 
 def test_census_hard_scenes_inlier_index_sets():
-    """hard scenes (moving objects + occluder): 30-60 % of the correspondences are outliers, the RANSACs run hundreds of hypotheses.
+    """hard scenes (moving objects + occluder, and for PnP 35-55 % of the depth map wrong): 30-60 % outliers, the RANSACs run hundreds of hypotheses.
     Wherever the matcher reproduces the oracle's match set, the inlier INDEX SET (canonical order) is the oracle's, bit for bit."""
-    recs = census("sg_pnp", [5000 + i for i in range(16)], hard=True)
+    recs = census("sg_pnp", [5000 + i for i in range(16)], hard=2)
     s = PR.summarize(recs)
     print(json.dumps(s))
     assert s["status_agree"] == s["pairs"]
-    assert s["inlier_index_sets_compared"] >= 14 and s["median_inlier_fraction"] < 0.95, s          # SuperGlue (untrained) matches few of the moving objects
+    assert s["inlier_index_sets_compared"] >= 14 and s["median_inlier_fraction"] < 0.8, s           # 35-55 % of the lifted points carry a wrong depth
     for r in recs:
         if r["identical_set"] and "inlier_set_identical" in r:
             assert r["inlier_set_identical"] and r["rot_rad"] <= 1e-4 and r["trans_m"] <= 1e-4, r
@@ -61,7 +61,7 @@ def test_census_hard_scenes_inlier_index_sets():
 
 def test_census_procrustes_and_sift_leg():
     """f-1 (SuperGlue -> Procrustes RANSAC) and configs[0] (descriptor leg -> E-mat RANSAC): whole HIP path vs whole oracle path"""
-    s = PR.summarize(census("sg_procrustes", [5000 + i for i in range(8)], hard=True))
+    s = PR.summarize(census("sg_procrustes", [5000 + i for i in range(8)], hard=2))
     print(json.dumps(s))
     assert s["status_agree"] == s["pairs"] and s["pose_within_bar"] >= 6 and s["inlier_count_equal"] >= 6, s
     recs = census("sift_emat", list(range(8)))

@@ -56,6 +56,8 @@ def main():
     ap.add_argument("--configs", default="sg_pnp,loftr_emat")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "r03_fused_split_1gpu.json"))
     ap.add_argument("--writers", type=int, default=min(64, os.cpu_count() or 8))
+    ap.add_argument("--graph", type=int, default=0, help="1: HIP.GRAPH_FUSED (matcher stage replayed from one HIP graph per batch shape)")
+    ap.add_argument("--no-resume-legs", action="store_true")
     a = ap.parse_args()
     t0 = time.perf_counter()
     if not os.path.isdir(os.path.join(a.root, "test", f"s{a.scenes - 1:05d}")):
@@ -76,6 +78,7 @@ def main():
         cfg = get_cfg_defaults()
         cfg.DATASET.DATA_ROOT = a.root; cfg.DATASET.WIDTH = 540; cfg.DATASET.HEIGHT = 720; cfg.DATASET.ESTIMATED_DEPTH = "dptkitti"
         cfg.MODEL = "FeatureMatching"; cfg.ALLOW_SYNTHETIC_WEIGHTS = True
+        cfg.HIP.GRAPH_FUSED = bool(a.graph)
         if name == "sg_pnp":
             cfg.FEATURE_MATCHING, cfg.POSE_SOLVER = "SuperGlue", "PNP"
             cfg.PNP.RANSAC_ITER, cfg.PNP.REPROJECTION_INLIER_THRESHOLD, cfg.PNP.CONFIDENCE = 1000, 3, 0.9999
@@ -95,6 +98,14 @@ def main():
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         st = dict(submission.LAST_RUN_STATS)
+        base = dict(pairs=st["pairs"], seconds=round(dt, 2), pairs_per_s=round(st["pairs"] / dt, 1), batch_pairs=B, batches=st["batches"], graph=bool(a.graph),
+                    loader_wait_s=round(st["loader_wait_s"], 2), loader_stall_fraction=round(st["loader_wait_s"] / st["seconds"], 4),
+                    issue_s=round(st["issue_s"], 2), gpu_busy_s=round(st["gpu_busy_s"], 2), gpu_busy_fraction=round(st["gpu_busy_s"] / st["seconds"], 4),
+                    decode_workers=st["decode_workers"])
+        if a.no_resume_legs:
+            res[name] = base
+            print(name, json.dumps(base), flush=True)
+            continue
         # resume: every scene file present -> nothing is recomputed, the archive is rebuilt from the files
         t1 = time.perf_counter()
         z2 = submission.predict_fused(cfg, "test", out_root, batch_pairs=B)
@@ -111,9 +122,7 @@ def main():
         with zipfile.ZipFile(z) as zf:
             n_lines = sum(len(zf.read(nm).decode().strip().split("\n")) for nm in zf.namelist())
             n_files = len(zf.namelist())
-        res[name] = dict(pairs=st["pairs"], seconds=round(dt, 2), pairs_per_s=round(st["pairs"] / dt, 1), batch_pairs=B, batches=st["batches"],
-                         loader_wait_s=round(st["loader_wait_s"], 2), loader_stall_fraction=round(st["loader_wait_s"] / st["seconds"], 4),
-                         decode_workers=st["decode_workers"], zip_scene_files=n_files, zip_pose_lines=n_lines,
+        res[name] = dict(base, zip_scene_files=n_files, zip_pose_lines=n_lines,
                          resume_all_done=dict(seconds=round(dt_resume, 2), pairs_recomputed=st2["pairs"], same_zip=open(z, "rb").read() == open(z2, "rb").read()),
                          resume_half_done=dict(seconds=round(dt_half, 2), pairs_recomputed=st3["pairs"], scenes_recomputed=st3["scenes_computed"]))
         print(name, json.dumps(res[name]), flush=True)

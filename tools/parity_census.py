@@ -2,7 +2,7 @@
 per pair: match set identical?, INLIER INDEX SET identical (canonical order)?, pose delta, inlier-count delta -- on the easy
 3-band scenes and on the HARD ones (moving objects + occluder: 30-60 % outliers, images.synthetic_pair(hard=True)).
 Configurations: sg_pnp (configs[1]), loftr_emat (configs[2]), sg_procrustes (f-1), sift_emat (configs[0]: descriptor leg -> E-mat).
-Usage: python tools/parity_census.py [--sg 64] [--loftr 16] [--procrustes 16] [--sift 32] [--hard 1] [--out gpurun_out/census.json]"""
+Usage: python tools/parity_census.py [--sg 64] [--loftr 16] [--procrustes 16] [--sift 32] [--hard 2] [--out gpurun_out/census.json]"""
 import argparse
 import json
 import os
@@ -118,15 +118,16 @@ def main():
     ap.add_argument("--loftr", type=int, default=16)
     ap.add_argument("--procrustes", type=int, default=16)
     ap.add_argument("--sift", type=int, default=32)
-    ap.add_argument("--hard", type=int, default=1)
+    ap.add_argument("--hard", type=int, default=2, help="0 easy, 1 moving objects + occluder, 2 = 1 + corrupted depth blocks")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "parity_census.json"))
     a = ap.parse_args()
-    res = {"scenes": "hard (moving objects + occluder, images.synthetic_pair(hard=True))" if a.hard else "easy (3 depth bands)"}
+    res = {"scenes": {0: "easy (3 depth bands)", 1: "hard (moving objects + occluder, images.synthetic_pair(hard=1))",
+                      2: "hard=2 (moving objects + occluder + 35-55 % of each depth map wrong by a factor 1.2-1.8, images.synthetic_pair(hard=2))"}[int(a.hard)]}
     for kind, n, chunk in (("sg_pnp", a.sg, 8), ("loftr_emat", a.loftr, 4), ("sg_procrustes", a.procrustes, 8), ("sift_emat", a.sift, 1)):
         if n <= 0:
             continue
         t0 = time.perf_counter()
-        recs = census(kind, [5000 + i for i in range(n)], chunk=chunk, hard=bool(a.hard))
+        recs = census(kind, [5000 + i for i in range(n)], chunk=chunk, hard=int(a.hard))
         s = PR.summarize(recs)
         tr = [r["rot_err_vs_truth_deg"] for r in recs if "rot_err_vs_truth_deg" in r]
         if tr:
