@@ -301,6 +301,31 @@ int mfr_upsample2x_add(const float *lo, float *y, int planes, int H, int W, void
  *                       torch's arithmetic; dtype 0 = float32, 1 = bfloat16 storage (f32 arithmetic).  Reference call site: the
  *                       regression encoder's `upconv` (lib/models/regression/encoder/resunet.py:30-38, used at :121-126). */
 int mfr_upsample_bilinear(const void *in, void *out, int planes, int H, int W, int Ho, int Wo, int dtype, void *stream);
+/*   mfr_conv_gemm_bf16    the 3x3 decoder convolutions of the regression encoder (`conv` inside upconv4 / iconv4 / upconv3 / iconv3,
+ *                       lib/models/regression/encoder/resunet.py:16-38, 112-128; bf16 autocast of train.py:20-70) as implicit GEMMs on
+ *                       the bf16 matrix cores (csrc/conv_gemm_bf16.hip): forward, d/d input and d/d weight are ONE kernel,
+ *                           C[i, j] = sum_k A[i, k] B[j, k]      bf16 operands, fp32 accumulate,
+ *                       whose k axis is cut into segments of Lk elements (Lk % 32 == 0); chunk c of 32 elements, in segment s = 32 c / Lk,
+ *                       is read at A + zA[z] + i * sA + segA[s] + (32 c mod Lk) and at B + zB[z] + j * sB + segB[s] + (32 c mod Lk)
+ *                       (all offsets and strides in ELEMENTS, multiples of 8; segA / segB hold one entry MORE than there are segments).
+ *                       Slice z of the grid works on chunks [zk[z], min(zk[z] + nkc_z, nkc_total)) and writes C + zC[z] (element
+ *                       offset), row stride ldc; out_dtype 0 = float32, 1 = bfloat16 (round to nearest even); bias [N] f32 (added
+ *                       before rounding) or NULL; zA / zB / zC / zk may be NULL (= 0).  Rows i >= M / j >= N of a tile are neither read
+ *                       nor written.  How a convolution maps onto it: map-free-reloc_amd/regression/conv_bf16.py. */
+int mfr_conv_gemm_bf16(const void *A, long long sA, const long long *segA, const void *B, long long sB, const long long *segB,
+                       int Lk, int nkc_total, int nkc_z, const float *bias, void *C, long long ldc, int out_dtype,
+                       int M, int N, int nz, const long long *zA, const long long *zB, const long long *zC, const int *zk, void *stream);
+/*   operand images of those products (memory-bound, every element written incl. the zero halo; x_dtype 0 = float32, 1 = bfloat16):
+ *   mfr_conv_pack_nhwc_halo  x [B,C,H,W] -> out = guard_rows * C zeros | [B, H+2, Wp, C] bf16 | guard_rows * C zeros   (C % 8 == 0); Wp = W+2: a
+ *                            zero column on either side of a row; Wp = W+1: one zero column in front of every row, shared with the row before
+ *   mfr_conv_pack_cm_halo    x [BC,H,W] -> ncopies images, each  slack zeros | [BC][L] bf16 | slack zeros,  rows of Wq >= W+2 positions
+ *                            (Wq % 8 == 0, L >= (H+2) Wq, L % 8 == 0, slack % 8 == 0); copy k holds the haloed image shifted by
+ *                            first_shift + k positions along its rows (the kx tap shift of the d/d weight product) */
+int mfr_conv_pack_nhwc_halo(const void *x, int x_dtype, int B, int C, int H, int W, int Wp, void *out, int guard_rows, void *stream);
+int mfr_conv_pack_cm_halo(const void *x, int x_dtype, long long BC, int H, int W, int Wq, long long L, int ncopies, int first_shift, long long slack,
+                          void *out, void *stream);
+/*   mfr_conv_unpack_nchw    haloed NHWC result [B, H+2, Wp, N] bf16 (what the forward / d input product writes) -> y [B, N, H, W] bf16 */
+int mfr_conv_unpack_nchw(const void *haloed, int B, int N, int H, int W, int Wp, void *y, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Differentiable batched Kabsch rotation of the regression heads (csrc/kabsch.hip, csrc/kabsch_math.h).  Reference: `procrustes`,

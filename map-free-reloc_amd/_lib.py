@@ -67,6 +67,11 @@ SIGNATURES = {
     "mfr_conv3x3_wino": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "mfr_conv3x3_wino_variant": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "mfr_layernorm": (_i, [_vp, _i, _vp, _vp, _vp, _i, C.c_longlong, _i, C.c_float, _vp, _i, _vp]),
+    "mfr_conv_gemm_bf16": (_i, [_vp, C.c_longlong, _vp, _vp, C.c_longlong, _vp, _i, _i, _i, _vp, _vp, C.c_longlong, _i,
+                                _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "mfr_conv_pack_nhwc_halo": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp]),
+    "mfr_conv_unpack_nchw": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "mfr_conv_pack_cm_halo": (_i, [_vp, _i, C.c_longlong, _i, _i, _i, C.c_longlong, _i, _i, C.c_longlong, _vp, _vp]),
     "mfr_upsample2x_add": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "mfr_upsample_bilinear": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "mfr_corr_warp_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -11,7 +11,7 @@ keys this implementation adds (declared here because unknown keys are rejected o
   LOFTR.WEIGHTS      checkpoint of the online LoFTR matcher ('LoFTR' feature matching)
   ALLOW_SYNTHETIC_WEIGHTS  hand out seeded synthetic network weights when no checkpoint is configured (tests / benches)
   TRAINING.PRECISION 'bf16' (autocast; the aggregator kernel and the pose algebra stay fp32) | 'fp32'
-  TRAINING.SIAMESE_BATCH  encode both images of a pair in one encoder pass (BatchNorm statistics over both)
+  TRAINING.SIAMESE_BATCH  encode both images of a pair in one encoder pass; BatchNorm keeps per-view statistics (= the two-call arithmetic)
   TRAINING.DDP_BUCKET_MB  gradient all-reduce bucket size
   TRAINING.GRAPH_STEP     forward + loss + backward of the training step replayed from one captured HIP graph; gradients in one flat
                           buffer, one all-reduce per step instead of DDP's bucket hooks (regression/train.py)

@@ -2,15 +2,50 @@
 (reference: lib/models/regression/encoder/{preact.py:13-64, resnet.py:7-37, resunet.py:16-128}).
 
 Attribute names (bn1/conv1/.../shortcut.0, firstconv/firstbn, encoder1..3, upconv4.conv1.{conv,normalize}, iconv4, ...)
-are the reference's, so its checkpoints' `encoder.*` keys load unchanged.  The arithmetic is library convolutions
-(MIOpen through torch, bf16 under autocast, channels_last); the hand-written part of this row is the aggregator."""
+are the reference's, so its checkpoints' `encoder.*` keys load unchanged.  The decoder's four 3x3 convolutions (1024->512 twice at
+1/16, 512->256 twice at 1/8 of the input: 85 % of the encoder's flops) run, under bf16 autocast on the GPU, as implicit GEMMs on the bf16
+matrix cores (regression/conv_bf16.py, csrc/conv_gemm_bf16.hip: forward, d input, d weight); the strided / 7x7 / 1x1 / small-channel
+convolutions stay library calls (MIOpen through torch)."""
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import conv_bf16
+
+
+class ViewBatchNorm2d(nn.BatchNorm2d):
+    """nn.BatchNorm2d whose TRAINING statistics are taken per VIEW when the batch holds several views back to back
+    (`view_groups(2)`: images [0, B) are the reference views, [B, 2B) the queries).  The reference encodes the two images of a pair in
+    two encoder calls (lib/models/regression/model.py:64-66), i.e. BatchNorm normalises each view's batch with its own statistics and
+    updates the running estimates twice, view 0 first.  Running both views through the encoder in ONE pass (TRAINING.SIAMESE_BATCH:
+    half the launches, convolutions at twice the batch) keeps exactly that arithmetic when every BatchNorm does the same: per-view
+    statistics, two running updates in the same order.  Parameters, buffers and state-dict keys are nn.BatchNorm2d's."""
+    groups = 1                                              # class-wide switch, set by `view_groups`
+
+    def forward(self, x):
+        g = ViewBatchNorm2d.groups
+        if g <= 1 or not self.training or x.shape[0] % g:
+            return super().forward(x)
+        n = x.shape[0] // g
+        return torch.cat([super(ViewBatchNorm2d, self).forward(x[k * n:(k + 1) * n]) for k in range(g)], 0)
+
+
+class view_groups:
+    """context manager: BatchNorm layers of this module treat the batch as `g` consecutive views (see ViewBatchNorm2d)"""
+
+    def __init__(self, g):
+        self.g = int(g)
+
+    def __enter__(self):
+        self.prev, ViewBatchNorm2d.groups = ViewBatchNorm2d.groups, self.g
+
+    def __exit__(self, *exc):
+        ViewBatchNorm2d.groups = self.prev
+        return False
+
 
 def _norm(planes, enabled=True):
-    return nn.BatchNorm2d(planes) if enabled else nn.Identity()
+    return ViewBatchNorm2d(planes) if enabled else nn.Identity()
 
 
 class PreActUnit(nn.Module):
@@ -97,10 +132,17 @@ class conv(nn.Module):
     def __init__(self, cin, cout, kernel_size, stride):
         super().__init__()
         self.conv = nn.Conv2d(cin, cout, kernel_size, stride=stride, padding=(kernel_size - 1) // 2)
-        self.normalize = nn.BatchNorm2d(cout)
+        self.normalize = ViewBatchNorm2d(cout)
 
     def forward(self, x):
-        return F.elu(self.normalize(self.conv(x)))
+        c = self.conv
+        if (x.is_cuda and c.kernel_size == (3, 3) and torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16
+                and conv_bf16.supported(x, c.weight, c.stride, c.padding)):
+            # the decoder's 3x3 convolutions under bf16 autocast: implicit GEMMs on the bf16 matrix cores (csrc/conv_gemm_bf16.hip)
+            y = conv_bf16.conv3x3_bf16(x, c.weight, c.bias)
+        else:
+            y = c(x)
+        return F.elu(self.normalize(y))
 
 
 class _UpsampleAC(torch.autograd.Function):
@@ -163,7 +205,7 @@ class ResUNet(nn.Module):
         super().__init__()
         block, counts = _BLOCKS[cfg.BLOCK_TYPE], _block_counts(cfg)
         self.firstconv = nn.Conv2d(num_in_layers, 64, 7, stride=2, padding=3, bias=False)
-        self.firstbn = nn.BatchNorm2d(64)
+        self.firstbn = ViewBatchNorm2d(64)
         self.firstmaxpool = nn.MaxPool2d(3, stride=2, padding=1)
         self.encoder1, c1 = _stage(block, 64, 64, counts[0], 1)
         self.encoder2, c2 = _stage(block, c1, 128, counts[1], 2)

@@ -41,10 +41,13 @@ class RegressionModel(nn.Module):
 
     def forward(self, data):
         im0, im1 = data["image0"], self._second_image(data)
-        # one encoder pass over both images of every pair: same weights, half the launches, BatchNorm statistics over 2B
-        # images instead of B twice -- identical in eval mode; in training it is the statistics of the whole step
-        if self.training and getattr(self.cfg.TRAINING, "SIAMESE_BATCH", False):
-            vol = self.encoder(torch.cat([im0, im1], 0))
+        # one encoder pass over both images of every pair: same weights, half the launches, convolutions at twice the batch.  The
+        # BatchNorm layers keep the reference's arithmetic (two encoder calls, model.py:64-66): statistics per view, running estimates
+        # updated view 0 first (encoder.ViewBatchNorm2d) -- same outputs, gradients and buffers as the two-call path
+        if self.training and getattr(self.cfg.TRAINING, "SIAMESE_BATCH", False) and im0.shape == im1.shape:
+            from .encoder import view_groups
+            with view_groups(2):
+                vol = self.encoder(torch.cat([im0, im1], 0))
             vol0, vol1 = vol[:im0.shape[0]], vol[im0.shape[0]:]
         else:
             vol0, vol1 = self.encoder(im0), self.encoder(im1)

@@ -258,3 +258,38 @@ def test_graph_step_trainer_in_a_child_process():
     assert "b0 faithful True" in out and "b1 faithful True" in out, out[-1500:]
     assert "captured True finite True moved True" in out, out[-1500:]
     assert all(line.split()[-1] == "True" for line in out.splitlines() if line.startswith(("b0 ", "b1 "))), out[-1500:]     # losses equal
+
+
+def test_siamese_batch_matches_two_encoder_calls_on_device():
+    """TRAINING.SIAMESE_BATCH on the GPU, fp32 (so that round-off does not hide a wrong statistic): encoder output, its input gradient
+    and every BatchNorm buffer after one pass over both views == two encoder calls (the reference's model.py:64-66)."""
+    from mapfree_reloc_amd.regression.encoder import view_groups
+    model, data, g = build_case("3d3d", device=DEV, materialised=False)
+    enc = model.encoder
+    enc.train()
+    im0, im1 = data["image0"], data["image1"]
+    state = {k: v.clone() for k, v in enc.state_dict().items()}
+    a0, a1 = im0.clone().requires_grad_(), im1.clone().requires_grad_()
+    v0, v1 = enc(a0), enc(a1)
+    (v0.square().mean() + v1.abs().mean()).backward()
+    bufs_two = {k: v.clone() for k, v in enc.named_buffers()}
+    grads_two = {n: p.grad.clone() for n, p in enc.named_parameters() if p.grad is not None}
+    enc.load_state_dict(state)
+    enc.zero_grad()
+    b0, b1 = im0.clone().requires_grad_(), im1.clone().requires_grad_()
+    with view_groups(2):
+        v = enc(torch.cat([b0, b1], 0))
+    n = im0.shape[0]
+    (v[:n].square().mean() + v[n:].abs().mean()).backward()
+    rel = lambda x, y: float((x - y).abs().max() / y.abs().max().clamp_min(1e-12))
+    # tolerances: the library picks other convolution algorithms at twice the batch, and BatchNorm over 2 images per view amplifies
+    # their round-off (a wrong statistic -- e.g. one taken over both views -- moves these numbers by tens of percent)
+    assert rel(v[:n], v0) < 5e-3 and rel(v[n:], v1) < 5e-3, (rel(v[:n], v0), rel(v[n:], v1))
+    assert rel(b0.grad, a0.grad) < 5e-2 and rel(b1.grad, a1.grad) < 5e-2, (rel(b0.grad, a0.grad), rel(b1.grad, a1.grad))
+    worst = max((rel(p.grad, grads_two[k]), k) for k, p in enc.named_parameters() if p.grad is not None)
+    assert worst[0] < 5e-2, worst
+    for k, b in enc.named_buffers():
+        if "num_batches_tracked" in k:
+            assert int(b) == int(bufs_two[k]), k
+        else:
+            assert rel(b.float(), bufs_two[k].float()) < 2e-3, (k, rel(b.float(), bufs_two[k].float()))

@@ -291,3 +291,35 @@ def test_regression_model_through_the_submission_loop(tmp_path):
         lines = zf.read("pose_s00000.txt").decode().strip().splitlines()
     assert len(lines) == 3 and all(len(l.split()) == 9 and l.split()[-1] == "0" for l in lines)
     assert abs(sum(float(v) ** 2 for v in lines[0].split()[1:5]) - 1.0) < 1e-4          # unit quaternion
+
+
+def test_siamese_batch_keeps_the_two_call_arithmetic():
+    """TRAINING.SIAMESE_BATCH (both views of every pair in ONE encoder pass) with per-view BatchNorm statistics
+    (encoder.ViewBatchNorm2d) == the reference's two encoder calls (lib/models/regression/model.py:64-66): same loss, same
+    gradients, same running statistics and batch counters after the step."""
+    ns = _ns()
+    src = ns["SyntheticPairs"](3, 64, 48, "cpu", seed=5)
+    b0 = src.batch()
+    out = {}
+    for siamese in (False, True):
+        cfg = ns["make"]()
+        cfg.merge_from_list(["TRAINING.SIAMESE_BATCH", siamese])
+        torch.manual_seed(0)
+        tr = ns["Trainer"](cfg, "cpu", sample=b0).build()
+        tr.model.train()
+        data = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in b0.items()}
+        tr.model(data)
+        loss = tr.model.loss_fn(data)[0] if isinstance(tr.model.loss_fn(data), (tuple, list)) else tr.model.loss_fn(data)
+        loss.backward()
+        out[siamese] = (loss.item(), {n: p.grad.clone() for n, p in tr.model.named_parameters() if p.grad is not None},
+                        {n: b.clone() for n, b in tr.model.named_buffers()})
+    (l0, g0, s0), (l1, g1, s1) = out[False], out[True]
+    assert abs(l0 - l1) <= 1e-5 * max(1.0, abs(l0)), (l0, l1)
+    assert g0.keys() == g1.keys()
+    for n in g0:
+        assert float((g0[n] - g1[n]).abs().max()) <= 1e-4 * float(g0[n].abs().max()) + 1e-7, n
+    for n in s0:
+        if "num_batches_tracked" in n:
+            assert int(s0[n]) == int(s1[n]) and int(s0[n]) % 2 == 0, n                  # two updates per forward in both paths
+        else:
+            assert torch.allclose(s0[n].float(), s1[n].float(), rtol=1e-5, atol=1e-7), n
