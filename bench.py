@@ -67,8 +67,9 @@ def parse(argv=None):
                     "graph's static buffers every step), 0 = eager launches (default: at 8-32 pairs per step the eager step is GPU-bound, "
                     "measured 699 vs 694 pairs/s).  With 1 the roofline kernels are timed with HIP events over extra eager steps AFTER the "
                     "timed region (events cannot be recorded inside a replay).")
-    ap.add_argument("--rpr-opts", default="", help="rpr_train only, comma list: channels_last (NHWC activations / weights), siamese "
-                    "(TRAINING.SIAMESE_BATCH: both images of a pair in one encoder pass), fp32 (TRAINING.PRECISION fp32), graph (TRAINING.GRAPH_STEP)")
+    ap.add_argument("--rpr-opts", default="siamese,graph", help="rpr_train only, comma list: siamese (TRAINING.SIAMESE_BATCH: both images of a pair in one "
+                    "encoder pass, BatchNorm statistics per view = the arithmetic of the reference's two encoder calls), graph (TRAINING.GRAPH_STEP: "
+                    "forward + loss + backward replayed from one HIP graph), channels_last, fp32; 'none' = two encoder calls, eager launches")
     a = ap.parse_args(argv)
     if a.batch <= 0:
         a.batch = {"sg_pnp": 32, "loftr_emat": 16, "rpr_train": 10}[a.config]
@@ -410,15 +411,23 @@ def rpr_train_bench(args, rank, world, dev, use_dist):
     from mapfree_reloc_amd.regression.train import SyntheticPairs, Trainer
     lib = mfr._lib.load(require_gpu=True)
     B = args.batch
-    opts = tuple(o for o in args.rpr_opts.split(",") if o)
+    opts = tuple(o for o in args.rpr_opts.split(",") if o and o != "none")
     cfg = rpr_cfg("bf16", opts)
     src = SyntheticPairs(B, RPR_H, RPR_W, dev, seed=0, rank=rank)
     batches = [src.batch() for _ in range(2)]            # resident in HBM before the timed region, alternated
     torch.cuda.synchronize()
-    fwd_t, bwd_t = KernelTimer(), KernelTimer()
+    fwd_t, bwd_t, cg_t = KernelTimer(), KernelTimer(), KernelTimer()
+    cg_flops = []
     if not args.no_kernel_timer:
         lib.mfr_corr_warp_fwd = fwd_t.wrap(lib.mfr_corr_warp_fwd)
         lib.mfr_corr_warp_bwd = bwd_t.wrap(lib.mfr_corr_warp_bwd)
+        _cg = cg_t.wrap(lib.mfr_conv_gemm_bf16)
+
+        def cg_counted(*a):                                  # (A, sA, segA, B, sB, segB, Lk, nkc_total, nkc_z, bias, C, ldc, dtype, M, N, nz, ...)
+            if cg_t.enabled:
+                cg_flops.append(2.0 * a[13] * a[14] * 32.0 * a[7] * (a[15] if a[8] >= a[7] else 1))
+            return _cg(*a)
+        lib.mfr_conv_gemm_bf16 = cg_counted
     tr = Trainer(cfg, dev, sample=batches[0]).build()
     for i in range(3 + args.warmup):                     # 3 initialisation steps (MIOpen solution search), then the warm-up
         tr.train_step(batches[i & 1])
@@ -426,7 +435,7 @@ def rpr_train_bench(args, rank, world, dev, use_dist):
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
-    fwd_t.enabled = bwd_t.enabled = True
+    fwd_t.enabled = bwd_t.enabled = cg_t.enabled = True
     t0 = time.perf_counter()
     for i in range(args.steps):
         losses = tr.train_step(batches[i & 1])
@@ -443,7 +452,7 @@ def rpr_train_bench(args, rank, world, dev, use_dist):
             tr.train_step(batches[i & 1])
         torch.cuda.synchronize()
         tr._gstep, tr._gkeys = saved
-    fwd_t.enabled = bwd_t.enabled = False
+    fwd_t.enabled = bwd_t.enabled = cg_t.enabled = False
     if use_dist:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -461,6 +470,9 @@ def rpr_train_bench(args, rank, world, dev, use_dist):
     ach_f = f_fwd / (fm * 1e-3) / 1e12 if fm else None
     ach_b = f_bwd / (bm * 1e-3) / 1e12 if bm else None
     vol_bytes = 4.0 * N * N * B
+    cgm = cg_t.mean_ms()
+    ncg = min(len(cg_flops), len(cg_t.events))
+    ach_c = (sum(cg_flops[:ncg]) / max(ncg, 1)) / (cgm * 1e-3) / 1e12 if cgm and ncg else None
     line = {
         "metric": "image-pairs/sec trained (3d3d relative-pose regression, bf16 autocast, 360x270)", "value": round(B * args.steps * world / elapsed, 3),
         "unit": "image-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
@@ -480,7 +492,13 @@ def rpr_train_bench(args, rank, world, dev, use_dist):
                              "fp32 matrix cores; HBM-side algorithmic bytes are the q/k/v/gradient maps only (a few MB)",
                      "other_kernels": [{"kernel": "cw_fwd_kernel (mfr_corr_warp_fwd)", "bound": "mfma", "achieved": round(ach_f, 2) if ach_f else None,
                                         "peak": FP32_MFMA_PEAK_TFLOPS, "frac": round(ach_f / FP32_MFMA_PEAK_TFLOPS, 4) if ach_f else None,
-                                        "avg_launch_ms": round(fm, 4) if fm else None, "launches_timed": len(fwd_t.events), "flops_per_launch": f_fwd}]},
+                                        "avg_launch_ms": round(fm, 4) if fm else None, "launches_timed": len(fwd_t.events), "flops_per_launch": f_fwd},
+                                       {"kernel": "conv_gemm_bf16_kernel (mfr_conv_gemm_bf16: the decoder's 3x3 convolutions as implicit GEMMs, forward; "
+                                                  "backward = " + os.environ.get("MFR_RPR_CONV_BWD", "lib") + ")", "bound": "mfma",
+                                        "achieved": round(ach_c, 1) if ach_c else None, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                        "frac": round(ach_c / BF16_MFMA_PEAK_TFLOPS, 4) if ach_c else None,
+                                        "avg_launch_ms": round(cgm, 4) if cgm else None, "launches_timed": len(cg_t.events),
+                                        "flops_per_launch": round(sum(cg_flops[:ncg]) / max(ncg, 1)) if ncg else None}]},
     }
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline_subprocess("rpr_train", args.cpu_pairs, args.cpu_threads, "")
