@@ -55,6 +55,7 @@ def parse(argv=None):
     ap.add_argument("--batch", type=int, default=0, help="image pairs per GPU per step (default 32 for sg_pnp, 16 for loftr_emat)")
     ap.add_argument("--cpu-pairs", type=int, default=0, help="pairs timed for the CPU baseline (rank 0, N=1); default 6 / 3")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-all-cores", action="store_true", help="skip the whole-host leg of the CPU baseline (the secondary lines of the default run do)")
     ap.add_argument("--cpu-threads", type=int, default=16, help="host threads for the all-threads CPU baseline figure")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-out", default="", help=argparse.SUPPRESS)
@@ -146,7 +147,7 @@ def cpu_baseline(config, n_pairs, seeds, threads, out_path=""):
                        f"1 pair on 1 thread, {d1:.1f}s", single_thread_value=round(1.0 / d1, 4), host_cores=host)
 
 
-def cpu_baseline_subprocess(config, n_pairs, threads, out_path, budget_s=300):
+def cpu_baseline_subprocess(config, n_pairs, threads, out_path, budget_s=300, all_cores=True):
     """run the CPU baseline in a child process (no GPU visible) with a hard time budget so that it can never
     block the bench line.  Besides the `threads`-thread and the 1-thread figures of the child, the WHOLE host is measured too:
     host_cores // threads children of `threads` threads each work on their own pairs at the same time (the reference is one
@@ -172,10 +173,10 @@ def cpu_baseline_subprocess(config, n_pairs, threads, out_path, budget_s=300):
         return {"value": None, "error": f"CPU baseline exceeded its {budget_s}s budget"}
     host = os.cpu_count() or 1
     k = host // max(threads, 1)
-    if k >= 2 and config != "rpr_train":
+    if k >= 2 and config != "rpr_train" and all_cores:
         try:
             t0 = time.perf_counter()
-            procs = [subprocess.Popen(cmd(2, ""), stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=env) for _ in range(k)]
+            procs = [subprocess.Popen(cmd(1, ""), stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=env) for _ in range(k)]
             vals = []
             for p in procs:
                 out, _ = p.communicate(timeout=budget_s)
@@ -183,7 +184,7 @@ def cpu_baseline_subprocess(config, n_pairs, threads, out_path, budget_s=300):
                 if j and j.get("value"):
                     vals.append(j["value"])
             res.update(all_cores_value=round(float(sum(vals)), 3), all_cores=len(vals) * threads,
-                       all_cores_sample=f"{len(vals)} concurrent processes x {threads} threads, 2 pairs each (each process's own pairs/s, summed), "
+                       all_cores_sample=f"{len(vals)} concurrent processes x {threads} threads, 1 pair each (each process's own pairs/s, summed), "
                                         f"{time.perf_counter() - t0:.1f}s wall")
         except Exception as e:     # never lose the bench line over the all-cores side figure
             res["all_cores_error"] = str(e)[:200]
@@ -511,7 +512,7 @@ def secondary_line(config, extra, budget_s):
     t0 = time.perf_counter()
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
     try:
-        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--gpus", "1", "--config", config, "--no-secondary"] + extra,
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--gpus", "1", "--config", config, "--no-secondary", "--no-all-cores"] + extra,
                            capture_output=True, text=True, timeout=budget_s, env=env)
         for ln in reversed(r.stdout.strip().splitlines()):
             if ln.startswith("{"):
@@ -527,7 +528,7 @@ def _traffic(tag, B):
     """HBM traffic of the dominant kernel: PMC counters cannot be read inside this process, so the per-launch figure
     comes from the committed rocprofv3 --pmc passes of this same command (2 x FETCH_SIZE + WRITE_SIZE, the guide's
     gfx950 correction), profiles/r02_pmc_<tag>.json"""
-    for rnd in ("r02", "r01"):
+    for rnd in ("r03", "r02", "r01"):
         try:
             name = {"conv1b": "wino"}.get(tag, tag) if rnd == "r01" else tag
             pj = json.load(open(os.path.join(ROOT, "profiles", f"{rnd}_pmc_{name}.json")))
@@ -709,7 +710,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             with tempfile.TemporaryDirectory() as td:
                 npz = os.path.join(td, "oracle_pairs.npz")
-                line["cpu_baseline"] = cpu_baseline_subprocess(args.config, args.cpu_pairs, args.cpu_threads, npz)
+                line["cpu_baseline"] = cpu_baseline_subprocess(args.config, args.cpu_pairs, args.cpu_threads, npz, all_cores=not args.no_all_cores)
                 if os.path.exists(npz):
                     try:
                         cfg["parity"] = parity_leg(wl, npz, dev)

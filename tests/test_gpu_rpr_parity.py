@@ -286,7 +286,11 @@ def test_siamese_batch_matches_two_encoder_calls_on_device():
     # their round-off (a wrong statistic -- e.g. one taken over both views -- moves these numbers by tens of percent)
     assert rel(v[:n], v0) < 5e-3 and rel(v[n:], v1) < 5e-3, (rel(v[:n], v0), rel(v[n:], v1))
     assert rel(b0.grad, a0.grad) < 5e-2 and rel(b1.grad, a1.grad) < 5e-2, (rel(b0.grad, a0.grad), rel(b1.grad, a1.grad))
-    worst = max((rel(p.grad, grads_two[k]), k) for k, p in enc.named_parameters() if p.grad is not None)
+    # (a convolution bias in front of a BatchNorm has a gradient of exactly zero; what is computed there is round-off, so the bar is
+    # relative to the largest gradient of the encoder, not to the tensor's own)
+    gmax = max(float(g.abs().max()) for g in grads_two.values())
+    worst = max((float((p.grad - grads_two[k]).abs().max()) / (float(grads_two[k].abs().max()) + 1e-3 * gmax), k)
+                for k, p in enc.named_parameters() if p.grad is not None)
     assert worst[0] < 5e-2, worst
     for k, b in enc.named_buffers():
         if "num_batches_tracked" in k:

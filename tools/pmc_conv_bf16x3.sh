@@ -21,7 +21,9 @@ torch.cuda.synchronize()
 PY
 cd /tmp && export TMPDIR=/tmp
 i=0
+PASSES=${PMC_PASSES:-6}
 for ctrs in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_WAVES" "SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_MFMA GRBM_GUI_ACTIVE" "TA_BUSY_avr TA_TA_BUSY_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum"; do
+  if [ $i -ge $PASSES ]; then break; fi
   i=$((i+1))
   timeout 200 rocprofv3 --kernel-trace --pmc $ctrs -d /root/repo/gpurun_out/pmc3/p$i -o run --output-format csv -- python /tmp/run_conv1b3.py > /root/repo/gpurun_out/pmc3/p$i.log 2>&1
 done
@@ -47,6 +49,15 @@ for k in acc:
     out[k] = d
 out["algorithmic_bytes"] = {"input": 64 * 64 * 720 * 540 * 4, "output_pooled": 64 * 64 * 360 * 270 * 4}
 json.dump(out, open("gpurun_out/pmc3/summary.json", "w"), indent=1)
+if "bf16x3" in out and "FETCH_SIZE" in out["bf16x3"] and "WRITE_SIZE" in out["bf16x3"]:
+    d = out["bf16x3"]
+    json.dump({"kernel": "wino_bf16x3_kernel<true> (conv1b: 64->64 channels, 64 images 720x540, pooled output)", "FETCH_SIZE_KB": d["FETCH_SIZE"], "WRITE_SIZE_KB": d["WRITE_SIZE"],
+               "hbm_bytes_per_launch": 2 * d["FETCH_SIZE"] * 1024 + d["WRITE_SIZE"] * 1024,
+               "algorithmic_bytes_per_launch": out["algorithmic_bytes"]["input"] + out["algorithmic_bytes"]["output_pooled"], "pairs_per_step": 32,
+               "l2_hit_rate": d.get("l2_hit_rate"), "launch_ms_under_pmc": d["launch_ms_under_pmc"],
+               "correction": "FETCH_SIZE doubled (gfx950 reports 1/2 of wide coalesced reads, MI355X_MICROARCH.md HBM section); WRITE_SIZE as reported; separate --pmc passes",
+               "command": "tools/pmc_conv_bf16x3.sh (rocprofv3 --kernel-trace --pmc <one counter group per pass> on the isolated conv1b launch)", "round": 3},
+              open("gpurun_out/r03_pmc_conv1b.json", "w"), indent=1)
 print(json.dumps(out, indent=1))
 PY
 tail -3 gpurun_out/pmc3/p6.log
