@@ -183,19 +183,30 @@ class MapFreeScene:
         sa, ia, sb, ib = self.pairs[index]
         return f"seq{sb}/frame_{ib:05}.jpg"
 
+    def _frame(self, rel, keep=False):
+        """decoded image [3,h,w] f32 + depth map [h,w] f32 (or an empty tensor) of one frame.  keep=True remembers the LAST such frame:
+        a val / test scene pairs its one keyframe with every query (mapfree.py:148-165), the reference re-reads and re-decodes it 116
+        times per scene; here it is decoded once per scene (read-only tensors, shared by the samples)."""
+        c = getattr(self, "_kept", None)
+        if keep and c is not None and c[0] == rel:
+            return c[1], c[2]
+        img = read_color_image(os.path.join(self.scene_root, rel), self.resize)
+        if self.black_white:                                    # torchvision Grayscale: ITU-R 601-2 luma, replicated
+            img = _luma3(img)
+        if self.estimated_depth is not None:
+            d = read_depth_image(os.path.join(self.scene_root, rel).replace(".jpg", f".{self.estimated_depth}.png"))
+        else:
+            d = torch.tensor([])
+        if keep:
+            self._kept = (rel, img, d)
+        return img, d
+
     def __getitem__(self, index):
         from . import evaluation as E
         sa, ia, sb, ib = self.pairs[index]
         p1, p2 = f"seq{sa}/frame_{ia:05}.jpg", f"seq{sb}/frame_{ib:05}.jpg"
-        img1 = read_color_image(os.path.join(self.scene_root, p1), self.resize)
-        img2 = read_color_image(os.path.join(self.scene_root, p2), self.resize)
-        if self.black_white:                                    # torchvision Grayscale: ITU-R 601-2 luma, replicated
-            img1, img2 = (_luma3(im) for im in (img1, img2))
-        if self.estimated_depth is not None:
-            d1 = read_depth_image(os.path.join(self.scene_root, p1).replace(".jpg", f".{self.estimated_depth}.png"))
-            d2 = read_depth_image(os.path.join(self.scene_root, p2).replace(".jpg", f".{self.estimated_depth}.png"))
-        else:
-            d1 = d2 = torch.tensor([])
+        img1, d1 = self._frame(p1, keep=True)                    # the map frame: the same file for every query of a val / test scene
+        img2, d2 = self._frame(p2)
         (q1, t1), (q2, t2) = self.poses[p1], self.poses[p2]
         q12 = E.qmult(q2, E.qinverse(q1))
         t12 = t2 - E.rotate_vector(t1, q12)
@@ -362,42 +373,58 @@ class PairBatchLoader:
         return len(self.batches)
 
     def _load(self, items):
+        """decode the pairs of one batch STRAIGHT INTO the batch's (pinned) buffers: every worker thread decodes its pair, converts to
+        gray and writes its slots itself; the loader thread only allocates and collects the small fields (a serial gray conversion +
+        copy of 64 images per batch on this thread capped the loader at ~300 pairs/s)"""
         get = lambda it: self.scenes[it[0]][it[1]]
-        if self.workers > 1 and len(items) > 1:
-            if self._pool is None:
-                import concurrent.futures
-                self._pool = concurrent.futures.ThreadPoolExecutor(max_workers=self.workers, thread_name_prefix="mfr-decode")
-            samples = list(self._pool.map(get, items))                         # order preserved
-        else:
-            samples = [get(it) for it in items]
-        b = len(samples)
-        Hh, Ww = samples[0]["image0"].shape[-2:]
+        first = get(items[0])                                  # shapes / dtypes come from the first pair
+        b = len(items)
+        Hh, Ww = first["image0"].shape[-2:]
         mk = (lambda *shape, dtype=torch.float32: torch.empty(*shape, dtype=dtype, pin_memory=True)) if self.pin else \
              (lambda *shape, dtype=torch.float32: torch.empty(*shape, dtype=dtype))
-        # intrinsics keep the loader's dtype (float64 on Map-free, float32 on resize=None datasets): the solvers evaluate
-        # inv(K) / the K-normalisation in that dtype, as the reference does (include/mfr_hip.h k_dtype)
-        kdt = torch.float64 if any(torch.as_tensor(smp[k]).dtype == torch.float64 for smp in samples for k in ("K_color0", "K_color1")) \
-            else torch.float32
-        images = mk(2 * b, 1, Hh, Ww); K0 = mk(b, 3, 3, dtype=kdt); K1 = mk(b, 3, 3, dtype=kdt)
-        has_depth = samples[0]["depth0"].numel() > 0
+        images = mk(2 * b, 1, Hh, Ww)
+        has_depth = first["depth0"].numel() > 0
         depth0 = mk(b, Hh, Ww) if has_depth else None
         depth1 = mk(b, Hh, Ww) if has_depth else None
-        # packing through the buffers' numpy views: plain memcpy on this thread (a torch copy_ of a 1.5 MB plane is dispatched to
-        # the intra-op thread pool)
+        # packing through the buffers' numpy views: plain memcpy on the worker's own thread (a torch copy_ of a 1.5 MB plane is
+        # dispatched to the intra-op thread pool)
         npv = lambda t: t.numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
         im_np = images.numpy()
         d0_np, d1_np = (depth0.numpy(), depth1.numpy()) if has_depth else (None, None)
-        for p, smp in enumerate(samples):
-            im_np[2 * p, 0] = npv(to_gray(smp["image0"])); im_np[2 * p + 1, 0] = npv(to_gray(smp["image1"]))
-            K0[p] = torch.as_tensor(smp["K_color0"]); K1[p] = torch.as_tensor(smp["K_color1"])
+        gray_of = {}                                           # id(map-frame tensor) -> (the tensor, its gray plane): one conversion per scene
+                                                               # keyframe; the tensor is held so that its id cannot be reused inside the batch
+
+        def fill(p, smp=None):
+            smp = get(items[p]) if smp is None else smp
+            k0 = id(smp["image0"])
+            hit = gray_of.get(k0)
+            if hit is None or hit[0] is not smp["image0"]:
+                hit = gray_of[k0] = (smp["image0"], npv(to_gray(smp["image0"])))
+            im_np[2 * p, 0] = hit[1]
+            im_np[2 * p + 1, 0] = npv(to_gray(smp["image1"]))
             if has_depth:
                 d0_np[p] = npv(smp["depth0"]); d1_np[p] = npv(smp["depth1"])
+            return (torch.as_tensor(smp["K_color0"]), torch.as_tensor(smp["K_color1"]), int(smp["pair_id"]), smp["pair_names"][1])
+        if self.workers > 1 and b > 1:
+            if self._pool is None:
+                import concurrent.futures
+                self._pool = concurrent.futures.ThreadPoolExecutor(max_workers=self.workers, thread_name_prefix="mfr-decode")
+            futs = [self._pool.submit(fill, p) for p in range(1, b)]
+            meta = [fill(0, first)] + [f.result() for f in futs]             # order preserved
+        else:
+            meta = [fill(0, first)] + [fill(p) for p in range(1, b)]
+        # intrinsics keep the loader's dtype (float64 on Map-free, float32 on resize=None datasets): the solvers evaluate
+        # inv(K) / the K-normalisation in that dtype, as the reference does (include/mfr_hip.h k_dtype)
+        kdt = torch.float64 if any(m[0].dtype == torch.float64 or m[1].dtype == torch.float64 for m in meta) else torch.float32
+        K0 = mk(b, 3, 3, dtype=kdt); K1 = mk(b, 3, 3, dtype=kdt)
+        for p, m in enumerate(meta):
+            K0[p] = m[0]; K1[p] = m[1]
         sc = self.scenes[items[-1][0]]
         done = [self.scenes[si].scene_id for si, i in items if i == len(self.scenes[si]) - 1]
         return dict(images=images, depth0=depth0, depth1=depth1, K0=K0, K1=K1,
-                    seed_ids=torch.tensor([int(smp["pair_id"]) for smp in samples], dtype=torch.int64),
+                    seed_ids=torch.tensor([m[2] for m in meta], dtype=torch.int64),
                     global_ids=torch.tensor([self.offsets[si] + i for si, i in items], dtype=torch.int64),
-                    names=[smp["pair_names"][1] for smp in samples], scene_ids=[self.scenes[si].scene_id for si, _ in items],
+                    names=[m[3] for m in meta], scene_ids=[self.scenes[si].scene_id for si, _ in items],
                     scene_roots=[self.scenes[si].scene_root for si, _ in items], scenes_done=done,
                     scene_id=sc.scene_id, scene_root=sc.scene_root, scene_index=items[-1][0], last_of_scene=bool(done and done[-1] == sc.scene_id))
 

@@ -366,3 +366,35 @@ def test_run_signature_ties_resume_to_the_configuration():
     assert _run_signature(a, "val") == _run_signature(b, "val") != _run_signature(a, "test")
     b.POSE_SOLVER = "EssentialMatrixMetric"
     assert _run_signature(a, "val") != _run_signature(b, "val")
+
+
+def test_pair_batch_loader_equals_the_per_sample_reader(tmp_path):
+    """PairBatchLoader (decode threads writing straight into the batch buffers, the scene keyframe decoded once, batches spanning
+    scenes) hands out exactly what the per-pair reader + to_gray produce, pair by pair, in submission order"""
+    from PIL import Image
+    from mapfree_reloc_amd.datasets import MapFreeScene, PairBatchLoader, to_gray
+    rng = np.random.default_rng(1)
+    scenes = []
+    for s in range(3):
+        sc = tmp_path / "test" / f"s{s:05d}"
+        (sc / "seq0").mkdir(parents=True); (sc / "seq1").mkdir()
+        lp, lk = ["# c"], ["# c"]
+        for nme in ["seq0/frame_00000.jpg"] + [f"seq1/frame_{i:05d}.jpg" for i in range(7)]:
+            Image.fromarray(rng.integers(0, 255, (48, 36, 3), dtype=np.uint8)).save(sc / nme, format="PNG")
+            Image.fromarray((rng.uniform(0.5, 6.0, (48, 36)) * 1000).astype(np.uint16)).save(str(sc / nme).replace(".jpg", ".dptkitti.png"))
+            lp.append(nme + " 1 0 0 0 0 0 0"); lk.append(nme + f" {100.0 + s} 110.0 17.5 23.5 36 48")
+        (sc / "poses.txt").write_text("\n".join(lp) + "\n"); (sc / "intrinsics.txt").write_text("\n".join(lk) + "\n")
+        scenes.append(MapFreeScene(sc, resize=(36, 48), sample_factor=1, estimated_depth="dptkitti"))
+    ref = [(si, i, sc[i]) for si, sc in enumerate(scenes) for i in range(len(sc))]
+    assert len(ref) == 21
+    for workers in (1, 4):
+        got = 0
+        for b in PairBatchLoader(scenes, batch_pairs=8, prefetch=2, pin=False, workers=workers):
+            for p in range(len(b["names"])):
+                si, i, smp = ref[got]
+                assert b["scene_ids"][p] == scenes[si].scene_id and b["names"][p] == smp["pair_names"][1] and int(b["seed_ids"][p]) == smp["pair_id"]
+                assert torch.equal(b["images"][2 * p, 0], to_gray(smp["image0"])) and torch.equal(b["images"][2 * p + 1, 0], to_gray(smp["image1"]))
+                assert torch.equal(b["depth0"][p], smp["depth0"]) and torch.equal(b["depth1"][p], smp["depth1"])
+                assert b["K0"].dtype == torch.float64 and torch.equal(b["K0"][p], smp["K_color0"]) and torch.equal(b["K1"][p], smp["K_color1"])
+                got += 1
+        assert got == 21
