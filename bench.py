@@ -211,7 +211,7 @@ def parity_leg(wl, oracle_npz, dev):
         recs.append(PR.compare_pair(ref, np.concatenate([o["pts0"][i, :n], o["pts1"][i, :n]], 1), o["R"][i], o["t"][i],
                                     o["n_inliers"][i], o["status"][i]))
     s = PR.summarize(recs)
-    s["against"] = "oracle/pipeline_ref.py (CPU restatement of the reference path) on the cpu_baseline pairs; full census: profiles/r02_parity_census.json"
+    s["against"] = "oracle/pipeline_ref.py (CPU restatement of the reference path) on the cpu_baseline pairs; full census: profiles/r03_parity_census_hard.json, r03_parity_census_hard2.json"
     return s
 
 
