@@ -261,18 +261,23 @@ __global__ void __launch_bounds__(256, 2) sg_attention_bf16x3_kernel(
     float4 kr0, kr1;
     float v0, v1, v2, v3, v4, v5, v6, v7;
     auto gload = [&](int t) {
-        // out-of-range keys: load a valid row (clamped) and zero it afterwards -- `c ? *p : 0` makes hipcc select between the global
-        // pointer and a private-memory zero and issue FLAT loads
+        // out-of-range keys: load a valid row (clamped); it is zeroed when the tile is SPLIT (lstore), after the MFMAs of the current
+        // tile -- a select on the loaded value here makes the wave wait for its loads before it multiplies anything (`c ? *p : 0`
+        // would be worse still: hipcc selects between the global pointer and a private-memory zero and issues FLAT loads)
         const int k0 = t * AT_KT + sr, k1 = k0 + 16, kl = nk - 1;
         kr0 = *(const float4 *)(kbase + (size_t)min(k0, kl) * ld);
         kr1 = *(const float4 *)(kbase + (size_t)min(k1, kl) * ld);
-        if (k0 >= nk) kr0 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (k1 >= nk) kr1 = make_float4(0.f, 0.f, 0.f, 0.f);
         const int kv = t * AT_KT + 8 * wid;
         v0 = vbase[(size_t)min(kv + 0, kl) * ld]; v1 = vbase[(size_t)min(kv + 1, kl) * ld];
         v2 = vbase[(size_t)min(kv + 2, kl) * ld]; v3 = vbase[(size_t)min(kv + 3, kl) * ld];
         v4 = vbase[(size_t)min(kv + 4, kl) * ld]; v5 = vbase[(size_t)min(kv + 5, kl) * ld];
         v6 = vbase[(size_t)min(kv + 6, kl) * ld]; v7 = vbase[(size_t)min(kv + 7, kl) * ld];
+    };
+    auto gmask = [&](int t) {
+        const int k0 = t * AT_KT + sr, k1 = k0 + 16;
+        if (k0 >= nk) kr0 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k1 >= nk) kr1 = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int kv = t * AT_KT + 8 * wid;
         if (kv + 0 >= nk) v0 = 0.f;
         if (kv + 1 >= nk) v1 = 0.f;
         if (kv + 2 >= nk) v2 = 0.f;
@@ -300,12 +305,13 @@ __global__ void __launch_bounds__(256, 2) sg_attention_bf16x3_kernel(
         *(uint2 *)&Vt[buf][1][lane][p0] = make_uint2(vm[0], vm[1]); *(uint2 *)&Vt[buf][1][lane][p0 + 8] = make_uint2(vm[2], vm[3]);
         *(uint2 *)&Vt[buf][2][lane][p0] = make_uint2(vl[0], vl[1]); *(uint2 *)&Vt[buf][2][lane][p0 + 8] = make_uint2(vl[2], vl[3]);
     };
-    if (ntiles > 0) { gload(0); lstore(0); }
+    if (ntiles > 0) { gload(0); gmask(0); lstore(0); }
     __syncthreads();
 
     for (int t = 0; t < ntiles; ++t) {
         const int buf = t & 1;
         if (t + 1 < ntiles) gload(t + 1);
+        __builtin_amdgcn_sched_barrier(0);                  // the loads stay ahead of the MFMAs, their consumers (mask, split) behind them
 
         // ---- S^T = K Q^T: 4 steps of 16 channels x 6 partial products, two accumulators (small terms / leading terms)
         f32x16 s, s2;
@@ -370,7 +376,8 @@ __global__ void __launch_bounds__(256, 2) sg_attention_bf16x3_kernel(
             o0 = MFMA_BF16(v0m.v, ph.v, o0); o1 = MFMA_BF16(v1m.v, ph.v, o1);
             o0 = MFMA_BF16(v0h.v, ph.v, o0); o1 = MFMA_BF16(v1h.v, ph.v, o1);
         }
-        if (t + 1 < ntiles) lstore(buf ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 1 < ntiles) { gmask(t + 1); lstore(buf ^ 1); }
         __syncthreads();
     }
 

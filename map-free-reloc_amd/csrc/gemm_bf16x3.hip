@@ -137,6 +137,9 @@ __global__ void __launch_bounds__(256, 2) gemm_bf16x3_kernel(const float *__rest
         GB_LSTORE();
         __syncthreads();
         { const int kn = min(kb + 1, nkb - 1); GB_GLOAD(kn); }   // in flight during the MFMAs below (the last step re-reads its own tile)
+        // without this fence hipcc sinks the loads BELOW the 48 MFMAs (ten live 16-byte registers fewer across them) and every K step
+        // pays the full memory latency before its split: load -> wait -> split -> store -> MFMA, nothing overlapped inside a workgroup
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             GbFrag a[2][3], b[2][3];
