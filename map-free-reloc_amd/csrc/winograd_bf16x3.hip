@@ -278,6 +278,7 @@ __global__ void __launch_bounds__(256, 1) wino_bf16x3_kernel(
         }
     };
     // six partial products per accumulator, small terms first; the four accumulators of a position alternate
+#define WB_FENCE() do { if (!(ABL & 32)) __builtin_amdgcn_sched_barrier(0); } while (0)
 #define WB_PROD(j, af, vf, ta, tb) do { \
         acc[j][0][0] = WB_MFMA(af[0][ta].v, vf[0][tb].v, acc[j][0][0]); acc[j][1][0] = WB_MFMA(af[1][ta].v, vf[0][tb].v, acc[j][1][0]); \
         acc[j][0][1] = WB_MFMA(af[0][ta].v, vf[1][tb].v, acc[j][0][1]); acc[j][1][1] = WB_MFMA(af[1][ta].v, vf[1][tb].v, acc[j][1][1]); } while (0)
@@ -308,37 +309,42 @@ __global__ void __launch_bounds__(256, 1) wino_bf16x3_kernel(
         // request and a whole step ahead of their own use -- and the loop never waits on them.
         for (; c + 1 < nks; ++c) {
             WB_STAMP(3 + 6 * c);
-            aload(afB, c, 1); vmake(vfB, 1);
+            // (WB_FENCE: the six filter requests of the next phase go out BEFORE anything else of this phase -- left alone, hipcc spreads
+            // them between the phase's MFMAs and the late ones are waited for at the top of the next phase)
+            aload(afB, c, 1); WB_FENCE(); vmake(vfB, 1);
             WB_PHASE(0, afA, vfA);
             WB_STAMP(4 + 6 * c);
-            aload(afA, c, 2); vmake(vfA, 2);
+            aload(afA, c, 2); WB_FENCE(); vmake(vfA, 2);
             WB_PHASE(1, afB, vfB);
             WB_STAMP(5 + 6 * c);
-            aload(afB, c, 3); vmake(vfB, 3);
+            aload(afB, c, 3); WB_FENCE(); vmake(vfB, 3);
             WB_PHASE(2, afA, vfA);
             WB_STAMP(6 + 6 * c);
-            pstore((c + 1) & 1);
+            pstore((c + 1) & 1);                            // (moving this under phases 1-2 costs 5 spilled registers and measured 5 % slower)
             aload(afA, c + 1, 0);
             __builtin_amdgcn_sched_barrier(0);
             pload(c + 2);                                   // beyond the last step: channels >= Cin -> out of range, returns zeros
             WB_STAMP(7 + 6 * c);
             __syncthreads();
             WB_STAMP(8 + 6 * c);
+            // (queueing half of phase 3 before the barrier, so that the matrix pipe works while the wavefronts meet, measured 6 % SLOWER:
+            // the row combinations and the V split after the barrier then have 12 instead of 24 MFMAs to hide under)
             wread((c + 1) & 1, c + 1); vmake(vfA, 0);
             WB_PHASE(3, afB, vfB);
         }
         WB_STAMP(3 + 6 * c);
-        aload(afB, c, 1); vmake(vfB, 1);
+        aload(afB, c, 1); WB_FENCE(); vmake(vfB, 1);
         WB_PHASE(0, afA, vfA);
-        aload(afA, c, 2); vmake(vfA, 2);
+        aload(afA, c, 2); WB_FENCE(); vmake(vfA, 2);
         WB_PHASE(1, afB, vfB);
-        aload(afB, c, 3); vmake(vfB, 3);
+        aload(afB, c, 3); WB_FENCE(); vmake(vfB, 3);
         WB_PHASE(2, afA, vfA);
         WB_PHASE(3, afB, vfB);
     }
     WB_STAMP(40);
 #undef WB_PHASE
 #undef WB_PROD
+#undef WB_FENCE
 
     if (ABL & 1) {
         float t = 0.f;
