@@ -127,6 +127,13 @@ def read_color_image(path, resize):
     return torch.from_numpy(a)
 
 
+import collections as _collections
+import threading as _threading
+
+_FRAME_CACHE = _collections.OrderedDict()        # (scene_root, frame, resize, depth kind, bw) -> (image, depth): the keyframes of the scenes in flight
+_FRAME_LOCK = _threading.Lock()
+
+
 class MapFreeScene:
     """reader of one scene directory (lib/datasets/mapfree.py:16-270, single-frame queries): intrinsics.txt / poses.txt
     parsing (:36-75); val/test scenes: pairs = keyframe seq0/frame_00000 x every `sample_factor`-th seq1 frame (:148-165);
@@ -184,12 +191,17 @@ class MapFreeScene:
         return f"seq{sb}/frame_{ib:05}.jpg"
 
     def _frame(self, rel, keep=False):
-        """decoded image [3,h,w] f32 + depth map [h,w] f32 (or an empty tensor) of one frame.  keep=True remembers the LAST such frame:
-        a val / test scene pairs its one keyframe with every query (mapfree.py:148-165), the reference re-reads and re-decodes it 116
-        times per scene; here it is decoded once per scene (read-only tensors, shared by the samples)."""
-        c = getattr(self, "_kept", None)
-        if keep and c is not None and c[0] == rel:
-            return c[1], c[2]
+        """decoded image [3,h,w] f32 + depth map [h,w] f32 (or an empty tensor) of one frame.  keep=True goes through a small
+        process-wide cache: a val / test scene pairs its one keyframe with every query (mapfree.py:148-165), the reference re-reads and
+        re-decodes it 116 times per scene; here it is decoded once per scene (read-only tensors, shared by the samples; 4 entries,
+        least recently used first out, so a run over 130 scenes holds a handful of frames, not 130)."""
+        key = (self.scene_root, rel, tuple(self.resize) if self.resize is not None else None, self.estimated_depth, self.black_white)
+        if keep:
+            with _FRAME_LOCK:
+                hit = _FRAME_CACHE.get(key)
+                if hit is not None:
+                    _FRAME_CACHE.move_to_end(key)
+                    return hit
         img = read_color_image(os.path.join(self.scene_root, rel), self.resize)
         if self.black_white:                                    # torchvision Grayscale: ITU-R 601-2 luma, replicated
             img = _luma3(img)
@@ -198,7 +210,13 @@ class MapFreeScene:
         else:
             d = torch.tensor([])
         if keep:
-            self._kept = (rel, img, d)
+            with _FRAME_LOCK:
+                hit = _FRAME_CACHE.get(key)                     # another thread may have decoded it meanwhile: hand out ONE object
+                if hit is not None:
+                    return hit
+                _FRAME_CACHE[key] = (img, d)
+                while len(_FRAME_CACHE) > 4:
+                    _FRAME_CACHE.popitem(last=False)
         return img, d
 
     def __getitem__(self, index):

@@ -189,42 +189,44 @@ def predict_fused(cfg, split, output_root, pipeline=None, batch_pairs=None, resu
     import sys
     old_switch = sys.getswitchinterval()
     sys.setswitchinterval(5e-4)
-    evs = []                                            # (start, end) event pairs around every step: GPU time of the steps, read at the end
-    while True:
-        tw = time.perf_counter()
-        batch = next(it, None)                          # time blocked here = the GPU waiting for decode / H2D ("loader stall")
-        stats['loader_wait_s'] += time.perf_counter() - tw
-        if batch is None:
-            break
-        ti = time.perf_counter()
-        if device.type == 'cuda':
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-        out = pipeline(batch)
-        rec = parallel.pose_records(batch['global_ids'].to(out['R'].device), out)
-        if device.type == 'cuda':
-            e1.record(); evs.append((e0, e1))
-        stats['issue_s'] += time.perf_counter() - ti    # host time to ISSUE the step (launches; any hidden synchronisation shows up here)
-        acc.append(rec)
-        sids = batch.get('scene_ids') or [batch['scene_id']] * len(batch['names'])
-        for gid, sid, nm in zip(batch['global_ids'].tolist(), sids, batch['names']):
-            names[gid] = (sid, nm)
-        stats['pairs'] += len(batch['names']); stats['batches'] += 1
-        done = batch.get('scenes_done')
-        if done is None:
-            done = [batch['scene_id']] if batch['last_of_scene'] else []
-        if done:                                        # >= 1 scene complete -> their files (one D2H copy; batches may span scenes)
-            srec = torch.cat(acc).cpu().numpy()
-            res = records_to_results(srec, names)
-            for sid in done:
-                _atomic_write(out_dir / f'pose_{sid}.txt', scene_text(res.get(sid, [])))
-            doneset = set(done)
-            keep = np.array([names[int(g)][0] not in doneset for g in srec[:, 0]], bool)
-            recs.append(srec[~keep])
-            acc = [torch.from_numpy(srec[keep]).to(rec.device)] if keep.any() else []
-    if acc:                                             # (cannot happen: the last pair of the rank's last scene ends a scene)
-        recs.append(torch.cat(acc).cpu().numpy())
-    sys.setswitchinterval(old_switch)
+    try:
+        evs = []                                            # (start, end) event pairs around every step: GPU time of the steps, read at the end
+        while True:
+            tw = time.perf_counter()
+            batch = next(it, None)                          # time blocked here = the GPU waiting for decode / H2D ("loader stall")
+            stats['loader_wait_s'] += time.perf_counter() - tw
+            if batch is None:
+                break
+            ti = time.perf_counter()
+            if device.type == 'cuda':
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            out = pipeline(batch)
+            rec = parallel.pose_records(batch['global_ids'].to(out['R'].device), out)
+            if device.type == 'cuda':
+                e1.record(); evs.append((e0, e1))
+            stats['issue_s'] += time.perf_counter() - ti    # host time to ISSUE the step (launches; any hidden synchronisation shows up here)
+            acc.append(rec)
+            sids = batch.get('scene_ids') or [batch['scene_id']] * len(batch['names'])
+            for gid, sid, nm in zip(batch['global_ids'].tolist(), sids, batch['names']):
+                names[gid] = (sid, nm)
+            stats['pairs'] += len(batch['names']); stats['batches'] += 1
+            done = batch.get('scenes_done')
+            if done is None:
+                done = [batch['scene_id']] if batch['last_of_scene'] else []
+            if done:                                        # >= 1 scene complete -> their files (one D2H copy; batches may span scenes)
+                srec = torch.cat(acc).cpu().numpy()
+                res = records_to_results(srec, names)
+                for sid in done:
+                    _atomic_write(out_dir / f'pose_{sid}.txt', scene_text(res.get(sid, [])))
+                doneset = set(done)
+                keep = np.array([names[int(g)][0] not in doneset for g in srec[:, 0]], bool)
+                recs.append(srec[~keep])
+                acc = [torch.from_numpy(srec[keep]).to(rec.device)] if keep.any() else []
+        if acc:                                             # (cannot happen: the last pair of the rank's last scene ends a scene)
+            recs.append(torch.cat(acc).cpu().numpy())
+    finally:
+        sys.setswitchinterval(old_switch)
     if evs:
         torch.cuda.synchronize(device)
         stats['gpu_busy_s'] = sum(a.elapsed_time(b) for a, b in evs) * 1e-3
