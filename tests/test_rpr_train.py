@@ -149,6 +149,20 @@ pp = [torch.zeros_like(f2) for _ in range(2)]
 dist.all_gather(pp, f2)
 assert torch.equal(pp[0], pp[1]), "flat-gradient replicas diverged"
 tr2.validate([src2.batch()])
+# what `bench.py --config rpr_train` runs by default on N ranks: both views in ONE encoder pass (per-view BatchNorm statistics) + the
+# flat-gradient step.  Same rank-averaged gradients as the two-call DDP route, replicas stay identical.
+cfg4 = make(); cfg4.TRAINING.GRAPH_STEP = True; cfg4.TRAINING.SIAMESE_BATCH = True
+tr4 = Trainer(cfg4, "cpu", sample=SyntheticPairs(2, 64, 48, "cpu", seed=0, rank=0).batch()).build()
+tr5 = Trainer(make(), "cpu", sample=SyntheticPairs(2, 64, 48, "cpu", seed=0, rank=0).batch()).build()
+tr4.train_step(bb); tr5.train_step(bb)
+gm = max(float(p.grad.abs().max()) for p in tr5.model.parameters())
+for a, c in zip(tr4.model.parameters(), tr5.model.parameters()):
+    assert torch.allclose(a.grad, c.grad, rtol=1e-3, atol=1e-5 * gm), "one-pass (siamese) flat-gradient step differs from the two-call DDP step"
+tr4.train_step(src2.batch())
+f4 = torch.cat([p.detach().reshape(-1) for p in tr4.model.parameters()] + [b.detach().float().reshape(-1) for b in tr4.model.buffers()])
+p4 = [torch.zeros_like(f4) for _ in range(2)]
+dist.all_gather(p4, f4)
+assert torch.equal(p4[0][:f2.numel()], p4[1][:f2.numel()]), "siamese flat-gradient replicas diverged"
 sys.stdout.write(f"rank {rank} ok {tr.global_step}\n"); sys.stdout.flush()
 dist.destroy_process_group()
 '''
