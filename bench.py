@@ -212,7 +212,24 @@ def parity_leg(wl, oracle_npz, dev):
                                     o["n_inliers"][i], o["status"][i]))
     s = PR.summarize(recs)
     s["against"] = "oracle/pipeline_ref.py (CPU restatement of the reference path) on the cpu_baseline pairs; full census: profiles/r03_parity_census_hard.json, r03_parity_census_hard2.json"
+    s["census"] = census_summary()
     return s
+
+
+def census_summary():
+    """the committed wide census (tools/parity_census.py on an MI355X, whole HIP pipeline vs whole CPU-oracle pipeline, nothing masked) in
+    a few numbers per configuration; the live comparison above covers only the pairs the CPU baseline was timed on"""
+    keep = ("pairs", "status_agree", "pose_within_bar", "inlier_count_equal", "inlier_index_sets_compared", "inlier_index_sets_identical",
+            "min_inlier_set_jaccard_q64", "median_inlier_fraction", "max_rot_rad", "max_trans_m")
+    out = {}
+    for tag, fn in (("hard1", "r03_parity_census_hard.json"), ("hard2", "r03_parity_census_hard2.json")):
+        try:
+            d = json.load(open(os.path.join(ROOT, "profiles", fn)))
+            out[tag] = {"scenes": d.get("scenes"), "file": "profiles/" + fn,
+                        **{k: {q: v["summary"][q] for q in keep if q in v["summary"]} for k, v in d.items() if isinstance(v, dict) and "summary" in v}}
+        except Exception as e:      # never lose the bench line over a side note
+            out[tag] = {"error": str(e)[:120]}
+    return out
 
 
 # ----------------------------------------------------------------------------------------------------------------
