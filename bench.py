@@ -717,7 +717,7 @@ def main():
         line = {
             "metric": wl.metric, "value": round(value, 3), "unit": "image-pairs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 in / f32 accumulate; matrix products of conv + attention as 3 x bf16 exact operand splits (6 partial products, error = fp32 class); f64 solver",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 in / f32 accumulate; matrix products of convolutions, attention and linear layers as 3 x bf16 exact operand splits (6 partial products, error = fp32 class); f64 solver",
             "data": "synthetic (3-band planar scenes, seeded random weights; no dataset/checkpoints offline)",
             "config": cfg, "roofline": wl.roofline(o),
             # scaling diagnostics: every rank's own pairs/s over its K steps (before the collective) and what the one gather cost it
