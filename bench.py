@@ -237,6 +237,8 @@ def census_summary():
 # ----------------------------------------------------------------------------------------------------------------
 class SgPnpWorkload:
     name = "sg_pnp"
+    dtype = ("f32 in / f32 accumulate; matrix products of convolutions, attention and linear layers as 3 x bf16 exact operand splits (6 partial "
+             "products, error = fp32 class); f64 solver")
     metric = "image-pairs/sec @ 540x720 (SuperPoint+SuperGlue + PnP w/ depth)"
     workload = "configs[1]: SuperPoint+SuperGlue matching + PnP w/ depth, 540x720"
 
@@ -324,6 +326,9 @@ class SgPnpWorkload:
 
 class LoftrEmatWorkload:
     name = "loftr_emat"
+    dtype = ("f32 in / f32 accumulate; 3x3 stride-1 convolutions and the transformer's linear layers as 3 x bf16 exact operand splits (6 partial "
+             "products, error = fp32 class); strided / 7x7 / 1x1 convolutions, similarity products and linear attention in fp32 (library / fp32 MFMA "
+             "kernels); f64 solver")
     metric = "image-pairs/sec @ 540x720 (LoFTR + E-mat RANSAC w/ scale from depth)"
     workload = "configs[2]: LoFTR coarse-to-fine matching + Essential-matrix RANSAC + metric scale, 540x720 (padded to 544)"
 
@@ -717,7 +722,7 @@ def main():
         line = {
             "metric": wl.metric, "value": round(value, 3), "unit": "image-pairs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 in / f32 accumulate; matrix products of convolutions, attention and linear layers as 3 x bf16 exact operand splits (6 partial products, error = fp32 class); f64 solver",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": wl.dtype,
             "data": "synthetic (3-band planar scenes, seeded random weights; no dataset/checkpoints offline)",
             "config": cfg, "roofline": wl.roofline(o),
             # scaling diagnostics: every rank's own pairs/s over its K steps (before the collective) and what the one gather cost it
