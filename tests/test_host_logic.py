@@ -398,3 +398,18 @@ def test_pair_batch_loader_equals_the_per_sample_reader(tmp_path):
                 assert b["K0"].dtype == torch.float64 and torch.equal(b["K0"][p], smp["K_color0"]) and torch.equal(b["K1"][p], smp["K_color1"])
                 got += 1
         assert got == 21
+
+
+def test_bench_module_contract_pieces_importable():
+    """bench.py parses its defaults, its workloads carry the strings the JSON line prints, the census summary reads the committed
+    profiles (no GPU needed for any of this)"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    a = b.parse([])
+    assert a.gpus == 1 and a.config == "sg_pnp" and a.steps > 0 and a.rpr_opts == "siamese,graph"
+    for wl in (b.SgPnpWorkload, b.LoftrEmatWorkload):
+        assert isinstance(wl.dtype, str) and "bf16" in wl.dtype and isinstance(wl.metric, str) and isinstance(wl.workload, str)
+    c = b.census_summary()
+    assert c["hard2"]["sg_pnp"]["pose_within_bar"] == c["hard2"]["sg_pnp"]["pairs"] and c["hard1"]["sg_pnp"]["inlier_index_sets_identical"] == 64
