@@ -136,7 +136,7 @@ class conv(nn.Module):
 
     def forward(self, x):
         c = self.conv
-        if (x.is_cuda and c.kernel_size == (3, 3) and torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16
+        if (x.is_cuda and c.kernel_size == (3, 3) and torch.is_autocast_enabled() and torch.get_autocast_dtype('cuda') == torch.bfloat16
                 and conv_bf16.supported(x, c.weight, c.stride, c.padding)):
             # the decoder's 3x3 convolutions under bf16 autocast: implicit GEMMs on the bf16 matrix cores (csrc/conv_gemm_bf16.hip)
             y = conv_bf16.conv3x3_bf16(x, c.weight, c.bias)
