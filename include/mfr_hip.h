@@ -42,7 +42,8 @@
 extern "C" {
 #endif
 
-#define MFR_ABI_VERSION 2   /* 2: intrinsics as (const void *K, int k_dtype) instead of const float * */
+#define MFR_ABI_VERSION 3   /* 2: intrinsics as (const void *K, int k_dtype) instead of const float *; 3: mfr_emat_solve_batch takes the
+                             * model-quality method (MAGSAC++ / count) and its table */
 
 /* intrinsics dtype tags */
 #define MFR_K_F32 0
@@ -134,20 +135,32 @@ int mfr_scale_from_depth_batch(const float *pts0, const float *pts1, const uint8
 /* ------------------------------------------------------------------------------------------
  * Essential-matrix path: EssentialMatrixSolver.estimate_pose, lib/models/matching/pose_solver.py:29-61
  *   K-normalise in K's dtype (:39-40) -> thr = pix_thr / mean(fx0, fy1, fy0, fx1) (:43, Q8)
- *   -> cv.findEssentialMat(USAC_MAGSAC, prob) (:46-48): 5-point RANSAC, max_iters (OpenCV default
- *      1000; the reference does not override it), adaptive iteration cap, Sampson inliers
- *   -> cv.recoverPose per E (:56-60): 4 decompositions, cheirality vote -> LM polish of (R,t).
- * Outputs: R [B,9], t [B,3] UNIT translation f64 (NaN on failure), n_inliers [B] = number of
+ *   -> cv.findEssentialMat(USAC_MAGSAC, prob) (:46-48): 5-point RANSAC, max_iters (OpenCV default 1000; the reference does
+ *      not override it), adaptive iteration cap driven by the number of points under thr, and -- score_method
+ *      MFR_EMAT_SCORE_MAGSAC, the method the reference names -- MAGSAC++ model quality (sigma-marginalised loss, 4 degrees of
+ *      freedom, k = 3.64, k sigma_max = max_thr_ratio * thr; smallest total loss wins) with sigma-consensus++ local optimisation
+ *      (IRLS with the MAGSAC++ weights on (R, unit t): every new best model from iteration 100 on, and the winner at the end).
+ *      MFR_EMAT_SCORE_COUNT: inlier count at thr + one LM polish of (R, t) (rounds 1-3; kept for A/B).
+ *   -> cv.recoverPose per E (:56-60): 4 decompositions, cheirality vote.
+ * magsac_lut: DEVICE copy of the table mfr_magsac_lut (host) fills, 2 * (lut_m + 1) doubles, lut_m <= 2048 (ignored for COUNT).
+ * Outputs: R [B,9] (orthonormal to rounding), t [B,3] UNIT translation f64 (NaN on failure), n_inliers [B] = number of
  * cheirality-passing inliers (the `n` recoverPose returns), inlier_mask [B,maxN] u8 = those
  * inliers (what self.mask aliases after the loop, Q7; feed it to mfr_scale_from_depth_batch),
- * status [B].  best_iter / iters_run / counts_out [B,max_iters] are optional diagnostics (NULL ok).
+ * status [B].  best_iter / iters_run / counts_out [B,max_iters] / losses_out [B,max_iters] (MAGSAC) / lo_runs [B] (number of
+ * local optimisations) are optional diagnostics (NULL ok).
  * ------------------------------------------------------------------------------------------ */
+#define MFR_EMAT_SCORE_MAGSAC 0
+#define MFR_EMAT_SCORE_COUNT  1
+#define MFR_MAGSAC_LUT_M 2048
+int mfr_magsac_lut(double *lut_host /* [2 * (M + 1)] */, int M);
 size_t mfr_emat_workspace_bytes(int B, int maxN, int max_iters);
 int mfr_emat_solve_batch(const float *pts0, const float *pts1, const int32_t *n_corr, int B, int maxN,
                          const void *K0, const void *K1, int k_dtype, double pix_thr, double confidence, int max_iters,
-                         uint64_t seed, const int64_t *pair_ids, void *workspace, size_t workspace_bytes,
+                         uint64_t seed, const int64_t *pair_ids, int score_method, const double *magsac_lut, int lut_m,
+                         double max_thr_ratio, void *workspace, size_t workspace_bytes,
                          double *R, double *t, int32_t *n_inliers, int32_t *status, uint8_t *inlier_mask,
-                         int32_t *best_iter, int32_t *iters_run, int32_t *counts_out, void *stream);
+                         int32_t *best_iter, int32_t *iters_run, int32_t *counts_out, double *losses_out, int32_t *lo_runs,
+                         void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Procrustes path: ProcrustesSolver.estimate_pose, lib/models/matching/pose_solver.py:238-320 with

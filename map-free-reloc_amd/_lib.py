@@ -28,8 +28,9 @@ SIGNATURES = {
     "mfr_pnp_ransac": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _i, _d, _d, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                             _vp, _vp, _vp, _vp]),
     "mfr_emat_workspace_bytes": (_sz, [_i, _i, _i]),
-    "mfr_emat_solve_batch": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _i, _d, _d, _i, _u64, _vp, _vp, _sz, _vp, _vp, _vp, _vp,
-                                  _vp, _vp, _vp, _vp, _vp]),
+    "mfr_magsac_lut": (_i, [_vp, _i]),
+    "mfr_emat_solve_batch": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _i, _d, _d, _i, _u64, _vp, _i, _vp, _i, _d, _vp, _sz,
+                                  _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mfr_procrustes_workspace_bytes": (_sz, [_i, _i, _i]),
     "mfr_procrustes_solve_batch": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _i, _d, _d, _i, _u64, _vp, _vp, _sz,
                                         _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -152,7 +152,8 @@ class EssentialMatrixSolver(_Base):
         super().__init__(cfg)
         self.ransac_pix_threshold = cfg.EMAT_RANSAC.PIX_THRESHOLD
         self.ransac_confidence = cfg.EMAT_RANSAC.CONFIDENCE
-        self._emat = ops.EssentialBatchSolver(self.ransac_pix_threshold, self.ransac_confidence, self.seed)
+        self._emat = ops.EssentialBatchSolver(self.ransac_pix_threshold, self.ransac_confidence, self.seed,
+                                               score=cfg.HIP.EMAT_SCORE, max_thr_ratio=cfg.HIP.MAGSAC_MAX_THR_RATIO)
         self.mask = None
 
     def _run(self, kpts0, kpts1, data, need_depth):

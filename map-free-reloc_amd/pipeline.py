@@ -71,13 +71,13 @@ class LoFTREmatPipeline:
     CONFIDENCE 0.9999), one device-resident pass over a batch of pairs.  Replaces
     LoFTR_matcher.match (matchers.py:24-59) + EssentialMatrixMetricSolver (pose_solver.py:115-172)."""
 
-    def __init__(self, device="cuda", loftr_state=None, pix_thr=2.0, scale_thr=0.1, conf=0.9999, seed=0, pad_to=8):
+    def __init__(self, device="cuda", loftr_state=None, pix_thr=2.0, scale_thr=0.1, conf=0.9999, seed=0, pad_to=8, emat_score="magsac"):
         from .nets.loftr import LoFTRHIP
         from .solver_ops import EssentialBatchSolver, ScaleFromDepthBatch
         _lib.load(require_gpu=True)
         self.device = torch.device(device)
         self.loftr = LoFTRHIP(loftr_state or WT.loftr_state_dict(), self.device)
-        self.emat = EssentialBatchSolver(pix_thr, conf, seed)
+        self.emat = EssentialBatchSolver(pix_thr, conf, seed, score=emat_score)
         self.scale = ScaleFromDepthBatch(scale_thr)
         self.pad_to = pad_to
 
@@ -183,7 +183,8 @@ class FusedPosePipeline:
             pnp = ops.PnPBatchSolver(cfg.PNP.RANSAC_ITER, cfg.PNP.REPROJECTION_INLIER_THRESHOLD, cfg.PNP.CONFIDENCE, seed)
             self.solve = lambda m, b: pnp(m["pts0"], m["pts1"], m["n_corr"], b["depth0"], b["K0"], b["K1"], b["seed_ids"])
         elif ps in ("EssentialMatrix", "EssentialMatrixMetric"):
-            em = ops.EssentialBatchSolver(cfg.EMAT_RANSAC.PIX_THRESHOLD, cfg.EMAT_RANSAC.CONFIDENCE, seed)
+            em = ops.EssentialBatchSolver(cfg.EMAT_RANSAC.PIX_THRESHOLD, cfg.EMAT_RANSAC.CONFIDENCE, seed,
+                                          score=cfg.HIP.EMAT_SCORE, max_thr_ratio=cfg.HIP.MAGSAC_MAX_THR_RATIO)
             sc = ops.ScaleFromDepthBatch(cfg.EMAT_RANSAC.SCALE_THRESHOLD) if ps == "EssentialMatrixMetric" else None
 
             def solve(m, b):

@@ -137,13 +137,38 @@ class PnPBatchSolver:
         return out
 
 
-class EssentialBatchSolver:
-    """EssentialMatrixSolver.estimate_pose (pose_solver.py:29-61) for a batch of pairs."""
+EMAT_SCORE = {"magsac": 0, "count": 1}      # MFR_EMAT_SCORE_* of include/mfr_hip.h
+MAGSAC_LUT_M = 2048
 
-    def __init__(self, pix_thr=2.0, confidence=0.9999, seed=0, max_iters=1000):
+
+def magsac_lut_host(M=MAGSAC_LUT_M):
+    """[M + 1, 2] float64 (normalised MAGSAC++ loss, IRLS weight) over r^2 / cut in [0, 1]: mfr_magsac_lut (host code of the library)"""
+    import numpy as np
+    t = np.zeros((M + 1, 2), dtype=np.float64)
+    _lib.check(_lib.load().mfr_magsac_lut(t.ctypes.data, M), "mfr_magsac_lut")
+    return t
+
+
+class EssentialBatchSolver:
+    """EssentialMatrixSolver.estimate_pose (pose_solver.py:29-61) for a batch of pairs.  score 'magsac' (default) = what the
+    reference asks OpenCV for (cv.USAC_MAGSAC, :46-48): MAGSAC++ model quality + sigma-consensus++; 'count' = inlier count + LM
+    polish (rounds 1-3, kept for A/B)."""
+
+    def __init__(self, pix_thr=2.0, confidence=0.9999, seed=0, max_iters=1000, score="magsac", max_thr_ratio=1.0):
+        if score not in EMAT_SCORE:
+            raise ValueError(f"EssentialBatchSolver: unknown score {score!r}; known: {sorted(EMAT_SCORE)}")
+        if not max_thr_ratio >= 1.0:
+            raise ValueError("EssentialBatchSolver: max_thr_ratio must be >= 1")
         self.pix_thr, self.confidence = float(pix_thr), float(confidence)
         self.seed, self.max_iters = int(seed), max(int(max_iters), 1)
+        self.score, self.max_thr_ratio = EMAT_SCORE[score], float(max_thr_ratio)
         self._ws = None
+        self._lut = None
+
+    def _table(self, dev):
+        if self._lut is None or self._lut.device != dev:
+            self._lut = torch.from_numpy(magsac_lut_host()).to(dev)
+        return self._lut
 
     def __call__(self, pts0, pts1, n_corr, K0, K1, pair_ids, diagnostics=False):
         lib = _lib.load(require_gpu=True)
@@ -156,23 +181,27 @@ class EssentialBatchSolver:
         need = lib.mfr_emat_workspace_bytes(B, maxN, self.max_iters)
         if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
             self._ws = _ws(need, dev)
+        lut = self._table(dev) if self.score == 0 else None
         R = torch.empty(B, 3, 3, dtype=torch.float64, device=dev)
         t = torch.empty(B, 3, dtype=torch.float64, device=dev)
         ni = torch.empty(B, dtype=torch.int32, device=dev)
         st = torch.empty(B, dtype=torch.int32, device=dev)
         mask = torch.empty(B, maxN, dtype=torch.uint8, device=dev)
-        bi = ir = cnt = None
+        bi = ir = cnt = los = lo = None
         if diagnostics:
             bi = torch.empty(B, dtype=torch.int32, device=dev); ir = torch.empty(B, dtype=torch.int32, device=dev)
+            lo = torch.empty(B, dtype=torch.int32, device=dev)
             cnt = torch.empty(B, self.max_iters, dtype=torch.int32, device=dev)
+            los = torch.zeros(B, self.max_iters, dtype=torch.float64, device=dev)
         _lib.check(lib.mfr_emat_solve_batch(
             _lib.ptr(pts0), _lib.ptr(pts1), _lib.ptr(n_corr), B, maxN, _lib.ptr(K0), _lib.ptr(K1), kdt, self.pix_thr,
-            self.confidence, self.max_iters, self.seed, _lib.ptr(pair_ids), _lib.ptr(self._ws), self._ws.numel(),
+            self.confidence, self.max_iters, self.seed, _lib.ptr(pair_ids), self.score, _lib.ptr(lut), MAGSAC_LUT_M,
+            self.max_thr_ratio, _lib.ptr(self._ws), self._ws.numel(),
             _lib.ptr(R), _lib.ptr(t), _lib.ptr(ni), _lib.ptr(st), _lib.ptr(mask), _lib.ptr(bi), _lib.ptr(ir),
-            _lib.ptr(cnt), _lib.stream_ptr()), "mfr_emat_solve_batch")
+            _lib.ptr(cnt), _lib.ptr(los), _lib.ptr(lo), _lib.stream_ptr()), "mfr_emat_solve_batch")
         out = dict(R=R, t=t, n_inliers=ni, status=st, mask=mask)
         if diagnostics:
-            out.update(best_iter=bi, iters_run=ir, counts=cnt)
+            out.update(best_iter=bi, iters_run=ir, counts=cnt, losses=los, lo_runs=lo)
         return out
 
 

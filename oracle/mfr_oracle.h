@@ -93,6 +93,13 @@ int mfr_ref_scale_lift(const float *pts0, const float *pts1, const uint8_t *mask
                        double *scale /* [n] */);
 int mfr_ref_scale_ransac(const double *scale, int n, double thr, double *best_scale, int *best_idx);
 
+/* E-matrix model quality (same values as include/mfr_hip.h) */
+#define MFR_EMAT_SCORE_MAGSAC 0   /* MAGSAC++ loss + sigma-consensus++ (what cv.USAC_MAGSAC names, pose_solver.py:46-48) */
+#define MFR_EMAT_SCORE_COUNT  1   /* inlier count + LM polish (rounds 1-3) */
+#define MFR_MAGSAC_LUT_M 2048     /* intervals of the loss / weight table the product ships with */
+void mfr_ref_magsac_lut(double *lut /* [2 * (M + 1)] */, int M);
+void mfr_ref_orthonormalize(double R[9]);
+
 /* LM refinement used by the PnP path (exposed for tests) */
 int mfr_ref_pnp_lm(const double *xyz, const double *obs, const int32_t *idx, int n_idx,
                    const double Kd[4], int max_iter, double R[9], double t[3]);

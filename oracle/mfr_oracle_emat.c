@@ -7,11 +7,26 @@
  *     cv.findEssentialMat(USAC_MAGSAC, prob) (:46-48), cv.recoverPose per E (:56-60).
  * The two cv calls live in opencv-python==4.8.0.74 (not available offline): restated from the
  * published algorithms -- Nister's 5-point solver, RANSAC with OpenCV's adaptive iteration cap,
- * Sampson-distance inliers, Horn's closed-form E decomposition, cheirality vote, and a
- * Gauss-Newton/LM polish of (R,t) on the inliers standing in for USAC's local optimisation /
- * final polisher.  MAGSAC++'s sigma-marginalised score is NOT reproduced (documented
- * substitution: inlier count at the same threshold).  PARITY UNPINNED against OpenCV; pinned by
- * known-answer synthetic geometry (tests/test_oracle_known_answers.py).
+ * Sampson distances, Horn's closed-form E decomposition, cheirality vote.
+ *
+ * Model quality and local optimisation (score_method):
+ *   MFR_EMAT_SCORE_MAGSAC (0, what the reference asks OpenCV for: method=cv.USAC_MAGSAC, pose_solver.py:46-48)
+ *       MAGSAC++ (Barath, Noskova, Ivashechkin, Matas, CVPR 2020): every hypothesis is scored by the sigma-marginalised loss
+ *       (noise scale integrated over (0, sigma_max], chi distribution with 4 degrees of freedom, k = 3.64 = its 0.99 quantile)
+ *       through a lookup table of the incomplete gamma functions -- OpenCV's USAC does the same (its GammaValues table) --, the
+ *       model with the smallest total loss wins, the number of points under the caller's threshold ("tentative inliers")
+ *       drives the adaptive iteration cap, and sigma-consensus++ (iteratively re-weighted least squares with the MAGSAC++
+ *       weights = d loss / d r^2) is the local optimisation: run on every new best model from iteration MFR_MAGSAC_LO_START
+ *       on (USAC: max_iters_before_LO = 100) and once more at the end if the winner never went through it.  The least-squares
+ *       problem inside each re-weighting round is solved on the essential manifold (one damped Gauss-Newton step on (R, unit t)
+ *       per round, accepted when the MAGSAC++ loss decreases) instead of USAC's weighted linear solver + projection.
+ *       k * sigma_max = max_thr_ratio * threshold; the final mask is residual^2 < threshold^2 (USAC's strict compare).
+ *   MFR_EMAT_SCORE_COUNT (1, rounds 1-3; kept for A/B): inlier count at the same threshold + one LM polish of (R,t) on the
+ *       inliers, kept if it does not lose inliers.
+ * opencv-python 4.8.0.74 is not available offline, so USAC's exact constants (how `threshold` maps to its maximum sigma, its
+ * table quantisation, LO sample size 50, polisher) are NOT reproduced: PARITY UNPINNED against OpenCV; pinned by known-answer
+ * synthetic geometry (tests/test_oracle_known_answers.py); tests/external/gen_cv_golden.py dumps OpenCV's E / mask / inlier
+ * count for the same seeded sets wherever cv2 exists.
  */
 #include "mfr_oracle.h"
 #include <math.h>
@@ -397,14 +412,193 @@ double mfr_ref_emat_threshold(double pix_thr, const void *K0, const void *K1, in
     return pix_thr / m;
 }
 
-/* one hypothesis: best (most inliers, first on ties) of the <= 10 five-point models */
-static int emat_hypothesis(const double *x0, const double *x1, int n, const int *s, double thr2, double *Ebest, int *nsol)
+/* ------------------------------------------------------------------------------------------------------------------
+ * MAGSAC++ quality + sigma-consensus++ local optimisation (score_method MFR_EMAT_SCORE_MAGSAC)
+ * ------------------------------------------------------------------------------------------------------------------ */
+#define MAGSAC_K 3.64            /* 0.99 quantile of the chi distribution with 4 degrees of freedom (the paper's k, OpenCV's sigma_quantile) */
+#define MAGSAC_TILE 1024         /* loss sums: wave64 order inside a tile of 1024 points, tiles added in sequence */
+
+/* Table of the normalised MAGSAC++ point loss and IRLS weight over u = r^2 / (k sigma_max)^2 in [0, 1], M intervals,
+ * lut[2 j] = loss(u_j), lut[2 j + 1] = weight(u_j), u_j = j / M (linear interpolation in between; n = 4 degrees of freedom):
+ *   x = r^2 / (2 sigma_max^2) = u k^2 / 2
+ *   rho(x) / sigma_max^2 = 1/2 gamma(5/2, x) + x/2 (Gamma(3/2, x) - Gamma(3/2, k^2/2))           (paper eq. 6-8 up to a constant)
+ *   loss(u)   = rho(x) / rho(k^2/2) - 1          in [-1, 0]: 0 for a point on the cut, -1 for a perfect fit
+ *   weight(u) = (Gamma(3/2, x) - Gamma(3/2, k^2/2)) / (Gamma(3/2, 0) - Gamma(3/2, k^2/2))   = d rho / d r^2 up to a constant
+ * closed forms: Gamma(1/2, x) = sqrt(pi) erfc(sqrt x), Gamma(a+1, x) = a Gamma(a, x) + x^a e^-x.
+ * The table is the ONLY place libm (erfc, exp) enters; everything downstream is + - * / on its entries. */
+void mfr_ref_magsac_lut(double *lut, int M)
+{
+    const double sqrt_pi = 1.7724538509055160273;
+    const double xk = 0.5 * MAGSAC_K * MAGSAC_K;
+    const double gk = 0.5 * sqrt_pi * erfc(sqrt(xk)) + sqrt(xk) * exp(-xk);                    /* Gamma(3/2, k^2/2) */
+    const double norm = 0.75 * sqrt_pi - (1.5 * gk + xk * sqrt(xk) * exp(-xk));                /* gamma(5/2, k^2/2) */
+    const double w0 = 0.5 * sqrt_pi - gk;
+    for (int j = 0; j <= M; ++j) {
+        const double x = xk * (double)j / (double)M;
+        const double sx = sqrt(x), ex = exp(-x);
+        const double gu15 = 0.5 * sqrt_pi * erfc(sx) + sx * ex;
+        const double gl25 = 0.75 * sqrt_pi - (1.5 * gu15 + x * sx * ex);
+        lut[2 * j] = (gl25 + x * (gu15 - gk)) / norm - 1.0;
+        lut[2 * j + 1] = (gu15 - gk) / w0;
+    }
+    lut[0] = -1.0; lut[1] = 1.0; lut[2 * M] = 0.0; lut[2 * M + 1] = 0.0;
+}
+
+typedef struct { const double *lut; int M; double cut, scale, thr2; } magsac_t;
+
+static inline void magsac_lookup(const magsac_t *ms, double r2, double *loss, double *wgt)
+{
+    const double u = r2 * ms->scale;                 /* scale = M / cut, r2 < cut */
+    int j = (int)u;
+    if (j > ms->M - 1) j = ms->M - 1;
+    const double f = u - (double)j;
+    if (loss) *loss = ms->lut[2 * j] + f * (ms->lut[2 * j + 2] - ms->lut[2 * j]);
+    if (wgt) *wgt = ms->lut[2 * j + 1] + f * (ms->lut[2 * j + 3] - ms->lut[2 * j + 1]);
+}
+
+static double butterfly64(double *a)
+{
+    for (int off = 32; off >= 1; off >>= 1) {
+        double tmp[64];
+        for (int l = 0; l < 64; ++l) tmp[l] = a[l] + a[l ^ off];
+        memcpy(a, tmp, sizeof(tmp));
+    }
+    return a[0];
+}
+
+/* total loss (lower is better) and tentative inlier count (r^2 < thr^2) of one model */
+static void magsac_score(const magsac_t *ms, const double *E, const double *x0, const double *x1, int n, double *loss, int *cnt)
+{
+    double L = 0.0; int c = 0;
+    for (int base = 0; base < n; base += MAGSAC_TILE) {
+        const int tn = (n - base < MAGSAC_TILE) ? n - base : MAGSAC_TILE;
+        double acc[64];
+        for (int l = 0; l < 64; ++l) acc[l] = 0.0;
+        for (int i = 0; i < tn; ++i) {
+            const int j = base + i;
+            const double r2 = sampson2(E, x0[2 * j], x0[2 * j + 1], x1[2 * j], x1[2 * j + 1]);
+            c += (r2 < ms->thr2);
+            if (r2 < ms->cut) { double v; magsac_lookup(ms, r2, &v, NULL); acc[i & 63] = acc[i & 63] + v; }
+        }
+        L = L + butterfly64(acc);
+    }
+    *loss = L; *cnt = c;
+}
+
+/* two Newton-Schulz steps towards the orthogonal polar factor: R <- R (3 I - R^T R) / 2 (quadratic convergence; the inputs
+ * are rotations up to ~1e-9, the outputs up to rounding) */
+void mfr_ref_orthonormalize(double R[9])
+{
+    for (int it = 0; it < 2; ++it) {
+        double S[9], Rn[9];
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
+            const double g = (R[i] * R[j] + R[3 + i] * R[3 + j]) + R[6 + i] * R[6 + j];
+            S[3 * i + j] = ((i == j) ? 3.0 : 0.0) - g;
+        }
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j)
+            Rn[3 * i + j] = 0.5 * ((R[3 * i] * S[j] + R[3 * i + 1] * S[3 + j]) + R[3 * i + 2] * S[6 + j]);
+        memcpy(R, Rn, 72);
+    }
+}
+
+#define MAGSAC_LO_START 100      /* USAC's max_iters_before_LO */
+#define MAGSAC_LO_ITERS 20       /* re-weighting rounds per local optimisation */
+
+/* sigma-consensus++: IRLS with the MAGSAC++ weights on (R, unit t); returns 0 and the optimised model / its score, or -1 */
+static int magsac_lo(const magsac_t *ms, const double *x0, const double *x1, int n, const double *Ein,
+                     double *Eout, double *loss_out, int *cnt_out)
+{
+    double R[9], Rb[9], t[3];
+    if (mfr_ref_emat_decompose(Ein, R, Rb, t)) return -1;
+    mfr_ref_orthonormalize(R);
+    double E[9]; skew_mul(t, R, E);
+    double loss; int cnt;
+    magsac_score(ms, E, x0, x1, n, &loss, &cnt);
+    if (!(loss == loss)) return -1;
+    double lambda = 1e-3;
+    wacc_t *w = (wacc_t *)malloc(sizeof(wacc_t));
+    for (int it = 0; it < MAGSAC_LO_ITERS; ++it) {
+        memset(w, 0, sizeof(*w));
+        for (int i = 0; i < n; ++i) {
+            double a = x0[2 * i], b = x0[2 * i + 1], c = x1[2 * i], d = x1[2 * i + 1];
+            double Ex0 = (E[0] * a + E[1] * b) + E[2], Ex1 = (E[3] * a + E[4] * b) + E[5], Ex2 = (E[6] * a + E[7] * b) + E[8];
+            double Et0 = (E[0] * c + E[3] * d) + E[6], Et1 = (E[1] * c + E[4] * d) + E[7];
+            double num = (c * Ex0 + d * Ex1) + Ex2;
+            double den = ((Ex0 * Ex0 + Ex1 * Ex1) + Et0 * Et0) + Et1 * Et1;
+            double r2 = (num * num) / den;
+            if (!(r2 < ms->cut)) continue;
+            double pw; magsac_lookup(ms, r2, NULL, &pw);
+            double wgt = 1.0 / sqrt(den);
+            double q[3] = { c, d, 1.0 }, p[3] = { a, b, 1.0 };
+            double txq[3] = { t[1] * q[2] - t[2] * q[1], t[2] * q[0] - t[0] * q[2], t[0] * q[1] - t[1] * q[0] };
+            double u[3] = { -((R[0] * txq[0] + R[3] * txq[1]) + R[6] * txq[2]),
+                            -((R[1] * txq[0] + R[4] * txq[1]) + R[7] * txq[2]),
+                            -((R[2] * txq[0] + R[5] * txq[1]) + R[8] * txq[2]) };
+            double Rp[3] = { (R[0] * p[0] + R[1] * p[1]) + R[2] * p[2], (R[3] * p[0] + R[4] * p[1]) + R[5] * p[2],
+                             (R[6] * p[0] + R[7] * p[1]) + R[8] * p[2] };
+            double J[6];
+            J[0] = (p[1] * u[2] - p[2] * u[1]) * wgt; J[1] = (p[2] * u[0] - p[0] * u[2]) * wgt; J[2] = (p[0] * u[1] - p[1] * u[0]) * wgt;
+            J[3] = (Rp[1] * q[2] - Rp[2] * q[1]) * wgt; J[4] = (Rp[2] * q[0] - Rp[0] * q[2]) * wgt; J[5] = (Rp[0] * q[1] - Rp[1] * q[0]) * wgt;
+            double r = num * wgt;
+            double *acc = w->a[i & 63];
+            int qq = 0;
+            for (int rr = 0; rr < 6; ++rr) { double wj = pw * J[rr]; for (int cc = rr; cc < 6; ++cc, ++qq) acc[qq] = acc[qq] + wj * J[cc]; }
+            for (int rr = 0; rr < 6; ++rr, ++qq) acc[qq] = acc[qq] + (pw * J[rr]) * r;
+        }
+        double s[27]; wacc_finish(w, 27, s);
+        double H[36], g[6];
+        { int qq = 0;
+          for (int rr = 0; rr < 6; ++rr) for (int cc = rr; cc < 6; ++cc, ++qq) { H[6 * rr + cc] = s[qq]; H[6 * cc + rr] = s[qq]; }
+          for (int rr = 0; rr < 6; ++rr, ++qq) g[rr] = -s[qq]; }
+        for (int rr = 0; rr < 6; ++rr) H[6 * rr + rr] = H[6 * rr + rr] + lambda * H[6 * rr + rr];
+        for (int rr = 0; rr < 3; ++rr) for (int cc = 0; cc < 3; ++cc) H[6 * (3 + rr) + 3 + cc] = H[6 * (3 + rr) + 3 + cc] + t[rr] * t[cc];
+        double dl[6];
+        if (chol6(H, g, dl)) { lambda = lambda * 10.0; if (lambda > 1e12) break; continue; }
+        double Rn[9], tn[3], En[9];
+        quat_right(R, dl, Rn);
+        tn[0] = t[0] + dl[3]; tn[1] = t[1] + dl[4]; tn[2] = t[2] + dl[5];
+        double nt = sqrt((tn[0] * tn[0] + tn[1] * tn[1]) + tn[2] * tn[2]);
+        if (!(nt > 0.0)) { lambda = lambda * 10.0; if (lambda > 1e12) break; continue; }
+        tn[0] = tn[0] / nt; tn[1] = tn[1] / nt; tn[2] = tn[2] / nt;
+        skew_mul(tn, Rn, En);
+        double ln; int cn;
+        magsac_score(ms, En, x0, x1, n, &ln, &cn);
+        double mx = 0.0;
+        for (int k = 0; k < 6; ++k) { double v = dl[k] < 0.0 ? -dl[k] : dl[k]; if (v > mx) mx = v; }
+        if (ln < loss) {
+            double dec = loss - ln, mag = loss < 0.0 ? -loss : loss;
+            memcpy(R, Rn, 72); memcpy(t, tn, 24); memcpy(E, En, 72);
+            int done = (dec <= 1e-12 * mag);
+            loss = ln; cnt = cn;
+            lambda = lambda * 0.1; if (lambda < 1e-12) lambda = 1e-12;
+            if (done) break;
+        } else { lambda = lambda * 10.0; if (lambda > 1e12) break; }
+        if (mx < 1e-13) break;
+    }
+    free(w);
+    memcpy(Eout, E, 72); *loss_out = loss; *cnt_out = cnt;
+    return 0;
+}
+
+/* one hypothesis: best of the <= 10 five-point models -- most inliers (COUNT) or smallest MAGSAC++ loss (MAGSAC), first on ties.
+ * Returns the tentative inlier count of that model; *loss_best its loss (MAGSAC only; 0 = no model). */
+static int emat_hypothesis(const double *x0, const double *x1, int n, const int *s, double thr2, const magsac_t *ms,
+                           double *Ebest, double *loss_best)
 {
     double a[10], b[10], Es[90];
     for (int k = 0; k < 5; ++k) { a[2 * k] = x0[2 * s[k]]; a[2 * k + 1] = x0[2 * s[k] + 1]; b[2 * k] = x1[2 * s[k]]; b[2 * k + 1] = x1[2 * s[k] + 1]; }
     int ns = mfr_ref_fivept(a, b, Es);
-    if (nsol) *nsol = ns;
     int best = 0;
+    if (ms) {
+        double bl = 0.0;
+        for (int m = 0; m < ns; ++m) {
+            double l; int c;
+            magsac_score(ms, Es + 9 * m, x0, x1, n, &l, &c);
+            if (l < bl) { bl = l; best = c; memcpy(Ebest, Es + 9 * m, 72); }
+        }
+        *loss_best = bl;
+        return best;
+    }
     for (int m = 0; m < ns; ++m) {
         int cnt = 0;
         for (int i = 0; i < n; ++i) cnt += (sampson2(Es + 9 * m, x0[2 * i], x0[2 * i + 1], x1[2 * i], x1[2 * i + 1]) <= thr2);
@@ -413,43 +607,87 @@ static int emat_hypothesis(const double *x0, const double *x1, int n, const int 
     return best;
 }
 
+/* cv.recoverPose (pose_solver.py:56-60): 4 decompositions, keep the one with most masked points in front of both cameras */
+static int recover_pose(const double *E, const double *x0, const double *x1, const int32_t *idx, int m, double *Rb, double *tb)
+{
+    double Ra[9], Rc[9], tu[3];
+    if (mfr_ref_emat_decompose(E, Ra, Rc, tu)) return -1;
+    int bestc = -1;
+    for (int c = 0; c < 4; ++c) {
+        const double *Rk = (c < 2) ? Ra : Rc;
+        double tk[3] = { (c & 1) ? -tu[0] : tu[0], (c & 1) ? -tu[1] : tu[1], (c & 1) ? -tu[2] : tu[2] };
+        int cnt = 0;
+        for (int q = 0; q < m; ++q) { int i = idx[q]; cnt += cheirality(Rk, tk, x0[2 * i], x0[2 * i + 1], x1[2 * i], x1[2 * i + 1]); }
+        if (cnt > bestc) { bestc = cnt; memcpy(Rb, Rk, 72); memcpy(tb, tk, 24); }
+    }
+    return bestc;
+}
+
 /* EssentialMatrixSolver.estimate_pose (pose_solver.py:29-61).  mask_out = cheirality-filtered
- * inliers (what self.mask holds after the recoverPose loop, quirk Q7), n_inl = their count. */
+ * inliers (what self.mask holds after the recoverPose loop, quirk Q7), n_inl = their count.
+ * score_method MFR_EMAT_SCORE_MAGSAC needs lut = mfr_ref_magsac_lut(.., lut_m); losses [max_iters] (may be NULL) receives the
+ * per-hypothesis loss of the iterations that ran (0 beyond). */
 int mfr_ref_emat_solve(const float *pts0, const float *pts1, int n, const void *K0, const void *K1, int k_dtype,
                        double pix_thr, double conf, int max_iters, uint64_t seed, uint64_t pair_id,
+                       int score_method, const double *lut, int lut_m, double max_thr_ratio,
                        double R[9], double t[3], uint8_t *mask_out, int *n_inl,
-                       int *best_iter, int *iters_run, int32_t *counts, uint8_t *ransac_mask)
+                       int *best_iter, int *iters_run, int32_t *counts, double *losses, uint8_t *ransac_mask, int *lo_runs)
 {
     for (int i = 0; i < 9; ++i) R[i] = NAN;
     for (int i = 0; i < 3; ++i) t[i] = NAN;
-    *n_inl = 0; if (best_iter) *best_iter = -1; if (iters_run) *iters_run = 0;
+    *n_inl = 0; if (best_iter) *best_iter = -1; if (iters_run) *iters_run = 0; if (lo_runs) *lo_runs = 0;
     if (mask_out) memset(mask_out, 0, (size_t)(n > 0 ? n : 0));
     if (ransac_mask) memset(ransac_mask, 0, (size_t)(n > 0 ? n : 0));
     if (n < 5) return MFR_ST_TOO_FEW;                                        /* :32-33 */
     if (max_iters < 1) max_iters = 1;
+    const int magsac = (score_method == MFR_EMAT_SCORE_MAGSAC);
+    if (magsac && (!lut || lut_m < 2 || !(max_thr_ratio >= 1.0))) return -1;
     double *x0 = (double *)malloc(sizeof(double) * 2 * (size_t)n), *x1 = (double *)malloc(sizeof(double) * 2 * (size_t)n);
     mfr_ref_normalize_points(pts0, n, K0, k_dtype, x0);                      /* :39 */
     mfr_ref_normalize_points(pts1, n, K1, k_dtype, x1);                      /* :40 */
     double thr = mfr_ref_emat_threshold(pix_thr, K0, K1, k_dtype), thr2 = thr * thr;  /* :43 */
+    magsac_t msv, *ms = NULL;
+    if (magsac) {
+        msv.lut = lut; msv.M = lut_m; msv.thr2 = thr2;
+        msv.cut = (max_thr_ratio * max_thr_ratio) * thr2;
+        msv.scale = (double)lut_m / msv.cut;
+        ms = &msv;
+    }
     double Eb[9], Eh[9];
-    int best = 4, bit = -1, niters = max_iters, it = 0;
+    int best = magsac ? 0 : 4, bit = -1, niters = max_iters, it = 0, nlo = 0, best_is_lo = 0;
+    double best_loss = 0.0;
     if (n == 5) {
         int s[5] = { 0, 1, 2, 3, 4 };
-        int c = emat_hypothesis(x0, x1, n, s, thr2, Eb, NULL);
+        double l = 0.0;
+        int c = emat_hypothesis(x0, x1, n, s, thr2, ms, Eb, &l);
         it = 1;
-        if (c > 0) { best = c; bit = 0; }
+        if (counts) counts[0] = c;
+        if (losses) losses[0] = l;
+        if (magsac ? (l < 0.0) : (c > 0)) { best = c; bit = 0; best_loss = l; }
+        if (counts) for (int k = 1; k < max_iters; ++k) counts[k] = -1;
+        if (losses) for (int k = 1; k < max_iters; ++k) losses[k] = 0.0;
     } else {
         for (it = 0; it < niters; ++it) {
             int s[5];
+            double l = 0.0;
             mfr_ref_sample_distinct(seed, pair_id, (uint32_t)it, n, 5, s);
-            int cnt = emat_hypothesis(x0, x1, n, s, thr2, Eh, NULL);
+            int cnt = emat_hypothesis(x0, x1, n, s, thr2, ms, Eh, &l);
             if (counts) counts[it] = cnt;
-            if (cnt > best) {
-                best = cnt; bit = it; memcpy(Eb, Eh, 72);
-                niters = mfr_ref_update_num_iters(conf, (double)(n - cnt) / (double)n, 5, niters);
+            if (losses) losses[it] = l;
+            if (magsac ? (l < best_loss) : (cnt > best)) {
+                best = cnt; bit = it; memcpy(Eb, Eh, 72); best_loss = l; best_is_lo = 0;
+                if (magsac && it >= MAGSAC_LO_START) {
+                    double El[9], ll; int cl;
+                    ++nlo;
+                    if (magsac_lo(ms, x0, x1, n, Eb, El, &ll, &cl) == 0 && ll < best_loss) {
+                        memcpy(Eb, El, 72); best_loss = ll; best = cl; best_is_lo = 1;
+                    }
+                }
+                niters = mfr_ref_update_num_iters(conf, (double)(n - best) / (double)n, 5, niters);
             }
         }
         if (counts) for (int k = it; k < max_iters; ++k) counts[k] = -1;
+        if (losses) for (int k = it; k < max_iters; ++k) losses[k] = 0.0;
     }
     if (iters_run) *iters_run = it;
     if (best_iter) *best_iter = bit;
@@ -458,26 +696,26 @@ int mfr_ref_emat_solve(const float *pts0, const float *pts1, int n, const void *
     int32_t *idx = (int32_t *)malloc(sizeof(int32_t) * (size_t)n);
     uint8_t *rm = (uint8_t *)calloc((size_t)n, 1);
     double Rb[9], tb[3];
-    if (st == MFR_ST_OK) {
+    if (st == MFR_ST_OK && magsac) {
+        if (!best_is_lo && n > 5) {                                           /* the winner never went through the local optimisation */
+            double El[9], ll; int cl;
+            ++nlo;
+            if (magsac_lo(ms, x0, x1, n, Eb, El, &ll, &cl) == 0 && ll < best_loss) { memcpy(Eb, El, 72); best_loss = ll; best = cl; }
+        }
+        int m = 0;
+        for (int i = 0; i < n; ++i) {
+            rm[i] = (uint8_t)(sampson2(Eb, x0[2 * i], x0[2 * i + 1], x1[2 * i], x1[2 * i + 1]) < thr2);
+            if (rm[i]) idx[m++] = i;
+        }
+        if (recover_pose(Eb, x0, x1, idx, m, Rb, tb) <= 0) st = MFR_ST_NO_MODEL;   /* n == 0 -> ret stays NaN (:54-60) */
+    } else if (st == MFR_ST_OK) {
         int m = 0;
         for (int i = 0; i < n; ++i) {
             rm[i] = (uint8_t)(sampson2(Eb, x0[2 * i], x0[2 * i + 1], x1[2 * i], x1[2 * i + 1]) <= thr2);
             if (rm[i]) idx[m++] = i;
         }
         /* recoverPose: 4 candidates, keep the one with most points in front of both cameras (:56-60) */
-        double Ra[9], Rc[9], tu[3];
-        if (mfr_ref_emat_decompose(Eb, Ra, Rc, tu)) st = MFR_ST_NO_MODEL;
-        else {
-            int bestc = -1;
-            for (int c = 0; c < 4; ++c) {
-                const double *Rk = (c < 2) ? Ra : Rc;
-                double tk[3] = { (c & 1) ? -tu[0] : tu[0], (c & 1) ? -tu[1] : tu[1], (c & 1) ? -tu[2] : tu[2] };
-                int cnt = 0;
-                for (int q = 0; q < m; ++q) { int i = idx[q]; cnt += cheirality(Rk, tk, x0[2 * i], x0[2 * i + 1], x1[2 * i], x1[2 * i + 1]); }
-                if (cnt > bestc) { bestc = cnt; memcpy(Rb, Rk, 72); memcpy(tb, tk, 24); }
-            }
-            if (bestc <= 0) st = MFR_ST_NO_MODEL;                             /* n == 0 -> ret stays NaN (:54-60) */
-        }
+        if (recover_pose(Eb, x0, x1, idx, m, Rb, tb) <= 0) st = MFR_ST_NO_MODEL;
         if (st == MFR_ST_OK && n > 5) {
             /* polish on the RANSAC inliers (stand-in for USAC LO + final polisher) */
             double Rr[9], tr[3];
@@ -494,6 +732,7 @@ int mfr_ref_emat_solve(const float *pts0, const float *pts1, int n, const void *
         }
     }
     if (st == MFR_ST_OK) {
+        mfr_ref_orthonormalize(Rb);                                           /* Horn's R inherits E's distance from the essential manifold */
         int cnt = 0;
         for (int i = 0; i < n; ++i) {
             int in = rm[i] && cheirality(Rb, tb, x0[2 * i], x0[2 * i + 1], x1[2 * i], x1[2 * i + 1]);
@@ -505,6 +744,7 @@ int mfr_ref_emat_solve(const float *pts0, const float *pts1, int n, const void *
         if (ransac_mask) memcpy(ransac_mask, rm, (size_t)n);
     }
     if (st != MFR_ST_OK && mask_out) memset(mask_out, 0, (size_t)n);
+    if (lo_runs) *lo_runs = nlo;
     free(x0); free(x1); free(idx); free(rm);
     return st;
 }

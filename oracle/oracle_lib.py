@@ -226,22 +226,48 @@ def normalize_points(pts, K):
     return out
 
 
-def emat_solve(pts0, pts1, K0, K1, pix_thr=2.0, conf=0.9999, max_iters=1000, seed=0, pair_id=0, want_counts=False):
+EMAT_MAGSAC, EMAT_COUNT = 0, 1
+MAGSAC_LUT_M = 2048
+_LUT = {}
+
+
+def magsac_lut(M=MAGSAC_LUT_M):
+    """[M + 1, 2] table of (normalised MAGSAC++ loss, IRLS weight) over r^2 / cut in [0, 1] (mfr_ref_magsac_lut)"""
+    if M not in _LUT:
+        t = np.zeros((M + 1, 2))
+        lib().mfr_ref_magsac_lut(_p(t), C.c_int(M))
+        _LUT[M] = t
+    return _LUT[M]
+
+
+def orthonormalize(R):
+    R = _f64(R).copy()
+    lib().mfr_ref_orthonormalize(_p(R))
+    return R
+
+
+def emat_solve(pts0, pts1, K0, K1, pix_thr=2.0, conf=0.9999, max_iters=1000, seed=0, pair_id=0, want_counts=False,
+               score=EMAT_MAGSAC, max_thr_ratio=1.0, lut_m=MAGSAC_LUT_M):
     pts0, pts1 = _f32(pts0).reshape(-1, 2), _f32(pts1).reshape(-1, 2)
     n = len(pts0)
     R = np.zeros((3, 3)); t = np.zeros(3)
     mask = np.zeros(max(n, 1), np.uint8); rmask = np.zeros(max(n, 1), np.uint8)
-    n_inl = C.c_int(0); bi = C.c_int(0); ir = C.c_int(0)
+    n_inl = C.c_int(0); bi = C.c_int(0); ir = C.c_int(0); lo = C.c_int(0)
     counts = np.zeros(max_iters, np.int32) if want_counts else None
+    losses = np.zeros(max_iters, np.float64) if want_counts else None
     K0, K1, kdt = _K2(K0, K1)
+    lut = magsac_lut(lut_m)
     st = lib().mfr_ref_emat_solve(_p(pts0), _p(pts1), C.c_int(n), _p(K0), _p(K1), C.c_int(kdt),
                                   C.c_double(pix_thr), C.c_double(conf), C.c_int(max_iters), C.c_uint64(seed),
-                                  C.c_uint64(pair_id), _p(R), _p(t), _p(mask), C.byref(n_inl), C.byref(bi), C.byref(ir),
-                                  _p(counts) if want_counts else None, _p(rmask))
+                                  C.c_uint64(pair_id), C.c_int(score), _p(lut), C.c_int(lut_m), C.c_double(max_thr_ratio),
+                                  _p(R), _p(t), _p(mask), C.byref(n_inl), C.byref(bi), C.byref(ir),
+                                  _p(counts) if want_counts else None, _p(losses) if want_counts else None, _p(rmask),
+                                  C.byref(lo))
     out = dict(status=st, R=R, t=t, mask=mask[:n].copy(), ransac_mask=rmask[:n].copy(), n_inl=n_inl.value,
-               best_iter=bi.value, iters_run=ir.value)
+               best_iter=bi.value, iters_run=ir.value, lo_runs=lo.value)
     if want_counts:
         out["counts"] = counts
+        out["losses"] = losses
     return out
 
 

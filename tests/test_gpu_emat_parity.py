@@ -1,6 +1,8 @@
 """-m gpu parity: E-matrix RANSAC path (csrc/emat.hip) vs the CPU oracle (oracle/mfr_oracle_emat.c),
-and the full EssentialMatrixMetric chain.  Bit-exact hypothesis counts, selected iteration, inlier
-masks and (because reductions are wave64-ordered on both sides) poses."""
+and the full EssentialMatrixMetric chain, for both model-quality methods: MAGSAC++ loss + sigma-consensus++ (the default; what
+the reference asks OpenCV for, pose_solver.py:46-48) and the inlier count + LM polish of rounds 1-3.  Bit-exact hypothesis
+losses / counts, selected iteration, iteration budget, number of local optimisations, inlier masks and (because reductions are
+wave64-ordered on both sides) poses."""
 import numpy as np
 import pytest
 import torch
@@ -17,41 +19,66 @@ def _dev(a):
     return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
 
 
-def _case(n_list, seeds, outl, iters=1000, seed=0, thr=2.0):
-    batch = synth.make_batch(seeds, n_list, maxN=max(max(n_list), 8), outlier_frac=outl, noise_px=1.0)
-    solver = ops.EssentialBatchSolver(thr, 0.9999, seed, iters)
+SCORES = {"magsac": O.EMAT_MAGSAC, "count": O.EMAT_COUNT}
+
+
+def test_magsac_table_is_the_oracles():
+    """the one place libm enters (erfc, exp at table-fill time): the library's host table and the oracle's are the same bits"""
+    np.testing.assert_array_equal(ops.magsac_lut_host(), O.magsac_lut())
+
+
+def _case(n_list, seeds, outl, iters=1000, seed=0, thr=2.0, score="magsac", ratio=1.0, noise=1.0):
+    batch = synth.make_batch(seeds, n_list, maxN=max(max(n_list), 8), outlier_frac=outl, noise_px=noise)
+    solver = ops.EssentialBatchSolver(thr, 0.9999, seed, iters, score=score, max_thr_ratio=ratio)
     out = solver(_dev(batch["pts0"]), _dev(batch["pts1"]), _dev(batch["n_corr"]), _dev(batch["K0"]), _dev(batch["K1"]),
                  _dev(batch["pair_ids"]), diagnostics=True)
     out = {k: v.cpu().numpy() for k, v in out.items()}
     for b, n in enumerate(n_list):
         ref = O.emat_solve(batch["pts0"][b, :n], batch["pts1"][b, :n], batch["K0"][b], batch["K1"][b], thr, 0.9999, iters,
-                           seed, int(batch["pair_ids"][b]), want_counts=True)
+                           seed, int(batch["pair_ids"][b]), want_counts=True, score=SCORES[score], max_thr_ratio=ratio)
         assert out["status"][b] == ref["status"], (b, out["status"][b], ref["status"])
         if n > 5:
             run = ref["iters_run"]
             np.testing.assert_array_equal(out["counts"][b, :run], ref["counts"][:run])
+            if score == "magsac":
+                np.testing.assert_array_equal(out["losses"][b, :run], ref["losses"][:run])
+                assert out["lo_runs"][b] == ref["lo_runs"]
             assert out["best_iter"][b] == ref["best_iter"] and out["iters_run"][b] == ref["iters_run"]
         assert out["n_inliers"][b] == ref["n_inl"]
         np.testing.assert_array_equal(out["mask"][b, :n], ref["mask"])
         if ref["status"] == 0:
             np.testing.assert_array_equal(out["R"][b], ref["R"])
             np.testing.assert_array_equal(out["t"][b], ref["t"])
+            assert np.abs(out["R"][b].T @ out["R"][b] - np.eye(3)).max() < 1e-14      # a rotation, not Horn's near-rotation
         else:
             assert np.isnan(out["R"][b]).all()
     return batch, out
 
 
-def test_emat_bit_exact_vs_oracle():
-    _case([256, 1024, 64, 5, 4, 0, 7, 2500], [1, 2, 3, 4, 5, 6, 7, 8], outl=0.3)
+@pytest.mark.parametrize("score", ["magsac", "count"])
+def test_emat_bit_exact_vs_oracle(score):
+    _case([256, 1024, 64, 5, 4, 0, 7, 2500], [1, 2, 3, 4, 5, 6, 7, 8], outl=0.3, score=score)
 
 
-def test_emat_heavy_outliers_seeds_and_short_budget():
-    _case([1024, 400], [11, 12], outl=0.6, seed=5)
-    _case([300, 800], [13, 14], outl=0.5, iters=41)
+@pytest.mark.parametrize("score", ["magsac", "count"])
+def test_emat_heavy_outliers_seeds_and_short_budget(score):
+    _case([1024, 400], [11, 12], outl=0.6, seed=5, score=score)
+    _case([300, 800], [13, 14], outl=0.5, iters=41, score=score)
 
 
-def test_emat_known_answer_pose():
-    batch, out = _case([2000, 800], [21, 22], outl=0.3)
+def test_emat_magsac_local_optimisation_inside_the_loop_and_wide_sigma():
+    """70 % outliers: new best models keep arriving after iteration 100, so sigma-consensus++ runs INSIDE the replay (lo_runs > 1)
+    and its result changes which later hypotheses become the best; max_thr_ratio 2: the loss cut and the tentative-inlier
+    threshold are different sets"""
+    _, out = _case([900, 1500, 3000], [41, 42, 43], outl=0.7, score="magsac")
+    assert (out["lo_runs"] > 1).any()
+    _case([700, 1100], [44, 45], outl=0.5, score="magsac", ratio=2.0)
+    _case([700, 1100], [46, 47], outl=0.4, score="magsac", ratio=1.5, noise=0.3, thr=1.0)
+
+
+@pytest.mark.parametrize("score", ["magsac", "count"])
+def test_emat_known_answer_pose(score):
+    batch, out = _case([2000, 800], [21, 22], outl=0.3, score=score)
     for b in range(2):
         tg = batch["t_gt"][b] / np.linalg.norm(batch["t_gt"][b])
         assert synth.rot_err_deg(out["R"][b], batch["R_gt"][b]) < 0.5
