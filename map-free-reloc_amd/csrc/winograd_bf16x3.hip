@@ -44,6 +44,9 @@
 
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float wb_f32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) float wb_lds_f32;
+typedef __attribute__((address_space(3))) wb_f32x2 wb_lds_f32x2;
 
 #define WB_RSRC_FLAGS 0x00020000
 #define WB_OOB 0x80000000u
@@ -516,6 +519,385 @@ __global__ void __launch_bounds__(256, 1) wino_bf16x3_kernel(
     WB_STAMP(45);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 4: the same arithmetic at TWO wavefronts per SIMD.  The kernel above owns the whole accumulator file (256 registers, one
+// wavefront per SIMD): every LDS / L2 latency, the prologue and the output transform of a tile run with the matrix pipe idle
+// (profiles/r03_ablate_conv_timeline.json: 45 k cycles per tile, 12.3 k of them MFMA).  Here a workgroup is still four wavefronts
+// -- wavefront i = Winograd row i, so no operand is shared between wavefronts and none crosses LDS -- but it covers 64 tiles x
+// 32 output channels: 128 accumulators, <= 256 registers, 64 KB of LDS, so TWO workgroups (two output-channel halves, or two
+// spatial blocks) live on a CU and one's stalls, prologue and epilogue are covered by the other's MFMAs; no barrier couples them.
+// What it costs: both workgroups of a tile produce the same V (the patch read, the row / column combinations and the 3-way
+// split are done twice per CU: ~10 VALU per MFMA instead of 5), which the second wavefront's issue slots absorb.
+// To fit 256 registers nothing is double-buffered in registers: per K step the 12 filter fragments of the row stay resident
+// (48 registers, re-requested one by one right after their last use), the row combinations exist for ONE 32-tile half at a time
+// (32 registers), V for one position at a time (12), and the patch pieces go to LDS by DMA (no register at all).
+// ABL != 0: timing ablations (results are WRONG): 1 = no output transform / stores, 2 = no filter fragment loads, 4 = no V production
+// (column combinations, split), 8 = no patch DMA and no LDS patch reads, 16 = no patch DMA only, 32 = no LDS patch reads only, 64 = no MFMAs.
+// TUNE: experiments that keep the result right: 1 = no scheduling fences inside the V production, 2 = row combinations four channels at a time
+template <bool POOL, int ABL = 0, int TUNE = 0>
+__global__ void __launch_bounds__(256, 2) wino_bf16x3_w2_kernel(
+    const float *__restrict__ x, const uint4 *__restrict__ upk, const float *__restrict__ bias, float *__restrict__ y,
+    const float *__restrict__ residual, int Cin, int Cout, int H, int W, int nbx, int nby, int S, int Sx, int ncg, int nks, int act)
+{
+    // [2][WB_STAGE] patch staging during the K loop (60 KB), the 4 x 16 KB row partials afterwards (64 KB)
+    __shared__ __attribute__((aligned(16))) float lds[16384];
+    const int id = blockIdx.x;
+    const int xcd = id & 7, jj = id >> 3;
+    const int cg = jj % ncg;                                              // 32-channel output group
+    const int sl = jj / ncg;
+    const int s = xcd * Sx + sl;
+    if (sl >= Sx || s >= S) return;
+    const int bx = s % nbx, by = (s / nbx) % nby, b = s / (nbx * nby);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wi = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int col = lane & 15, tysub = (lane >> 4) & 1, kg = lane >> 5;
+    const int HW = H * W;
+
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(x + (size_t)b * Cin * HW), 0, Cin * HW * 4, WB_RSRC_FLAGS);
+    // patch staging exactly as in the kernel above (same window, same piece <-> lane map, same border handling), one input channel
+    // (two pieces per lane) at a time
+    const int prow = lane / 12, pk = lane - 12 * prow;
+    const int pix = 32 * bx - 1 + 4 * pk;
+    unsigned voff[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int iy = 8 * by - 1 + 5 * h + prow;
+        const bool ok = prow < 5 && pk < 9 && iy >= 0 && iy < H && pix < W && pix + 3 >= 0;
+        voff[h] = ok ? (unsigned)(iy * W + max(pix, 0)) * 4u : WB_OOB;
+    }
+    const bool fixl = pix < 0;
+    unsigned keep = 0;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) if (pix + d >= 0 && pix + d < W) keep |= 1u << d;
+    const bool edge = (bx == 0) || (32 * bx + 35 >= W);
+    // LDS-DMA (buffer_load_dwordx4 ... lds): the staged layout is lane-linear per (channel, half) -- 5 rows x 12 pieces = 60 lanes x
+    // 16 bytes -- so a piece goes from L2 / HBM to its LDS slot without touching a register, a whole K step ahead of its use.
+    // Pieces outside the image come back as zeros (offset beyond the buffer); the few pieces that STRADDLE the left / right image
+    // border are patched in LDS by the lane that requested them (pfix; edge workgroups only).
+    // The request is inline asm on purpose: hipcc treats an LDS-DMA it knows about as a pending store to the whole LDS array and
+    // waits vmcnt(0) before the next ds_read -- i.e. right after issuing it.  Nothing in the step reads the stage being filled;
+    // the step's own vmcnt(0) (WB2_VMCNT0, a builtin hipcc does see) and the barrier order it before the next step's reads.
+    typedef unsigned wb_u32x4 __attribute__((ext_vector_type(4)));
+    wb_u32x4 xdesc;
+    {
+        const unsigned long long xa = (unsigned long long)(x + (size_t)b * Cin * HW);
+        xdesc.x = __builtin_amdgcn_readfirstlane((unsigned)xa);
+        xdesc.y = __builtin_amdgcn_readfirstlane((unsigned)(xa >> 32) & 0xffffu);
+        xdesc.z = (unsigned)(Cin * HW) * 4u;
+        xdesc.w = WB_RSRC_FLAGS;
+    }
+    const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) float *)lds;
+    auto pdma = [&](int c, int buf) {
+        if (ABL & (8 | 16)) return;
+        if (prow < 5) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const unsigned so = (unsigned)(16 * c + 4 * wi + q) * (unsigned)HW * 4u;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const unsigned m0v = lds0 + 4u * (unsigned)(buf * WB_STAGE + (4 * wi + q) * WB_CH + (5 * h) * WB_RS);
+                    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" :: "s"(m0v), "v"(voff[h]), "s"(xdesc), "s"(so) : "memory");
+                }
+            }
+        }
+    };
+    auto pfix = [&](int buf) {
+        if (edge && prow < 5 && (fixl || keep != 0xfu)) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                uint4 *pp = (uint4 *)(lds + buf * WB_STAGE + (4 * wi + (k >> 1)) * WB_CH + (5 * (k & 1)) * WB_RS + lane * 4);
+                uint4 v = *pp;
+                if (fixl) v = make_uint4(0u, v.x, v.y, v.z);
+                v.x = (keep & 1u) ? v.x : 0u; v.y = (keep & 2u) ? v.y : 0u; v.z = (keep & 4u) ? v.z : 0u; v.w = (keep & 8u) ? v.w : 0u;
+                *pp = v;
+            }
+        }
+    };
+#define WB2_VMCNT0() __builtin_amdgcn_s_waitcnt(0x0F70)                  /* vmcnt(0) only; the builtin (not inline asm) so that hipcc's own wait bookkeeping sees it */
+
+    const int ra = (wi == 0) ? 0 : (wi == 2) ? 2 : 1;
+    const int rb = (wi == 0) ? 2 : (wi == 2) ? 1 : (wi == 1) ? 2 : 3;
+    const float sg = (wi == 1) ? 1.0f : -1.0f;
+    const int ofa0 = (2 * tysub + ra) * WB_RS + 2 * col, ofb0 = (2 * tysub + rb) * WB_RS + 2 * col;    // tile block nb: + 4 nb WB_RS
+    float wv[8][4];
+    // row combinations of one 32-tile half, two input channels at a time (register budget: 16 in flight, not 64)
+    auto wread = [&](int buf, int nb) {
+        const wb_lds_f32 *st = (const wb_lds_f32 *)lds + buf * WB_STAGE + (8 * kg) * WB_CH + 4 * nb * WB_RS;
+        constexpr int EB = (TUNE & 2) ? 4 : 2;
+#pragma unroll
+        for (int e0 = 0; e0 < 8; e0 += EB) {
+            wb_f32x2 r2[EB][4];
+#pragma unroll
+            for (int e = 0; e < EB; ++e) {
+                const wb_lds_f32 *ch = st + (e0 + e) * WB_CH;
+                if (ABL & (8 | 32)) { r2[e][0] = wb_f32x2{1.f + e0, 2.f + nb}; r2[e][1] = wb_f32x2{3.f + e, 4.f + lane}; r2[e][2] = r2[e][1]; r2[e][3] = r2[e][0]; continue; }
+                // volatile: keeps hipcc from fusing the two 8-byte reads of a row into ds_read2_b64, which the LDS serves at a
+                // quarter of the rate of two ds_read_b64 (MI355X_MICROARCH.md, LDS table: 16 vs 2 + 2 cycles per wavefront)
+                r2[e][0] = *(const volatile wb_lds_f32x2 *)(ch + ofa0); r2[e][1] = *(const volatile wb_lds_f32x2 *)(ch + ofa0 + 2);
+                r2[e][2] = *(const volatile wb_lds_f32x2 *)(ch + ofb0); r2[e][3] = *(const volatile wb_lds_f32x2 *)(ch + ofb0 + 2);
+            }
+#pragma unroll
+            for (int e = 0; e < EB; ++e) {
+                wv[e0 + e][0] = __builtin_fmaf(sg, r2[e][2].x, r2[e][0].x); wv[e0 + e][1] = __builtin_fmaf(sg, r2[e][2].y, r2[e][0].y);
+                wv[e0 + e][2] = __builtin_fmaf(sg, r2[e][3].x, r2[e][1].x); wv[e0 + e][3] = __builtin_fmaf(sg, r2[e][3].y, r2[e][1].y);
+            }
+            // pin the combinations HERE: left alone, instruction selection sinks them below the next batches' reads and all 64 raw
+            // values are live at once (the 20 registers that spilled)
+#pragma unroll
+            for (int e = 0; e < EB; e += 2)
+                asm volatile("" : "+v"(wv[e0 + e][0]), "+v"(wv[e0 + e][1]), "+v"(wv[e0 + e][2]), "+v"(wv[e0 + e][3]),
+                                  "+v"(wv[e0 + e + 1][0]), "+v"(wv[e0 + e + 1][1]), "+v"(wv[e0 + e + 1][2]), "+v"(wv[e0 + e + 1][3]) :: "memory");
+        }
+    };
+    // V(wi, j) of the half, split and packed two input channels at a time
+    auto vmake = [&](WbFrag (&vf)[3], int j) {
+        if (ABL & 4) {
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) vf[t].u[k] = __float_as_uint(wv[2 * k][j]) ^ __float_as_uint(wv[2 * k + 1][t]);
+            return;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            unsigned h[2], m[2], l[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const float *q = wv[2 * k + e];
+                const float v = (j == 0) ? q[0] - q[2] : (j == 1) ? q[1] + q[2] : (j == 2) ? q[2] - q[1] : q[1] - q[3];
+                wb_split3(v, h[e], m[e], l[e]);
+            }
+            vf[0].u[k] = wb_pack(h[0], h[1]);
+            vf[1].u[k] = wb_pack(m[0], m[1]);
+            vf[2].u[k] = wb_pack(l[0], l[1]);
+            if (!(TUNE & 1)) __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    // filter fragments of row wi: the packed layout keeps 64-channel groups [mb][term]; this workgroup's half is mb = cg & 1.
+    // Buffer loads: the fragment index is wave-uniform (scalar offset), the only vector address is lane * 16.
+    const __amdgpu_buffer_rsrc_t rsF = __builtin_amdgcn_make_buffer_rsrc((void *)upk, 0, (int)(((ncg + 1) >> 1) * nks * WB_FRAGS_PER_KSTEP * 1024), WB_RSRC_FLAGS);
+    const unsigned fbase = (unsigned)(((cg >> 1) * nks * WB_FRAGS_PER_KSTEP + wi * 24 + (cg & 1) * 3) * 1024);
+    const unsigned lane16 = (unsigned)lane * 16u;
+    WbFrag F[4][3];
+    auto aload = [&](int c, int j) {
+        const unsigned so = fbase + (unsigned)((c * WB_FRAGS_PER_KSTEP + j * 6) * 1024);
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            if (ABL & 2) F[j][t].q = make_uint4(0x3f803f80u + lane, 0x3f803f80u + j, 0x3f803f80u + t, 0x3f803f80u + c);
+            else F[j][t].q = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsF, lane16, so + t * 1024u, 0));
+        }
+    };
+#define WB2_PROD(j, nb, ta, tb) do { if (ABL & 64) { acc[j][nb][ta] += __uint_as_float(F[j][ta].u[tb] ^ vf[tb].u[ta]); } else acc[j][nb] = WB_MFMA(F[j][ta].v, vf[tb].v, acc[j][nb]); } while (0)
+#define WB2_PHASE(j, nb) do { WB2_PROD(j, nb, 1, 1); WB2_PROD(j, nb, 0, 2); WB2_PROD(j, nb, 2, 0); \
+                              WB2_PROD(j, nb, 0, 1); WB2_PROD(j, nb, 1, 0); WB2_PROD(j, nb, 0, 0); } while (0)
+
+    // ---- prologue: the patches and the row's filter fragments of step 0
+#pragma unroll
+    for (int j = 0; j < 4; ++j) aload(0, j);
+    pdma(0, 0);
+    WB2_VMCNT0();
+    pfix(0);
+    __syncthreads();
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][nb][r] = 0.f;
+
+    // ---- K loop.  A step = 2 tile halves x 4 positions; sub-phase k = 4 nb + j: V(wi, j) of the half, then its six products.
+    // Top of step c: the eight patch pieces of step c + 1 are requested (LDS-DMA into the other stage: a whole step to land);
+    // the filter fragments of step c + 1 are requested right after the last product that reads those of step c; ONE vmcnt(0)
+    // before the step's barrier covers both.  vmcnt retires in order and hipcc waits vmcnt(0) for a register load whenever an
+    // LDS-DMA is in flight -- so no register load may be WAITED for between the DMA requests and that barrier: the fragments of
+    // step c are complete (same vmcnt(0), one step earlier) before the DMAs of step c + 1 go out.
+    int c = 0;
+    for (; c + 1 < nks; ++c) {
+        pdma(c + 1, (c + 1) & 1);
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            wread(c & 1, nb);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                WbFrag vf[3];
+                vmake(vf, j);
+                WB2_PHASE(j, nb);
+                if (nb == 1) aload(c + 1, j);
+            }
+        }
+        WB2_VMCNT0();
+        pfix((c + 1) & 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {                                      // last step: nothing left to request
+        wread(c & 1, nb);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            WbFrag vf[3];
+            vmake(vf, j);
+            WB2_PHASE(j, nb);
+        }
+    }
+#undef WB2_PHASE
+#undef WB2_PROD
+
+    if (ABL & 1) {
+        float t = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) t += acc[j][nb][r];
+        if (t == 12345.678f) y[tid] = t;
+        return;
+    }
+    // ---- output transform: as above with one 32-channel block; the four rows meet in LDS as part[row][ab][nb][r4][lane] (float4 =
+    // registers 4 r4 .. 4 r4 + 3); wavefront q finishes tile half q & 1, register groups r4 = 2 (q >> 1), 2 (q >> 1) + 1.
+    const int qnb = wi & 1, qh = wi >> 1;
+    const int co0 = cg * 32 + 4 * kg + 16 * qh;            // this lane's channels: co0 + (r' & 3) + 8 (r' >> 2), r' = 0..7
+    __syncthreads();                                        // every wavefront is done with the patch stages
+    float4 *part = (float4 *)lds;
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+            float pa[4], pb[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int r = 4 * r4 + k;
+                pa[k] = (acc[0][nb][r] + acc[1][nb][r]) + acc[2][nb][r];
+                pb[k] = (acc[1][nb][r] - acc[2][nb][r]) - acc[3][nb][r];
+            }
+            part[(((wi * 2 + 0) * 2 + nb) * 4 + r4) * 64 + lane] = make_float4(pa[0], pa[1], pa[2], pa[3]);
+            part[(((wi * 2 + 1) * 2 + nb) * 4 + r4) * 64 + lane] = make_float4(pb[0], pb[1], pb[2], pb[3]);
+        }
+    float bv[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) bv[r] = 0.f;
+    if (bias) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) bv[r] = bias[min(co0 + (r & 3) + 8 * (r >> 2), Cout - 1)];
+    }
+    __syncthreads();
+
+    const int tr = 2 * qnb + tysub;
+    const int ty = 4 * by + tr, tx = 16 * bx + col;
+    const int Ho = POOL ? (H >> 1) : H, Wo = POOL ? (W >> 1) : W;
+    const float4 *pq = part + (qnb * 4 + 2 * qh) * 64 + lane;          // + (row * 2 + ab) * 8 * 64 + r4' * 64
+    float Y[8][4];
+    {
+        float4 P[2][4][2];
+#pragma unroll
+        for (int r4 = 0; r4 < 2; ++r4)
+#pragma unroll
+            for (int row = 0; row < 4; ++row)
+#pragma unroll
+                for (int ab = 0; ab < 2; ++ab) P[r4][row][ab] = pq[((row * 2 + ab) * 8 + r4) * 64];
+#pragma unroll
+        for (int r4 = 0; r4 < 2; ++r4) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int r = 4 * r4 + k;
+#define WB_EL(v) (k == 0 ? (v).x : k == 1 ? (v).y : k == 2 ? (v).z : (v).w)
+                Y[r][0] = ((WB_EL(P[r4][0][0]) + WB_EL(P[r4][1][0])) + WB_EL(P[r4][2][0])) + bv[r];
+                Y[r][1] = ((WB_EL(P[r4][0][1]) + WB_EL(P[r4][1][1])) + WB_EL(P[r4][2][1])) + bv[r];
+                Y[r][2] = ((WB_EL(P[r4][1][0]) - WB_EL(P[r4][2][0])) - WB_EL(P[r4][3][0])) + bv[r];
+                Y[r][3] = ((WB_EL(P[r4][1][1]) - WB_EL(P[r4][2][1])) - WB_EL(P[r4][3][1])) + bv[r];
+#undef WB_EL
+            }
+        }
+    }
+    const size_t cstride = (size_t)Ho * Wo;
+    float *yb = y + ((size_t)b * Cout + co0) * cstride;
+    const bool allco = cg * 32 + 32 <= Cout;
+    if (POOL) {
+        float m[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) m[r] = fmaxf(fmaxf(Y[r][0], Y[r][1]), fmaxf(Y[r][2], Y[r][3]));
+        if (act == 1) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) m[r] = fmaxf(m[r], 0.f);
+        } else if (act == 2) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) m[r] = m[r] > 0.f ? m[r] : 0.01f * m[r];
+        }
+        if (ty < Ho && tx < Wo) {
+            float *yo = yb + (size_t)ty * Wo + tx;
+            if (allco) {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) yo[(size_t)((r & 3) + 8 * (r >> 2)) * cstride] = m[r];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const int dc = (r & 3) + 8 * (r >> 2);
+                    if (co0 + dc < Cout) yo[(size_t)dc * cstride] = m[r];
+                }
+            }
+        }
+    } else {
+        const int oy = 2 * ty, ox = 2 * tx;
+        const bool c0 = ox < W, c1 = ox + 1 < W, r0 = oy < H, r1 = oy + 1 < H;
+        if (residual) {
+            const float *rb0 = residual + ((size_t)b * Cout + co0) * cstride + (size_t)oy * W + ox;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int dc = (r & 3) + 8 * (r >> 2);
+                if (allco || co0 + dc < Cout) {
+                    const float *ro = rb0 + (size_t)dc * cstride;
+                    if (r0 && c0) Y[r][0] += ro[0];
+                    if (r0 && c1) Y[r][1] += ro[1];
+                    if (r1 && c0) Y[r][2] += ro[W];
+                    if (r1 && c1) Y[r][3] += ro[W + 1];
+                }
+            }
+        }
+        float *yo0 = yb + (size_t)oy * W + ox;
+        if (act == 1) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) Y[r][k] = fmaxf(Y[r][k], 0.f);
+        } else if (act == 2) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) Y[r][k] = Y[r][k] > 0.f ? Y[r][k] : 0.01f * Y[r][k];
+        }
+        const bool interior = allco && r0 && r1 && c1 && !(W & 1);
+        if (interior) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                float *yo = yo0 + (size_t)((r & 3) + 8 * (r >> 2)) * cstride;
+                *(float2 *)yo = make_float2(Y[r][0], Y[r][1]);
+                *(float2 *)(yo + W) = make_float2(Y[r][2], Y[r][3]);
+            }
+        } else
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const float y00 = Y[r][0], y01 = Y[r][1], y10 = Y[r][2], y11 = Y[r][3];
+            const int dc = (r & 3) + 8 * (r >> 2);
+            if (!(allco || co0 + dc < Cout)) continue;
+            float *yo = yo0 + (size_t)dc * cstride;
+            if (c1) {
+                if (!(W & 1)) {
+                    if (r0) *(float2 *)yo = make_float2(y00, y01);
+                    if (r1) *(float2 *)(yo + W) = make_float2(y10, y11);
+                } else {
+                    if (r0) { yo[0] = y00; yo[1] = y01; }
+                    if (r1) { yo[W] = y10; yo[W + 1] = y11; }
+                }
+            } else if (c0) {
+                if (r0) yo[0] = y00;
+                if (r1) yo[W] = y10;
+            }
+        }
+    }
+}
+
 extern "C" {
 
 size_t mfr_wino_bf16x3_filter_bytes(int Cin, int Cout)
@@ -547,7 +929,27 @@ int mfr_conv3x3_wino_bf16x3_variant(const float *x, const void *upk, const float
     if (grid > 0x7fffffffll) return MFR_E_ARG;
     hipStream_t st = (hipStream_t)stream;
 #define WB_GO(K) hipLaunchKernelGGL(K, dim3((unsigned)grid), dim3(256), 0, st, x, (const uint4 *)upk, bias, y, residual, Cin, Cout, H, W, nbx, nby, (int)S, (int)Sx, ncg, nks, act)
-    if (variant == 0) { if (pool) WB_GO((wino_bf16x3_kernel<true>)); else WB_GO((wino_bf16x3_kernel<false>)); }
+    if (variant >= 200 && variant < 328 && pool) {     // timing ablations of the two-workgroups-per-CU kernel: 200 + ABL (results are wrong)
+        const int ncg2 = (Cout + 31) / 32;
+        const long long grid2 = Sx * 8 * ncg2;
+        switch (variant - 200) {
+#define WB_ABL2(A) case A: hipLaunchKernelGGL((wino_bf16x3_w2_kernel<true, A>), dim3((unsigned)grid2), dim3(256), 0, st, x, (const uint4 *)upk, bias, y, residual, Cin, Cout, H, W, nbx, nby, (int)S, (int)Sx, ncg2, nks, act); break;
+        WB_ABL2(1) WB_ABL2(2) WB_ABL2(4) WB_ABL2(8) WB_ABL2(12) WB_ABL2(14) WB_ABL2(15) WB_ABL2(64) WB_ABL2(16) WB_ABL2(32)
+        case 101: hipLaunchKernelGGL((wino_bf16x3_w2_kernel<true, 0, 1>), dim3((unsigned)grid2), dim3(256), 0, st, x, (const uint4 *)upk, bias, y, residual, Cin, Cout, H, W, nbx, nby, (int)S, (int)Sx, ncg2, nks, act); break;
+        case 102: hipLaunchKernelGGL((wino_bf16x3_w2_kernel<true, 0, 2>), dim3((unsigned)grid2), dim3(256), 0, st, x, (const uint4 *)upk, bias, y, residual, Cin, Cout, H, W, nbx, nby, (int)S, (int)Sx, ncg2, nks, act); break;
+        case 103: hipLaunchKernelGGL((wino_bf16x3_w2_kernel<true, 0, 3>), dim3((unsigned)grid2), dim3(256), 0, st, x, (const uint4 *)upk, bias, y, residual, Cin, Cout, H, W, nbx, nby, (int)S, (int)Sx, ncg2, nks, act); break;
+#undef WB_ABL2
+        default: return MFR_E_ARG;
+        }
+    }
+    else if (variant == 2) {                           // two workgroups per CU: 64 tiles x 32 output channels each
+        const int ncg2 = (Cout + 31) / 32;
+        const long long grid2 = Sx * 8 * ncg2;
+        if (grid2 > 0x7fffffffll) return MFR_E_ARG;
+        if (pool) hipLaunchKernelGGL((wino_bf16x3_w2_kernel<true>), dim3((unsigned)grid2), dim3(256), 0, st, x, (const uint4 *)upk, bias, y, residual, Cin, Cout, H, W, nbx, nby, (int)S, (int)Sx, ncg2, nks, act);
+        else hipLaunchKernelGGL((wino_bf16x3_w2_kernel<false>), dim3((unsigned)grid2), dim3(256), 0, st, x, (const uint4 *)upk, bias, y, residual, Cin, Cout, H, W, nbx, nby, (int)S, (int)Sx, ncg2, nks, act);
+    }
+    else if (variant == 0 || variant == 32) { if (pool) WB_GO((wino_bf16x3_kernel<true>)); else WB_GO((wino_bf16x3_kernel<false>)); }
     else if (pool) {                                   // timing ablations (tools/bench_conv.py): pooled layers only
         switch (variant) {
 #define WB_ABL(A) case A: WB_GO((wino_bf16x3_kernel<true, A>)); break;

@@ -22,15 +22,18 @@ def _pack(w):
     return u
 
 
-def _conv(x, w, b, act, pool, residual=None):
+VARIANTS = {"default": 0, "one_wave_per_simd": 32, "two_workgroups_per_cu": 2}      # mfr_conv3x3_wino_bf16x3_variant
+
+
+def _conv(x, w, b, act, pool, residual=None, variant=0):
     lib = _lib.load(require_gpu=True)
     B, ci, H, W = x.shape
     co = w.shape[0]
     u = _pack(w)
     y = torch.full((B, co, H // 2, W // 2) if pool else (B, co, H, W), float("nan"), dtype=torch.float32, device=x.device)
-    _lib.check(lib.mfr_conv3x3_wino_bf16x3(_lib.ptr(x), _lib.ptr(u), _lib.ptr(b) if b is not None else None,
-                                           _lib.ptr(residual) if residual is not None else None, B, ci, co, H, W, int(act), int(pool),
-                                           _lib.ptr(y), _lib.stream_ptr()), "conv")
+    _lib.check(lib.mfr_conv3x3_wino_bf16x3_variant(_lib.ptr(x), _lib.ptr(u), _lib.ptr(b) if b is not None else None,
+                                                   _lib.ptr(residual) if residual is not None else None, B, ci, co, H, W, int(act), int(pool),
+                                                   int(variant), _lib.ptr(y), _lib.stream_ptr()), "conv")
     return y
 
 
@@ -64,13 +67,14 @@ def _ref(x, w, b, act, pool, residual=None):
     # LoFTR backbone shapes: 196-channel stages, LeakyReLU, residual
     (1, 196, 196, 23, 34, 1, 0, 1, 1), (2, 196, 128, 20, 17, 2, 0, 1, 0), (1, 128, 128, 30, 44, 1, 0, 1, 1), (2, 8, 5, 9, 10, 2, 0, 1, 1),
     (1, 256, 196, 45, 34, 2, 1, 1, 0), (1, 12, 40, 7, 9, 0, 0, 1, 1), (1, 128, 196, 136, 180, 1, 0, 1, 1)])
-def test_bf16x3_conv_vs_float64(B, ci, co, H, W, act, pool, bias, res):
+@pytest.mark.parametrize("variant", sorted(VARIANTS))
+def test_bf16x3_conv_vs_float64(B, ci, co, H, W, act, pool, bias, res, variant):
     g = torch.Generator().manual_seed(B * 1000 + ci + H)
     x = torch.randn(B, ci, H, W, generator=g).to(DEV)
     w = (torch.randn(co, ci, 3, 3, generator=g) / (3.0 * ci ** 0.5)).to(DEV)
     b = torch.randn(co, generator=g).to(DEV) if bias else None
     r = torch.randn(B, co, H, W, generator=g).to(DEV) if res else None
-    y = _conv(x, w, b, act, pool, r)
+    y = _conv(x, w, b, act, pool, r, VARIANTS[variant])
     want = _ref(x, w, b, act, pool, r)
     assert y.shape == want.shape
     assert torch.isfinite(y).all()                       # every output element written
@@ -89,6 +93,20 @@ def test_bf16x3_error_class_equals_exact_fp32_kernel():
         e1 = (_exact(x, w, None, 0, 0).double().cpu() - want) / scale
         assert e3.abs().max() <= 1.5 * e1.abs().max() and e3.pow(2).mean().sqrt() <= 1.5 * e1.pow(2).mean().sqrt(), \
             (scale, float(e3.abs().max()), float(e1.abs().max()))
+
+
+def test_bf16x3_kernel_generations_agree_bitwise():
+    """the two-workgroups-per-CU kernel (round 4) runs the SAME products in the SAME order per output as the one-wavefront-per-SIMD
+    kernel (round 3): outputs are the same bits, on a full-size layer of every kind the networks use"""
+    g = torch.Generator().manual_seed(5)
+    for (B, ci, co, H, W, act, pool, res) in ((2, 64, 64, 720, 540, 1, 1, 0), (2, 64, 128, 180, 135, 1, 0, 0), (1, 196, 196, 360, 272, 2, 0, 1),
+                                              (1, 256, 196, 90, 68, 1, 0, 1)):
+        x = torch.randn(B, ci, H, W, generator=g).to(DEV)
+        w = (torch.randn(co, ci, 3, 3, generator=g) / (3.0 * ci ** 0.5)).to(DEV)
+        b = torch.randn(co, generator=g).to(DEV)
+        r = torch.randn(B, co, H, W, generator=g).to(DEV) if res else None
+        y1, y2 = _conv(x, w, b, act, pool, r, 32), _conv(x, w, b, act, pool, r, 2)
+        assert torch.equal(y1, y2)
 
 
 def test_bf16x3_linearity_and_shift():

@@ -27,8 +27,11 @@ for name, ci, co, H, W, pool in LAYERS:
     u3 = torch.empty(lib.mfr_wino_bf16x3_filter_bytes(ci, co), dtype=torch.uint8, device=dev)
     lib.mfr_wino_bf16x3_filter_transform(_lib.ptr(w), ci, co, _lib.ptr(u3), _lib.stream_ptr())
     rec = {}
-    for tag, fn, u in (("exact_fp32", lib.mfr_conv3x3_wino, u1), ("bf16x3", lib.mfr_conv3x3_wino_bf16x3, u3), ("exact_fp32_b", lib.mfr_conv3x3_wino, u1),
-                       ("bf16x3_b", lib.mfr_conv3x3_wino_bf16x3, u3)):
+    def variant(v):
+        return lambda *a: lib.mfr_conv3x3_wino_bf16x3_variant(*a[:11], v, *a[11:])
+    for tag, fn, u in (("exact_fp32", lib.mfr_conv3x3_wino, u1), ("bf16x3", variant(0), u3), ("bf16x3_1wave", variant(32), u3),
+                       ("bf16x3_w2", variant(2), u3), ("exact_fp32_b", lib.mfr_conv3x3_wino, u1),
+                       ("bf16x3_b", variant(0), u3), ("bf16x3_1wave_b", variant(32), u3), ("bf16x3_w2_b", variant(2), u3)):
         for _ in range(2):
             fn(_lib.ptr(x), _lib.ptr(u), _lib.ptr(b), None, n, ci, co, H, W, 1, pool, _lib.ptr(y), _lib.stream_ptr())
         torch.cuda.synchronize()
@@ -42,6 +45,8 @@ for name, ci, co, H, W, pool in LAYERS:
     rec["images"] = n
     rec["fp32_equiv_tflops_bf16x3"] = round(wino_flops / min(rec["bf16x3"], rec["bf16x3_b"]) / 1e9, 1)
     rec["fp32_tflops_exact"] = round(wino_flops / min(rec["exact_fp32"], rec["exact_fp32_b"]) / 1e9, 1)
+    rec["bf16_tflops_w2"] = round(6 * wino_flops / min(rec["bf16x3_w2"], rec["bf16x3_w2_b"]) / 1e9, 1)
+    rec["bf16_tflops_1wave"] = round(6 * wino_flops / min(rec["bf16x3_1wave"], rec["bf16x3_1wave_b"]) / 1e9, 1)
     res[name] = rec
     print(name, rec, flush=True)
 if len(sys.argv) > 1:
