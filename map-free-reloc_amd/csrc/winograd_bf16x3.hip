@@ -898,6 +898,382 @@ __global__ void __launch_bounds__(256, 2) wino_bf16x3_w2_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 4, second step: EIGHT wavefronts per workgroup, two per SIMD, nothing produced twice.
+// What the counters say about the two kernels above (profiles/r04_pmc_conv1b_w2_vs_1wave.json): the SIMD issues ONE instruction
+// per 4 cycles whatever the wavefront, a VALU instruction and an MFMA issue do not overlap, and the launch time is the SUM
+// (VALU 63 % + matrix pipe 36 % of the SIMD's cycles in the two-workgroup kernel, 2703 VALU per 192 MFMAs per wavefront).  So
+// the lever is the instruction count per tile, and what sets it is how often V -- 5.5 VALU per element for the exact 3-way split
+// -- is produced.  Here a workgroup is the 64-tile x 64-channel block of the first kernel again, and wavefront w owns Winograd row
+// i = w >> 1 and the column pair j in {2 jp, 2 jp + 1}, jp = w & 1: 2 positions x 2 channel blocks x 2 tile blocks = 128
+// accumulators; every position's V is produced by exactly one wavefront (272 VALU per 48 MFMAs instead of 566), every filter
+// fragment is requested by exactly one wavefront (12 per K step, resident, re-requested after their last use), the patches are
+// staged once per workgroup by LDS-DMA (four 16-byte pieces per wavefront and K step).  Only the row combination B^T d of a row is
+// evaluated by both wavefronts of a pair (48 of the 272).  The column pair decides which three of the four patch columns a
+// wavefront needs -- jp = 0: 0, 1, 2; jp = 1: 1, 2, 3 -- and they are fetched as one 8-byte and one 4-byte LDS read whose OFFSETS
+// depend on jp, so that the code is the same for both: X, Y = columns (0, 1) | (2, 3), Z = column 2 | 1, V(jj = 0) = X - Z,
+// V(jj = 1) = Z + beta Y with beta = +1 | -1.
+// The output transform needs all four rows and both column pairs of a tile: two rounds (one per 32-channel block) through the
+// 128 KB the patch stages no longer need; wavefront q finishes tile block q & 1, channel group q >> 1 of the round.
+template <bool POOL, int ABL = 0, int TUNE = 0>
+__global__ void __launch_bounds__(512, 2) wino_bf16x3_p8_kernel(
+    const float *__restrict__ x, const uint4 *__restrict__ upk, const float *__restrict__ bias, float *__restrict__ y,
+    const float *__restrict__ residual, int Cin, int Cout, int H, int W, int nbx, int nby, int S, int Sx, int ncg, int nks, int act)
+{
+    __shared__ __attribute__((aligned(16))) float lds[32768];
+    const int id = blockIdx.x;
+    const int xcd = id & 7, jq = id >> 3;
+    const int cg = jq % ncg;
+    const int sl = jq / ncg;
+    const int s = xcd * Sx + sl;
+    if (sl >= Sx || s >= S) return;
+    const int bx = s % nbx, by = (s / nbx) % nby, b = s / (nbx * nby);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wi = w >> 1, jp = w & 1;
+    const int col = lane & 15, tysub = (lane >> 4) & 1, kg = lane >> 5;
+    const int HW = H * W;
+
+    // ---- patch staging by LDS-DMA (see the kernel above): this wavefront stages input channels 2 w, 2 w + 1 of the step
+    const int prow = lane / 12, pk = lane - 12 * prow;
+    const int pix = 32 * bx - 1 + 4 * pk;
+    unsigned voff[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int iy = 8 * by - 1 + 5 * h + prow;
+        const bool ok = prow < 5 && pk < 9 && iy >= 0 && iy < H && pix < W && pix + 3 >= 0;
+        voff[h] = ok ? (unsigned)(iy * W + max(pix, 0)) * 4u : WB_OOB;
+    }
+    const bool fixl = pix < 0;
+    unsigned keep = 0;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) if (pix + d >= 0 && pix + d < W) keep |= 1u << d;
+    const bool edge = (bx == 0) || (32 * bx + 35 >= W);
+    typedef unsigned wb_u32x4 __attribute__((ext_vector_type(4)));
+    wb_u32x4 xdesc;
+    {
+        const unsigned long long xa = (unsigned long long)(x + (size_t)b * Cin * HW);
+        xdesc.x = __builtin_amdgcn_readfirstlane((unsigned)xa);
+        xdesc.y = __builtin_amdgcn_readfirstlane((unsigned)(xa >> 32) & 0xffffu);
+        xdesc.z = (unsigned)(Cin * HW) * 4u;
+        xdesc.w = WB_RSRC_FLAGS;
+    }
+    const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) float *)lds;
+    auto pdma = [&](int c, int buf) {
+        if (ABL & (8 | 16)) return;
+        if (prow < 5) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const unsigned so = (unsigned)(16 * c + 2 * w + q) * (unsigned)HW * 4u;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const unsigned m0v = lds0 + 4u * (unsigned)(buf * WB_STAGE + (2 * w + q) * WB_CH + (5 * h) * WB_RS);
+                    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" :: "s"(m0v), "v"(voff[h]), "s"(xdesc), "s"(so) : "memory");
+                }
+            }
+        }
+    };
+    auto pfix = [&](int buf) {
+        if (edge && prow < 5 && (fixl || keep != 0xfu)) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                uint4 *pp = (uint4 *)(lds + buf * WB_STAGE + (2 * w + (k >> 1)) * WB_CH + (5 * (k & 1)) * WB_RS + lane * 4);
+                uint4 v = *pp;
+                if (fixl) v = make_uint4(0u, v.x, v.y, v.z);
+                v.x = (keep & 1u) ? v.x : 0u; v.y = (keep & 2u) ? v.y : 0u; v.z = (keep & 4u) ? v.z : 0u; v.w = (keep & 8u) ? v.w : 0u;
+                *pp = v;
+            }
+        }
+    };
+
+    // ---- row combination of Winograd row wi (as above) for the three patch columns of column pair jp
+    const int ra = (wi == 0) ? 0 : (wi == 2) ? 2 : 1;
+    const int rb = (wi == 0) ? 2 : (wi == 2) ? 1 : (wi == 1) ? 2 : 3;
+    const float sg = (wi == 1) ? 1.0f : -1.0f;
+    const float beta = jp ? -1.0f : 1.0f;
+    const int cX = jp ? 2 : 0, cZ = jp ? 1 : 2;
+    const int ofa = (2 * tysub + ra) * WB_RS + 2 * col, ofb = (2 * tysub + rb) * WB_RS + 2 * col;    // tile block nb: + 4 nb WB_RS
+    float wX[8], wY[8], wZ[8];
+    auto wread = [&](int buf, int nb) {
+        const wb_lds_f32 *st = (const wb_lds_f32 *)lds + buf * WB_STAGE + (8 * kg) * WB_CH + 4 * nb * WB_RS;
+#pragma unroll
+        for (int e0 = 0; e0 < 8; e0 += 4) {
+            wb_f32x2 a2[4], b2[4];
+            float a1[4], b1[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const wb_lds_f32 *ch = st + (e0 + e) * WB_CH;
+                if (ABL & (8 | 32)) { a2[e] = wb_f32x2{1.f + e0, 2.f + nb}; b2[e] = wb_f32x2{3.f + e, 4.f + lane}; a1[e] = 5.f + e; b1[e] = 6.f + lane; continue; }
+                a2[e] = *(const volatile wb_lds_f32x2 *)(ch + ofa + cX); a1[e] = *(const volatile wb_lds_f32 *)(ch + ofa + cZ);
+                b2[e] = *(const volatile wb_lds_f32x2 *)(ch + ofb + cX); b1[e] = *(const volatile wb_lds_f32 *)(ch + ofb + cZ);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                wX[e0 + e] = __builtin_fmaf(sg, b2[e].x, a2[e].x); wY[e0 + e] = __builtin_fmaf(sg, b2[e].y, a2[e].y);
+                wZ[e0 + e] = __builtin_fmaf(sg, b1[e], a1[e]);
+            }
+            // pin the combinations here (otherwise they sink below the next batch's reads and the raw values pile up)
+            asm volatile("" : "+v"(wX[e0]), "+v"(wY[e0]), "+v"(wZ[e0]), "+v"(wX[e0 + 1]), "+v"(wY[e0 + 1]), "+v"(wZ[e0 + 1]),
+                              "+v"(wX[e0 + 2]), "+v"(wY[e0 + 2]), "+v"(wZ[e0 + 2]), "+v"(wX[e0 + 3]), "+v"(wY[e0 + 3]), "+v"(wZ[e0 + 3]) :: "memory");
+        }
+    };
+    // V(wi, 2 jp + jj) of the tile block, split and packed two input channels at a time
+    auto vmake = [&](WbFrag (&vf)[3], int jj) {
+        if (ABL & 4) {
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) vf[t].u[k] = __float_as_uint(wX[2 * k]) ^ __float_as_uint(jj ? wY[2 * k + 1] : wZ[2 * k + 1]) ^ (unsigned)t;
+            return;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            unsigned h[2], m[2], l[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int q = 2 * k + e;
+                const float v = jj ? __builtin_fmaf(beta, wY[q], wZ[q]) : wX[q] - wZ[q];
+                wb_split3(v, h[e], m[e], l[e]);
+            }
+            vf[0].u[k] = wb_pack(h[0], h[1]);
+            vf[1].u[k] = wb_pack(m[0], m[1]);
+            vf[2].u[k] = wb_pack(l[0], l[1]);
+        }
+    };
+
+    // ---- filter fragments of positions (wi, 2 jp), (wi, 2 jp + 1): [jj][mb][term], 12 consecutive fragments of the packed layout
+    const __amdgpu_buffer_rsrc_t rsF = __builtin_amdgcn_make_buffer_rsrc((void *)upk, 0, (int)(ncg * nks * WB_FRAGS_PER_KSTEP * 1024), WB_RSRC_FLAGS);
+    const unsigned fbase = (unsigned)((cg * nks * WB_FRAGS_PER_KSTEP + wi * 24 + jp * 12) * 1024);
+    const unsigned lane16 = (unsigned)lane * 16u;
+    WbFrag F[2][2][3];
+    auto aload = [&](int c, int jj) {
+        const unsigned so = fbase + (unsigned)((c * WB_FRAGS_PER_KSTEP + jj * 6) * 1024);
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                if (ABL & 2) F[jj][mb][t].q = make_uint4(0x3f803f80u + lane, 0x3f803f80u + jj, 0x3f803f80u + t, 0x3f803f80u + c);
+                else F[jj][mb][t].q = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsF, lane16, so + (unsigned)((mb * 3 + t) * 1024), 0));
+            }
+    };
+#define WB8_PROD(jj, nb, vf, ta, tb) do { \
+        if (ABL & 64) { acc[jj][0][nb][ta] += __uint_as_float(F[jj][0][ta].u[tb] ^ vf[tb].u[ta]); acc[jj][1][nb][ta] += __uint_as_float(F[jj][1][ta].u[tb] ^ vf[tb].u[ta]); } \
+        else { acc[jj][0][nb] = WB_MFMA(F[jj][0][ta].v, vf[tb].v, acc[jj][0][nb]); acc[jj][1][nb] = WB_MFMA(F[jj][1][ta].v, vf[tb].v, acc[jj][1][nb]); } } while (0)
+#define WB8_PHASE(jj, nb, vf) do { WB8_PROD(jj, nb, vf, 1, 1); WB8_PROD(jj, nb, vf, 0, 2); WB8_PROD(jj, nb, vf, 2, 0); \
+                                   WB8_PROD(jj, nb, vf, 0, 1); WB8_PROD(jj, nb, vf, 1, 0); WB8_PROD(jj, nb, vf, 0, 0); } while (0)
+#define WB8_VMCNT(n) __builtin_amdgcn_s_waitcnt(0x0F70 | ((n) & 15) | (((n) >> 4) << 14))      /* vmcnt(n) only */
+
+    // ---- prologue
+    aload(0, 0); aload(0, 1);
+    pdma(0, 0);
+    WB8_VMCNT(0);
+    pfix(0);
+    __syncthreads();
+    f32x16 acc[2][2][2];
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[jj][mb][nb][r] = 0.f;
+
+    // ---- K loop, software-pipelined.  A wavefront that alternates "produce V (52 VALU)" and "12 MFMAs" is blocked at the MFMA
+    // issue while the matrix pipe drains -- and with the barrier its SIMD partner is in the same phase at the same time, so
+    // nothing overlaps (6.5 ms: the sum).  tools/ubench/mfma_valu_bf16.hip: five VALU instructions per MFMA are free when they
+    // sit BETWEEN the MFMAs in program order.  So V is double-buffered (vfA / vfB) and every block of 12 MFMAs is written
+    // together with the production of the NEXT block's V:
+    //     S1  products (jj 0, nb 0; vfA)   +  V(jj 1, nb 0) -> vfB
+    //     S2  products (jj 1, nb 0; vfB)   +  row combinations of tile block 1, V(jj 0, nb 1) -> vfA
+    //     S3  products (jj 0, nb 1; vfA)   +  V(jj 1, nb 1) -> vfB;   fragments (jj 0) of the next step requested
+    //     -- vmcnt: the next step's patches are in; border fix-up; barrier --
+    //     S4  products (jj 1, nb 1; vfB)   +  row combinations of tile block 0 of the NEXT step, V(jj 0, nb 0) -> vfA;
+    //         fragments (jj 1) of the next step requested
+    // Top of a step: vmcnt(0) (the step's fragments are in; hipcc would otherwise wait vmcnt(0) at their first use, i.e. for
+    // the DMAs it cannot see), then the patch DMAs of the step after go out: three blocks of time to land.
+    // TUNE & 1: pin the interleave -- one MFMA, then nv VALU (+ nd LDS reads) -- with sched_group_barrier instead of leaving it to hipcc
+#define WB8_SCHED(nv, nd) do { if (TUNE & 1) { _Pragma("unroll") for (int q_ = 0; q_ < 12; ++q_) { __builtin_amdgcn_sched_group_barrier(0x8, 1, 0); \
+        if (nd) __builtin_amdgcn_sched_group_barrier(0x100, nd, 0); __builtin_amdgcn_sched_group_barrier(0x2, nv, 0); } } } while (0)
+    WbFrag vfA[3], vfB[3];
+    wread(0, 0);
+    vmake(vfA, 0);
+    int c = 0;
+    for (; c + 1 < nks; ++c) {
+        WB8_VMCNT(0);
+        pdma(c + 1, (c + 1) & 1);
+        vmake(vfB, 1);
+        WB8_PHASE(0, 0, vfA);
+        WB8_SCHED(5, 0);
+        if (TUNE & 2) __builtin_amdgcn_sched_barrier(0);
+        wread(c & 1, 1);
+        vmake(vfA, 0);
+        WB8_PHASE(1, 0, vfB);
+        WB8_SCHED(7, 3);
+        if (TUNE & 2) __builtin_amdgcn_sched_barrier(0);
+        vmake(vfB, 1);
+        WB8_PHASE(0, 1, vfA);
+        WB8_SCHED(5, 0);
+        aload(c + 1, 0);
+        WB8_VMCNT(6);                                                     // the four DMAs are older than the six fragment loads
+        pfix((c + 1) & 1);
+        __syncthreads();
+        wread((c + 1) & 1, 0);
+        vmake(vfA, 0);
+        WB8_PHASE(1, 1, vfB);
+        WB8_SCHED(7, 3);
+        aload(c + 1, 1);
+    }
+    WB8_VMCNT(0);
+    vmake(vfB, 1);
+    WB8_PHASE(0, 0, vfA);
+    WB8_SCHED(5, 0);
+    wread(c & 1, 1);
+    vmake(vfA, 0);
+    WB8_PHASE(1, 0, vfB);
+    WB8_SCHED(7, 3);
+    vmake(vfB, 1);
+    WB8_PHASE(0, 1, vfA);
+    WB8_SCHED(5, 0);
+    WB8_PHASE(1, 1, vfB);
+#undef WB8_SCHED
+#undef WB8_PHASE
+#undef WB8_PROD
+#undef WB8_VMCNT
+
+    if (ABL & 1) {
+        float t = 0.f;
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) t += acc[jj][mb][nb][r];
+        if (t == 12345.678f) y[tid] = t;
+        return;
+    }
+    // ---- output transform.  Row partials over j: pa = M0 + M1 + M2, pb = M1 - M2 - M3; wavefront (wi, 0) contributes (M0 + M1, M1),
+    // wavefront (wi, 1) contributes (M2, -(M2 + M3)).  Round mb: part[row][jp][ab][nb][r4][lane] (float4 = registers 4 r4 .. 4 r4 + 3),
+    // 8 x 16 KB; wavefront q then finishes tile block q & 1, register group q >> 1 (four channels) of the round.
+    const int qnb = w & 1, qr4 = w >> 1;
+    const int tr = 2 * qnb + tysub;
+    const int ty = 4 * by + tr, tx = 16 * bx + col;
+    const int Ho = POOL ? (H >> 1) : H, Wo = POOL ? (W >> 1) : W;
+    const size_t cstride = (size_t)Ho * Wo;
+    float4 *part = (float4 *)lds;
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+        __syncthreads();                                    // patch stages (mb = 0) / the previous round's partials (mb = 1) are dead
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                float pa[4], pb[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int r = 4 * r4 + k;
+                    const float sum = acc[0][mb][nb][r] + acc[1][mb][nb][r];
+                    pa[k] = jp ? acc[0][mb][nb][r] : sum;
+                    pb[k] = jp ? -sum : acc[1][mb][nb][r];
+                }
+                part[((((wi * 2 + jp) * 2 + 0) * 2 + nb) * 4 + r4) * 64 + lane] = make_float4(pa[0], pa[1], pa[2], pa[3]);
+                part[((((wi * 2 + jp) * 2 + 1) * 2 + nb) * 4 + r4) * 64 + lane] = make_float4(pb[0], pb[1], pb[2], pb[3]);
+            }
+        const int co0 = cg * 64 + mb * 32 + 4 * kg + 8 * qr4;       // this lane's four channels of the round: co0 + k
+        float bv[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) bv[k] = bias ? bias[min(co0 + k, Cout - 1)] : 0.f;
+        __syncthreads();
+        const float4 *pq = part + (qnb * 4 + qr4) * 64 + lane;      // + ((row * 2 + jp) * 2 + ab) * 8 * 64
+        float4 P[4][2];
+#pragma unroll
+        for (int row = 0; row < 4; ++row)
+#pragma unroll
+            for (int ab = 0; ab < 2; ++ab) {
+                const float4 u = pq[(((row * 2 + 0) * 2 + ab) * 8) * 64], v = pq[(((row * 2 + 1) * 2 + ab) * 8) * 64];
+                P[row][ab] = make_float4(u.x + v.x, u.y + v.y, u.z + v.z, u.w + v.w);
+            }
+        float Y[4][4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+#define WB_EL(v) (k == 0 ? (v).x : k == 1 ? (v).y : k == 2 ? (v).z : (v).w)
+            Y[k][0] = ((WB_EL(P[0][0]) + WB_EL(P[1][0])) + WB_EL(P[2][0])) + bv[k];
+            Y[k][1] = ((WB_EL(P[0][1]) + WB_EL(P[1][1])) + WB_EL(P[2][1])) + bv[k];
+            Y[k][2] = ((WB_EL(P[1][0]) - WB_EL(P[2][0])) - WB_EL(P[3][0])) + bv[k];
+            Y[k][3] = ((WB_EL(P[1][1]) - WB_EL(P[2][1])) - WB_EL(P[3][1])) + bv[k];
+#undef WB_EL
+        }
+        float *yb = y + ((size_t)b * Cout + co0) * cstride;
+        const bool allco = cg * 64 + mb * 32 + 32 <= Cout;
+        if (POOL) {
+            float m[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                m[k] = fmaxf(fmaxf(Y[k][0], Y[k][1]), fmaxf(Y[k][2], Y[k][3]));
+                if (act == 1) m[k] = fmaxf(m[k], 0.f);
+                else if (act == 2) m[k] = m[k] > 0.f ? m[k] : 0.01f * m[k];
+            }
+            if (ty < Ho && tx < Wo) {
+                float *yo = yb + (size_t)ty * Wo + tx;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (allco || co0 + k < Cout) yo[(size_t)k * cstride] = m[k];
+            }
+        } else {
+            const int oy = 2 * ty, ox = 2 * tx;
+            const bool c0 = ox < W, c1 = ox + 1 < W, r0 = oy < H, r1 = oy + 1 < H;
+            if (residual) {
+                const float *rb0 = residual + ((size_t)b * Cout + co0) * cstride + (size_t)oy * W + ox;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (allco || co0 + k < Cout) {
+                        const float *ro = rb0 + (size_t)k * cstride;
+                        if (r0 && c0) Y[k][0] += ro[0];
+                        if (r0 && c1) Y[k][1] += ro[1];
+                        if (r1 && c0) Y[k][2] += ro[W];
+                        if (r1 && c1) Y[k][3] += ro[W + 1];
+                    }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (act == 1) Y[k][q] = fmaxf(Y[k][q], 0.f);
+                    else if (act == 2) Y[k][q] = Y[k][q] > 0.f ? Y[k][q] : 0.01f * Y[k][q];
+                }
+            float *yo0 = yb + (size_t)oy * W + ox;
+            const bool interior = allco && r0 && r1 && c1 && !(W & 1);
+            if (interior) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float *yo = yo0 + (size_t)k * cstride;
+                    *(float2 *)yo = make_float2(Y[k][0], Y[k][1]);
+                    *(float2 *)(yo + W) = make_float2(Y[k][2], Y[k][3]);
+                }
+            } else
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (!(allco || co0 + k < Cout)) continue;
+                float *yo = yo0 + (size_t)k * cstride;
+                if (c1) {
+                    if (!(W & 1)) {
+                        if (r0) *(float2 *)yo = make_float2(Y[k][0], Y[k][1]);
+                        if (r1) *(float2 *)(yo + W) = make_float2(Y[k][2], Y[k][3]);
+                    } else {
+                        if (r0) { yo[0] = Y[k][0]; yo[1] = Y[k][1]; }
+                        if (r1) { yo[W] = Y[k][2]; yo[W + 1] = Y[k][3]; }
+                    }
+                } else if (c0) {
+                    if (r0) yo[0] = Y[k][0];
+                    if (r1) yo[W] = Y[k][2];
+                }
+            }
+        }
+    }
+}
+
 extern "C" {
 
 size_t mfr_wino_bf16x3_filter_bytes(int Cin, int Cout)
@@ -929,7 +1305,21 @@ int mfr_conv3x3_wino_bf16x3_variant(const float *x, const void *upk, const float
     if (grid > 0x7fffffffll) return MFR_E_ARG;
     hipStream_t st = (hipStream_t)stream;
 #define WB_GO(K) hipLaunchKernelGGL(K, dim3((unsigned)grid), dim3(256), 0, st, x, (const uint4 *)upk, bias, y, residual, Cin, Cout, H, W, nbx, nby, (int)S, (int)Sx, ncg, nks, act)
-    if (variant >= 200 && variant < 328 && pool) {     // timing ablations of the two-workgroups-per-CU kernel: 200 + ABL (results are wrong)
+    if (variant == 0 || variant == 3 || (variant >= 400 && variant < 528 && pool)) {     // default since round 4 (501..503: TUNE builds, results right)     // eight wavefronts per workgroup (400 + ABL: timing ablations, results are wrong)
+#define WB_GO8(K) hipLaunchKernelGGL(K, dim3((unsigned)grid), dim3(512), 0, st, x, (const uint4 *)upk, bias, y, residual, Cin, Cout, H, W, nbx, nby, (int)S, (int)Sx, ncg, nks, act)
+        if (variant == 0 || variant == 3) { if (pool) WB_GO8((wino_bf16x3_p8_kernel<true>)); else WB_GO8((wino_bf16x3_p8_kernel<false>)); }
+        else if (variant == 501 && pool) WB_GO8((wino_bf16x3_p8_kernel<true, 0, 1>));
+        else if (variant == 502 && pool) WB_GO8((wino_bf16x3_p8_kernel<true, 0, 2>));
+        else if (variant == 503 && pool) WB_GO8((wino_bf16x3_p8_kernel<true, 0, 3>));
+        else switch (variant - 400) {
+#define WB_ABL8(A) case A: WB_GO8((wino_bf16x3_p8_kernel<true, A>)); break;
+        WB_ABL8(1) WB_ABL8(2) WB_ABL8(4) WB_ABL8(8) WB_ABL8(12) WB_ABL8(15) WB_ABL8(64) WB_ABL8(16) WB_ABL8(32) WB_ABL8(71) WB_ABL8(79) WB_ABL8(103) WB_ABL8(87)
+#undef WB_ABL8
+        default: return MFR_E_ARG;
+        }
+#undef WB_GO8
+    }
+    else if (variant >= 200 && variant < 328 && pool) {     // timing ablations of the two-workgroups-per-CU kernel: 200 + ABL (results are wrong)
         const int ncg2 = (Cout + 31) / 32;
         const long long grid2 = Sx * 8 * ncg2;
         switch (variant - 200) {
@@ -949,7 +1339,7 @@ int mfr_conv3x3_wino_bf16x3_variant(const float *x, const void *upk, const float
         if (pool) hipLaunchKernelGGL((wino_bf16x3_w2_kernel<true>), dim3((unsigned)grid2), dim3(256), 0, st, x, (const uint4 *)upk, bias, y, residual, Cin, Cout, H, W, nbx, nby, (int)S, (int)Sx, ncg2, nks, act);
         else hipLaunchKernelGGL((wino_bf16x3_w2_kernel<false>), dim3((unsigned)grid2), dim3(256), 0, st, x, (const uint4 *)upk, bias, y, residual, Cin, Cout, H, W, nbx, nby, (int)S, (int)Sx, ncg2, nks, act);
     }
-    else if (variant == 0 || variant == 32) { if (pool) WB_GO((wino_bf16x3_kernel<true>)); else WB_GO((wino_bf16x3_kernel<false>)); }
+    else if (variant == 32) { if (pool) WB_GO((wino_bf16x3_kernel<true>)); else WB_GO((wino_bf16x3_kernel<false>)); }
     else if (pool) {                                   // timing ablations (tools/bench_conv.py): pooled layers only
         switch (variant) {
 #define WB_ABL(A) case A: WB_GO((wino_bf16x3_kernel<true, A>)); break;

@@ -22,7 +22,7 @@ def _pack(w):
     return u
 
 
-VARIANTS = {"default": 0, "one_wave_per_simd": 32, "two_workgroups_per_cu": 2}      # mfr_conv3x3_wino_bf16x3_variant
+VARIANTS = {"default": 0, "one_wave_per_simd": 32, "two_workgroups_per_cu": 2, "eight_wavefronts": 3}      # mfr_conv3x3_wino_bf16x3_variant
 
 
 def _conv(x, w, b, act, pool, residual=None, variant=0):

@@ -19,7 +19,7 @@ y = torch.empty(n, co, H // 2, W // 2, device=dev)
 u3 = torch.empty(lib.mfr_wino_bf16x3_filter_bytes(ci, co), dtype=torch.uint8, device=dev)
 lib.mfr_wino_bf16x3_filter_transform(_lib.ptr(w), ci, co, _lib.ptr(u3), _lib.stream_ptr())
 res = {}
-names = {32: "one wavefront per SIMD (round 3)", 2: "two workgroups per CU", 201: "- output transform", 202: "- filter loads", 204: "- V production",
+names = {32: "one wavefront per SIMD (round 3)", 3: "EIGHT wavefronts (p8)", 471: "p8 patches ONLY (DMA + LDS reads + row combos)", 479: "p8 nothing (launch + barriers)", 503: "p8 patch DMA only, nothing else", 487: "p8 LDS reads only, nothing else", 401: "p8 - output transform", 402: "p8 - filter loads", 404: "p8 - V production", 408: "p8 - patch DMA + LDS reads", 416: "p8 - patch DMA only", 432: "p8 - LDS patch reads only", 415: "p8 MFMA only", 464: "p8 no MFMA", 2: "two workgroups per CU", 201: "- output transform", 202: "- filter loads", 204: "- V production",
          208: "- patch DMA + LDS reads", 212: "- V - patches", 214: "- V - patches - filters", 215: "MFMA only", 264: "no MFMA",
          216: "- patch DMA only", 232: "- LDS patch reads only", 301: "TUNE 1: no fences in V production (correct)",
          302: "TUNE 2: row combinations 4 channels at a time (correct)", 303: "TUNE 3: both (correct)"}

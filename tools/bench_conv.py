@@ -30,8 +30,8 @@ for name, ci, co, H, W, pool in LAYERS:
     def variant(v):
         return lambda *a: lib.mfr_conv3x3_wino_bf16x3_variant(*a[:11], v, *a[11:])
     for tag, fn, u in (("exact_fp32", lib.mfr_conv3x3_wino, u1), ("bf16x3", variant(0), u3), ("bf16x3_1wave", variant(32), u3),
-                       ("bf16x3_w2", variant(2), u3), ("exact_fp32_b", lib.mfr_conv3x3_wino, u1),
-                       ("bf16x3_b", variant(0), u3), ("bf16x3_1wave_b", variant(32), u3), ("bf16x3_w2_b", variant(2), u3)):
+                       ("bf16x3_w2", variant(2), u3), ("bf16x3_p8", variant(3), u3), ("exact_fp32_b", lib.mfr_conv3x3_wino, u1),
+                       ("bf16x3_b", variant(0), u3), ("bf16x3_1wave_b", variant(32), u3), ("bf16x3_w2_b", variant(2), u3), ("bf16x3_p8_b", variant(3), u3)):
         for _ in range(2):
             fn(_lib.ptr(x), _lib.ptr(u), _lib.ptr(b), None, n, ci, co, H, W, 1, pool, _lib.ptr(y), _lib.stream_ptr())
         torch.cuda.synchronize()
@@ -45,6 +45,7 @@ for name, ci, co, H, W, pool in LAYERS:
     rec["images"] = n
     rec["fp32_equiv_tflops_bf16x3"] = round(wino_flops / min(rec["bf16x3"], rec["bf16x3_b"]) / 1e9, 1)
     rec["fp32_tflops_exact"] = round(wino_flops / min(rec["exact_fp32"], rec["exact_fp32_b"]) / 1e9, 1)
+    rec["bf16_tflops_p8"] = round(6 * wino_flops / min(rec["bf16x3_p8"], rec["bf16x3_p8_b"]) / 1e9, 1)
     rec["bf16_tflops_w2"] = round(6 * wino_flops / min(rec["bf16x3_w2"], rec["bf16x3_w2_b"]) / 1e9, 1)
     rec["bf16_tflops_1wave"] = round(6 * wino_flops / min(rec["bf16x3_1wave"], rec["bf16x3_1wave_b"]) / 1e9, 1)
     res[name] = rec
