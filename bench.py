@@ -285,8 +285,8 @@ class SgPnpWorkload:
         achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms else None
         eq = conv_fp32 / (conv_ms * 1e-3) / 1e12 if conv_ms else None
         att_exec = 6.0 * att_tf if att_tf else None
-        return {"kernel": "wino_bf16x3_kernel conv1b launch (dominant kernel: fused Winograd F(2x2,3x3) convolution on the bf16 matrix cores at "
-                          "fp32 accuracy, 64->64 ch, pooled output)",
+        return {"kernel": "wino_bf16x3_p8_kernel conv1b launch (dominant kernel: fused Winograd F(2x2,3x3) convolution on the bf16 matrix cores at "
+                          "fp32 accuracy, 64->64 ch, pooled output; eight wavefronts per workgroup, two per SIMD)",
                 "bound": "mfma", "achieved": round(achieved, 1) if achieved else None, "peak": BF16_MFMA_PEAK_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4) if achieved else None,
                 "traffic": _traffic("conv1b", B), "avg_launch_ms": round(conv_ms, 4) if conv_ms else None,
@@ -369,10 +369,19 @@ class LoftrEmatWorkload:
         cm_tf = cm_flops / (cm_ms * 1e-3) / 1e12 if cm_ms else None
         cm_impl_bytes = (3.0 * L * L * 4 + 2.0 * L * 256 * 4) * B   # as implemented: S written once, swept twice, features in
         cm_impl_gbs = cm_impl_bytes / (cm_ms * 1e-3) / 1e9 if cm_ms else None
-        return {"kernel": "wino_conv3x3 layer1_outconv2.0 launch, 196->196 ch at 360x272 (dominant kernel: fused Winograd F(2x2,3x3) convolutions of the ResNet-FPN backbone)",
-                "bound": "mfma", "achieved": round(achieved, 2) if achieved else None, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4) if achieved else None, "traffic": _traffic("loftr_l1out2", B),
-                "avg_launch_ms": round(conv_ms, 4) if conv_ms else None, "launches_timed": len(self.conv_timer.events), "flops_per_launch": conv_flops,
+        # the layer runs the bf16x3 Winograd kernel (nets/conv.py: prefer_bf16x3(360, 272)): six bf16 partial products per fp32
+        # multiply-add -> priced against the DENSE bf16 MFMA peak; useful flops count the 196 real channels (the kernel also
+        # multiplies the zero padding: Cin 196 -> 208 = 13 K steps of 16, Cout 196 -> 256 = 4 groups of 64: x1.39 executed)
+        exe = 6.0 * achieved if achieved else None
+        return {"kernel": "wino_bf16x3_p8_kernel layer1_outconv2.0 launch, 196->196 ch at 360x272 (dominant kernel: fused Winograd F(2x2,3x3) convolutions of the "
+                          "ResNet-FPN backbone on the bf16 matrix cores at fp32 accuracy; 34 % of the step's GPU time, profiles/r04_bench_loftr_emat_kernel_stats.csv)",
+                "bound": "mfma", "achieved": round(exe, 1) if exe else None, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(exe / BF16_MFMA_PEAK_TFLOPS, 4) if exe else None, "traffic": _traffic("loftr_l1out2", B),
+                "avg_launch_ms": round(conv_ms, 4) if conv_ms else None, "launches_timed": len(self.conv_timer.events), "flops_per_launch": 6.0 * conv_flops,
+                "note": "achieved = useful bf16 flops (6 partial products per fp32 multiply-add of the 16 Winograd GEMMs over the 196 real channels) / launch "
+                        "time against the dense bf16 peak; executed incl. channel padding = x1.39",
+                "fp32_equivalent": {"tflops": round(achieved, 2) if achieved else None, "flops_per_launch": conv_flops,
+                                    "vs_fp32_mfma_peak": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4) if achieved else None},
                 "other_kernels": [{"kernel": "dual-softmax coarse matching (similarity + row/col softmax statistics + mutual-NN selection)",
                                    "bound": "mfma + hbm (fp32 similarity GEMM, then two streaming sweeps over the materialised S)",
                                    "achieved": round(cm_tf, 2) if cm_tf else None, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -426,6 +435,70 @@ def rpr_cpu_baseline(n_pairs, cores, host):
     return dict(value=round(n_pairs / dt, 4), unit="image-pairs/s", cores=cores, kind="port", host_cores=host,
                 sample=f"1 training step of {n_pairs} synthetic {RPR_H}x{RPR_W} pairs, PyTorch-CPU fp32 ({cores} threads), correlation "
                        f"volume materialised like the reference, {dt:.1f}s")
+
+
+
+RPR_FAMILIES = (("library convolutions (MIOpen / CK implicit-GEMM: forward of the encoder, d input and d weight of every convolution)",
+                 ("igemm", "ck::", "miopenSp3", "naive_conv", "Cijk_", "gemm_kernel", "miopen_conv")),
+                ("layout transposes around the library convolutions (NCHW <-> NHWC)", ("batched_transpose", "transpose")),
+                ("BatchNorm (MIOpen)", ("BatchNorm",)),
+                ("own kernels (correlation volume, decoder convolution forward, upsampling, Kabsch, packing)",
+                 ("cw_", "conv_gemm_bf16", "conv_pack", "conv_unpack", "upsample_ac", "kabsch", "zero_fill")))
+
+
+def rpr_kernel_families():
+    """GPU time of the training step by kernel family, from the committed rocprofv3 kernel trace of THIS command's timed steps
+    (profiles/r04_bench_rpr_train_kernel_stats.csv, tools/kernel_stats_timed.py: warm-up and the library's solution search excluded)"""
+    import csv
+    path = os.path.join(ROOT, "profiles", "r04_bench_rpr_train_kernel_stats.csv")
+    if not os.path.exists(path):
+        return None
+    fam = {name: 0.0 for name, _ in RPR_FAMILIES}
+    fam["everything else (elementwise, reductions, optimizer, copies)"] = 0.0
+    total = 0.0
+    for r in csv.DictReader(open(path)):
+        ms = float(r["MsPerStep"]); total += ms
+        for name, keys in RPR_FAMILIES:
+            if any(k in r["Name"] for k in keys):
+                fam[name] += ms
+                break
+        else:
+            fam["everything else (elementwise, reductions, optimizer, copies)"] += ms
+    return {"source": "profiles/r04_bench_rpr_train_kernel_stats.csv", "kernel_ms_per_step": round(total, 3),
+            "ms_per_step": {k: round(v, 3) for k, v in fam.items()}, "share": {k: round(v / total, 4) for k, v in fam.items()}}
+
+
+def rpr_roofline(tr, batch, B, ms_per_step, own):
+    """The family that dominates the step is the LIBRARY's convolutions, so that is what the roofline prices: the model's convolution
+    flops (counted on the modules: 2 Cin Cout k^2 Hout Wout per image and layer; forward + d input + d weight = 3x, minus the
+    decoder forward passes that run the own kernel) over the family's GPU time, against the dense bf16 peak.  The family's time
+    is its share in the committed profile of this command applied to the step time measured now."""
+    flops = {"all": 0.0, "own_fwd": 0.0}
+
+    def hook(mod, inp, out):
+        f = 2.0 * mod.in_channels // mod.groups * mod.out_channels * mod.kernel_size[0] * mod.kernel_size[1] * out.shape[-1] * out.shape[-2] * out.shape[0]
+        flops["all"] += f
+    hs = [m.register_forward_hook(hook) for m in tr.model.modules() if isinstance(m, torch.nn.Conv2d)]
+    try:
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+            tr.model.encoder(torch.cat([batch["image0"], batch["image1"]]))
+    finally:
+        for h in hs:
+            h.remove()
+    fams = rpr_kernel_families()
+    lib_name = RPR_FAMILIES[0][0]
+    own_fwd = sum(k.get("flops_per_launch") or 0 for k in own if "conv_gemm_bf16" in k["kernel"]) * 4      # four decoder layers per step
+    lib_flops = 3.0 * flops["all"] - own_fwd
+    lib_ms = fams["share"][lib_name] * ms_per_step if fams else None
+    ach = lib_flops / (lib_ms * 1e-3) / 1e12 if lib_ms else None
+    return {"kernel": lib_name + " -- the family with the largest share of the step's GPU time", "bound": "mfma",
+            "achieved": round(ach, 1) if ach else None, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(ach / BF16_MFMA_PEAK_TFLOPS, 4) if ach else None, "traffic": None,
+            "family_ms_per_step": round(lib_ms, 3) if lib_ms else None, "flops_per_step": lib_flops,
+            "encoder_conv_flops_forward_per_step": flops["all"],
+            "note": "family time = its share of the kernel time in the committed profile x the step time of this run; flops = 3 x the encoder's forward "
+                    "convolution flops (both views) minus the decoder forward passes the own kernel runs",
+            "kernel_families": fams, "other_kernels": own}
 
 
 def rpr_train_bench(args, rank, world, dev, use_dist):
@@ -497,6 +570,20 @@ def rpr_train_bench(args, rank, world, dev, use_dist):
     cgm = cg_t.mean_ms()
     ncg = min(len(cg_flops), len(cg_t.events))
     ach_c = (sum(cg_flops[:ncg]) / max(ncg, 1)) / (cgm * 1e-3) / 1e12 if cgm and ncg else None
+    own = [{"kernel": "cw_bwd_q_kernel + cw_bwd_kv_kernel (mfr_corr_warp_bwd: fused correlation-volume warping, backward)", "bound": "mfma",
+            "achieved": round(ach_b, 2) if ach_b else None, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(ach_b / FP32_MFMA_PEAK_TFLOPS, 4) if ach_b else None, "traffic": _traffic("cw_bwd_kv", B),
+            "avg_launch_ms": round(bm, 4) if bm else None, "launches_timed": len(bwd_t.events), "flops_per_launch": f_bwd,
+            "note": f"the [B, N, N] volume ({vol_bytes / 1e9:.2f} GB fp32 at this batch) is never written: it is recomputed tile by tile on the "
+                    "fp32 matrix cores; HBM-side algorithmic bytes are the q/k/v/gradient maps only (a few MB)"},
+           {"kernel": "cw_fwd_kernel (mfr_corr_warp_fwd)", "bound": "mfma", "achieved": round(ach_f, 2) if ach_f else None,
+            "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach_f / FP32_MFMA_PEAK_TFLOPS, 4) if ach_f else None,
+            "avg_launch_ms": round(fm, 4) if fm else None, "launches_timed": len(fwd_t.events), "flops_per_launch": f_fwd},
+           {"kernel": "conv_gemm_bf16_kernel (mfr_conv_gemm_bf16: the decoder's 3x3 convolutions as implicit GEMMs, forward; backward = library)",
+            "bound": "mfma", "achieved": round(ach_c, 1) if ach_c else None, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(ach_c / BF16_MFMA_PEAK_TFLOPS, 4) if ach_c else None,
+            "avg_launch_ms": round(cgm, 4) if cgm else None, "launches_timed": len(cg_t.events),
+            "flops_per_launch": round(sum(cg_flops[:ncg]) / max(ncg, 1)) if ncg else None}]
     line = {
         "metric": "image-pairs/sec trained (3d3d relative-pose regression, bf16 autocast, 360x270)", "value": round(B * args.steps * world / elapsed, 3),
         "unit": "image-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
@@ -508,21 +595,7 @@ def rpr_train_bench(args, rank, world, dev, use_dist):
                    "precision": cfg.TRAINING.PRECISION, "siamese_batch": bool(cfg.TRAINING.SIAMESE_BATCH), "channels_last": bool(cfg.TRAINING.CHANNELS_LAST), "graph_step": bool(tr.graph_step),
                    "volume_positions": N, "feature_channels": D, "parameters": n_param, "optimizer": "Adam (fused), eps 1e-6",
                    "last_losses": [round(float(x.float().sum()), 5) for x in losses]},
-        "roofline": {"kernel": "cw_bwd_q_kernel + cw_bwd_kv_kernel (mfr_corr_warp_bwd: fused correlation-volume warping, backward)", "bound": "mfma",
-                     "achieved": round(ach_b, 2) if ach_b else None, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(ach_b / FP32_MFMA_PEAK_TFLOPS, 4) if ach_b else None, "traffic": _traffic("cw_bwd_kv", B),
-                     "avg_launch_ms": round(bm, 4) if bm else None, "launches_timed": len(bwd_t.events), "flops_per_launch": f_bwd,
-                     "note": f"the [B, N, N] volume ({vol_bytes / 1e9:.2f} GB fp32 at this batch) is never written: it is recomputed tile by tile on the "
-                             "fp32 matrix cores; HBM-side algorithmic bytes are the q/k/v/gradient maps only (a few MB)",
-                     "other_kernels": [{"kernel": "cw_fwd_kernel (mfr_corr_warp_fwd)", "bound": "mfma", "achieved": round(ach_f, 2) if ach_f else None,
-                                        "peak": FP32_MFMA_PEAK_TFLOPS, "frac": round(ach_f / FP32_MFMA_PEAK_TFLOPS, 4) if ach_f else None,
-                                        "avg_launch_ms": round(fm, 4) if fm else None, "launches_timed": len(fwd_t.events), "flops_per_launch": f_fwd},
-                                       {"kernel": "conv_gemm_bf16_kernel (mfr_conv_gemm_bf16: the decoder's 3x3 convolutions as implicit GEMMs, forward; "
-                                                  "backward = " + os.environ.get("MFR_RPR_CONV_BWD", "lib") + ")", "bound": "mfma",
-                                        "achieved": round(ach_c, 1) if ach_c else None, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                        "frac": round(ach_c / BF16_MFMA_PEAK_TFLOPS, 4) if ach_c else None,
-                                        "avg_launch_ms": round(cgm, 4) if cgm else None, "launches_timed": len(cg_t.events),
-                                        "flops_per_launch": round(sum(cg_flops[:ncg]) / max(ncg, 1)) if ncg else None}]},
+        "roofline": rpr_roofline(tr, batches[0], B, 1e3 * elapsed / args.steps, own),
     }
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline_subprocess("rpr_train", args.cpu_pairs, args.cpu_threads, "")
@@ -551,7 +624,7 @@ def _traffic(tag, B):
     """HBM traffic of the dominant kernel: PMC counters cannot be read inside this process, so the per-launch figure
     comes from the committed rocprofv3 --pmc passes of this same command (2 x FETCH_SIZE + WRITE_SIZE, the guide's
     gfx950 correction), profiles/r02_pmc_<tag>.json"""
-    for rnd in ("r03", "r02", "r01"):
+    for rnd in ("r04", "r03", "r02", "r01"):
         try:
             name = {"conv1b": "wino"}.get(tag, tag) if rnd == "r01" else tag
             pj = json.load(open(os.path.join(ROOT, "profiles", f"{rnd}_pmc_{name}.json")))

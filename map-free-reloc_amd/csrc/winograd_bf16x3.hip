@@ -918,13 +918,23 @@ __global__ void __launch_bounds__(256, 2) wino_bf16x3_w2_kernel(
 template <bool POOL, int ABL = 0, int TUNE = 0>
 __global__ void __launch_bounds__(512, 2) wino_bf16x3_p8_kernel(
     const float *__restrict__ x, const uint4 *__restrict__ upk, const float *__restrict__ bias, float *__restrict__ y,
-    const float *__restrict__ residual, int Cin, int Cout, int H, int W, int nbx, int nby, int S, int Sx, int ncg, int nks, int act)
+    const float *__restrict__ residual, int Cin, int Cout, int H, int W, int nbx, int nby, int S, int Sx, int ncg, int nks, int act, int chunk)
 {
     __shared__ __attribute__((aligned(16))) float lds[32768];
+    // workgroup -> (spatial block, 64-channel output group): every XCD walks its own contiguous raster range of Sx spatial blocks in
+    // chunks of `chunk` blocks, and inside a chunk all blocks of one output group before the next group.  chunk = 1 is "output groups
+    // innermost" (the groups of a block run back to back and share its patches in L2) -- right while the packed filters of ALL groups
+    // fit the XCD's 4 MB L2 beside them; for the 196- / 256-channel layers they do not (5 - 6 MB: every fragment request missed L2,
+    // 32 GB of fabric reads per launch against 4.9 GB algorithmic, profiles/r04_pmc_loftr_l1out2.json), so there a chunk is 8
+    // blocks: one group's fragments (1.2 - 1.5 MB) stay L2-resident for 8 workgroups and the chunk's patches (~2 MB) for all groups.
     const int id = blockIdx.x;
     const int xcd = id & 7, jq = id >> 3;
-    const int cg = jq % ncg;
-    const int sl = jq / ncg;
+    const int per = chunk * ncg;
+    const int ck = jq / per, rr = jq - ck * per;
+    const int left = min(chunk, Sx - ck * chunk);           // blocks in this (possibly last, partial) chunk
+    if (left <= 0) return;
+    const int cg = rr / left, sl = ck * chunk + (rr - cg * left);
+    if (cg >= ncg) return;
     const int s = xcd * Sx + sl;
     if (sl >= Sx || s >= S) return;
     const int bx = s % nbx, by = (s / nbx) % nby, b = s / (nbx * nby);
@@ -1306,7 +1316,10 @@ int mfr_conv3x3_wino_bf16x3_variant(const float *x, const void *upk, const float
     hipStream_t st = (hipStream_t)stream;
 #define WB_GO(K) hipLaunchKernelGGL(K, dim3((unsigned)grid), dim3(256), 0, st, x, (const uint4 *)upk, bias, y, residual, Cin, Cout, H, W, nbx, nby, (int)S, (int)Sx, ncg, nks, act)
     if (variant == 0 || variant == 3 || (variant >= 400 && variant < 528 && pool)) {     // default since round 4 (501..503: TUNE builds, results right)     // eight wavefronts per workgroup (400 + ABL: timing ablations, results are wrong)
-#define WB_GO8(K) hipLaunchKernelGGL(K, dim3((unsigned)grid), dim3(512), 0, st, x, (const uint4 *)upk, bias, y, residual, Cin, Cout, H, W, nbx, nby, (int)S, (int)Sx, ncg, nks, act)
+        const int chunk = ((size_t)ncg * nks * WB_FRAGS_PER_KSTEP * 1024 > (size_t)(2u << 20)) ? 8 : 1;       // packed filters of all groups vs half an XCD's L2
+        const long long grid8 = ((Sx + chunk - 1) / chunk) * (long long)chunk * ncg * 8;
+        if (grid8 > 0x7fffffffll) return MFR_E_ARG;
+#define WB_GO8(K) hipLaunchKernelGGL(K, dim3((unsigned)grid8), dim3(512), 0, st, x, (const uint4 *)upk, bias, y, residual, Cin, Cout, H, W, nbx, nby, (int)S, (int)Sx, ncg, nks, act, chunk)
         if (variant == 0 || variant == 3) { if (pool) WB_GO8((wino_bf16x3_p8_kernel<true>)); else WB_GO8((wino_bf16x3_p8_kernel<false>)); }
         else if (variant == 501 && pool) WB_GO8((wino_bf16x3_p8_kernel<true, 0, 1>));
         else if (variant == 502 && pool) WB_GO8((wino_bf16x3_p8_kernel<true, 0, 2>));
