@@ -253,6 +253,8 @@ int mfr_sg_sinkhorn_match(const float *S, int B, int ldS, const int32_t *n0, con
  *                                (ascending i), mconf [B,L0], n_match [B]
  *   mfr_loftr_gather_windows     FinePreprocess unfold(win, stride, pad win/2) restricted to the
  *                                matched cells: feat [Bimg,Hf,Wf,C] NHWC -> out [M, win*win, C]
+ *   mfr_loftr_fine_match         FineMatching: centre-feature correlation, softmax, spatial expectation,
+ *                                sub-pixel update of the view-1 keypoints
  * ------------------------------------------------------------------------------------------ */
 size_t mfr_loftr_linear_attention_workspace_bytes(int B, int L, int heads);
 int mfr_loftr_linear_attention(const float *q, int ldq, const float *k, const float *v, int ld, int B, int L, int heads,
@@ -271,6 +273,13 @@ int mfr_loftr_coarse_match_variant(const float *S, int B, int h0, int w0, int h1
                                    int32_t *n_match, int variant, void *stream);
 int mfr_loftr_gather_windows(const float *feat, int Bimg, int Hf, int Wf, int C, const int32_t *img_ids,
                              const int32_t *cell_ids, int M, int wc, int stride, int win, float *out, void *stream);
+/* FineMatching (the last step of LoFTR_matcher.match, matchers.py:50-55 -> mkpts1_f): per matched window, similarity of view 0's centre
+ * feature against the W*W fine features of view 1 (/ sqrt C), softmax, spatial expectation over linspace(-1, 1, W)^2, and
+ * pts1[lin_idx[m]] = k1[lin_idx[m]] + expectation * out_scale (out_scale = (W / 2) * image-to-fine-map scale).
+ * g0, g1 [M, W*W, ld] f32 (first C columns), lin_idx [M] i32 slots into the [B * L0, 2] tensors k1 / pts1; expec [M, 2] optional
+ * (the normalised expectation; pts1 / lin_idx / k1 may be NULL when only expec is wanted).  W*W <= 64. */
+int mfr_loftr_fine_match(const float *g0, const float *g1, int ld, int C, int M, int W, float out_scale, const int32_t *lin_idx,
+                         const float *k1, float *pts1, float *expec, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Fused conv epilogues of the SuperPoint encoder (NCHW f32; same call site as above): the MIOpen

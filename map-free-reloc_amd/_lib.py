@@ -55,6 +55,7 @@ SIGNATURES = {
     "mfr_loftr_coarse_match_variant": (_i, [_vp, _i, _i, _i, _i, _i, C.c_float, C.c_float, _i, _vp, _sz, _vp, _vp, _vp, _vp, _i, _vp]),
     "mfr_loftr_fine_attention": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp]),
     "mfr_loftr_gather_windows": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "mfr_loftr_fine_match": (_i, [_vp, _vp, _i, _i, _i, _i, C.c_float, _vp, _vp, _vp, _vp, _vp]),
     "mfr_conv3x3_c1_relu": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "mfr_bias_relu_nchw": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "mfr_bias_pool2_relu_nchw": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),

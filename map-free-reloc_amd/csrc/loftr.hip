@@ -566,6 +566,53 @@ __global__ void __launch_bounds__(128) fine_attention_kernel(const float *__rest
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// fine matching (LoFTR FineMatching, reached from LoFTR_matcher.match, etc/feature_matching_baselines/matchers.py:50-55 -> mkpts1_f):
+// per matched window m: sim[r] = <g0[m, centre], g1[m, r]> / sqrt(C) over the W*W taps, heat = softmax(sim), sub-pixel offset =
+// spatial expectation of heat over the normalised grid linspace(-1, 1, W)^2 (kornia dsnt.spatial_expectation2d), and
+// mkpts1_f = mkpts1_c + offset * (W // 2) * (image / fine-map scale).  One wavefront per window: the two feature rows of a tap are
+// read once (coalesced, C / 64 values per lane), the W*W dot products are wave reductions, the softmax and the expectation live in
+// lanes 0 .. W*W - 1.  The result goes straight into the correspondence tensor at the match's slot.
+__global__ void __launch_bounds__(256) fine_match_kernel(const float *__restrict__ g0, const float *__restrict__ g1, int ld, int C, int M, int W,
+                                                         float inv_sqrt_c, float out_scale, const int32_t *__restrict__ lin_idx,
+                                                         const float *__restrict__ k1, float *__restrict__ pts1, float *__restrict__ expec)
+{
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (m >= M) return;
+    const int WW = W * W;
+    const float *pc = g0 + ((size_t)m * WW + WW / 2) * ld;
+    float mine = -3.0e38f;
+    for (int r = 0; r < WW; ++r) {
+        const float *q = g1 + ((size_t)m * WW + r) * ld;
+        float sacc = 0.f;
+        for (int c = lane; c < C; c += 64) sacc = sacc + pc[c] * q[c];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) sacc = sacc + __shfl_xor(sacc, off, 64);
+        if (lane == r) mine = sacc * inv_sqrt_c;
+    }
+    float mx = mine;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    const float e = (lane < WW) ? __expf(mine - mx) : 0.f;
+    float sum = e;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) sum = sum + __shfl_xor(sum, off, 64);
+    const float heat = e / sum;
+    const float step = (W > 1) ? 2.0f / (float)(W - 1) : 0.f;
+    float cx = (lane < WW) ? heat * (-1.0f + step * (float)(lane % W)) : 0.f;
+    float cy = (lane < WW) ? heat * (-1.0f + step * (float)(lane / W)) : 0.f;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { cx = cx + __shfl_xor(cx, off, 64); cy = cy + __shfl_xor(cy, off, 64); }
+    if (lane == 0) {
+        if (expec) { expec[2 * (size_t)m] = cx; expec[2 * (size_t)m + 1] = cy; }
+        if (pts1) {
+            const size_t o = 2 * (size_t)lin_idx[m];
+            pts1[o] = k1[o] + cx * out_scale; pts1[o + 1] = k1[o + 1] + cy * out_scale;
+        }
+    }
+}
+
 extern "C" {
 
 size_t mfr_loftr_linear_attention_workspace_bytes(int B, int L, int heads)
@@ -678,6 +725,20 @@ int mfr_loftr_fine_attention(const float *q, int ldq, const float *k, const floa
     if (!q || !k || !v || !out || Bw < 0 || L != FA_L || D != FA_D || heads != 8 || ldq < D || ld < D || ldo < D) return MFR_E_ARG;
     if (Bw == 0) return 0;
     hipLaunchKernelGGL(fine_attention_kernel, dim3((Bw + 1) / 2), dim3(128), 0, (hipStream_t)stream, q, ldq, k, v, ld, Bw, out, ldo);
+    CHECK_LAUNCH();
+    return 0;
+}
+
+// g0, g1 [M, W*W, ld] (first C columns are the fine features of view 0 / view 1), lin_idx [M] (slot of the match in the flattened
+// [B * L0] correspondence layout), k1 / pts1 [B * L0, 2]: pts1[slot] = k1[slot] + expectation * out_scale; expec [M, 2] optional
+// (the normalised expectation itself); pts1 / lin_idx / k1 may be NULL when only expec is wanted.
+int mfr_loftr_fine_match(const float *g0, const float *g1, int ld, int C, int M, int W, float out_scale, const int32_t *lin_idx,
+                         const float *k1, float *pts1, float *expec, void *stream)
+{
+    if (!g0 || !g1 || ld < C || C <= 0 || M < 0 || W < 1 || W * W > 64 || (!pts1 && !expec) || (pts1 && (!lin_idx || !k1))) return MFR_E_ARG;
+    if (M == 0) return 0;
+    hipLaunchKernelGGL(fine_match_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, g0, g1, ld, C, M, W, 1.0f / sqrtf((float)C),
+                       out_scale, lin_idx, k1, pts1, expec);
     CHECK_LAUNCH();
     return 0;
 }

@@ -207,6 +207,14 @@ class LoFTRHIP:
             S.mul_(1.0 / C)
         return self.coarse_match(S, hw, hw)
 
+    def fine_match(self, xf, M, lin_idx, k1, pts1, out_scale, expec=None):
+        """xf [2, M * W * W, 256] (fine features in the first 128 columns) -> pts1[lin_idx] = k1[lin_idx] + expectation * out_scale (in place)"""
+        lib = _lib.load()
+        _lib.check(lib.mfr_loftr_fine_match(_lib.ptr(xf[0]), _lib.ptr(xf[1]), xf.shape[-1], 128, M, self.W, out_scale,
+                                            _lib.ptr(lin_idx) if lin_idx is not None else None, _lib.ptr(k1) if k1 is not None else None,
+                                            _lib.ptr(pts1) if pts1 is not None else None, _lib.ptr(expec) if expec is not None else None,
+                                            _lib.stream_ptr()), "mfr_loftr_fine_match")
+
     def gather_windows(self, feat_nhwc, img_ids, cell_ids, wc, stride, out=None):
         lib = _lib.load()
         Bimg, Hf, Wf, C = feat_nhwc.shape
@@ -326,13 +334,8 @@ class LoFTRHIP:
             torch.add(torch.mm(win.view(2 * M * WW, 128), wmf[:, :128].t()).view(2 * M, WW, 128), cw[:, None, :],
                       out=xf.view(2 * M, WW, 256)[..., :128])
             self._transformer(self.fine, xf, self.fine_attention if self.W == 5 else self._torch_linear_attention(8), M, WW)
-            g0, g1 = xf[0].view(M, WW, 256)[..., :128], xf[1].view(M, WW, 256)[..., :128]
-            picked = g0[:, WW // 2]
-            heat = torch.softmax(torch.einsum('mc,mrc->mr', picked, g1) / g0.shape[-1] ** .5, dim=1).view(-1, self.W, self.W)
-            lin = torch.linspace(-1, 1, self.W, device=dev)
-            coords = torch.stack([(heat * lin[None, None, :]).sum((1, 2)), (heat * lin[None, :, None]).sum((1, 2))], 1)
-            scale1 = H // Hf
-            pts1[b_ids, slot] = k1[b_ids, slot] + coords * (self.W // 2) * scale1
+            # FineMatching: centre-feature correlation, softmax, spatial expectation and the sub-pixel update in one kernel
+            self.fine_match(xf, M, (b_ids * L0 + slot).int(), k1, pts1, float((self.W // 2) * (H // Hf)))
         zero = torch.zeros_like(k0)
         return dict(pts0=torch.where(valid[..., None], k0, zero).contiguous(), pts1=torch.where(valid[..., None], pts1, zero).contiguous(),
                     n_corr=n, mconf=mconf, i_ids=i_ids, j_ids=j_ids)

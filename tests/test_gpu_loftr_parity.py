@@ -184,3 +184,29 @@ def test_fused_upsample2x_add_vs_torch(pair, B, C, H, W):
     # the source coordinate o * (H-1)/(2H-1) is formed in f32 (as in torch's kernel): ~1e-5 of a pixel at 180 rows, so
     # either f32 evaluation sits within a few 1e-5 of the f64 one (unit-scale data)
     assert (got - lib32).abs().max().item() < 5e-5 and (got - want).abs().max().item() < 5e-5
+
+
+def test_fine_match_kernel_vs_torch_formula():
+    """mfr_loftr_fine_match (FineMatching: matchers.py:50-55 -> mkpts1_f) against the torch statement of upstream's fine_matching.py:
+    softmax(<f0 centre, f1 window> / sqrt C), dsnt.spatial_expectation2d over linspace(-1, 1, W)^2, mkpts1_f = mkpts1_c + expectation * (W // 2) * scale"""
+    from mapfree_reloc_amd import _lib
+    lib = _lib.load(require_gpu=True)
+    g = torch.Generator().manual_seed(3)
+    for M, W, C, ld in ((1, 5, 128, 256), (777, 5, 128, 256), (40, 3, 128, 128), (9, 7, 64, 96)):
+        WW = W * W
+        xf = torch.randn(2, M * WW, ld, generator=g).to(DEV) * 1.5
+        L0 = 4 * M + 3
+        k1 = (torch.rand(L0, 2, generator=g) * 500).to(DEV)
+        lin = torch.randperm(L0, generator=g)[:M].int().to(DEV)
+        pts1 = k1.clone(); expec = torch.empty(M, 2, device=DEV)
+        _lib.check(lib.mfr_loftr_fine_match(_lib.ptr(xf[0]), _lib.ptr(xf[1]), ld, C, M, W, 4.0, _lib.ptr(lin), _lib.ptr(k1), _lib.ptr(pts1), _lib.ptr(expec),
+                                            _lib.stream_ptr()), "fine_match")
+        g0, g1 = xf[0].view(M, WW, ld)[..., :C].double(), xf[1].view(M, WW, ld)[..., :C].double()
+        heat = torch.softmax(torch.einsum("mc,mrc->mr", g0[:, WW // 2], g1) / C ** .5, dim=1).view(M, W, W)
+        l = torch.linspace(-1, 1, W, device=DEV, dtype=torch.float64)
+        want = torch.stack([(heat * l[None, None, :]).sum((1, 2)), (heat * l[None, :, None]).sum((1, 2))], 1)
+        assert (expec.double() - want).abs().max().item() < 2e-6
+        ref = k1.double().clone(); ref[lin.long()] += want * 4.0
+        assert (pts1.double() - ref).abs().max().item() < 2e-4           # 500-pixel coordinates in f32
+        untouched = torch.ones(L0, dtype=torch.bool, device=DEV); untouched[lin.long()] = False
+        assert torch.equal(pts1[untouched], k1[untouched])
