@@ -68,6 +68,7 @@ def parse(argv=None):
                     "graph's static buffers every step), 0 = eager launches (default: at 8-32 pairs per step the eager step is GPU-bound, "
                     "measured 699 vs 694 pairs/s).  With 1 the roofline kernels are timed with HIP events over extra eager steps AFTER the "
                     "timed region (events cannot be recorded inside a replay).")
+    ap.add_argument("--hip-opt", action="append", default=[], metavar="NAME=VALUE", help="set a declared kernel-selection option (mapfree_reloc_amd/options.py), e.g. CONV_KERNEL=exact, RPR_CONV=miopen; repeatable")
     ap.add_argument("--rpr-opts", default="siamese,graph", help="rpr_train only, comma list: siamese (TRAINING.SIAMESE_BATCH: both images of a pair in one "
                     "encoder pass, BatchNorm statistics per view = the arithmetic of the reference's two encoder calls), graph (TRAINING.GRAPH_STEP: "
                     "forward + loss + backward replayed from one HIP graph), channels_last, fp32; 'none' = two encoder calls, eager launches")
@@ -667,6 +668,11 @@ def _fail(msg):
 
 def main():
     args = parse()
+    if args.hip_opt:
+        from mapfree_reloc_amd import options as hip_options
+        for kv in args.hip_opt:
+            k, _, v = kv.partition("=")
+            hip_options.set(k.strip(), v.strip())
     if args.cpu_baseline_only:
         print(json.dumps(cpu_baseline(args.config, args.cpu_pairs, [1000 + i for i in range(args.cpu_pairs)], args.cpu_threads, args.cpu_out)))
         return

@@ -4,6 +4,8 @@ from .matching.model import FeatureMatchingModel
 
 
 def build_model(cfg, checkpoint=''):
+    from . import options
+    options.apply_cfg(cfg)                         # declared kernel-selection options under cfg.HIP (options.py)
     if cfg.MODEL == 'FeatureMatching':
         return FeatureMatchingModel(cfg)
     if cfg.MODEL in ('Regression', 'RegressionMultiFrame'):

@@ -10,7 +10,9 @@ keys this implementation adds (declared here because unknown keys are rejected o
                      matcher stage of the fused batched pipeline (opt-in: batches of >= 8 pairs are GPU-bound, measured no gain);
                      EMAT_SCORE: model quality of the E-matrix RANSAC -- 'magsac' (MAGSAC++ loss + sigma-consensus++, the method the
                      reference asks OpenCV for: cv.USAC_MAGSAC, pose_solver.py:46-48) | 'count' (inlier count + LM polish, rounds 1-3);
-                     MAGSAC_MAX_THR_RATIO: k * sigma_max of MAGSAC++ as a multiple of EMAT_RANSAC.PIX_THRESHOLD (>= 1)
+                     MAGSAC_MAX_THR_RATIO: k * sigma_max of MAGSAC++ as a multiple of EMAT_RANSAC.PIX_THRESHOLD (>= 1);
+                     CONV / CONV_KERNEL / FUSED_CONV_RELU / RPR_CONV / RPR_CONV_BWD / RPR_CONV_ORDER / RPR_WGRAD_SPLITS: which of two
+                     implementations of a layer runs (A/B measurement, parity tests) -- options.py lists values and defaults
   LOFTR.WEIGHTS      checkpoint of the online LoFTR matcher ('LoFTR' feature matching)
   ALLOW_SYNTHETIC_WEIGHTS  hand out seeded synthetic network weights when no checkpoint is configured (tests / benches)
   TRAINING.PRECISION 'bf16' (autocast; the aggregator kernel and the pose algebra stay fp32) | 'fp32'
@@ -69,6 +71,9 @@ def get_cfg_defaults():
     c.RANSAC = CN(); c.RANSAC.SEED = 0
     c.HIP = CN(); c.HIP.BATCH_PAIRS = 16; c.HIP.MAX_KEYPOINTS = 1024; c.HIP.MAX_CORRESPONDENCES = 8192; c.HIP.GRAPH_BATCH1 = True; c.HIP.GRAPH_FUSED = False
     c.HIP.EMAT_SCORE = 'magsac'; c.HIP.MAGSAC_MAX_THR_RATIO = 1.0
+    from .. import options as _opt                     # kernel-selection options (options.py): declared with their defaults, applied by apply_cfg
+    for _k in _opt.names():
+        c.HIP[_k] = _opt.default(_k)
     c.SUPERGLUE = CN()
     for k, v in dict(NMS_RADIUS=4, KEYPOINT_THRESHOLD=0.005, MAX_KEYPOINTS=1024, SINKHORN_ITERATIONS=20,
                      MATCH_THRESHOLD=0.2, SUPERPOINT_WEIGHTS=None, SUPERGLUE_WEIGHTS=None, SYNTHETIC_SEED=1234).items():

@@ -21,7 +21,7 @@ def correct_intrinsic_scale(K, scale_x, scale_y):
     K = np.array(K, dtype=np.float64)
     K[0, 0] *= scale_x; K[0, 2] = (K[0, 2] + 0.5) * scale_x - 0.5
     K[1, 1] *= scale_y; K[1, 2] = (K[1, 2] + 0.5) * scale_y - 0.5
-    return K.astype(np.float32)
+    return K                                               # float64, as upstream (the float64 eye(3) promotes the product)
 
 
 def read_depth_image(path):
@@ -134,6 +134,12 @@ _FRAME_CACHE = _collections.OrderedDict()        # (scene_root, frame, resize, d
 _FRAME_LOCK = _threading.Lock()
 
 
+def clear_frame_cache():
+    """drop the cached keyframes (tools / tests that rewrite a scene directory in place)"""
+    with _FRAME_LOCK:
+        _FRAME_CACHE.clear()
+
+
 class MapFreeScene:
     """reader of one scene directory (lib/datasets/mapfree.py:16-270, single-frame queries): intrinsics.txt / poses.txt
     parsing (:36-75); val/test scenes: pairs = keyframe seq0/frame_00000 x every `sample_factor`-th seq1 frame (:148-165);
@@ -195,7 +201,13 @@ class MapFreeScene:
         process-wide cache: a val / test scene pairs its one keyframe with every query (mapfree.py:148-165), the reference re-reads and
         re-decodes it 116 times per scene; here it is decoded once per scene (read-only tensors, shared by the samples; 4 entries,
         least recently used first out, so a run over 130 scenes holds a handful of frames, not 130)."""
-        key = (self.scene_root, rel, tuple(self.resize) if self.resize is not None else None, self.estimated_depth, self.black_white)
+        path = os.path.join(self.scene_root, rel)
+        try:
+            st = os.stat(path)
+            ident = (st.st_mtime_ns, st.st_size)                # a scene regenerated at the same path is a different frame
+        except OSError:
+            ident = None
+        key = (self.scene_root, rel, ident, tuple(self.resize) if self.resize is not None else None, self.estimated_depth, self.black_white)
         if keep:
             with _FRAME_LOCK:
                 hit = _FRAME_CACHE.get(key)
@@ -214,7 +226,7 @@ class MapFreeScene:
                 hit = _FRAME_CACHE.get(key)                     # another thread may have decoded it meanwhile: hand out ONE object
                 if hit is not None:
                     return hit
-                _FRAME_CACHE[key] = (img, d)
+                _FRAME_CACHE[key] = (img, d)                    # shared by every sample of the scene: consumers must not write into them
                 while len(_FRAME_CACHE) > 4:
                     _FRAME_CACHE.popitem(last=False)
         return img, d
@@ -395,8 +407,15 @@ class PairBatchLoader:
         gray and writes its slots itself; the loader thread only allocates and collects the small fields (a serial gray conversion +
         copy of 64 images per batch on this thread capped the loader at ~300 pairs/s)"""
         get = lambda it: self.scenes[it[0]][it[1]]
-        first = get(items[0])                                  # shapes / dtypes come from the first pair
         b = len(items)
+        fut0 = None
+        if self.workers > 1 and b > 1:
+            if self._pool is None:
+                import concurrent.futures
+                self._pool = concurrent.futures.ThreadPoolExecutor(max_workers=self.workers, thread_name_prefix="mfr-decode")
+            # the other pairs start decoding NOW, while this thread decodes the first one (its shapes / dtypes size the batch buffers)
+            fut0 = [self._pool.submit(get, items[p]) for p in range(1, b)]
+        first = get(items[0])
         Hh, Ww = first["image0"].shape[-2:]
         mk = (lambda *shape, dtype=torch.float32: torch.empty(*shape, dtype=dtype, pin_memory=True)) if self.pin else \
              (lambda *shape, dtype=torch.float32: torch.empty(*shape, dtype=dtype))
@@ -423,11 +442,8 @@ class PairBatchLoader:
             if has_depth:
                 d0_np[p] = npv(smp["depth0"]); d1_np[p] = npv(smp["depth1"])
             return (torch.as_tensor(smp["K_color0"]), torch.as_tensor(smp["K_color1"]), int(smp["pair_id"]), smp["pair_names"][1])
-        if self.workers > 1 and b > 1:
-            if self._pool is None:
-                import concurrent.futures
-                self._pool = concurrent.futures.ThreadPoolExecutor(max_workers=self.workers, thread_name_prefix="mfr-decode")
-            futs = [self._pool.submit(fill, p) for p in range(1, b)]
+        if fut0 is not None:
+            futs = [self._pool.submit(lambda p=p, f=f: fill(p, f.result())) for p, f in zip(range(1, b), fut0)]
             meta = [fill(0, first)] + [f.result() for f in futs]             # order preserved
         else:
             meta = [fill(0, first)] + [fill(p) for p in range(1, b)]

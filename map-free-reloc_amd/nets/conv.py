@@ -8,16 +8,14 @@ Both meet the same parity bar (<= 2e-5 against a float64 convolution, tests/test
 the image in blocks of 16 Winograd tiles along x; for the narrow odd-width maps of SuperPoint's 1/8 level (67 pixels = 34 tiles
 -> 48 computed) the exact-fp32 kernel's linear tiling wastes nothing and is the faster of the two (tools/bench_conv.py,
 profiles/r03_ab_conv_*.json), so the choice is made per layer shape, once, here."""
-import os
-
 import torch
 
-from .. import _lib
+from .. import _lib, options
 
 
 def prefer_bf16x3(H, W):
     """tile-block waste of the bf16x3 kernel along x: ceil(tiles / 16) * 16 / tiles - 1; above 20 % the exact kernel wins"""
-    mode = os.environ.get("MFR_CONV_KERNEL", "auto")        # "bf16x3" / "exact" force one kernel (A/B runs, tests)
+    mode = options.get("CONV_KERNEL")                        # "bf16x3" / "exact" force one kernel (A/B runs, tests; options.py)
     if mode == "bf16x3":
         return True
     if mode == "exact":

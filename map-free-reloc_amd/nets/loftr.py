@@ -16,7 +16,7 @@ import math
 import torch
 import torch.nn.functional as F
 
-from .. import _lib
+from .. import _lib, options
 
 
 def _fold(w, sd, bn):
@@ -62,11 +62,10 @@ class LoFTRHIP:
         convbn("l1out2.0", "backbone.layer1_outconv2.0", "backbone.layer1_outconv2.1"); conv("l1out2.3", "backbone.layer1_outconv2.3")
         self.w = w
         # stride-1 3x3 convolutions go through the fused Winograd/MFMA kernel (csrc/winograd_conv.hip): transformed
-        # filters packed once here; BatchNorm is already folded into (w, b).  MFR_CONV=miopen keeps the library path.
-        import os
+        # filters packed once here; BatchNorm is already folded into (w, b).  options CONV = "miopen" keeps the library path.
         self.upk = {}
         lib = _lib.load()
-        if os.environ.get("MFR_CONV", "wino") == "wino":
+        if options.get("CONV") == "wino":
             from .conv import WinoConv3x3
             for name, (cw, cb) in w.items():
                 if tuple(cw.shape[2:]) != (3, 3) or name.endswith(".ds") or name == "conv1":

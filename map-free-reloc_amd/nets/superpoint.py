@@ -11,7 +11,7 @@ superpoint_v1.pth loads unchanged.
 import torch
 import torch.nn.functional as F
 
-from .. import _lib
+from .. import _lib, options
 from .conv import WinoConv3x3
 
 CAND_CAP = 32768
@@ -26,9 +26,8 @@ class SuperPointHIP:
         self.device = torch.device(device)
         self.nms_radius, self.thr = int(nms_radius), float(keypoint_threshold)
         self.K, self.border = int(max_keypoints), int(remove_borders)
-        import os
-        self.fused_conv_relu = os.environ.get("MFR_FUSED_CONV_RELU", "0") == "1"
-        self.use_wino = os.environ.get("MFR_CONV", "wino") == "wino"      # "miopen": library conv + epilogue kernels
+        self.fused_conv_relu = bool(options.get("FUSED_CONV_RELU"))
+        self.use_wino = options.get("CONV") == "wino"                     # "miopen": library conv + epilogue kernels (options.py)
         self.w = {k: v.to(self.device, torch.float32).contiguous() for k, v in state_dict.items()}
         # 1x1 heads as plain matrices
         self.w["convDb.mat"] = self.w["convDb.weight"].reshape(256, 256).contiguous()

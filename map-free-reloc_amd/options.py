@@ -1,0 +1,65 @@
+"""Declared kernel-selection options (A/B measurement and parity tests).  The C-ABI library reads no environment variable and neither
+does this package: every switch that picks between two implementations of the same layer lives here, has a default, a closed set
+of values, and is set either from the configuration (`cfg.HIP.<NAME>`, declared in config/default.py: unknown keys are rejected on
+merge) through `apply_cfg(cfg)`, or directly by a tool / test (`options.set("CONV_KERNEL", "exact")`, `bench.py --hip-opt K=V`).
+
+  CONV              'wino' (own Winograd kernels) | 'miopen' (library convolution + own epilogue kernels): 3x3 layers of the matchers
+  CONV_KERNEL       'auto' (per layer shape, nets/conv.py) | 'bf16x3' | 'exact': which own Winograd kernel
+  FUSED_CONV_RELU   SuperPoint conv1a through the fused first-layer kernel with ReLU folded (True / False)
+  RPR_CONV          'hip' (own implicit-GEMM forward of the regression decoder's 3x3 convolutions) | 'miopen'
+  RPR_CONV_BWD      'lib' (torch / MIOpen backward; the measured default) | 'hip' (own d input / d weight products)
+  RPR_CONV_ORDER    'tap_inner' | 'tap_outer': K order of the forward / d input product
+  RPR_WGRAD_SPLITS  K splits of the own d weight product (int >= 1)
+"""
+_SPEC = {
+    "CONV": ("wino", ("wino", "miopen")),
+    "CONV_KERNEL": ("auto", ("auto", "bf16x3", "exact")),
+    "FUSED_CONV_RELU": (False, (False, True)),
+    "RPR_CONV": ("hip", ("hip", "miopen")),
+    "RPR_CONV_BWD": ("lib", ("lib", "hip")),
+    "RPR_CONV_ORDER": ("tap_inner", ("tap_inner", "tap_outer")),
+    "RPR_WGRAD_SPLITS": (16, None),
+}
+_VALUES = {k: v[0] for k, v in _SPEC.items()}
+
+
+def names():
+    return sorted(_SPEC)
+
+
+def default(name):
+    return _SPEC[name][0]
+
+
+def get(name):
+    return _VALUES[name]
+
+
+def set(name, value):           # noqa: A001  (mirrors dict-like usage on purpose)
+    if name not in _SPEC:
+        raise KeyError(f"unknown HIP option {name!r}; known: {names()}")
+    dflt, allowed = _SPEC[name]
+    if isinstance(dflt, bool):
+        if isinstance(value, str):
+            value = value.lower() in ("1", "true", "yes", "on")
+        value = bool(value)
+    elif isinstance(dflt, int):
+        value = int(value)
+        if value < 1:
+            raise ValueError(f"HIP option {name}: must be >= 1")
+    if allowed is not None and value not in allowed:
+        raise ValueError(f"HIP option {name}={value!r}: allowed {allowed}")
+    _VALUES[name] = value
+
+
+def reset():
+    for k, v in _SPEC.items():
+        _VALUES[k] = v[0]
+
+
+def apply_cfg(cfg):
+    """copy every declared option that the configuration carries under HIP.*"""
+    hip = cfg.HIP if "HIP" in cfg else {}
+    for k in _SPEC:
+        if k in hip:
+            set(k, hip[k])

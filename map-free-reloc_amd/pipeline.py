@@ -45,7 +45,7 @@ class SuperGluePnPPipeline:
         if self.graph and not want_mask:
             from .nets.graph import GraphCaptureError, GraphedCall
             args = [images, depth0, K0, K1, pair_ids]
-            key = tuple(tuple(a.shape) for a in args)
+            key = tuple((tuple(a.shape), a.dtype) for a in args)      # dtype too: float32 K and float64 K are different arithmetic (k_dtype)
             try:
                 if key not in self._graphs:
                     self._graphs[key] = GraphedCall(self._run, args, clone_outputs=True)

@@ -17,19 +17,28 @@ d weight   k = pixels.  Both operands are channel-major zero-haloed images [B][C
     what a shifted read picks up from a neighbouring row / channel / image is multiplied by the zero halo of the gradient image).
     One grid slice per (tap, K split); fp32 partial sums, added up in a fixed order: no atomics, bit-reproducible.
 """
-import os
-
 import torch
 import torch.nn.functional as F
 
-# MFR_RPR_CONV=miopen keeps the library convolution (A/B timing); default: the kernel of this package
-ENABLED = os.environ.get("MFR_RPR_CONV", "hip") != "miopen"
+from .. import options
+
+# options RPR_CONV = "miopen" keeps the library convolution (A/B timing); default: the kernel of this package.  The module-level names
+# are read at CALL time (tests and tools may also set them directly: None = follow the declared option)
+ENABLED = None
 # Backward: "hip" = the d input / d weight products of this file; "lib" = torch's convolution_backward (MIOpen).  Measured on MI355X
 # (tools/bench_conv_bf16.py, profiles/r03_ab_conv_bf16*.json): the forward product beats the library 1.4-1.6x at 20 images per call and
 # 2.7-3.6x at 10 (0.25-0.33 vs 0.90 ms), the backward pair does not (1.37-1.43 vs 1.09-1.23 ms at 20 images: the three shifted
 # channel-major copies of the d weight product cost as much as its matrix work) -- so the default pairs the own forward with the
-# library's backward; MFR_RPR_CONV_BWD=hip runs everything here (what the parity tests do).
-BACKWARD = os.environ.get("MFR_RPR_CONV_BWD", "lib")
+# library's backward; options RPR_CONV_BWD = "hip" runs everything here (what the parity tests do).
+BACKWARD = None
+
+
+def _enabled():
+    return (options.get("RPR_CONV") != "miopen") if ENABLED is None else bool(ENABLED)
+
+
+def _backward():
+    return options.get("RPR_CONV_BWD") if BACKWARD is None else BACKWARD
 _TABLES = {}
 
 
@@ -86,14 +95,14 @@ def pack_cm_halo(x, Wq, L, ncopies, first_shift, slack):
     return out
 
 
-TAP_ORDER = os.environ.get("MFR_RPR_CONV_ORDER", "tap_inner")
+TAP_ORDER = None                                           # None = options RPR_CONV_ORDER
 
 
 def tap_tables(C, Wp, dev, order=None):
     """segment tables of the forward / d input product: k = (tap, channel).  'tap_outer': 9 segments of C channels (all channels of
     tap 0, then tap 1, ...).  'tap_inner': segments of 32 channels, the 9 taps of one channel chunk back to back -- the rows a workgroup
     reads for the 9 taps of a chunk are the same rows shifted by at most W+3, so eight of the nine reads hit the CU's L1 instead of L2."""
-    order = order or TAP_ORDER
+    order = order or TAP_ORDER or options.get("RPR_CONV_ORDER")
     shift = lambda t: ((t // 3 - 1) * Wp + (t % 3 - 1)) * C
     if order == "tap_outer":
         segA = _table(("fwdA", C, Wp), dev, lambda: ([shift(t) for t in range(9)] + [0], torch.int64))
@@ -143,7 +152,7 @@ def _wgrad(x, gy, splits=None):
     buf = pack_cm_halo(x, Wq, L, 3, -1, slack)              # copy kx holds x_haloed[p + kx - 1] at position p
     gq = pack_cm_halo(gy, Wq, L, 1, 0, 0)
     tiles = ((C + 255) // 256) * ((N + 127) // 128) * 9
-    S = int(splits or max(1, min(int(os.environ.get('MFR_RPR_WGRAD_SPLITS', 16)), 512 // tiles)))          # all slices resident at once: 256 CUs x 2 workgroups
+    S = int(splits or max(1, min(int(options.get('RPR_WGRAD_SPLITS')), 512 // tiles)))          # all slices resident at once: 256 CUs x 2 workgroups
     nkc_total = B * L // 32
     nkc_z = -(-nkc_total // S)
     S = -(-nkc_total // nkc_z)
@@ -159,9 +168,25 @@ def _wgrad(x, gy, splits=None):
     return dw.view(3, 3, C, N).permute(3, 2, 0, 1)
 
 
+_LIB_OK = None
+
+
+def _library_usable():
+    """the HIP library loads and a GPU is visible (probed once): otherwise the caller keeps the library convolution instead of raising
+    from inside the autograd Function"""
+    global _LIB_OK
+    if _LIB_OK is None:
+        try:
+            load(require_gpu=True)
+            _LIB_OK = True
+        except Exception:
+            _LIB_OK = False
+    return _LIB_OK
+
+
 def supported(x, weight, stride=1, padding=1):
     N, C, kh, kw = weight.shape
-    return (ENABLED and x.is_cuda and kh == 3 and kw == 3 and stride in (1, (1, 1)) and padding in (1, (1, 1))
+    return (_enabled() and x.is_cuda and _library_usable() and kh == 3 and kw == 3 and stride in (1, (1, 1)) and padding in (1, (1, 1))
             and C % 32 == 0 and N % 32 == 0 and x.dim() == 4)
 
 
@@ -182,7 +207,7 @@ class _Conv3x3BF16(torch.autograd.Function):
         x, weight = ctx.saved_tensors
         N, C = weight.shape[:2]
         gx = gw = gb = None
-        if BACKWARD == "lib":
+        if _backward() == "lib":
             mask = [ctx.needs_input_grad[0], ctx.needs_input_grad[1], bool(ctx.has_bias and ctx.needs_input_grad[2])]
             xb, wb, gyb = x.detach().to(torch.bfloat16), weight.detach().to(torch.bfloat16), gy.to(torch.bfloat16).contiguous()
             gx, gw, gb = torch.ops.aten.convolution_backward(gyb, xb, wb, [N] if ctx.has_bias else None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, mask)

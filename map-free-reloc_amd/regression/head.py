@@ -21,7 +21,12 @@ def _mlp(out_dims, in_features=None):
 class _Trunk(nn.Module):
     def _flag(self, *tensors):
         ok = torch.stack([torch.isfinite(t.detach()).all() for t in tensors]).all()
-        self.invalid = ~ok
+        # sticky on the device: a NaN in ANY forward since the last read stays visible (the reader clears it: clear_invalid)
+        prev = getattr(self, "invalid", None)
+        self.invalid = ~ok if prev is None or prev.device != ok.device else (prev | ~ok)
+
+    def clear_invalid(self):
+        self.invalid = None
 
 
 class ResBlockMLP(_Trunk):

@@ -60,9 +60,12 @@ class RegressionModel(nn.Module):
     def check_finite(self):
         """raise the reference's exit (head.py:88-101) if a head flagged NaN/Inf outputs; one host read"""
         flag = getattr(self.head, "invalid", None)
-        if flag is not None and bool(flag):
-            print("Invalid anchors!")
-            raise SystemExit("Stopped")
+        if flag is not None:
+            bad = bool(flag)
+            self.head.clear_invalid()
+            if bad:
+                print("Invalid anchors!")
+                raise SystemExit("Stopped")
 
     def loss_fn(self, data):
         R_loss, t_loss = self.rot_loss(data), self.trans_loss(data)

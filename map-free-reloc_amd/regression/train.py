@@ -131,6 +131,8 @@ class Trainer:
 
     def __init__(self, cfg, device=None, sample=None):
         self.cfg = cfg
+        from .. import options
+        options.apply_cfg(cfg)                     # declared kernel-selection options under cfg.HIP (options.py)
         self.rank, self.world, self.device = init_distributed(device)
         torch.manual_seed(0)                                    # pl.seed_everything(0), train.py:25: identical replicas
         cls = {"Regression": RegressionModel, "RegressionMultiFrame": RegressionMultiFrameModel}[cfg.MODEL]
@@ -321,6 +323,7 @@ class Trainer:
         flag = getattr(getattr(self.model, "head", None), "invalid", None)
         if flag is not None:
             bad += flag.to(bad.dtype).reshape(-1)[0]
+            self.model.head.clear_invalid()                      # sticky between reads (head._flag ORs every forward in)
         bad += (~torch.isfinite(loss.detach().float().sum())).to(bad.dtype)
         if self.world > 1 and dist.is_initialized():
             dist.all_reduce(bad, op=dist.ReduceOp.MAX)
@@ -355,8 +358,10 @@ class Trainer:
                     if self.rank == 0:
                         log(f"validation @ {self.global_step}: " + ", ".join(f"{k} {v:.4f}" for k, v in sorted(last.items())[:6]))
                     if out_dir:
+                        self.check_finite(loss)                 # never checkpoint weights that went through a NaN step
                         self.save(os.path.join(out_dir, "last.ckpt"))
             if out_dir:
+                self.check_finite(loss)
                 self.epoch += 1                                 # a resumed run starts at the next epoch
                 self.save(os.path.join(out_dir, f"e{self.epoch - 1}-last.ckpt"))
                 self.epoch -= 1

@@ -137,6 +137,8 @@ def predict_fused(cfg, split, output_root, pipeline=None, batch_pairs=None, resu
     n_inliers, status) works) -> `pose_{scene}.txt` written atomically into output_root/poses (= the resume marker).
     Then ONE all_gather of the pose records of the pairs solved in this run; rank 0 assembles the zip in global scene
     order from those records (scenes finished in an earlier run: from their files)."""
+    from . import options
+    options.apply_cfg(cfg)
     import torch.distributed as dist
     from . import parallel
     from .datasets import list_scenes, PairBatchLoader, DevicePrefetcher

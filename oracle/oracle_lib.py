@@ -11,6 +11,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "_build", "libmfr_oracle.so")
+_SO_OVERRIDE = os.environ.get("MFR_ORACLE_SO", "")          # test infrastructure only: the sanitizer build (tests/test_oracle_sanitizers.py)
 
 ST_OK, ST_TOO_FEW, ST_BAD_DEPTH, ST_NO_MODEL, ST_DEGENERATE = range(5)
 
@@ -29,8 +30,11 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        build()
-        _lib = C.CDLL(_SO)
+        if _SO_OVERRIDE:
+            _lib = C.CDLL(_SO_OVERRIDE)
+        else:
+            build()
+            _lib = C.CDLL(_SO)
         _lib.mfr_ref_det_log.restype = C.c_double
         _lib.mfr_ref_det_log.argtypes = [C.c_double]
         _lib.mfr_ref_depth_min.restype = C.c_float

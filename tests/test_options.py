@@ -1,0 +1,48 @@
+"""Kernel-selection options are DECLARED (mapfree_reloc_amd/options.py + cfg.HIP.*), never read from the environment."""
+import os
+import re
+
+import pytest
+
+import mapfree_reloc_amd  # noqa: F401
+from mapfree_reloc_amd import options
+from mapfree_reloc_amd.config import get_cfg_defaults
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_options_are_declared_validated_and_in_the_config_schema():
+    cfg = get_cfg_defaults()
+    for k in options.names():
+        assert k in cfg.HIP and cfg.HIP[k] == options.default(k)
+    with pytest.raises(KeyError):
+        options.set("NOT_AN_OPTION", 1)
+    with pytest.raises(ValueError):
+        options.set("CONV_KERNEL", "fastest")
+    try:
+        cfg.HIP.CONV_KERNEL = "exact"; cfg.HIP.RPR_WGRAD_SPLITS = 8
+        options.apply_cfg(cfg)
+        assert options.get("CONV_KERNEL") == "exact" and options.get("RPR_WGRAD_SPLITS") == 8
+        from mapfree_reloc_amd.nets.conv import prefer_bf16x3
+        assert prefer_bf16x3(720, 540) is False
+        options.set("CONV_KERNEL", "bf16x3")
+        assert prefer_bf16x3(90, 67) is True
+    finally:
+        options.reset()
+    assert options.get("CONV_KERNEL") == "auto"
+
+
+def test_product_reads_no_mfr_environment_variable():
+    """the only environment the package looks at is the launcher's rendezvous (RANK / WORLD_SIZE / LOCAL_* / MASTER_*)"""
+    allowed = {"RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"}
+    pkg = os.path.join(ROOT, "map-free-reloc_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if not f.endswith((".py", ".hip", ".h")):
+                continue
+            src = open(os.path.join(dp, f)).read()
+            assert "getenv" not in src or f.endswith(".py"), f
+            for m in re.finditer(r"environ(?:\.get|\.setdefault)?\s*[\[(]\s*['\"]([A-Z_0-9]+)['\"]", src):
+                assert m.group(1) in allowed, (f, m.group(1))
+            for m in re.finditer(r"['\"]([A-Z_0-9]+)['\"]\s+in\s+os\.environ", src):
+                assert m.group(1) in allowed, (f, m.group(1))

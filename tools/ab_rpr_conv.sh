@@ -1,6 +1,6 @@
 # A/B of the regression training step: library (MIOpen) vs own implicit-GEMM decoder convolutions x training options
 for o in "" siamese siamese,graph; do for v in miopen hip; do
-MFR_RPR_CONV=$v timeout 150 python bench.py --config rpr_train --no-cpu-baseline --rpr-opts "$o" 2>/tmp/err.log | python -c "
+timeout 150 python bench.py --config rpr_train --no-cpu-baseline --hip-opt RPR_CONV=$v --rpr-opts "$o" 2>/tmp/err.log | python -c "
 import sys,json
 try:
     d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$v', '[$o]', d['value'], d['ms_per_step'])
