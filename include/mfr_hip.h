@@ -293,6 +293,9 @@ int mfr_loftr_fine_match(const float *g0, const float *g1, int ld, int C, int M,
 int mfr_conv3x3_c1_relu(const float *x, const float *w, const float *bias, int B, int H, int W, int out_channels,
                         float *y, void *stream);
 int mfr_bias_relu_nchw(float *x, const float *bias, int B, int C, int HW, void *stream);
+/* 1x1 convolution with few output channels (SuperPoint's detector head convPb 256 -> 65, same call site): y [B,Cout,HW] = w [Cout,Cin] x [B,Cin,HW]
+ * + bias, one ascending fused-multiply-add chain per output: a pixel's result does not depend on the batch size.  Cin <= 512. */
+int mfr_conv1x1_nchw(const float *x, const float *w, const float *bias, int B, int Cin, int Cout, int HW, float *y, void *stream);
 int mfr_bias_pool2_relu_nchw(const float *x, const float *bias, int B, int C, int H, int W, float *y, void *stream);
 
 /* ------------------------------------------------------------------------------------------

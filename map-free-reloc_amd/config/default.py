@@ -11,6 +11,8 @@ keys this implementation adds (declared here because unknown keys are rejected o
                      EMAT_SCORE: model quality of the E-matrix RANSAC -- 'magsac' (MAGSAC++ loss + sigma-consensus++, the method the
                      reference asks OpenCV for: cv.USAC_MAGSAC, pose_solver.py:46-48) | 'count' (inlier count + LM polish, rounds 1-3);
                      MAGSAC_MAX_THR_RATIO: k * sigma_max of MAGSAC++ as a multiple of EMAT_RANSAC.PIX_THRESHOLD (>= 1);
+                     REF_FEATURE_CACHE: the fused pipeline runs SuperPoint once per distinct reference view of a batch (and keeps the
+                     last few across batches) instead of once per pair -- same bits, fewer images (pipeline.py);
                      CONV / CONV_KERNEL / FUSED_CONV_RELU / RPR_CONV / RPR_CONV_BWD / RPR_CONV_ORDER / RPR_WGRAD_SPLITS: which of two
                      implementations of a layer runs (A/B measurement, parity tests) -- options.py lists values and defaults
   LOFTR.WEIGHTS      checkpoint of the online LoFTR matcher ('LoFTR' feature matching)
@@ -70,7 +72,7 @@ def get_cfg_defaults():
     # ---- additions of this implementation ----
     c.RANSAC = CN(); c.RANSAC.SEED = 0
     c.HIP = CN(); c.HIP.BATCH_PAIRS = 16; c.HIP.MAX_KEYPOINTS = 1024; c.HIP.MAX_CORRESPONDENCES = 8192; c.HIP.GRAPH_BATCH1 = True; c.HIP.GRAPH_FUSED = False
-    c.HIP.EMAT_SCORE = 'magsac'; c.HIP.MAGSAC_MAX_THR_RATIO = 1.0
+    c.HIP.EMAT_SCORE = 'magsac'; c.HIP.MAGSAC_MAX_THR_RATIO = 1.0; c.HIP.REF_FEATURE_CACHE = True
     from .. import options as _opt                     # kernel-selection options (options.py): declared with their defaults, applied by apply_cfg
     for _k in _opt.names():
         c.HIP[_k] = _opt.default(_k)

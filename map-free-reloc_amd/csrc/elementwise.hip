@@ -118,6 +118,44 @@ __global__ void __launch_bounds__(256) conv3x3_c1_relu_kernel(const float *__res
     }
 }
 
+
+// 1x1 convolution with few output channels, NCHW f32 (SuperPoint's detector head convPb, 256 -> 65): y[b, co, p] = bias[co] +
+// sum_c w[co, c] x[b, c, p], one thread per pixel, 16 output channels per workgroup row, the weights of the block broadcast from LDS,
+// ONE fused-multiply-add chain over c in ascending order per output -- so a pixel's logits do not depend on how many images are in the
+// batch (the library's batched GEMM picked its tile, and with it the summation order, from the batch size: the reference-view feature
+// cache of pipeline.py needs per-image results that are the same bits in a batch of 33 and in a batch of 64).
+#define C1_CB 16
+__global__ void __launch_bounds__(256) conv1x1_nchw_kernel(const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
+                                                           int Cin, int Cout, int HW, float *__restrict__ y)
+{
+    __shared__ float ws[512 * C1_CB];                       // [c][k]
+    const int b = blockIdx.z, cb0 = blockIdx.y * C1_CB, p = blockIdx.x * 256 + threadIdx.x;
+    for (int i = threadIdx.x; i < Cin * C1_CB; i += 256) {
+        const int c = i / C1_CB, k = i - c * C1_CB;
+        ws[i] = (cb0 + k < Cout) ? w[(size_t)(cb0 + k) * Cin + c] : 0.f;
+    }
+    __syncthreads();
+    if (p >= HW) return;
+    float acc[C1_CB];
+#pragma unroll
+    for (int k = 0; k < C1_CB; ++k) acc[k] = (bias && cb0 + k < Cout) ? bias[cb0 + k] : 0.f;
+    const float *xp = x + (size_t)b * Cin * HW + p;
+    for (int c = 0; c < Cin; ++c) {
+        const float xv = xp[(size_t)c * HW];
+        const float4 *wr = (const float4 *)(ws + c * C1_CB);
+#pragma unroll
+        for (int q = 0; q < C1_CB / 4; ++q) {
+            const float4 wv = wr[q];
+            acc[4 * q] = __builtin_fmaf(wv.x, xv, acc[4 * q]); acc[4 * q + 1] = __builtin_fmaf(wv.y, xv, acc[4 * q + 1]);
+            acc[4 * q + 2] = __builtin_fmaf(wv.z, xv, acc[4 * q + 2]); acc[4 * q + 3] = __builtin_fmaf(wv.w, xv, acc[4 * q + 3]);
+        }
+    }
+    float *yp = y + ((size_t)b * Cout + cb0) * HW + p;
+#pragma unroll
+    for (int k = 0; k < C1_CB; ++k)
+        if (cb0 + k < Cout) yp[(size_t)k * HW] = acc[k];
+}
+
 extern "C" {
 
 int mfr_conv3x3_c1_relu(const float *x, const float *w, const float *bias, int B, int H, int W, int out_channels,
@@ -127,6 +165,14 @@ int mfr_conv3x3_c1_relu(const float *x, const float *w, const float *bias, int B
         (((size_t)y) & 15)) return MFR_E_ARG;
     hipLaunchKernelGGL(conv3x3_c1_relu_kernel, dim3((H * (W / 4) + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, x, w, bias,
                        H, W, y);
+    CHECK_LAUNCH();
+    return 0;
+}
+
+int mfr_conv1x1_nchw(const float *x, const float *w, const float *bias, int B, int Cin, int Cout, int HW, float *y, void *stream)
+{
+    if (!x || !w || !y || B <= 0 || Cin <= 0 || Cin > 512 || Cout <= 0 || HW <= 0 || B > 65535) return MFR_E_ARG;
+    hipLaunchKernelGGL(conv1x1_nchw_kernel, dim3((HW + 255) / 256, (Cout + C1_CB - 1) / C1_CB, B), dim3(256), 0, (hipStream_t)stream, x, w, bias, Cin, Cout, HW, y);
     CHECK_LAUNCH();
     return 0;
 }

@@ -188,6 +188,8 @@ class MapFreeScene:
         else:
             ids = sorted(int(re.search(r"_(\d+)\..*$", fn).group(1)) for fn in self.poses if "seq0" not in fn)
             self.pairs = [(0, 0, 1, i) for i in ids][0::sample_factor]
+        # every pair of a val / test scene has the SAME reference view (the keyframe): consumers may compute its features once
+        self.shared_reference = len({(sa, ia) for sa, ia, _, _ in self.pairs}) == 1 and len(self.pairs) > 0
 
     def __len__(self):
         return len(self.pairs)
@@ -441,7 +443,7 @@ class PairBatchLoader:
             im_np[2 * p + 1, 0] = npv(to_gray(smp["image1"]))
             if has_depth:
                 d0_np[p] = npv(smp["depth0"]); d1_np[p] = npv(smp["depth1"])
-            return (torch.as_tensor(smp["K_color0"]), torch.as_tensor(smp["K_color1"]), int(smp["pair_id"]), smp["pair_names"][1])
+            return (torch.as_tensor(smp["K_color0"]), torch.as_tensor(smp["K_color1"]), int(smp["pair_id"]), smp["pair_names"][1], smp["pair_names"][0])
         if fut0 is not None:
             futs = [self._pool.submit(lambda p=p, f=f: fill(p, f.result())) for p, f in zip(range(1, b), fut0)]
             meta = [fill(0, first)] + [f.result() for f in futs]             # order preserved
@@ -460,6 +462,11 @@ class PairBatchLoader:
                     global_ids=torch.tensor([self.offsets[si] + i for si, i in items], dtype=torch.int64),
                     names=[m[3] for m in meta], scene_ids=[self.scenes[si].scene_id for si, _ in items],
                     scene_roots=[self.scenes[si].scene_root for si, _ in items], scenes_done=done,
+                    # identity of every pair's REFERENCE view (a val / test scene pairs one keyframe with all its queries, mapfree.py:148-165):
+                    # what FusedPosePipeline keys its reference-view feature cache on
+                    # -- only for scenes that DECLARE the sharing (`shared_reference`: MapFreeScene val / test); None = do not cache
+                    ref_keys=[(self.scenes[si].scene_root, m[4]) if getattr(self.scenes[si], "shared_reference", False) else None
+                              for (si, _), m in zip(items, meta)],
                     scene_id=sc.scene_id, scene_root=sc.scene_root, scene_index=items[-1][0], last_of_scene=bool(done and done[-1] == sc.scene_id))
 
     def __iter__(self):

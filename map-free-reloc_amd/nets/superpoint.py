@@ -31,6 +31,8 @@ class SuperPointHIP:
         self.w = {k: v.to(self.device, torch.float32).contiguous() for k, v in state_dict.items()}
         # 1x1 heads as plain matrices
         self.w["convDb.mat"] = self.w["convDb.weight"].reshape(256, 256).contiguous()
+        from .linear import SplitLinear
+        self.convDb = SplitLinear(self.w["convDb.mat"], self.w["convDb.bias"])
         # Winograd-transformed 3x3 filters, packed in MFMA operand order (csrc/winograd_conv.hip), once per weight set
         self.upk = {}
         for name in ("conv1b", "conv2a", "conv2b", "conv3a", "conv3b", "conv4a", "conv4b", "convPa", "convDa"):
@@ -49,7 +51,13 @@ class SuperPointHIP:
         if self.use_wino and relu and name in self.upk:
             return self.upk[name](x, act=1, pool=pool)
         if not relu:
-            if w.shape[-1] == 1:            # 1x1 head (convPb): one batched library GEMM [Cout,Cin] x [Cin,HW] per image, no MIOpen
+            if w.shape[-1] == 1 and self.use_wino:   # 1x1 head (convPb): own kernel, one ascending FMA chain per logit (batch-size independent bits)
+                B, C, H, W = x.shape
+                x = x.contiguous()
+                y = torch.empty(B, w.shape[0], H, W, dtype=torch.float32, device=x.device)
+                _lib.check(lib.mfr_conv1x1_nchw(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), B, C, w.shape[0], H * W, _lib.ptr(y), _lib.stream_ptr()), "mfr_conv1x1_nchw")
+                return y
+            if w.shape[-1] == 1:            # options CONV = "miopen": one batched library GEMM [Cout,Cin] x [Cin,HW] per image
                 B, C, H, W = x.shape
                 return torch.baddbmm(b.view(1, -1, 1), w.view(1, w.shape[0], C).expand(B, -1, -1), x.reshape(B, C, H * W)).view(B, -1, H, W)
             return F.conv2d(x, w, b, padding=pad)
@@ -136,6 +144,7 @@ class SuperPointHIP:
         kpts, sc, n = self.select(cand, cnt, scores.shape[2])
         cDa = self._conv(x, "convDa")
         B, C, Hc, Wc = cDa.shape
-        dense = torch.addmm(self.w["convDb.bias"], cDa.permute(0, 2, 3, 1).reshape(-1, C), self.w["convDb.mat"].t())
+        # 1x1 descriptor head (convDb) through the own GEMM: every row's K loop runs in the same order whatever the number of rows
+        dense = self.convDb(cDa.permute(0, 2, 3, 1).reshape(-1, C))
         desc = self.sample(dense.view(B, Hc, Wc, 256), kpts, n)
         return dict(kpts=kpts, scores=sc, desc=desc, n=n)

@@ -103,3 +103,49 @@ def test_submission_cli_fused_on_synthetic(tmp_path):
         lines = z.read("pose_s00001.txt").decode().split("\n")
     assert len(lines) == 2 and lines[0].startswith("seq1/frame_00000.jpg ") and len(lines[0].split(" ")) == 9
     assert (out / "poses" / "pose_s00000.txt").exists()
+
+
+class _SharedRefScene:
+    """a scene whose pairs all have the SAME reference image (what every Map-free val / test scene is, mapfree.py:148-165): three queries
+    of one synthetic scene (plain, with moving objects + occluder, with corrupted depth on top)"""
+    shared_reference = True
+
+    def __init__(self, seed, sid):
+        from mapfree_reloc_amd import images as IM
+        self.scene_id, self.scene_root = sid, f"/synthetic/{sid}"
+        self.p = [IM.synthetic_pair(seed, 720, 540, hard=h) for h in (0, 1, 2)]
+        self.img0 = torch.from_numpy(self.p[0]["img0"])[None].expand(3, -1, -1).contiguous()        # ONE tensor for all pairs
+        assert all(np.array_equal(q["img0"], self.p[0]["img0"]) for q in self.p)
+
+    def __len__(self):
+        return len(self.p)
+
+    def pair_name(self, i):
+        return f"seq1/frame_{5 * i:05d}.jpg"
+
+    def __getitem__(self, i):
+        q = self.p[i]
+        return {"image0": self.img0, "image1": torch.from_numpy(q["img1"])[None].expand(3, -1, -1).contiguous(),
+                "depth0": torch.from_numpy(q["depth0"]), "depth1": torch.from_numpy(q["depth1"]),
+                "K_color0": torch.from_numpy(q["K"].copy()), "K_color1": torch.from_numpy(q["K"].copy()), "pair_id": 5 * i,
+                "scene_id": self.scene_id, "scene_root": self.scene_root, "pair_names": ("seq0/frame_00000.jpg", self.pair_name(i))}
+
+
+def test_reference_view_feature_cache_is_bitwise_neutral(tmp_path):
+    """SuperPoint once per distinct reference view (HIP.REF_FEATURE_CACHE) vs once per pair: the same archive byte for byte, on two
+    scenes whose batches (4 pairs) straddle the scene boundary, so both the in-batch grouping and the cross-batch cache are used"""
+    from mapfree_reloc_amd.pipeline import FusedPosePipeline
+    scenes = [_SharedRefScene(11, "s00000"), _SharedRefScene(12, "s00001")]
+    zs, stats = [], None
+    for cache in (True, False):
+        cfg = _cfg("PNP", "SuperGlue")
+        cfg.HIP.REF_FEATURE_CACHE = cache
+        pipe = FusedPosePipeline(cfg)
+        zs.append(submission.predict_fused(cfg, "test", tmp_path / f"c{int(cache)}", pipeline=pipe, batch_pairs=4, scenes=scenes))
+        if cache:
+            stats = pipe.match.stats
+    assert stats == {"reference_views_run": 2, "reference_views_reused": 4}, stats
+    assert open(zs[0], "rb").read() == open(zs[1], "rb").read()
+    with zipfile.ZipFile(zs[0]) as a:
+        lines = a.read("pose_s00000.txt").decode().split("\n")
+    assert len(lines) == 3 and all("nan" not in l for l in lines)                  # real poses were compared, not failures
