@@ -410,13 +410,9 @@ class PairBatchLoader:
         copy of 64 images per batch on this thread capped the loader at ~300 pairs/s)"""
         get = lambda it: self.scenes[it[0]][it[1]]
         b = len(items)
-        fut0 = None
-        if self.workers > 1 and b > 1:
-            if self._pool is None:
-                import concurrent.futures
-                self._pool = concurrent.futures.ThreadPoolExecutor(max_workers=self.workers, thread_name_prefix="mfr-decode")
-            # the other pairs start decoding NOW, while this thread decodes the first one (its shapes / dtypes size the batch buffers)
-            fut0 = [self._pool.submit(get, items[p]) for p in range(1, b)]
+        # shapes / dtypes of the batch buffers come from the first pair; it is decoded on this thread before the pool gets the others (an
+        # attempt to overlap the two -- pool tasks that decode, then pool tasks that wait for them and fill -- halved the loader's rate:
+        # workers parked in .result() while the next batches' decodes queued behind them; tools/bench_fused_split.py, round 4)
         first = get(items[0])
         Hh, Ww = first["image0"].shape[-2:]
         mk = (lambda *shape, dtype=torch.float32: torch.empty(*shape, dtype=dtype, pin_memory=True)) if self.pin else \
@@ -444,8 +440,11 @@ class PairBatchLoader:
             if has_depth:
                 d0_np[p] = npv(smp["depth0"]); d1_np[p] = npv(smp["depth1"])
             return (torch.as_tensor(smp["K_color0"]), torch.as_tensor(smp["K_color1"]), int(smp["pair_id"]), smp["pair_names"][1], smp["pair_names"][0])
-        if fut0 is not None:
-            futs = [self._pool.submit(lambda p=p, f=f: fill(p, f.result())) for p, f in zip(range(1, b), fut0)]
+        if self.workers > 1 and b > 1:
+            if self._pool is None:
+                import concurrent.futures
+                self._pool = concurrent.futures.ThreadPoolExecutor(max_workers=self.workers, thread_name_prefix="mfr-decode")
+            futs = [self._pool.submit(fill, p) for p in range(1, b)]
             meta = [fill(0, first)] + [f.result() for f in futs]             # order preserved
         else:
             meta = [fill(0, first)] + [fill(p) for p in range(1, b)]

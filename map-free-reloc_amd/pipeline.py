@@ -160,11 +160,10 @@ class _RefCachedSuperGlue:
         self.stats["reference_views_run"] += u
         self.stats["reference_views_reused"] += B - u
         order = list(first)
-        slot = torch.tensor([order.index(k) for k in keys], device=im.device)
         sp2 = {}
         for f in ("kpts", "scores", "desc", "n"):
-            ref = torch.cat([self.cache[k][f] for k in order])[slot]               # [B, ...] reference rows
-            qry = out[f][u:]
+            ref = torch.cat([self.cache[k][f] for k in keys])                      # [B, ...] reference rows (no index tensor: an H2D copy would
+            qry = out[f][u:]                                                       # synchronise the stream once per batch)
             sp2[f] = torch.stack([ref, qry], 1).reshape((2 * B,) + tuple(qry.shape[1:]))
         for k in order:                                                           # most recently used last; bounded
             if k[0] == "__pair__":
