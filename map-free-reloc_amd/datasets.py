@@ -359,6 +359,24 @@ def make_loader(cfg, split="val"):
     return (collate_batch1(sc[i]) for sc in scenes for i in range(len(sc)))
 
 
+def usable_cpus():
+    """CPUs this process may actually use: the affinity mask capped by the container's CFS quota (cgroup v2 cpu.max / v1 cfs_quota): a GPU box
+    shows 256 cores and grants 16"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def to_gray(img):
     """[3,H,W] or [1,H,W] float in [0,1] -> [H,W] float32 luma (BT.601 weights, what cv2.imread(GRAYSCALE) computes)"""
     if img.shape[0] == 1:
@@ -369,6 +387,92 @@ def to_gray(img):
         a = img.numpy()
         return torch.from_numpy(np.float32(0.299) * a[0] + np.float32(0.587) * a[1] + np.float32(0.114) * a[2])
     return 0.299 * img[0] + 0.587 * img[1] + 0.114 * img[2]
+
+
+# ---- decode in worker PROCESSES (PairBatchLoader(decode="process")) ------------------------------------------------------------------
+# The thread pool shares ONE interpreter lock between up to 32 decode threads, the loader thread and the thread that issues the GPU
+# step (and 8 ranks on a host would run 8 such crowds): round 4's boxes delivered 350-400 pairs/s from it where the GPU side takes
+# ~880.  Here the pairs of a batch are decoded by worker processes that write the gray planes / depth maps straight into a ring of
+# SHARED-MEMORY batch slots (torch shared-memory tensors handed to the workers once, at pool start); the parent registers the slots
+# as pinned host memory, so the H2D copy of a slot is an asynchronous DMA exactly as from a pinned buffer.
+_PW = {}
+
+
+def _slot_views(flat, n_slots, B, Hh, Ww, has_depth):
+    """carve the ring's batch slots out of ONE shared tensor (one shared-memory segment = one descriptor per worker)"""
+    per = 2 * B * Hh * Ww + (2 * B * Hh * Ww if has_depth else 0)
+    out = []
+    for k in range(n_slots):
+        o = k * per
+        im = flat[o:o + 2 * B * Hh * Ww].view(2 * B, 1, Hh, Ww)
+        d0 = flat[o + 2 * B * Hh * Ww:o + 3 * B * Hh * Ww].view(B, Hh, Ww) if has_depth else None
+        d1 = flat[o + 3 * B * Hh * Ww:o + 4 * B * Hh * Ww].view(B, Hh, Ww) if has_depth else None
+        out.append(dict(images=im, depth0=d0, depth1=d1))
+    return out
+
+
+def _pw_init(scenes, flat, layout):
+    torch.set_num_threads(1)
+    _PW["scenes"], _PW["slots"] = scenes, _slot_views(flat, *layout)
+
+
+def _pw_fill(task):
+    """decode one pair into slot `k`, position `p`; `want_ref` False: the reference plane is a duplicate the parent copies"""
+    import time as _t
+    t0 = _t.perf_counter()
+    k, p, si, i, want_ref = task
+    smp = _PW["scenes"][si][i]
+    sl = _PW["slots"][k]
+    npv = lambda t: t.numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
+    im = sl["images"].numpy()
+    if want_ref:
+        im[2 * p, 0] = npv(to_gray(smp["image0"]))
+    im[2 * p + 1, 0] = npv(to_gray(smp["image1"]))
+    if sl["depth0"] is not None and smp["depth0"].numel() > 0:
+        sl["depth0"].numpy()[p] = npv(smp["depth0"]); sl["depth1"].numpy()[p] = npv(smp["depth1"])
+    return (np.asarray(smp["K_color0"]), np.asarray(smp["K_color1"]), int(smp["pair_id"]), smp["pair_names"][1], smp["pair_names"][0],
+            _t.perf_counter() - t0)
+
+
+def _pw_ping(i):
+    return os.getpid()
+
+
+class _ProcessDecoder:
+    """pool of decode processes + ring of shared-memory batch slots (see above).  A slot is reused only after the H2D copies issued from it
+    have completed (DevicePrefetcher stores its event in `events[k]`)."""
+
+    def __init__(self, scenes, B, Hh, Ww, has_depth, workers, n_slots, pin):
+        import torch.multiprocessing as mp
+        layout = (n_slots, B, Hh, Ww, has_depth)
+        per = 2 * B * Hh * Ww + (2 * B * Hh * Ww if has_depth else 0)
+        self.flat = torch.empty(n_slots * per, dtype=torch.float32).share_memory_()
+        self.slots = _slot_views(self.flat, *layout)
+        self.events = [None] * n_slots
+        self.pinned = False
+        if pin and torch.cuda.is_available():
+            self.pinned = int(torch.cuda.cudart().cudaHostRegister(self.flat.data_ptr(), self.flat.numel() * 4, 0)) == 0
+        # FORK, like torch's DataLoader workers: the children inherit the scene objects and the shared segment without re-importing anything
+        # (spawned workers each re-imported torch: 36 s to start 32 of them under a 16-CPU container quota, tools/bench_fused_split.py) and
+        # never touch the HIP runtime -- they run PIL / zlib / numpy only
+        self.pool = mp.get_context("fork").Pool(workers, initializer=_pw_init, initargs=(scenes, self.flat, layout))
+        self.next = 0
+
+    def acquire(self):
+        k = self.next
+        self.next = (self.next + 1) % len(self.slots)
+        ev = self.events[k]
+        if ev is not None:
+            ev.synchronize()                                   # the copies out of this slot are done
+            self.events[k] = None
+        return k
+
+    def close(self):
+        if self.pool is not None:
+            self.pool.terminate(); self.pool.join(); self.pool = None
+        if self.pinned:
+            torch.cuda.cudart().cudaHostUnregister(self.flat.data_ptr())
+            self.pinned = False
 
 
 class PairBatchLoader:
@@ -383,12 +487,16 @@ class PairBatchLoader:
     global_ids [b] i64, names [b], scene_ids [b] / scene_roots [b] (per pair), scenes_done (ids of the scenes whose LAST pair is in
     this batch), scene_id / scene_root / last_of_scene (of the batch's last pair, kept for single-scene consumers))."""
 
-    def __init__(self, scenes, batch_pairs=32, prefetch=2, pin=None, global_offsets=None, workers=8, span_scenes=True):
+    def __init__(self, scenes, batch_pairs=32, prefetch=2, pin=None, global_offsets=None, workers=8, span_scenes=True, decode="thread"):
         """workers: decode threads per batch (PIL / zlib / numpy release the GIL): a pair is two JPEGs + one or two 16-bit PNGs,
         ~12 ms of decode on one core, so one thread feeds ~80 pairs/s where the fused pipeline consumes ~700"""
         self.scenes, self.B, self.prefetch = list(scenes), int(batch_pairs), int(prefetch)
         self.workers = max(1, int(workers))
         self._pool = None
+        if decode not in ("thread", "process"):
+            raise ValueError(f"PairBatchLoader: decode must be 'thread' or 'process', got {decode!r}")
+        self.decode, self._proc = decode, None
+        self.stats = {}                                        # process decoder: pool start, time in pool.map, summed worker task time, ...
         self.pin = torch.cuda.is_available() if pin is None else pin
         self.offsets = global_offsets
         if self.offsets is None:
@@ -408,6 +516,8 @@ class PairBatchLoader:
         """decode the pairs of one batch STRAIGHT INTO the batch's (pinned) buffers: every worker thread decodes its pair, converts to
         gray and writes its slots itself; the loader thread only allocates and collects the small fields (a serial gray conversion +
         copy of 64 images per batch on this thread capped the loader at ~300 pairs/s)"""
+        if self.decode == "process" and self.workers > 1:
+            return self._load_process(items)
         get = lambda it: self.scenes[it[0]][it[1]]
         b = len(items)
         # shapes / dtypes of the batch buffers come from the first pair; it is decoded on this thread before the pool gets the others (an
@@ -468,6 +578,62 @@ class PairBatchLoader:
                               for (si, _), m in zip(items, meta)],
                     scene_id=sc.scene_id, scene_root=sc.scene_root, scene_index=items[-1][0], last_of_scene=bool(done and done[-1] == sc.scene_id))
 
+    def _load_process(self, items):
+        """the same batch through the process pool: workers write into a shared-memory slot; the first pair of the loader's life is
+        decoded here once to learn the shapes"""
+        import time as _t
+        b = len(items)
+        st = self.stats
+        if self._proc is None:
+            t0 = _t.perf_counter()
+            first = self.scenes[items[0][0]][items[0][1]]
+            Hh, Ww = first["image0"].shape[-2:]
+            self._proc = _ProcessDecoder(self.scenes, self.B, Hh, Ww, first["depth0"].numel() > 0, self.workers, max(self.prefetch, 0) + 4, self.pin)
+            self._proc.pool.map(_pw_ping, range(self.workers * 2), chunksize=1)        # every worker has started and imported its modules
+            st["process_pool_start_s"] = _t.perf_counter() - t0
+        pr = self._proc
+        t0 = _t.perf_counter()
+        k = pr.acquire()
+        st["slot_wait_s"] = st.get("slot_wait_s", 0.0) + _t.perf_counter() - t0
+        t0 = _t.perf_counter()
+        sl = pr.slots[k]
+        # reference views: decoded once per distinct (scene, shared reference) of the batch, duplicates copied below
+        first_of, want = {}, []
+        for p, (si, i) in enumerate(items):
+            key = si if getattr(self.scenes[si], "shared_reference", False) else ("pair", p)
+            want.append(key not in first_of)
+            first_of.setdefault(key, p)
+        meta = pr.pool.map(_pw_fill, [(k, p, si, i, want[p]) for p, (si, i) in enumerate(items)], chunksize=1)
+        st["decode_map_s"] = st.get("decode_map_s", 0.0) + _t.perf_counter() - t0
+        st["worker_task_s"] = st.get("worker_task_s", 0.0) + sum(m[5] for m in meta)
+        st["batches"] = st.get("batches", 0) + 1
+        t0 = _t.perf_counter()
+        im = sl["images"].numpy()
+        for p, (si, i) in enumerate(items):
+            if not want[p]:
+                q = first_of[si]
+                np.copyto(im[2 * p, 0], im[2 * q, 0])
+        st["ref_copy_s"] = st.get("ref_copy_s", 0.0) + _t.perf_counter() - t0
+        K0 = torch.stack([torch.as_tensor(m[0]) for m in meta]); K1 = torch.stack([torch.as_tensor(m[1]) for m in meta])
+        sc = self.scenes[items[-1][0]]
+        done = [self.scenes[si].scene_id for si, i in items if i == len(self.scenes[si]) - 1]
+        has_depth = sl["depth0"] is not None
+        return dict(images=sl["images"][:2 * b], depth0=sl["depth0"][:b] if has_depth else None, depth1=sl["depth1"][:b] if has_depth else None,
+                    K0=K0, K1=K1, seed_ids=torch.tensor([m[2] for m in meta], dtype=torch.int64),
+                    global_ids=torch.tensor([self.offsets[si] + i for si, i in items], dtype=torch.int64),
+                    names=[m[3] for m in meta], scene_ids=[self.scenes[si].scene_id for si, _ in items],
+                    scene_roots=[self.scenes[si].scene_root for si, _ in items], scenes_done=done,
+                    ref_keys=[(self.scenes[si].scene_root, m[4]) if getattr(self.scenes[si], "shared_reference", False) else None
+                              for (si, _), m in zip(items, meta)],
+                    scene_id=sc.scene_id, scene_root=sc.scene_root, scene_index=items[-1][0], last_of_scene=bool(done and done[-1] == sc.scene_id),
+                    _slot=(pr, k))
+
+    def close(self):
+        if self._proc is not None:
+            self._proc.close(); self._proc = None
+        if self._pool is not None:
+            self._pool.shutdown(wait=False); self._pool = None
+
     def __iter__(self):
         if self.prefetch <= 0:
             for b in self.batches:
@@ -515,8 +681,11 @@ class DevicePrefetcher:
         if self.stream is None:
             return dict(hb), None
         with torch.cuda.stream(self.stream):
-            db = {k: (v.to(self.device, non_blocking=True) if isinstance(v, torch.Tensor) else v) for k, v in hb.items()}
+            db = {k: (v.to(self.device, non_blocking=True) if isinstance(v, torch.Tensor) else v) for k, v in hb.items() if k != "_slot"}
             ev = torch.cuda.Event(); ev.record(self.stream)
+            if "_slot" in hb:                                  # shared-memory slot of the process decoder: reusable once these copies are done
+                pr, k = hb["_slot"]
+                pr.events[k] = ev
         return db, ev
 
     def __iter__(self):

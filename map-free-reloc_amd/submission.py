@@ -179,9 +179,11 @@ def predict_fused(cfg, split, output_root, pipeline=None, batch_pairs=None, resu
     # decode threads: a pair costs ~45 ms of JPEG / PNG decode on one core (2 images + depth maps), the pipeline consumes 100-700 pairs/s
     # per GPU: the host's cores are split between the ranks of this node
     local_world = int(os.environ.get('LOCAL_WORLD_SIZE', world)) if world > 1 else 1
-    workers = max(4, min(32, (os.cpu_count() or 8) // max(1, local_world)))
+    from .datasets import usable_cpus
+    workers = max(2, min(32, usable_cpus() // max(1, local_world)))        # the CPUs the container grants, not the ones the box shows
+    decode = str(cfg.HIP.LOADER_DECODE) if 'LOADER_DECODE' in cfg.HIP else 'process'
     loader = PairBatchLoader([scenes[i] for i in todo], B, prefetch=prefetch, pin=device.type == 'cuda',
-                             global_offsets=[int(offsets[i]) for i in todo], workers=workers)
+                             global_offsets=[int(offsets[i]) for i in todo], workers=workers, decode=decode)
     recs, names, acc = [], {}, []
     stats = dict(pairs=0, batches=0, loader_wait_s=0.0, issue_s=0.0, gpu_busy_s=0.0, t0=time.perf_counter())
     it = iter(DevicePrefetcher(loader, device))
@@ -232,8 +234,9 @@ def predict_fused(cfg, split, output_root, pipeline=None, batch_pairs=None, resu
     if evs:
         torch.cuda.synchronize(device)
         stats['gpu_busy_s'] = sum(a.elapsed_time(b) for a, b in evs) * 1e-3
+    loader.close()                                          # decode processes / shared-memory slots of this run
     stats['seconds'] = time.perf_counter() - stats.pop('t0')
-    LAST_RUN_STATS.clear(); LAST_RUN_STATS.update(stats, rank=rank, world=world, scenes_computed=len(todo), decode_workers=workers, batch_pairs=B)
+    LAST_RUN_STATS.clear(); LAST_RUN_STATS.update(stats, rank=rank, world=world, scenes_computed=len(todo), decode_workers=workers, decode=decode, batch_pairs=B, loader_stats=dict(getattr(loader, 'stats', {})))
     mine = torch.from_numpy(np.concatenate(recs) if recs else np.zeros((0, parallel.REC_W))).to(device)
     allrec = parallel.gather_records(mine, world).cpu().numpy()
     if rank != 0:

@@ -387,16 +387,19 @@ def test_pair_batch_loader_equals_the_per_sample_reader(tmp_path):
         scenes.append(MapFreeScene(sc, resize=(36, 48), sample_factor=1, estimated_depth="dptkitti"))
     ref = [(si, i, sc[i]) for si, sc in enumerate(scenes) for i in range(len(sc))]
     assert len(ref) == 21
-    for workers in (1, 4):
+    for workers, decode in ((1, "thread"), (4, "thread"), (3, "process")):     # "process": worker processes writing into shared-memory batch slots
         got = 0
-        for b in PairBatchLoader(scenes, batch_pairs=8, prefetch=2, pin=False, workers=workers):
+        ld = PairBatchLoader(scenes, batch_pairs=8, prefetch=2, pin=False, workers=workers, decode=decode)
+        for b in ld:
             for p in range(len(b["names"])):
                 si, i, smp = ref[got]
                 assert b["scene_ids"][p] == scenes[si].scene_id and b["names"][p] == smp["pair_names"][1] and int(b["seed_ids"][p]) == smp["pair_id"]
                 assert torch.equal(b["images"][2 * p, 0], to_gray(smp["image0"])) and torch.equal(b["images"][2 * p + 1, 0], to_gray(smp["image1"]))
                 assert torch.equal(b["depth0"][p], smp["depth0"]) and torch.equal(b["depth1"][p], smp["depth1"])
                 assert b["K0"].dtype == torch.float64 and torch.equal(b["K0"][p], smp["K_color0"]) and torch.equal(b["K1"][p], smp["K_color1"])
+                assert b["ref_keys"][p] == (scenes[si].scene_root, smp["pair_names"][0])      # every pair of these scenes shares its keyframe
                 got += 1
+        ld.close()
         assert got == 21
 
 

@@ -58,6 +58,7 @@ def main():
     ap.add_argument("--writers", type=int, default=min(64, os.cpu_count() or 8))
     ap.add_argument("--graph", type=int, default=0, help="1: HIP.GRAPH_FUSED (matcher stage replayed from one HIP graph per batch shape)")
     ap.add_argument("--no-resume-legs", action="store_true")
+    ap.add_argument("--decode", default="process", help="thread | process (HIP.LOADER_DECODE)")
     ap.add_argument("--ref-cache", type=int, default=1, help="0: HIP.REF_FEATURE_CACHE off (SuperPoint on the reference view of every pair)")
     a = ap.parse_args()
     t0 = time.perf_counter()
@@ -81,6 +82,7 @@ def main():
         cfg.MODEL = "FeatureMatching"; cfg.ALLOW_SYNTHETIC_WEIGHTS = True
         cfg.HIP.GRAPH_FUSED = bool(a.graph)
         cfg.HIP.REF_FEATURE_CACHE = bool(a.ref_cache)
+        cfg.HIP.LOADER_DECODE = a.decode
         if name == "sg_pnp":
             cfg.FEATURE_MATCHING, cfg.POSE_SOLVER = "SuperGlue", "PNP"
             cfg.PNP.RANSAC_ITER, cfg.PNP.REPROJECTION_INLIER_THRESHOLD, cfg.PNP.CONFIDENCE = 1000, 3, 0.9999
@@ -103,7 +105,7 @@ def main():
         base = dict(pairs=st["pairs"], seconds=round(dt, 2), pairs_per_s=round(st["pairs"] / dt, 1), batch_pairs=B, batches=st["batches"], graph=bool(a.graph),
                     loader_wait_s=round(st["loader_wait_s"], 2), loader_stall_fraction=round(st["loader_wait_s"] / st["seconds"], 4),
                     issue_s=round(st["issue_s"], 2), gpu_busy_s=round(st["gpu_busy_s"], 2), gpu_busy_fraction=round(st["gpu_busy_s"] / st["seconds"], 4),
-                    decode_workers=st["decode_workers"], ref_feature_cache=bool(a.ref_cache))
+                    decode_workers=st["decode_workers"], ref_feature_cache=bool(a.ref_cache), decode=a.decode, loader_stats={k: round(v, 3) for k, v in st.get("loader_stats", {}).items()})
         if a.no_resume_legs:
             res[name] = base
             print(name, json.dumps(base), flush=True)
