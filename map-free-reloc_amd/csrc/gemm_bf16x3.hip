@@ -181,6 +181,176 @@ __global__ void __launch_bounds__(256, 2) gemm_bf16x3_kernel(const float *__rest
     }
 }
 
+
+// ---- round 4: PERSISTENT workgroups -------------------------------------------------------------------------------------------------------
+// Measured on the SuperGlue shapes (M = 65536; profiles/r04_bench_sg_pnp_kernel_stats.csv) the one-tile-per-workgroup kernel above takes
+// matrix-core time + HBM time + ~30 us, not their maximum: all resident workgroups start together, run the same K loop and store their
+// 64 KB tiles together, so the matrix cores idle while 50 MB of tiles drain and HBM idles while they multiply; a new workgroup waits for the
+// previous one's stores and then for its own first loads.  Here a workgroup walks over tiles: the loads of the next tile's first K step are
+// in flight during the current tile's last multiply and -- for the accumulating epilogue -- Y is fetched during the last K step.
+// DEFER: the finished tile (bias / ReLU / residual applied) moves to 64 spare registers and is stored in four groups during the first four
+// K steps of the NEXT tile, each group right after that step's loads were issued.  gfx950 counts loads and stores in ONE in-order counter
+// (vmcnt), so a wavefront that stores a tile and then waits for any load waits for the whole tile to reach L2 first; issued this way every
+// wait for a K step's loads only covers stores that are a full K step old.
+// Same arithmetic per output element as the kernel above, bit for bit (tests/test_gpu_gemm_bf16x3.py).  Grid = 2 workgroups per CU (512: the
+// SuperGlue shapes are 1024 / 2048 / 3072 tiles); tiles are dealt per XCD so that the workgroups sharing an X row block share an L2 (row
+// block mb lives on XCD mb % 8).  ABL (measurement only, tools/ablate_gemm.py): 1 = no output stores.
+#define GB_RSRC_FLAGS 0x00020000
+template <int FLAGS, int DEFER, int ABL>
+__global__ void __launch_bounds__(256, 2) gemm_bf16x3_pk_kernel(const float *__restrict__ X, int ldx, const uint4 *__restrict__ Wp, const float *__restrict__ bias,
+                                                                float *__restrict__ Y, int ldy, int M, int N, int K, int nnb, int nmb)
+{
+    __shared__ uint4 lds[6 * GB_TERM_UNITS];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    const int nkb = K / GB_BK;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
+    const int items = ((nmb + 7) >> 3) * nnb;               // work items of one XCD: (local row block, feature block), feature block innermost
+    // item j of this XCD -> tile; row blocks beyond nmb do not exist (they can only be the last local row block: the walk ends there)
+#define GB_TILE(j, mb_, nb_) const int nb_ = (j) % nnb, mb_ = ((j) / nnb) * 8 + xcd
+    int j = slot;
+    if (j >= items) return;
+    { GB_TILE(j, mb, nb); (void)nb; if (mb >= nmb) return; }
+
+    int xdst[2], xr[2], xk[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int u = tid + 256 * i;
+        xr[i] = u >> 2; xk[i] = 8 * (u & 3);
+        xdst[i] = (u & 3) * GB_KG_STRIDE + xr[i];
+    }
+    int wdst[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int u = tid + 256 * i, term = u / 512, kg = (u % 512) / 128, f = u % 128;
+        wdst[i] = (3 + term) * GB_TERM_UNITS + kg * GB_KG_STRIDE + f;
+    }
+    const int arow = (lane >> 5) * GB_KG_STRIDE + 64 * wm + (lane & 31);
+    const int brow = (lane >> 5) * GB_KG_STRIDE + 64 * wn + (lane & 31);
+    const unsigned rowb = (unsigned)ldy * 4u;              // bytes per row of Y
+    const __amdgpu_buffer_rsrc_t rbias = __builtin_amdgcn_make_buffer_rsrc((void *)bias, 0, bias ? N * 4 : 0, GB_RSRC_FLAGS);   // no bias: every read returns 0
+
+    // the LOAD stream runs one K step ahead of the multiply, across tile boundaries
+    const float *lx0, *lx1;
+    const uint4 *lw;
+    int lk, lj = j;                                        // K step / item the load stream is at
+    auto load_tile_start = [&](int jj) {
+        GB_TILE(jj, mb, nb);
+        lx0 = X + (size_t)min(mb * GB_BM + xr[0], M - 1) * ldx + xk[0];      // rows beyond M: a valid row is read, its results are never stored
+        lx1 = X + (size_t)min(mb * GB_BM + xr[1], M - 1) * ldx + xk[1];
+        lw = Wp + (size_t)nb * nkb * GB_W_TILE_UNITS + tid;
+        lk = 0;
+    };
+    float4 xa0, xa1, xb0, xb1;
+    uint4 w0, w1, w2, w3, w4, w5;
+#define GB_PLOAD() do { \
+        xa0 = *(const float4 *)lx0; xa1 = *(const float4 *)(lx0 + 4); xb0 = *(const float4 *)lx1; xb1 = *(const float4 *)(lx1 + 4); \
+        w0 = lw[0]; w1 = lw[256]; w2 = lw[512]; w3 = lw[768]; w4 = lw[1024]; w5 = lw[1280]; \
+        lx0 += GB_BK; lx1 += GB_BK; lw += GB_W_TILE_UNITS; \
+        if (++lk == nkb) { int jn = lj + per_xcd; if (jn < items) { GB_TILE(jn, mbn_, nbn_); (void)nbn_; if (mbn_ >= nmb) jn = items; } \
+                           if (jn < items) lj = jn; load_tile_start(lj); } } while (0)        /* no next tile: the last load re-reads this tile's start */
+    auto xsplit_store = [&](const float4 &p, const float4 &q, int dst) {
+        const float x[8] = { p.x, p.y, p.z, p.w, q.x, q.y, q.z, q.w };
+        unsigned h[8], m[8], l[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) gb_split3(x[e], h[e], m[e], l[e]);
+        lds[0 * GB_TERM_UNITS + dst] = make_uint4(gb_pack(h[0], h[1]), gb_pack(h[2], h[3]), gb_pack(h[4], h[5]), gb_pack(h[6], h[7]));
+        lds[1 * GB_TERM_UNITS + dst] = make_uint4(gb_pack(m[0], m[1]), gb_pack(m[2], m[3]), gb_pack(m[4], m[5]), gb_pack(m[6], m[7]));
+        lds[2 * GB_TERM_UNITS + dst] = make_uint4(gb_pack(l[0], l[1]), gb_pack(l[2], l[3]), gb_pack(l[4], l[5]), gb_pack(l[6], l[7]));
+    };
+
+    f32x16 acc[2][2];
+    // ov: the finished tile on its way out (DEFER), and -- FLAGS & 2 -- the tile of Y fetched during the last K step
+    unsigned ov[2][2][16];
+    __amdgpu_buffer_rsrc_t rp = rbias;                     // the buffer / lane offset / lane's first feature of the tile held in ov
+    unsigned offp = 0;
+    int np = 0;
+    bool pending = false;
+    const bool defer = DEFER && nkb >= 5;                  // four store groups + the Y fetch of the last step need five K steps
+    // accumulator register r of tile (i, jj) of a wavefront: row 32 i + (r & 3) + 8 (r >> 2) (+ 64 wm + 4 (lane >> 5): the lane offset), feature + 32 jj
+#define GB_SOFF(i, r) ((unsigned)(32 * (i) + ((r) & 3) + 8 * ((r) >> 2)) * rowb)
+#define GB_STORE_GROUP(g) do { \
+        if (np + 32 * ((g) >> 1) < N) { \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) { \
+                if (ABL == 1 && ov[(g) & 1][(g) >> 1][r] != 0x12345678u) continue; \
+                __builtin_amdgcn_raw_buffer_store_b32(ov[(g) & 1][(g) >> 1][r], rp, offp + 128u * ((g) >> 1), GB_SOFF((g) & 1, r), 0); } } } while (0)
+
+    load_tile_start(j);
+    GB_PLOAD();
+    for (;;) {
+        GB_TILE(j, mb, nb);
+        const int m0 = mb * GB_BM;
+        // this tile's rows of Y as one buffer (rows beyond M fall outside it: reads return 0, stores are dropped)
+        const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void *)(Y + (size_t)m0 * ldy), 0, (int)((unsigned)min(GB_BM, M - m0) * rowb), GB_RSRC_FLAGS);
+        const int n0 = nb * GB_BN + 64 * wn + (lane & 31);
+        const unsigned yoff = (unsigned)(64 * wm + 4 * (lane >> 5)) * rowb + 4u * (unsigned)n0;
+        const float bv0 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rbias, 4u * (unsigned)n0, 0, 0));
+        const float bv1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rbias, 4u * (unsigned)n0 + 128u, 0, 0));
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.f;
+#define GB_PPROD(ta, tb) do { \
+                acc[0][0] = GB_MFMA(a[0][ta].v, b[0][tb].v, acc[0][0]); acc[0][1] = GB_MFMA(a[0][ta].v, b[1][tb].v, acc[0][1]); \
+                acc[1][0] = GB_MFMA(a[1][ta].v, b[0][tb].v, acc[1][0]); acc[1][1] = GB_MFMA(a[1][ta].v, b[1][tb].v, acc[1][1]); } while (0)
+#define GB_PSTEP(LAST) do { \
+            __syncthreads(); \
+            xsplit_store(xa0, xa1, xdst[0]); xsplit_store(xb0, xb1, xdst[1]); \
+            lds[wdst[0]] = w0; lds[wdst[1]] = w1; lds[wdst[2]] = w2; lds[wdst[3]] = w3; lds[wdst[4]] = w4; lds[wdst[5]] = w5; \
+            __syncthreads(); \
+            GB_PLOAD(); \
+            if (!(LAST) && pending) { \
+                if (kb == 0) GB_STORE_GROUP(0); else if (kb == 1) GB_STORE_GROUP(1); else if (kb == 2) GB_STORE_GROUP(2); else if (kb == 3) GB_STORE_GROUP(3); } \
+            if ((LAST) && (FLAGS & 2)) { \
+                _Pragma("unroll") for (int jj = 0; jj < 2; ++jj) \
+                    _Pragma("unroll") for (int i = 0; i < 2; ++i) \
+                        _Pragma("unroll") for (int r = 0; r < 16; ++r) \
+                            ov[i][jj][r] = __builtin_amdgcn_raw_buffer_load_b32(ry, yoff + 128u * jj, GB_SOFF(i, r), 0); } \
+            __builtin_amdgcn_sched_barrier(0); \
+            _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) { \
+                GbFrag a[2][3], b[2][3]; \
+                _Pragma("unroll") for (int t = 0; t < 3; ++t) \
+                    _Pragma("unroll") for (int i = 0; i < 2; ++i) { \
+                        a[i][t].q = lds[t * GB_TERM_UNITS + 2 * ks * GB_KG_STRIDE + arow + 32 * i]; \
+                        b[i][t].q = lds[(3 + t) * GB_TERM_UNITS + 2 * ks * GB_KG_STRIDE + brow + 32 * i]; } \
+                GB_PPROD(1, 1); GB_PPROD(0, 2); GB_PPROD(2, 0); GB_PPROD(0, 1); GB_PPROD(1, 0); GB_PPROD(0, 0); } } while (0)
+        for (int kb = 0; kb < nkb - 1; ++kb) GB_PSTEP(false);
+        pending = false;                                   // defer: the four groups went out at K steps 0 .. 3 (nkb >= 5)
+        { const int kb = nkb - 1; (void)kb; GB_PSTEP(true); }
+
+        // the finished tile -> ov
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const float bv = jj ? bv1 : bv0;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = acc[i][jj][r] + bv;
+                    if (FLAGS & 1) v = fmaxf(v, 0.f);
+                    if (FLAGS & 2) v += __builtin_bit_cast(float, ov[i][jj][r]);
+                    ov[i][jj][r] = __builtin_bit_cast(unsigned, v);
+                }
+        }
+        rp = ry; offp = yoff; np = n0;
+        // next item of this workgroup
+        int jn = j + per_xcd;
+        if (jn < items) { GB_TILE(jn, mbn, nbn); (void)nbn; if (mbn >= nmb) jn = items; }
+        if (!defer || jn >= items) { GB_STORE_GROUP(0); GB_STORE_GROUP(1); GB_STORE_GROUP(2); GB_STORE_GROUP(3); }
+        else pending = true;
+        if (jn >= items) break;
+        j = jn;
+    }
+#undef GB_PSTEP
+#undef GB_PPROD
+#undef GB_PLOAD
+#undef GB_TILE
+#undef GB_SOFF
+#undef GB_STORE_GROUP
+}
+
 extern "C" {
 
 size_t mfr_gemm_bf16x3_pack_bytes(int N, int K)
@@ -200,15 +370,30 @@ int mfr_gemm_bf16x3_pack(const float *w, int N, int K, void *packed, void *strea
 
 int mfr_gemm_bf16x3(const float *x, int ldx, const void *packed_w, const float *bias, float *y, int ldy, int M, int N, int K, int flags, void *stream)
 {
-    if (!x || !packed_w || !y || M <= 0 || N <= 0 || K <= 0 || (K % GB_BK) || (ldx & 3) || ldx < K || ldy < N || flags < 0 || flags > 3) return MFR_E_ARG;
+    // flags: 1 = ReLU, 2 = accumulate; A/B and the bitwise-agreement test: 4 = one tile per workgroup (the round-3 kernel), 8 = persistent without
+    // deferred stores; 256 = ablation 1 (no output stores, measurement only)
+    const int f = flags & 3, one_tile = flags & 4, nodefer = flags & 8, abl = (flags >> 8) & 1;
+    if (!x || !packed_w || !y || M <= 0 || N <= 0 || K <= 0 || (K % GB_BK) || (ldx & 3) || ldx < K || ldy < N || flags < 0 || (flags & ~0x10f)) return MFR_E_ARG;
     if (((uintptr_t)x & 15)) return MFR_E_ARG;
-    const int nnb = (N + GB_BN - 1) / GB_BN;
-    const long long grid = (long long)((M + GB_BM - 1) / GB_BM) * nnb;
-    if (grid > 0x7fffffffll) return MFR_E_ARG;
+    const int nnb = (N + GB_BN - 1) / GB_BN, nmb = (M + GB_BM - 1) / GB_BM;
+    const long long tiles = (long long)nmb * nnb;
+    if (tiles > 0x7fffffffll) return MFR_E_ARG;
     hipStream_t st = (hipStream_t)stream;
-#define GB_GO(F) hipLaunchKernelGGL((gemm_bf16x3_kernel<F>), dim3((unsigned)grid), dim3(256), 0, st, x, ldx, (const uint4 *)packed_w, bias, y, ldy, M, N, K, nnb)
-    switch (flags) { case 0: GB_GO(0); break; case 1: GB_GO(1); break; case 2: GB_GO(2); break; default: GB_GO(3); break; }
+    if (one_tile) {
+#define GB_GO(F) hipLaunchKernelGGL((gemm_bf16x3_kernel<F>), dim3((unsigned)tiles), dim3(256), 0, st, x, ldx, (const uint4 *)packed_w, bias, y, ldy, M, N, K, nnb)
+        switch (f) { case 0: GB_GO(0); break; case 1: GB_GO(1); break; case 2: GB_GO(2); break; default: GB_GO(3); break; }
 #undef GB_GO
+    } else {
+        // 2 workgroups per CU on 256 CUs; fewer when there are fewer tiles (multiple of 8: one share per XCD)
+        const long long per_xcd = (long long)((nmb + 7) / 8) * nnb;
+        const unsigned grid = 8u * (unsigned)(per_xcd < 64 ? per_xcd : 64);
+#define GB_GO(F, D, A) hipLaunchKernelGGL((gemm_bf16x3_pk_kernel<F, D, A>), dim3(grid), dim3(256), 0, st, x, ldx, (const uint4 *)packed_w, bias, y, ldy, M, N, K, nnb, nmb)
+#define GB_SW(D, A) switch (f) { case 0: GB_GO(0, D, A); break; case 1: GB_GO(1, D, A); break; case 2: GB_GO(2, D, A); break; default: GB_GO(3, D, A); break; }
+        if (abl) { if (nodefer) { GB_SW(0, 1) } else { GB_SW(1, 1) } }
+        else     { if (nodefer) { GB_SW(0, 0) } else { GB_SW(1, 0) } }
+#undef GB_SW
+#undef GB_GO
+    }
     CHECK_LAUNCH();
     return 0;
 }
