@@ -221,7 +221,11 @@ int mfr_sp_sample_descriptors(const float *dense_nhwc, int B, int Hc, int Wc, co
  *                          bf16 matrix cores at fp32 accuracy (csrc/gemm_bf16x3.hip: exact 3-way bf16 operand split, six partial products,
  *                          fp32 accumulate; rounds 1-2 called the library's fp32 GEMM here).  W is split and packed once per weight set
  *                          (mfr_gemm_bf16x3_pack, size from mfr_gemm_bf16x3_pack_bytes; 0 if K % 32 != 0).  flags: 1 = ReLU, 2 = accumulate
- *                          into y (y += x W^T + bias).  x 16-byte aligned, ldx % 4 == 0; bias may be NULL. */
+ *                          into y (y += x W^T + bias).  x 16-byte aligned, ldx % 4 == 0; bias may be NULL.  Kernel selection for A/B runs and
+ *                          the bitwise-agreement test (every variant sums each output element in the same order): + 4 one tile per
+ *                          workgroup (rounds 1-3), + 8 / 16 persistent workgroups without / with deferred tile stores, + 32 eight
+ *                          wavefronts on 256 x 128 tiles; none = persistent, W by LDS-DMA (K % 64 == 0; other K run as + 8).
+ *                          + 256 / 512 / 768: measurement ablations (tools/ablate_gemm.py), results undefined. */
 size_t mfr_gemm_bf16x3_pack_bytes(int N, int K);
 int mfr_gemm_bf16x3_pack(const float *w, int N, int K, void *packed, void *stream);
 int mfr_gemm_bf16x3(const float *x, int ldx, const void *packed_w, const float *bias, float *y, int ldy, int M, int N, int K, int flags, void *stream);

@@ -31,6 +31,37 @@ def test_split_linear_vs_float64(M, K, N, relu, acc, bias):
     assert (y.double() - want).abs().max().item() < 2e-5
 
 
+@pytest.mark.parametrize("M,K,N,relu,acc", [(8192 + 77, 256, 768, 0, 0), (4096, 512, 512, 1, 0), (5000, 512, 256, 0, 1), (300, 128, 200, 1, 1), (129, 64, 130, 0, 1),
+                                            (70000, 160, 256, 0, 0), (1000, 64, 100, 1, 0), (33000, 192, 384, 0, 1)])
+def test_kernel_generations_agree_bitwise(M, K, N, relu, acc):
+    """one tile per workgroup (round 3, flag 4), persistent 128x128 workgroups (flag 8; 16 = with deferred tile stores), the eight-wavefront
+    256x128 kernel (32) and the default (W by LDS-DMA, X two steps ahead; K % 64 != 0 runs flag 8): the same sums in the same order for every output element -- only where and when a tile is computed differs"""
+    from mapfree_reloc_amd import _lib
+    lib = _lib.load(require_gpu=True)
+    g = torch.Generator().manual_seed(M ^ N)
+    x = torch.randn(M, K + 32, generator=g).to(DEV)[:, :K]                  # row stride > K
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(DEV)
+    b = torch.randn(N, generator=g).to(DEV)
+    y0 = torch.randn(M, N + 8, generator=g).to(DEV)
+    lin = SplitLinear(w, b)
+    outs = []
+    for fl in (4, 8, 16, 32, 0):
+        y = y0.clone()
+        yv = y[:, :N]
+        _lib.check(lib.mfr_gemm_bf16x3(x.data_ptr(), x.stride(0), _lib.ptr(lin.packed), _lib.ptr(lin.bias), yv.data_ptr(), yv.stride(0), M, N, K,
+                                       relu | (2 * acc) | fl, _lib.stream_ptr()), "mfr_gemm_bf16x3")
+        torch.cuda.synchronize()
+        assert torch.equal(y[:, N:], y0[:, N:])                             # nothing written beyond the N columns
+        outs.append(yv.clone())
+    assert all(torch.equal(outs[0], o) for o in outs[1:])
+    want = x.double() @ w.double().t() + b.double()
+    if relu:
+        want = want.relu()
+    if acc:
+        want = want + y0[:, :N].double()
+    assert (outs[-1].double() - want).abs().max().item() < 2e-5
+
+
 def test_split_linear_strided_in_place():
     """the SuperGlue layer's operands: x~ = left half of the [x~ | a] buffer (row stride 512), the MLP reads all 512 columns and
     its second layer accumulates into the left half in place"""
