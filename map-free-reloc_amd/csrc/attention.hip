@@ -194,14 +194,25 @@ __device__ __forceinline__ void split3(float x, unsigned &h, unsigned &m, unsign
 // pack the bf16 (upper) halves of two fp32 bit patterns: lo -> bits 15:0, hi -> bits 31:16
 __device__ __forceinline__ unsigned pack_hi16(unsigned lo, unsigned hi) { return __builtin_amdgcn_perm(hi, lo, 0x07060302u); }
 
+// two values at a time: the subtractions are packed fp32 instructions (v_pk_add_f32 with a negated operand, one issue slot for two lanes of data)
+typedef float at_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split_pair(at_f2 x, unsigned &ph, unsigned &pm, unsigned &pl)
+{
+    const unsigned x0 = __float_as_uint(x.x), x1 = __float_as_uint(x.y);
+    at_f2 h; h.x = __uint_as_float(x0 & 0xffff0000u); h.y = __uint_as_float(x1 & 0xffff0000u);
+    const at_f2 r = x - h;
+    const unsigned r0 = __float_as_uint(r.x), r1 = __float_as_uint(r.y);
+    at_f2 m; m.x = __uint_as_float(r0 & 0xffff0000u); m.y = __uint_as_float(r1 & 0xffff0000u);
+    const at_f2 l = r - m;
+    ph = pack_hi16(x0, x1); pm = pack_hi16(r0, r1); pl = pack_hi16(__float_as_uint(l.x), __float_as_uint(l.y));
+}
 template <int N8>
 __device__ __forceinline__ void split_pack(const float (&x)[N8], unsigned (&ph)[N8 / 2], unsigned (&pm)[N8 / 2], unsigned (&pl)[N8 / 2])
 {
 #pragma unroll
     for (int j = 0; j < N8 / 2; ++j) {
-        unsigned h0, m0, l0, h1, m1, l1;
-        split3(x[2 * j], h0, m0, l0); split3(x[2 * j + 1], h1, m1, l1);
-        ph[j] = pack_hi16(h0, h1); pm[j] = pack_hi16(m0, m1); pl[j] = pack_hi16(l0, l1);
+        at_f2 v; v.x = x[2 * j]; v.y = x[2 * j + 1];
+        split_pair(v, ph[j], pm[j], pl[j]);
     }
 }
 
@@ -339,15 +350,24 @@ __global__ void __launch_bounds__(256, 2) sg_attention_bf16x3_kernel(
             for (int r = 0; r < 16; ++r)
                 if (kb + (r & 3) + 8 * (r >> 2) >= nk) s[r] = -INFINITY;
         }
-        float mx = fmaxf(s[0], s[1]);
+        float mx = s[0];
 #pragma unroll
-        for (int r = 2; r < 16; r += 2) mx = fmaxf(mx, fmaxf(s[r], s[r + 1]));
+        for (int r = 1; r < 15; r += 2) mx = fmaxf(fmaxf(mx, s[r]), s[r + 1]);      // v_max3_f32
+        mx = fmaxf(mx, s[15]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float m_new = fmaxf(m_run, mx);
-        float rs = 0.f;
         float p[16];
+        at_f2 rs2; rs2.x = 0.f; rs2.y = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { p[r] = __builtin_amdgcn_exp2f(s[r] - m_new); rs += p[r]; }
+        for (int r = 0; r < 16; r += 2) {                                            // two keys per packed instruction
+            at_f2 d; d.x = s[r]; d.y = s[r + 1];
+            at_f2 mm; mm.x = m_new; mm.y = m_new;
+            d = d - mm;
+            at_f2 e; e.x = __builtin_amdgcn_exp2f(d.x); e.y = __builtin_amdgcn_exp2f(d.y);
+            rs2 += e;
+            p[r] = e.x; p[r + 1] = e.y;
+        }
+        float rs = rs2.x + rs2.y;
         rs += __shfl_xor(rs, 32, 64);
         if (__ballot(m_new != m_run) != 0ull) {             // the running maximum moved for some query of this wavefront: rescale
             const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
@@ -392,26 +412,462 @@ __global__ void __launch_bounds__(256, 2) sg_attention_bf16x3_kernel(
     }
 }
 
+// ---- round 4 (variant 3): the same kernel with 256 queries (eight wavefronts) per workgroup and buffer addressing -------------------------
+// The loop above issues ~420 VALU slots per 48 MFMAs (8.8 per MFMA; tools/ubench/mfma_valu_bf16.hip: more than 5 stop being free), a third of
+// them not arithmetic: clamped row addresses, the zeroing of keys >= nk, and the operand split of the K / V tile, which every workgroup of an
+// (image, head) repeats.  Here
+//   * K / V rows are read through buffer descriptors that end at row nk: the row offset of a tile is a SCALAR (no address VALU), rows beyond
+//     nk read as zero in hardware (no clamp, no select);
+//   * a workgroup serves 256 queries, so a K / V tile is split once per 256 instead of once per 128 queries (8 instead of 16 elements per
+//     thread and tile) and read from L2 half as often.
+// One workgroup of eight wavefronts per CU (two per SIMD, as before).  Per query the arithmetic is the kernel's above, bit for bit.
+#define AB_WAVES 8
+__global__ void __launch_bounds__(512, 1) sg_attention_bf16x3_w8_kernel(
+    const float *__restrict__ Q, const float *__restrict__ Kp, const float *__restrict__ Vp, int ld,
+    int N, int heads, int B2, const int *__restrict__ n_tok, int cross, float scale_log2e, float *__restrict__ O, int ldo)
+{
+    __shared__ __attribute__((aligned(16))) unsigned short Ks[2][3][AT_KT][AB_KS];
+    __shared__ __attribute__((aligned(16))) unsigned short Vt[2][3][AT_D][AB_VS];
+    const int nbh = heads * B2;
+    const int bh = blockIdx.x % nbh, qb = blockIdx.x / nbh;
+    const int b = bh / heads, h = bh - b * heads;
+    const int bk = cross ? (b ^ 1) : b;
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ql = lane & 31, half = lane >> 5;
+    const int nq = n_tok[b], nk = n_tok[bk];
+    const int q0 = qb * (AT_QW * AB_WAVES);
+    const int q = q0 + wid * AT_QW + ql;
+    if (q0 >= nq) {
+        if (q < N) {
+            float4 *op = (float4 *)(O + ((size_t)b * N + q) * ldo + h * AT_D + 32 * half);
+#pragma unroll
+            for (int g = 0; g < 8; ++g) op[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        return;
+    }
+
+    Frag8 qf[4][3];
+    {
+        const bool ok = q < N;
+        const float *qp = Q + ((size_t)b * N + (ok ? q : 0)) * ld + h * AT_D + half * 8;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            float x[8];
+            float4 t0 = *(const float4 *)(qp + 16 * s), t1 = *(const float4 *)(qp + 16 * s + 4);
+            if (!ok) { t0 = make_float4(0.f, 0.f, 0.f, 0.f); t1 = t0; }
+            x[0] = t0.x * scale_log2e; x[1] = t0.y * scale_log2e; x[2] = t0.z * scale_log2e; x[3] = t0.w * scale_log2e;
+            x[4] = t1.x * scale_log2e; x[5] = t1.y * scale_log2e; x[6] = t1.z * scale_log2e; x[7] = t1.w * scale_log2e;
+            split_pack<8>(x, qf[s][0].u, qf[s][1].u, qf[s][2].u);
+        }
+    }
+    f32x16 o0, o1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+    float m_run = -INFINITY, l_run = 0.f;
+
+    // staging: K -- thread -> key row sr (0..31), 4 floats at column sc; V -- one d per lane, wavefront w -> keys 4 w .. 4 w + 3.
+    // Both through buffers that hold exactly the nk rows of this (image, head): base = row 0 / channel 0 of the head, the last valid byte is
+    // the end of row nk - 1's 64 channels; a row >= nk lies beyond it and reads as zero.
+    const int sr = tid >> 4, sc = (tid & 15) * 4;
+    const unsigned rowb = (unsigned)ld * 4u;
+    const unsigned span = nk > 0 ? (unsigned)(nk - 1) * rowb + AT_D * 4u : 0u;
+    const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void *)(Kp + (size_t)bk * N * ld + h * AT_D), 0, (int)span, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void *)(Vp + (size_t)bk * N * ld + h * AT_D), 0, (int)span, 0x00020000);
+    const unsigned koff = (unsigned)sr * rowb + 4u * (unsigned)sc, voff = 4u * (unsigned)lane;
+    const int ntiles = (nk + AT_KT - 1) / AT_KT;
+    float4 kr;
+    float v0, v1, v2, v3;
+    auto gload = [&](int t) {
+        const unsigned so = (unsigned)(t * AT_KT) * rowb;                            // scalar: the tile's first row
+        kr = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rk, koff, so, 0));
+        const unsigned sv = so + (unsigned)(4 * wid) * rowb;
+        v0 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rv, voff, sv, 0));
+        v1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rv, voff, sv + rowb, 0));
+        v2 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rv, voff, sv + 2u * rowb, 0));
+        v3 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rv, voff, sv + 3u * rowb, 0));
+    };
+    auto lstore = [&](int buf) {
+        unsigned ph[2], pm[2], pl[2];
+        const float ka[4] = { kr.x, kr.y, kr.z, kr.w };
+        split_pack<4>(ka, ph, pm, pl);
+        *(uint2 *)&Ks[buf][0][sr][sc] = make_uint2(ph[0], ph[1]); *(uint2 *)&Ks[buf][1][sr][sc] = make_uint2(pm[0], pm[1]);
+        *(uint2 *)&Ks[buf][2][sr][sc] = make_uint2(pl[0], pl[1]);
+        // wavefront w holds keys 4 w + j: key = 16 s + 8 g + 4 hh + j with s = w >> 2, g = (w >> 1) & 1, hh = w & 1 -> position 16 s + 8 hh + 4 g + j
+        const float vr[4] = { v0, v1, v2, v3 };
+        split_pack<4>(vr, ph, pm, pl);
+        const int p0 = 16 * (wid >> 2) + 8 * (wid & 1) + 4 * ((wid >> 1) & 1);
+        *(uint2 *)&Vt[buf][0][lane][p0] = make_uint2(ph[0], ph[1]); *(uint2 *)&Vt[buf][1][lane][p0] = make_uint2(pm[0], pm[1]);
+        *(uint2 *)&Vt[buf][2][lane][p0] = make_uint2(pl[0], pl[1]);
+    };
+    if (ntiles > 0) { gload(0); lstore(0); }
+    __syncthreads();
+
+    for (int t = 0; t < ntiles; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < ntiles) gload(t + 1);
+        __builtin_amdgcn_sched_barrier(0);
+
+        // one lane-dependent LDS address per operand; stage, term, step and the second 32 channels of V are immediate offsets
+        const unsigned short *kq = &Ks[0][0][ql][8 * half] + buf * (3 * AT_KT * AB_KS);
+        const unsigned short *vq = &Vt[0][0][ql][8 * half] + buf * (3 * AT_D * AB_VS);
+        f32x16 s, s2;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = 0.f; s2[r] = 0.f; }
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            Frag8 kh, km, kl;
+            kh.q = *(const uint4 *)(kq + 16 * st);
+            km.q = *(const uint4 *)(kq + AT_KT * AB_KS + 16 * st);
+            kl.q = *(const uint4 *)(kq + 2 * AT_KT * AB_KS + 16 * st);
+            s2 = MFMA_BF16(km.v, qf[st][1].v, s2);
+            s = MFMA_BF16(kh.v, qf[st][2].v, s);
+            s2 = MFMA_BF16(kl.v, qf[st][0].v, s2);
+            s = MFMA_BF16(kh.v, qf[st][1].v, s);
+            s2 = MFMA_BF16(km.v, qf[st][0].v, s2);
+            s = MFMA_BF16(kh.v, qf[st][0].v, s);
+        }
+        const int kb = t * AT_KT + 4 * half;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] += s2[r];
+        if ((t + 1) * AT_KT > nk) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (kb + (r & 3) + 8 * (r >> 2) >= nk) s[r] = -INFINITY;
+        }
+        float mx = s[0];
+#pragma unroll
+        for (int r = 1; r < 15; r += 2) mx = fmaxf(fmaxf(mx, s[r]), s[r + 1]);      // v_max3_f32
+        mx = fmaxf(mx, s[15]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        float p[16];
+        at_f2 rs2; rs2.x = 0.f; rs2.y = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {                                            // two keys per packed instruction
+            at_f2 d; d.x = s[r]; d.y = s[r + 1];
+            at_f2 mm; mm.x = m_new; mm.y = m_new;
+            d = d - mm;
+            at_f2 e; e.x = __builtin_amdgcn_exp2f(d.x); e.y = __builtin_amdgcn_exp2f(d.y);
+            rs2 += e;
+            p[r] = e.x; p[r + 1] = e.y;
+        }
+        float rs = rs2.x + rs2.y;
+        rs += __shfl_xor(rs, 32, 64);
+        if (__ballot(m_new != m_run) != 0ull) {
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            l_run *= alpha;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+        }
+        l_run += rs;
+        m_run = m_new;
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            Frag8 ph, pm, pl;
+            float pp[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pp[j] = p[8 * st + j];
+            split_pack<8>(pp, ph.u, pm.u, pl.u);
+            Frag8 v0h, v0m, v0l, v1h, v1m, v1l;
+            v0h.q = *(const uint4 *)(vq + 16 * st); v1h.q = *(const uint4 *)(vq + 32 * AB_VS + 16 * st);
+            v0m.q = *(const uint4 *)(vq + AT_D * AB_VS + 16 * st); v1m.q = *(const uint4 *)(vq + AT_D * AB_VS + 32 * AB_VS + 16 * st);
+            v0l.q = *(const uint4 *)(vq + 2 * AT_D * AB_VS + 16 * st); v1l.q = *(const uint4 *)(vq + 2 * AT_D * AB_VS + 32 * AB_VS + 16 * st);
+            o0 = MFMA_BF16(v0m.v, pm.v, o0); o1 = MFMA_BF16(v1m.v, pm.v, o1);
+            o0 = MFMA_BF16(v0h.v, pl.v, o0); o1 = MFMA_BF16(v1h.v, pl.v, o1);
+            o0 = MFMA_BF16(v0l.v, ph.v, o0); o1 = MFMA_BF16(v1l.v, ph.v, o1);
+            o0 = MFMA_BF16(v0h.v, pm.v, o0); o1 = MFMA_BF16(v1h.v, pm.v, o1);
+            o0 = MFMA_BF16(v0m.v, ph.v, o0); o1 = MFMA_BF16(v1m.v, ph.v, o1);
+            o0 = MFMA_BF16(v0h.v, ph.v, o0); o1 = MFMA_BF16(v1h.v, ph.v, o1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 1 < ntiles) lstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    if (q < N) {
+        const float inv = (l_run > 0.f && q < nq) ? 1.f / l_run : 0.f;
+        float *op = O + ((size_t)b * N + q) * ldo + h * AT_D + 4 * half;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            *(float4 *)(op + 8 * g) = make_float4(o0[4 * g] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv);
+            *(float4 *)(op + 32 + 8 * g) = make_float4(o1[4 * g] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv);
+        }
+    }
+}
+
+// ---- round 4, the default: the eight-wavefront kernel, software-pipelined ------------------------------------------------------------------
+// In the kernels above a wavefront's tile is [24 MFMAs: S^T] -> [softmax: ~120 VALU slots, no MFMA] -> [24 MFMAs: O^T, with the split of P];
+// the barrier per tile keeps all wavefronts of the CU in the same phase, so the matrix core idles through every softmax (measured: a tile
+// costs a SIMD the SUM of its two wavefronts' MFMA and VALU time, 5400 cycles for 3072 of MFMA).  Here the score product runs one tile ahead:
+// iteration t issues S^T(t+1) = K(t+1) Q^T in four steps of six MFMAs, and between them the softmax of tile t (whose scores were finished an
+// iteration ago) -- independent instruction streams that one wavefront overlaps by itself; then O^T += V(t)^T P(t).  K is therefore staged one
+// tile further ahead than V (K(t+2) and V(t+1) are written during iteration t; two LDS stages each, as before).  Per query the same
+// arithmetic in the same order as the two kernels above.
+__global__ void __launch_bounds__(512, 1) sg_attention_bf16x3_p_kernel(
+    const float *__restrict__ Q, const float *__restrict__ Kp, const float *__restrict__ Vp, int ld,
+    int N, int heads, int B2, const int *__restrict__ n_tok, int cross, float scale_log2e, float *__restrict__ O, int ldo)
+{
+    __shared__ __attribute__((aligned(16))) unsigned short Ks[2][3][AT_KT][AB_KS];
+    __shared__ __attribute__((aligned(16))) unsigned short Vt[2][3][AT_D][AB_VS];
+    const int nbh = heads * B2;
+    const int bh = blockIdx.x % nbh, qb = blockIdx.x / nbh;
+    const int b = bh / heads, h = bh - b * heads;
+    const int bk = cross ? (b ^ 1) : b;
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ql = lane & 31, half = lane >> 5;
+    const int nq = n_tok[b], nk = n_tok[bk];
+    const int q0 = qb * (AT_QW * AB_WAVES);
+    const int q = q0 + wid * AT_QW + ql;
+    if (q0 >= nq) {
+        if (q < N) {
+            float4 *op = (float4 *)(O + ((size_t)b * N + q) * ldo + h * AT_D + 32 * half);
+#pragma unroll
+            for (int g = 0; g < 8; ++g) op[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        return;
+    }
+
+    Frag8 qf[4][3];
+    {
+        const bool ok = q < N;
+        const float *qp = Q + ((size_t)b * N + (ok ? q : 0)) * ld + h * AT_D + half * 8;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            float x[8];
+            float4 t0 = *(const float4 *)(qp + 16 * s), t1 = *(const float4 *)(qp + 16 * s + 4);
+            if (!ok) { t0 = make_float4(0.f, 0.f, 0.f, 0.f); t1 = t0; }
+            x[0] = t0.x * scale_log2e; x[1] = t0.y * scale_log2e; x[2] = t0.z * scale_log2e; x[3] = t0.w * scale_log2e;
+            x[4] = t1.x * scale_log2e; x[5] = t1.y * scale_log2e; x[6] = t1.z * scale_log2e; x[7] = t1.w * scale_log2e;
+            split_pack<8>(x, qf[s][0].u, qf[s][1].u, qf[s][2].u);
+        }
+    }
+    f32x16 o0, o1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+    float m_run = -INFINITY, l_run = 0.f;
+
+    const int sr = tid >> 4, sc4 = (tid & 15) * 4;
+    const unsigned rowb = (unsigned)ld * 4u;
+    const unsigned span = nk > 0 ? (unsigned)(nk - 1) * rowb + AT_D * 4u : 0u;
+    const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void *)(Kp + (size_t)bk * N * ld + h * AT_D), 0, (int)span, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void *)(Vp + (size_t)bk * N * ld + h * AT_D), 0, (int)span, 0x00020000);
+    const unsigned koff = (unsigned)sr * rowb + 4u * (unsigned)sc4, voff = 4u * (unsigned)lane;
+    const int ntiles = (nk + AT_KT - 1) / AT_KT;
+    float4 kr;
+    float v0, v1, v2, v3;
+    auto gload_k = [&](int t) { kr = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rk, koff, (unsigned)(t * AT_KT) * rowb, 0)); };
+    auto gload_v = [&](int t) {
+        const unsigned sv = (unsigned)(t * AT_KT + 4 * wid) * rowb;
+        v0 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rv, voff, sv, 0));
+        v1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rv, voff, sv + rowb, 0));
+        v2 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rv, voff, sv + 2u * rowb, 0));
+        v3 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rv, voff, sv + 3u * rowb, 0));
+    };
+    auto lstore_k = [&](int buf) {
+        unsigned ph[2], pm[2], pl[2];
+        const float ka[4] = { kr.x, kr.y, kr.z, kr.w };
+        split_pack<4>(ka, ph, pm, pl);
+        *(uint2 *)&Ks[buf][0][sr][sc4] = make_uint2(ph[0], ph[1]); *(uint2 *)&Ks[buf][1][sr][sc4] = make_uint2(pm[0], pm[1]);
+        *(uint2 *)&Ks[buf][2][sr][sc4] = make_uint2(pl[0], pl[1]);
+    };
+    auto lstore_v = [&](int buf) {
+        unsigned ph[2], pm[2], pl[2];
+        const float vr[4] = { v0, v1, v2, v3 };
+        split_pack<4>(vr, ph, pm, pl);
+        const int p0 = 16 * (wid >> 2) + 8 * (wid & 1) + 4 * ((wid >> 1) & 1);
+        *(uint2 *)&Vt[buf][0][lane][p0] = make_uint2(ph[0], ph[1]); *(uint2 *)&Vt[buf][1][lane][p0] = make_uint2(pm[0], pm[1]);
+        *(uint2 *)&Vt[buf][2][lane][p0] = make_uint2(pl[0], pl[1]);
+    };
+    const unsigned short *kq0 = &Ks[0][0][ql][8 * half], *vq0 = &Vt[0][0][ql][8 * half];
+    // six MFMAs of step st of S^T = K Q^T from the K stage at kq
+#define AP_QK_STEP(kq, st, s, s2) do { \
+        Frag8 kh, km, kl; \
+        kh.q = *(const uint4 *)((kq) + 16 * (st)); km.q = *(const uint4 *)((kq) + AT_KT * AB_KS + 16 * (st)); kl.q = *(const uint4 *)((kq) + 2 * AT_KT * AB_KS + 16 * (st)); \
+        s2 = MFMA_BF16(km.v, qf[st][1].v, s2); s = MFMA_BF16(kh.v, qf[st][2].v, s); s2 = MFMA_BF16(kl.v, qf[st][0].v, s2); \
+        s = MFMA_BF16(kh.v, qf[st][1].v, s); s2 = MFMA_BF16(km.v, qf[st][0].v, s2); s = MFMA_BF16(kh.v, qf[st][0].v, s); } while (0)
+
+    f32x16 sc;                                              // the scores of the tile whose softmax is due
+    gload_k(0); gload_v(0); lstore_k(0); lstore_v(0);       // (tiles beyond nk: zeros)
+    gload_k(1); lstore_k(1);
+    gload_k(2); gload_v(1);                                 // staged during iteration 0
+    __syncthreads();
+    {
+        f32x16 s, s2;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = 0.f; s2[r] = 0.f; }
+        if (ntiles > 0) { AP_QK_STEP(kq0, 0, s, s2); AP_QK_STEP(kq0, 1, s, s2); AP_QK_STEP(kq0, 2, s, s2); AP_QK_STEP(kq0, 3, s, s2); }
+        sc = s + s2;
+    }
+    __syncthreads();                                        // K stage 0 is rewritten during iteration 0
+
+    // fragments of S^T's step st (K stage at kq) / the six MFMAs on them; one MFMA then up to nv VALU, six times (sched_group_barrier)
+#define AP_KLOAD(f, kq, st) do { f[0].q = *(const uint4 *)((kq) + 16 * (st)); f[1].q = *(const uint4 *)((kq) + AT_KT * AB_KS + 16 * (st)); \
+        f[2].q = *(const uint4 *)((kq) + 2 * AT_KT * AB_KS + 16 * (st)); } while (0)
+#define AP_QK6(f, st, s, s2) do { \
+        s2 = MFMA_BF16(f[1].v, qf[st][1].v, s2); s = MFMA_BF16(f[0].v, qf[st][2].v, s); s2 = MFMA_BF16(f[2].v, qf[st][0].v, s2); \
+        s = MFMA_BF16(f[0].v, qf[st][1].v, s); s2 = MFMA_BF16(f[1].v, qf[st][0].v, s2); s = MFMA_BF16(f[0].v, qf[st][0].v, s); } while (0)
+#define AP_WEAVE(nm, nv) do { _Pragma("unroll") for (int w_ = 0; w_ < (nm); ++w_) { \
+        __builtin_amdgcn_sched_group_barrier(0x8, 1, 0); __builtin_amdgcn_sched_group_barrier(0x2, (nv), 0); } } while (0)
+#define AP_VLOAD(f, vq, st) do { \
+        f[0].q = *(const uint4 *)((vq) + 16 * (st)); f[1].q = *(const uint4 *)((vq) + 32 * AB_VS + 16 * (st)); \
+        f[2].q = *(const uint4 *)((vq) + AT_D * AB_VS + 16 * (st)); f[3].q = *(const uint4 *)((vq) + AT_D * AB_VS + 32 * AB_VS + 16 * (st)); \
+        f[4].q = *(const uint4 *)((vq) + 2 * AT_D * AB_VS + 16 * (st)); f[5].q = *(const uint4 *)((vq) + 2 * AT_D * AB_VS + 32 * AB_VS + 16 * (st)); } while (0)
+    // f: 0 / 1 = h term of channels 0-31 / 32-63, 2 / 3 = m, 4 / 5 = l
+#define AP_PV12(f, ph, pm, pl) do { \
+        o0 = MFMA_BF16(f[2].v, pm.v, o0); o1 = MFMA_BF16(f[3].v, pm.v, o1); o0 = MFMA_BF16(f[0].v, pl.v, o0); o1 = MFMA_BF16(f[1].v, pl.v, o1); \
+        o0 = MFMA_BF16(f[4].v, ph.v, o0); o1 = MFMA_BF16(f[5].v, ph.v, o1); o0 = MFMA_BF16(f[0].v, pm.v, o0); o1 = MFMA_BF16(f[1].v, pm.v, o1); \
+        o0 = MFMA_BF16(f[2].v, ph.v, o0); o1 = MFMA_BF16(f[3].v, ph.v, o1); o0 = MFMA_BF16(f[0].v, ph.v, o0); o1 = MFMA_BF16(f[1].v, ph.v, o1); } while (0)
+    // The last iteration multiplies a K stage of zeros (tile ntiles does not exist) and stages tiles that are never used: one basic block per
+    // chunk, so that the MFMAs and the VALU work can be woven together, is worth more than the 24 MFMAs it wastes.
+    for (int t = 0; t < ntiles; ++t) {
+        const int buf = t & 1;
+        const unsigned short *kq = kq0 + (buf ^ 1) * (3 * AT_KT * AB_KS);
+        const unsigned short *vq = vq0 + buf * (3 * AT_D * AB_VS);
+        f32x16 s, s2;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = 0.f; s2[r] = 0.f; }
+        Frag8 ka[3], kb2[3];
+        AP_KLOAD(ka, kq, 0);
+        AP_KLOAD(kb2, kq, 1);
+        const int kb = t * AT_KT + 4 * half;
+        if ((t + 1) * AT_KT > nk) {                         // only the last tile can hold keys >= nk (wave-uniform branch)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (kb + (r & 3) + 8 * (r >> 2) >= nk) sc[r] = -INFINITY;
+        }
+        // ---- S^T(t+1), step 0  ||  softmax(t): row maximum
+        AP_QK6(ka, 0, s, s2);
+        AP_KLOAD(ka, kq, 2);
+        float mx = sc[0];
+#pragma unroll
+        for (int r = 1; r < 15; r += 2) mx = fmaxf(fmaxf(mx, sc[r]), sc[r + 1]);
+        mx = fmaxf(mx, sc[15]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        AP_WEAVE(6, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- step 1  ||  exponentials of keys 0 .. 7
+        AP_QK6(kb2, 1, s, s2);
+        AP_KLOAD(kb2, kq, 3);
+        float p[16];
+        at_f2 rs2; rs2.x = 0.f; rs2.y = 0.f;
+        at_f2 mm; mm.x = m_new; mm.y = m_new;
+#pragma unroll
+        for (int r = 0; r < 8; r += 2) {
+            at_f2 d; d.x = sc[r]; d.y = sc[r + 1];
+            d = d - mm;
+            at_f2 e; e.x = __builtin_amdgcn_exp2f(d.x); e.y = __builtin_amdgcn_exp2f(d.y);
+            rs2 += e;
+            p[r] = e.x; p[r + 1] = e.y;
+        }
+        AP_WEAVE(6, 3);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- step 2  ||  exponentials of keys 8 .. 15
+        AP_QK6(ka, 2, s, s2);
+#pragma unroll
+        for (int r = 8; r < 16; r += 2) {
+            at_f2 d; d.x = sc[r]; d.y = sc[r + 1];
+            d = d - mm;
+            at_f2 e; e.x = __builtin_amdgcn_exp2f(d.x); e.y = __builtin_amdgcn_exp2f(d.y);
+            rs2 += e;
+            p[r] = e.x; p[r + 1] = e.y;
+        }
+        float rs = rs2.x + rs2.y;
+        rs += __shfl_xor(rs, 32, 64);
+        AP_WEAVE(6, 3);
+        __builtin_amdgcn_sched_barrier(0);
+        if (__ballot(m_new != m_run) != 0ull) {             // the running maximum moved for some query of this wavefront: rescale
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            l_run *= alpha;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+        }
+        l_run += rs;
+        m_run = m_new;
+        // ---- step 3  ||  split of P (first 16 keys), staging of K(t+2) / V(t+1)
+        AP_QK6(kb2, 3, s, s2);
+        Frag8 va[6];
+        AP_VLOAD(va, vq, 0);
+        Frag8 ph0, pm0, pl0;
+        {
+            float pp[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pp[j] = p[j];
+            split_pack<8>(pp, ph0.u, pm0.u, pl0.u);
+        }
+        lstore_k(buf); lstore_v(buf ^ 1);
+        gload_k(t + 3); gload_v(t + 2);
+        AP_WEAVE(6, 14);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- O^T += V^T P: keys 0 .. 15  ||  split of P (last 16 keys); then keys 16 .. 31
+        AP_PV12(va, ph0, pm0, pl0);
+        Frag8 vb[6];
+        AP_VLOAD(vb, vq, 1);
+        Frag8 ph1, pm1, pl1;
+        {
+            float pp[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pp[j] = p[8 + j];
+            split_pack<8>(pp, ph1.u, pm1.u, pl1.u);
+        }
+        AP_WEAVE(12, 4);
+        __builtin_amdgcn_sched_barrier(0);
+        AP_PV12(vb, ph1, pm1, pl1);
+        sc = s + s2;
+        __syncthreads();
+    }
+#undef AP_PV12
+#undef AP_VLOAD
+#undef AP_WEAVE
+#undef AP_QK6
+#undef AP_KLOAD
+#undef AP_QK_STEP
+
+    if (q < N) {
+        const float inv = (l_run > 0.f && q < nq) ? 1.f / l_run : 0.f;
+        float *op = O + ((size_t)b * N + q) * ldo + h * AT_D + 4 * half;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            *(float4 *)(op + 8 * g) = make_float4(o0[4 * g] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv);
+            *(float4 *)(op + 32 + 8 * g) = make_float4(o1[4 * g] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv);
+        }
+    }
+}
+
 extern "C" {
 
 // q,k,v: [B2, N, ld] fp32 (row = keypoint; channels of head h at [h*64, h*64+64) from the given base
 // pointers, so a fused [.., 768] qkv buffer is passed as base, base+256, base+512 with ld = 768).
 // out: [B2, N, ldo].  cross != 0: image b attends to image b^1 (the other image of its pair).
+// variant: 0 = bf16x3, 256 queries per workgroup, score product one tile ahead of the softmax (default); 1 = exact-fp32 matrix instruction;
+// 2 = bf16x3, 128 queries per workgroup (round 3); 3 = bf16x3, 256 queries per workgroup, not pipelined
 int mfr_sg_attention_variant(const float *q, const float *k, const float *v, int ld, int B2, int N, int heads,
                              const int32_t *n_tok, int cross, float *out, int ldo, int variant, void *stream)
 {
     if (!q || !k || !v || !n_tok || !out || B2 <= 0 || N <= 0 || heads <= 0 || (ld & 3) || (ldo & 3)) return MFR_E_ARG;
     if (cross && (B2 & 1)) return MFR_E_ARG;
-    if (variant != 0 && variant != 1) return MFR_E_ARG;
+    if (variant < 0 || variant > 3) return MFR_E_ARG;
+    // the buffer descriptors of variants 0 / 3 address an (image, head)'s rows with 32-bit offsets
+    if ((variant == 0 || variant == 3) && (size_t)N * ld * 4 >= 0x7fffffffull) variant = 2;
     const float scale_log2e = 1.4426950408889634f / 8.0f;          // log2(e) / sqrt(64)
-    const int nqb = (N + AT_QW * AT_WAVES - 1) / (AT_QW * AT_WAVES);
-    dim3 grid(nqb * heads * B2);
-    if (variant == 0)
-        hipLaunchKernelGGL(sg_attention_bf16x3_kernel, grid, dim3(256), 0, (hipStream_t)stream, q, k, v, ld, N, heads, B2, n_tok, cross,
-                           scale_log2e, out, ldo);
-    else
-        hipLaunchKernelGGL(sg_attention_kernel, grid, dim3(256), 0, (hipStream_t)stream, q, k, v, ld, N, heads, B2, n_tok, cross,
-                           scale_log2e, out, ldo);
+    if (variant == 0 || variant == 3) {
+        const int nqb = (N + AT_QW * AB_WAVES - 1) / (AT_QW * AB_WAVES);
+        if (variant == 0)
+            hipLaunchKernelGGL(sg_attention_bf16x3_p_kernel, dim3(nqb * heads * B2), dim3(512), 0, (hipStream_t)stream, q, k, v, ld, N, heads, B2, n_tok, cross,
+                               scale_log2e, out, ldo);
+        else
+            hipLaunchKernelGGL(sg_attention_bf16x3_w8_kernel, dim3(nqb * heads * B2), dim3(512), 0, (hipStream_t)stream, q, k, v, ld, N, heads, B2, n_tok, cross,
+                               scale_log2e, out, ldo);
+    } else {
+        const int nqb = (N + AT_QW * AT_WAVES - 1) / (AT_QW * AT_WAVES);
+        dim3 grid(nqb * heads * B2);
+        if (variant == 2)
+            hipLaunchKernelGGL(sg_attention_bf16x3_kernel, grid, dim3(256), 0, (hipStream_t)stream, q, k, v, ld, N, heads, B2, n_tok, cross,
+                               scale_log2e, out, ldo);
+        else
+            hipLaunchKernelGGL(sg_attention_kernel, grid, dim3(256), 0, (hipStream_t)stream, q, k, v, ld, N, heads, B2, n_tok, cross,
+                               scale_log2e, out, ldo);
+    }
     CHECK_LAUNCH();
     return 0;
 }

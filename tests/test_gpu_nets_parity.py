@@ -109,11 +109,12 @@ def test_descriptor_sampling(sp_pair):
         assert (got[b, n[b]:] == 0).all()
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
 @pytest.mark.parametrize("cross", [False, True])
 def test_attention_vs_fp64_reference(sg_pair, cross, variant):
-    """variant 0: bf16x3 on the bf16 matrix cores (3-way exact operand split, 6 partial products, fp32 accumulate);
-    variant 1: exact-fp32 matrix cores.  SAME tolerance for both (the fp32-accuracy claim of the split kernel)."""
+    """variant 0: bf16x3 on the bf16 matrix cores (3-way exact operand split, 6 partial products, fp32 accumulate), 256 queries per
+    workgroup; 2: the same with 128 queries per workgroup (round 3); 1: exact-fp32 matrix cores.  SAME tolerance for all (the
+    fp32-accuracy claim of the split kernels)."""
     ref, hip = sg_pair
     g = torch.Generator().manual_seed(4)
     B2, K = 4, 1024
@@ -128,6 +129,21 @@ def test_attention_vs_fp64_reference(sg_pair, cross, variant):
         want = torch.einsum("hnm,mhd->nhd", s.softmax(-1), v[bk, :nk]).reshape(nq, 256)
         np.testing.assert_allclose(got[b, :nq].numpy(), want.float().numpy(), rtol=1e-4, atol=2e-5)
         assert (got[b, nq:] == 0).all()
+
+
+@pytest.mark.parametrize("cross", [False, True])
+def test_attention_bf16x3_generations_agree_bitwise(sg_pair, cross):
+    """256 queries per workgroup + buffer addressing, score product one tile ahead (variant 0) / not pipelined (3) vs 128 queries per
+    workgroup (variant 2): per query the same products in the same order; keys beyond n are zeroed by the buffer range instead of a select"""
+    ref, hip = sg_pair
+    g = torch.Generator().manual_seed(43)
+    B2, K = 6, 1024
+    qkv = (torch.randn(B2, K, 768, generator=g) * 1.5).to(DEV)
+    n = torch.tensor([1024, 700, 33, 1000, 257, 1], dtype=torch.int32).to(DEV)
+    a = hip.attention(qkv, n, cross, variant=0)
+    b = hip.attention(qkv, n, cross, variant=2)
+    c = hip.attention(qkv, n, cross, variant=3)
+    assert torch.isfinite(a).all() and torch.equal(a, b) and torch.equal(a, c)
 
 
 def test_attention_bf16x3_error_is_fp32_class(sg_pair):

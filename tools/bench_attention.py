@@ -1,5 +1,5 @@
 """A/B timing of the SuperGlue attention kernel variants on the bench shape (2B = 64 images x 4 heads x 1024 keypoints):
-variant 0 = bf16x3 matrix-core kernel, 1 = exact-fp32 matrix-core kernel.  python tools/bench_attention.py [out.json]"""
+variant 0 = bf16x3 matrix-core kernel with 256 queries per workgroup (default), 2 = with 128 (round 3), 1 = exact-fp32 matrix-core kernel.  python tools/bench_attention.py [out.json]"""
 import json
 import sys
 import os
@@ -16,7 +16,7 @@ qkv = torch.randn(B2, K, 768, device=dev)
 n = torch.full((B2,), K, dtype=torch.int32, device=dev)
 out = torch.empty(B2, K, 256, device=dev)
 res = {}
-for variant in (1, 0, 1, 0):
+for variant in (1, 2, 3, 0, 1, 2, 3, 0):
     for cross in (False, True):
         for _ in range(3):
             sg.attention(qkv, n, cross, out=out, variant=variant)
@@ -28,7 +28,9 @@ for variant in (1, 0, 1, 0):
         e1.record(); torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / 20
         flops = 2 * 2.0 * K * K * 64 * 4 * B2
-        res[f"variant{variant}_{'cross' if cross else 'self'}"] = dict(ms=round(ms, 4), fp32_equiv_tflops=round(flops / ms / 1e9, 1))
+        key = f"variant{variant}_{'cross' if cross else 'self'}"
+        if key not in res or ms < res[key]["ms"]:
+            res[key] = dict(ms=round(ms, 4), fp32_equiv_tflops=round(flops / ms / 1e9, 1))
 print(json.dumps(res, indent=1))
 if len(sys.argv) > 1:
     json.dump(res, open(sys.argv[1], "w"), indent=1)
