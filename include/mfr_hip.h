@@ -216,6 +216,8 @@ int mfr_sp_sample_descriptors(const float *dense_nhwc, int B, int Hc, int Wc, co
  *                          n_corr [B] -- the layout mfr_pnp_solve_batch consumes.
  *                          S [B,ldS,ldS] = mdesc0^T mdesc1 / 16, n0/n1 [B] true keypoint counts,
  *                          kpts0/kpts1 [B,K,2]; also matches0 [B,ldS] (-1 = none), mscores0 [B,ldS].
+ *                          mfr_sg_sinkhorn_match_variant: 0 = one sweep over S per iteration (round 4, default when ldS % 4 == 0 and
+ *                          ldS <= 1024), 1 = a row pass and a column pass per iteration (rounds 1-3); the same bits either way.
  * ------------------------------------------------------------------------------------------ */
 /*   mfr_gemm_bf16x3        the transformers' linear layers, y [M, ldy] (+)= act(x [M, ldx] W [N, K]^T + bias), fp32 in / fp32 out, on the
  *                          bf16 matrix cores at fp32 accuracy (csrc/gemm_bf16x3.hip: exact 3-way bf16 operand split, six partial products,
@@ -240,6 +242,12 @@ int mfr_sg_sinkhorn_match(const float *S, int B, int ldS, const int32_t *n0, con
                           void *workspace, size_t workspace_bytes,
                           int32_t *matches0, float *mscores0, float *pts0, float *pts1, int maxN, int32_t *n_corr,
                           void *stream);
+int mfr_sg_sinkhorn_match_variant(const float *S, int B, int ldS, const int32_t *n0, const int32_t *n1,
+                                  float bin_score, int iters, float match_thr,
+                                  const float *kpts0, const float *kpts1, int K,
+                                  void *workspace, size_t workspace_bytes,
+                                  int32_t *matches0, float *mscores0, float *pts0, float *pts1, int maxN, int32_t *n_corr,
+                                  int variant, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * LoFTR kernels.  Reference call site: LoFTR_matcher.match, etc/feature_matching_baselines/

@@ -48,6 +48,8 @@ SIGNATURES = {
     "mfr_sg_match_workspace_bytes": (_sz, [_i, _i]),
     "mfr_sg_sinkhorn_match": (_i, [_vp, _i, _i, _vp, _vp, C.c_float, _i, C.c_float, _vp, _vp, _i, _vp, _sz,
                                    _vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    "mfr_sg_sinkhorn_match_variant": (_i, [_vp, _i, _i, _vp, _vp, C.c_float, _i, C.c_float, _vp, _vp, _i, _vp, _sz,
+                                           _vp, _vp, _vp, _vp, _i, _vp, _i, _vp]),
     "mfr_loftr_linear_attention_workspace_bytes": (_sz, [_i, _i, _i]),
     "mfr_loftr_linear_attention": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp, _i, _vp]),
     "mfr_loftr_coarse_match_workspace_bytes": (_sz, [_i, _i, _i]),

@@ -96,7 +96,7 @@ class SuperGlueHIP:
                                                 1 if cross else 0, out.data_ptr(), ldo, int(variant), _lib.stream_ptr()), "mfr_sg_attention")
         return out
 
-    def sinkhorn_match(self, S, n0, n1, kpts0, kpts1, maxN=None):
+    def sinkhorn_match(self, S, n0, n1, kpts0, kpts1, maxN=None, variant=0):
         lib = _lib.load()
         B, ldS, _ = S.shape
         K = kpts0.shape[1]
@@ -110,10 +110,10 @@ class SuperGlueHIP:
         pts0 = torch.zeros(B, maxN, 2, dtype=torch.float32, device=dev)
         pts1 = torch.zeros(B, maxN, 2, dtype=torch.float32, device=dev)
         nc = torch.empty(B, dtype=torch.int32, device=dev)
-        _lib.check(lib.mfr_sg_sinkhorn_match(
+        _lib.check(lib.mfr_sg_sinkhorn_match_variant(
             _lib.ptr(S.contiguous()), B, ldS, _lib.ptr(n0), _lib.ptr(n1), self.bin_score, self.iters, self.match_thr,
             _lib.ptr(kpts0.contiguous()), _lib.ptr(kpts1.contiguous()), K, _lib.ptr(self._ws), self._ws.numel(),
-            _lib.ptr(m0), _lib.ptr(ms0), _lib.ptr(pts0), _lib.ptr(pts1), maxN, _lib.ptr(nc), _lib.stream_ptr()),
+            _lib.ptr(m0), _lib.ptr(ms0), _lib.ptr(pts0), _lib.ptr(pts1), maxN, _lib.ptr(nc), int(variant), _lib.stream_ptr()),
             "mfr_sg_sinkhorn_match")
         return dict(matches0=m0, matching_scores0=ms0, pts0=pts0, pts1=pts1, n_corr=nc)
 

@@ -208,6 +208,25 @@ def _structured_scores(g, B, m_list, n_list, ld):
     return S
 
 
+def test_sinkhorn_one_sweep_equals_two_pass_bitwise(sg_pair):
+    """one sweep over S per iteration (variant 0) keeps the two-pass kernels' (variant 1) order of every sum: matches, scores, point lists
+    and counts are the same bits -- full, ragged, tiny and empty keypoint sets"""
+    ref, hip = sg_pair
+    g = torch.Generator().manual_seed(61)
+    m_list = [1024, 611, 40, 1, 1000, 65, 0, 777, 16, 49]
+    n_list = [1024, 1000, 17, 5, 3, 64, 12, 778, 1023, 48]
+    B, ld = len(m_list), 1024
+    S = _structured_scores(g, B, [max(m, 1) for m in m_list], [max(n, 1) for n in n_list], ld).to(DEV)
+    k0 = (torch.rand(B, ld, 2, generator=g) * 500).to(DEV); k1 = (torch.rand(B, ld, 2, generator=g) * 500).to(DEV)
+    n0 = torch.tensor(m_list, dtype=torch.int32, device=DEV); n1 = torch.tensor(n_list, dtype=torch.int32, device=DEV)
+    a = hip.sinkhorn_match(S, n0, n1, k0, k1, variant=0)
+    a = {k: v.clone() for k, v in a.items()}
+    b = hip.sinkhorn_match(S, n0, n1, k0, k1, variant=1)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    assert int(a["n_corr"].sum()) > 1000
+
+
 def test_sinkhorn_match_vs_oracle(sg_pair):
     ref, hip = sg_pair
     g = torch.Generator().manual_seed(6)
