@@ -308,6 +308,10 @@ int mfr_bias_relu_nchw(float *x, const float *bias, int B, int C, int HW, void *
 /* 1x1 convolution with few output channels (SuperPoint's detector head convPb 256 -> 65, same call site): y [B,Cout,HW] = w [Cout,Cin] x [B,Cin,HW]
  * + bias, one ascending fused-multiply-add chain per output: a pixel's result does not depend on the batch size.  Cin <= 512. */
 int mfr_conv1x1_nchw(const float *x, const float *w, const float *bias, int B, int Cin, int Cout, int HW, float *y, void *stream);
+/*   mfr_nchw_to_rows       x [B, C, HW] (+ add [C, HW], may be NULL) -> out[img'][p][c] with row stride ldo and image stride out_img_stride
+ *                          (floats): the token-major operand of the linear layers, written in place of torch's permute().contiguous();
+ *                          deinterleave != 0: image 2 k + s of a pair-interleaved batch goes to slot s * (B / 2) + k. */
+int mfr_nchw_to_rows(const float *x, const float *add, int B, int C, int HW, int deinterleave, float *out, long long out_img_stride, int ldo, void *stream);
 int mfr_bias_pool2_relu_nchw(const float *x, const float *bias, int B, int C, int H, int W, float *y, void *stream);
 
 /* ------------------------------------------------------------------------------------------

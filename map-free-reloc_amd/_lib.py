@@ -61,6 +61,7 @@ SIGNATURES = {
     "mfr_conv3x3_c1_relu": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "mfr_bias_relu_nchw": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "mfr_conv1x1_nchw": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "mfr_nchw_to_rows": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, C.c_longlong, _i, _vp]),
     "mfr_bias_pool2_relu_nchw": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "mfr_wino_bf16x3_filter_bytes": (_sz, [_i, _i]),
     "mfr_wino_bf16x3_filter_transform": (_i, [_vp, _i, _i, _vp, _vp]),

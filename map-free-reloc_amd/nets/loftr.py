@@ -291,7 +291,8 @@ class LoFTRHIP:
         L0 = hc * wc
         xm = torch.empty(2, B * L0, 512, dtype=torch.float32, device=images.device)
         # + positional encoding, NCHW -> token-major, pairs de-interleaved (side-major): one strided copy into the left half
-        xm.view(2, B, L0, 512)[..., :256].copy_((fc + self._pe[key][None]).view(B, 2, 256, L0).permute(1, 0, 3, 2))
+        _lib.check(_lib.load().mfr_nchw_to_rows(_lib.ptr(fc.contiguous()), _lib.ptr(self._pe[key].contiguous()), B2, 256, L0, 1, _lib.ptr(xm), L0 * 512, 512,
+                                                _lib.stream_ptr()), "mfr_nchw_to_rows")
         self._transformer(self.coarse, xm, self.linear_attention, B, L0)
         f0, f1 = xm[0].view(B, L0, 512)[..., :256], xm[1].view(B, L0, 512)[..., :256]     # row-strided views
         i_ids, j_ids, mconf, n = self.coarse_match_features(f0, f1, (hc, wc))

@@ -145,6 +145,9 @@ class SuperPointHIP:
         cDa = self._conv(x, "convDa")
         B, C, Hc, Wc = cDa.shape
         # 1x1 descriptor head (convDb) through the own GEMM: every row's K loop runs in the same order whatever the number of rows
-        dense = self.convDb(cDa.permute(0, 2, 3, 1).reshape(-1, C))
+        rows = torch.empty(B * Hc * Wc, C, dtype=torch.float32, device=cDa.device)        # NCHW -> token-major rows (csrc/elementwise.hip)
+        _lib.check(_lib.load().mfr_nchw_to_rows(_lib.ptr(cDa.contiguous()), None, B, C, Hc * Wc, 0, _lib.ptr(rows), Hc * Wc * C, C, _lib.stream_ptr()),
+                   "mfr_nchw_to_rows")
+        dense = self.convDb(rows)
         desc = self.sample(dense.view(B, Hc, Wc, 256), kpts, n)
         return dict(kpts=kpts, scores=sc, desc=desc, n=n)
