@@ -302,7 +302,10 @@ class LoFTRHIP:
         valid = torch.arange(L0, device=images.device)[None] < n[:, None]
         k0 = torch.stack([ii % wc, ii // wc], -1).float() * scale
         k1 = torch.stack([jj % wc, jj // wc], -1).float() * scale
-        ff_nhwc = ff.permute(0, 2, 3, 1).contiguous()                                   # [2B, Hf, Wf, 128]
+        Cf, Hf, Wf = ff.shape[1:]
+        ff_nhwc = torch.empty(B2, Hf, Wf, Cf, dtype=torch.float32, device=ff.device)    # [2B, Hf, Wf, 128]: LDS-tiled transpose (csrc/elementwise.hip)
+        _lib.check(_lib.load().mfr_nchw_to_rows(_lib.ptr(ff.contiguous()), None, B2, Cf, Hf * Wf, 0, _lib.ptr(ff_nhwc), Hf * Wf * Cf, Cf, _lib.stream_ptr()),
+                   "mfr_nchw_to_rows")
         return dict(xm=xm, ff_nhwc=ff_nhwc, i_ids=i_ids, j_ids=j_ids, ii=ii, jj=jj, mconf=mconf, n=n, valid=valid, k0=k0, k1=k1,
                     hc=hc, wc=wc, H=H)
 
