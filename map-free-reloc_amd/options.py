@@ -10,6 +10,8 @@ merge) through `apply_cfg(cfg)`, or directly by a tool / test (`options.set("CON
   RPR_CONV_BWD      'lib' (torch / MIOpen backward; the measured default) | 'hip' (own d input / d weight products)
   RPR_CONV_ORDER    'tap_inner' | 'tap_outer': K order of the forward / d input product
   RPR_WGRAD_SPLITS  K splits of the own d weight product (int >= 1)
+  RPR_ENCODER_NHWC  the regression encoder's strided stages run on channels-last tensors (True / False): the library's NHWC kernels then
+                    take their operands as they are instead of transposing every one (regression/encoder.py)
 """
 _SPEC = {
     "CONV": ("wino", ("wino", "miopen")),
@@ -19,8 +21,10 @@ _SPEC = {
     "RPR_CONV_BWD": ("lib", ("lib", "hip")),
     "RPR_CONV_ORDER": ("tap_inner", ("tap_inner", "tap_outer")),
     "RPR_WGRAD_SPLITS": (16, None),
+    "RPR_ENCODER_NHWC": (False, (False, True)),
 }
 _VALUES = {k: v[0] for k, v in _SPEC.items()}
+_EXPLICIT = set()           # names set directly (tool / test / bench.py --hip-opt): a configuration that still carries the DEFAULT does not undo them
 
 
 def names():
@@ -50,11 +54,13 @@ def set(name, value):           # noqa: A001  (mirrors dict-like usage on purpos
     if allowed is not None and value not in allowed:
         raise ValueError(f"HIP option {name}={value!r}: allowed {allowed}")
     _VALUES[name] = value
+    _EXPLICIT.add(name)
 
 
 def reset():
     for k, v in _SPEC.items():
         _VALUES[k] = v[0]
+    _EXPLICIT.clear()
 
 
 def apply_cfg(cfg):
@@ -62,4 +68,9 @@ def apply_cfg(cfg):
     hip = cfg.HIP if "HIP" in cfg else {}
     for k in _SPEC:
         if k in hip:
+            if k in _EXPLICIT and hip[k] == _SPEC[k][0]:
+                continue                               # set directly, and the configuration only carries the declared default
+            explicit = k in _EXPLICIT
             set(k, hip[k])
+            if not explicit:
+                _EXPLICIT.discard(k)

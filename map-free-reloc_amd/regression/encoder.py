@@ -221,10 +221,19 @@ class ResUNet(nn.Module):
         self.outconv = conv(256, self.num_out_layers, 1, 1)
 
     def forward(self, x):
+        from .. import options
+        nhwc = bool(options.get("RPR_ENCODER_NHWC")) and x.is_cuda
+        if nhwc:
+            # the strided stages on channels-last ACTIVATIONS: MIOpen's convolutions are NHWC kernels and transposed every NCHW operand in
+            # and out (236 transposes, 2.8 ms of a 26.7 ms training step).  The weights keep their layout (the fused optimizer wants
+            # parameters, gradients and moments in one layout; their transposes are small).
+            x = x.contiguous(memory_format=torch.channels_last)
         x1 = self.firstmaxpool(F.relu(self.firstbn(self.firstconv(x))))
         x2 = self.encoder1(x1)
         x3 = self.encoder2(x2)
         x4 = self.encoder3(x3)
+        if nhwc:                                            # the decoder's own kernels (upsampling, implicit-GEMM convolutions) take NCHW
+            x2, x3, x4 = x2.contiguous(), x3.contiguous(), x4.contiguous()
         y = self.upconv4(x4)
         if not self.not_concat:
             y = torch.cat([y, _centre_pad_to(x3, y)], dim=1)
