@@ -249,7 +249,10 @@ class SgPnpWorkload:
         self.B = B
         self.pipe = SuperGluePnPPipeline(dev, seed=0, graph=graph)
         self.att_timer, self.conv_timer, self.sk_timer = KernelTimer(every=9), KernelTimer(every=1), KernelTimer(every=1)
+        self.gemm_timer = KernelTimer(every=6)
         if timers:
+            for L in self.pipe.sg.layers:                       # the 512 -> 512 (+ReLU) layer of every GNN block, sampled
+                L["lin1"] = self.gemm_timer.wrap(L["lin1"])
             self.pipe.sg.attention = self.att_timer.wrap(self.pipe.sg.attention)
             self.pipe.sg.sinkhorn_match = self.sk_timer.wrap(self.pipe.sg.sinkhorn_match)
             sp_conv, timed_conv = self.pipe.sp._conv, self.conv_timer.wrap(self.pipe.sp._conv)
@@ -257,7 +260,7 @@ class SgPnpWorkload:
         self.kp_sum, self.kp_cnt = 0.0, 0
 
     def timers(self):
-        return [self.att_timer, self.conv_timer, self.sk_timer]
+        return [self.att_timer, self.conv_timer, self.sk_timer, self.gemm_timer]
 
     def run(self, d):
         return self.pipe(d["images"], d["depth0"], d["K0"], d["K1"], d["pair_ids"])
@@ -298,13 +301,24 @@ class SgPnpWorkload:
                                     "vs_fp32_mfma_peak": round(eq / FP32_MFMA_PEAK_TFLOPS, 4) if eq else None,
                                     "round2_exact_fp32_kernel": "8.63 ms / launch, 94.5 TFLOP/s, 0.60 of the fp32 MFMA peak (BENCH_r02)"},
                 "direct_equivalent_tflops": round(conv_direct / (conv_ms * 1e-3) / 1e12, 2) if conv_ms else None,
-                "other_kernels": [{"kernel": "sg_attention_bf16x3_kernel (softmax(QK^T/8)V on the bf16 matrix cores, 3-way split operands)", "bound": "mfma",
+                "other_kernels": [self._gemm_line(), {"kernel": "sg_attention_bf16x3_p_kernel (softmax(QK^T/8)V on the bf16 matrix cores, 3-way split operands, 256 queries per workgroup, score product one tile ahead of the softmax)", "bound": "mfma",
                                    "achieved": round(att_exec, 1) if att_exec else None,
                                    "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(att_exec / BF16_MFMA_PEAK_TFLOPS, 4) if att_exec else None,
                                    "fp32_equivalent_tflops": round(att_tf, 2) if att_tf else None,
                                    "avg_launch_ms": round(att_ms, 4) if att_ms else None, "launches_timed": len(self.att_timer.events),
                                    "mean_keypoints_per_image": round(nk, 1)},
                                   self._sinkhorn_line(out)]}
+
+    def _gemm_line(self):
+        """the transformer's linear layers, on the 512 -> 512 (+ReLU) layer of a GNN block: M = 2B x 1024 rows"""
+        ms = self.gemm_timer.mean_ms()
+        M = 2 * self.B * 1024
+        fp32 = 2.0 * M * 512 * 512
+        ex = 6.0 * fp32 / (ms * 1e-3) / 1e12 if ms else None
+        return {"kernel": "gemm_bf16x3_d_kernel, the 512 -> 512 + ReLU layer of a GNN block (mfr_gemm_bf16x3: persistent workgroups, W by LDS-DMA, 3-way split operands)",
+                "bound": "mfma", "achieved": round(ex, 1) if ex else None, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(ex / BF16_MFMA_PEAK_TFLOPS, 4) if ex else None, "fp32_equivalent_tflops": round(ex / 6.0, 2) if ex else None,
+                "avg_launch_ms": round(ms, 4) if ms else None, "launches_timed": len(self.gemm_timer.events), "flops_per_launch": 6.0 * fp32}
 
     def _sinkhorn_line(self, out):
         """log-Sinkhorn + mutual arg-max stage.  Its binding resource is the transcendental ALU, not HBM: 2 x iters x (n+1)^2
