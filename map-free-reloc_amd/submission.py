@@ -191,14 +191,42 @@ def predict_fused(cfg, split, output_root, pipeline=None, batch_pairs=None, resu
     # between two C calls: with CPython's default 5 ms switch interval every contended acquisition can cost this thread 5 ms and the
     # GPU runs dry (measured: 59 ms to issue a 39 ms step); 0.5 ms keeps the hand-over latency below a launch burst
     import sys
+    from collections import deque
     old_switch = sys.getswitchinterval()
     sys.setswitchinterval(5e-4)
+    # Finished scenes leave the loop WITHOUT draining the launch queue: their records go to a pinned host buffer by an asynchronous copy
+    # and the files are written when the copy's event has completed (rounds 1-3 called .cpu() here: with a scene ending every 3-4
+    # batches the GPU sat idle 17 % of the run while the host caught up after each drain).  Rows of scenes that are not complete yet
+    # wait on the host side (host_rows), so nothing has to be filtered on the device.
+    pending, host_rows, pinned = deque(), {}, []
+
+    def land(block):
+        while pending:
+            ev, host, n, done = pending[0]
+            if ev is not None:
+                if block:
+                    ev.synchronize()
+                elif not ev.query():
+                    return
+            pending.popleft()
+            srec = host[:n].numpy().copy()
+            if ev is not None:
+                pinned.append(host)
+            for sid in {names[int(g)][0] for g in srec[:, 0]}:
+                host_rows.setdefault(sid, []).append(srec[np.array([names[int(g)][0] == sid for g in srec[:, 0]], bool)])
+            for sid in done:
+                rows = np.concatenate(host_rows.pop(sid, [np.zeros((0, parallel.REC_W))]))
+                _atomic_write(out_dir / f'pose_{sid}.txt', scene_text(records_to_results(rows, names).get(sid, [])))
+                recs.append(rows)
+
     try:
         evs = []                                            # (start, end) event pairs around every step: GPU time of the steps, read at the end
         while True:
             tw = time.perf_counter()
             batch = next(it, None)                          # time blocked here = the GPU waiting for decode / H2D ("loader stall")
             stats['loader_wait_s'] += time.perf_counter() - tw
+            if stats['batches'] == 0:
+                stats['first_batch_s'] = time.perf_counter() - stats['t0']
             if batch is None:
                 break
             ti = time.perf_counter()
@@ -218,23 +246,39 @@ def predict_fused(cfg, split, output_root, pipeline=None, batch_pairs=None, resu
             done = batch.get('scenes_done')
             if done is None:
                 done = [batch['scene_id']] if batch['last_of_scene'] else []
-            if done:                                        # >= 1 scene complete -> their files (one D2H copy; batches may span scenes)
-                srec = torch.cat(acc).cpu().numpy()
-                res = records_to_results(srec, names)
-                for sid in done:
-                    _atomic_write(out_dir / f'pose_{sid}.txt', scene_text(res.get(sid, [])))
-                doneset = set(done)
-                keep = np.array([names[int(g)][0] not in doneset for g in srec[:, 0]], bool)
-                recs.append(srec[~keep])
-                acc = [torch.from_numpy(srec[keep]).to(rec.device)] if keep.any() else []
+            if done:                                        # >= 1 scene complete -> one D2H copy of everything accumulated (batches may span scenes)
+                dcat = torch.cat(acc)
+                acc = []
+                n = int(dcat.shape[0])
+                if device.type == 'cuda':
+                    if len(pending) >= 8:
+                        land(True)                          # (never in practice: eight scene ends in flight)
+                    host = next((h for h in pinned if h.shape[0] >= n), None)
+                    if host is not None:
+                        pinned.remove(host)
+                    else:
+                        host = torch.empty(max(n, 1024), parallel.REC_W, dtype=dcat.dtype, pin_memory=True)
+                    host[:n].copy_(dcat, non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record()
+                    pending.append((ev, host, n, list(done)))
+                else:
+                    pending.append((None, dcat, n, list(done)))
+            land(False)
         if acc:                                             # (cannot happen: the last pair of the rank's last scene ends a scene)
-            recs.append(torch.cat(acc).cpu().numpy())
+            pending.append((None, torch.cat(acc).cpu(), int(sum(a.shape[0] for a in acc)), []))
+        land(True)
+        for rows in host_rows.values():                     # (likewise: rows whose scene never reported its end)
+            recs.extend(rows)
     finally:
         sys.setswitchinterval(old_switch)
+    stats['loop_s'] = time.perf_counter() - stats['t0']   # (includes landing the last scenes' records)
     if evs:
         torch.cuda.synchronize(device)
         stats['gpu_busy_s'] = sum(a.elapsed_time(b) for a, b in evs) * 1e-3
+    tc = time.perf_counter()
     loader.close()                                          # decode processes / shared-memory slots of this run
+    stats['close_s'] = time.perf_counter() - tc
     stats['seconds'] = time.perf_counter() - stats.pop('t0')
     LAST_RUN_STATS.clear(); LAST_RUN_STATS.update(stats, rank=rank, world=world, scenes_computed=len(todo), decode_workers=workers, decode=decode, batch_pairs=B, loader_stats=dict(getattr(loader, 'stats', {})))
     mine = torch.from_numpy(np.concatenate(recs) if recs else np.zeros((0, parallel.REC_W))).to(device)

@@ -105,7 +105,9 @@ def main():
         base = dict(pairs=st["pairs"], seconds=round(dt, 2), pairs_per_s=round(st["pairs"] / dt, 1), batch_pairs=B, batches=st["batches"], graph=bool(a.graph),
                     loader_wait_s=round(st["loader_wait_s"], 2), loader_stall_fraction=round(st["loader_wait_s"] / st["seconds"], 4),
                     issue_s=round(st["issue_s"], 2), gpu_busy_s=round(st["gpu_busy_s"], 2), gpu_busy_fraction=round(st["gpu_busy_s"] / st["seconds"], 4),
-                    decode_workers=st["decode_workers"], ref_feature_cache=bool(a.ref_cache), decode=a.decode, loader_stats={k: round(v, 3) for k, v in st.get("loader_stats", {}).items()})
+                    decode_workers=st["decode_workers"], ref_feature_cache=bool(a.ref_cache), decode=a.decode, loader_stats={k: round(v, 3) for k, v in st.get("loader_stats", {}).items()},
+                    phases_s=dict(predict_fused_call=round(dt, 2), inside_the_batch_loop=round(st["seconds"], 2), until_first_batch=round(st.get("first_batch_s", 0.0), 2),
+                                  loop_incl_last_records=round(st.get("loop_s", 0.0), 2), loader_close=round(st.get("close_s", 0.0), 2)))
         if a.no_resume_legs:
             res[name] = base
             print(name, json.dumps(base), flush=True)
