@@ -32,6 +32,25 @@ def test_options_are_declared_validated_and_in_the_config_schema():
     assert options.get("CONV_KERNEL") == "auto"
 
 
+def test_directly_set_option_survives_a_configuration_that_carries_the_default():
+    """bench.py --hip-opt / a test sets an option, then the trainer or predict_fused applies its configuration (which declares EVERY option
+    with its default): the direct setting stays; a configuration that really asks for another value wins; reset() forgets both"""
+    cfg = get_cfg_defaults()
+    try:
+        options.set("RPR_CONV", "miopen")
+        options.apply_cfg(cfg)                              # cfg.HIP.RPR_CONV == 'hip' (the default)
+        assert options.get("RPR_CONV") == "miopen"
+        cfg.HIP.RPR_CONV_ORDER = "tap_outer"                # a value the configuration sets itself
+        options.apply_cfg(cfg)
+        assert options.get("RPR_CONV_ORDER") == "tap_outer" and options.get("RPR_CONV") == "miopen"
+        cfg.HIP.RPR_CONV_ORDER = "tap_inner"                # ... and takes back: not a direct setting, so the configuration decides
+        options.apply_cfg(cfg)
+        assert options.get("RPR_CONV_ORDER") == "tap_inner"
+    finally:
+        options.reset()
+    assert options.get("RPR_CONV") == "hip"
+
+
 def test_product_reads_no_mfr_environment_variable():
     """the only environment the package looks at is the launcher's rendezvous (RANK / WORLD_SIZE / LOCAL_* / MASTER_*)"""
     allowed = {"RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"}
