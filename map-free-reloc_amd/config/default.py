@@ -13,6 +13,7 @@ keys this implementation adds (declared here because unknown keys are rejected o
                      MAGSAC_MAX_THR_RATIO: k * sigma_max of MAGSAC++ as a multiple of EMAT_RANSAC.PIX_THRESHOLD (>= 1);
                      REF_FEATURE_CACHE: the fused pipeline runs SuperPoint once per distinct reference view of a batch (and keeps the
                      last few across batches) instead of once per pair -- same bits, fewer images (pipeline.py);
+                     LOADER_WORKERS: decode workers per rank, 0 = the CPUs the container grants divided by the node's ranks (datasets.usable_cpus);
                      LOADER_DECODE: 'process' | 'thread' -- who decodes the JPEG / PNG files of predict_fused's batches: forked worker
                      processes writing into pinned shared-memory batch slots (default; 820 vs 437 pairs/s on the 16-CPU GPU box,
                      profiles/r04_fused_split_1gpu_sg_pnp_{process,thread}.json) or a thread pool under one interpreter lock (datasets.py);
@@ -75,7 +76,7 @@ def get_cfg_defaults():
     # ---- additions of this implementation ----
     c.RANSAC = CN(); c.RANSAC.SEED = 0
     c.HIP = CN(); c.HIP.BATCH_PAIRS = 16; c.HIP.MAX_KEYPOINTS = 1024; c.HIP.MAX_CORRESPONDENCES = 8192; c.HIP.GRAPH_BATCH1 = True; c.HIP.GRAPH_FUSED = False
-    c.HIP.EMAT_SCORE = 'magsac'; c.HIP.MAGSAC_MAX_THR_RATIO = 1.0; c.HIP.REF_FEATURE_CACHE = True; c.HIP.LOADER_DECODE = 'process'
+    c.HIP.EMAT_SCORE = 'magsac'; c.HIP.MAGSAC_MAX_THR_RATIO = 1.0; c.HIP.REF_FEATURE_CACHE = True; c.HIP.LOADER_DECODE = 'process'; c.HIP.LOADER_WORKERS = 0
     from .. import options as _opt                     # kernel-selection options (options.py): declared with their defaults, applied by apply_cfg
     for _k in _opt.names():
         c.HIP[_k] = _opt.default(_k)

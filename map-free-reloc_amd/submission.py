@@ -181,6 +181,8 @@ def predict_fused(cfg, split, output_root, pipeline=None, batch_pairs=None, resu
     local_world = int(os.environ.get('LOCAL_WORLD_SIZE', world)) if world > 1 else 1
     from .datasets import usable_cpus
     workers = max(2, min(32, usable_cpus() // max(1, local_world)))        # the CPUs the container grants, not the ones the box shows
+    if 'LOADER_WORKERS' in cfg.HIP and int(cfg.HIP.LOADER_WORKERS) > 0:
+        workers = int(cfg.HIP.LOADER_WORKERS)
     decode = str(cfg.HIP.LOADER_DECODE) if 'LOADER_DECODE' in cfg.HIP else 'process'
     loader = PairBatchLoader([scenes[i] for i in todo], B, prefetch=prefetch, pin=device.type == 'cuda',
                              global_offsets=[int(offsets[i]) for i in todo], workers=workers, decode=decode)

@@ -59,6 +59,7 @@ def main():
     ap.add_argument("--graph", type=int, default=0, help="1: HIP.GRAPH_FUSED (matcher stage replayed from one HIP graph per batch shape)")
     ap.add_argument("--no-resume-legs", action="store_true")
     ap.add_argument("--decode", default="process", help="thread | process (HIP.LOADER_DECODE)")
+    ap.add_argument("--workers", type=int, default=0, help="decode workers (HIP.LOADER_WORKERS; 0 = the granted CPUs)")
     ap.add_argument("--ref-cache", type=int, default=1, help="0: HIP.REF_FEATURE_CACHE off (SuperPoint on the reference view of every pair)")
     a = ap.parse_args()
     t0 = time.perf_counter()
@@ -83,6 +84,7 @@ def main():
         cfg.HIP.GRAPH_FUSED = bool(a.graph)
         cfg.HIP.REF_FEATURE_CACHE = bool(a.ref_cache)
         cfg.HIP.LOADER_DECODE = a.decode
+        cfg.HIP.LOADER_WORKERS = a.workers
         if name == "sg_pnp":
             cfg.FEATURE_MATCHING, cfg.POSE_SOLVER = "SuperGlue", "PNP"
             cfg.PNP.RANSAC_ITER, cfg.PNP.REPROJECTION_INLIER_THRESHOLD, cfg.PNP.CONFIDENCE = 1000, 3, 0.9999
