@@ -283,6 +283,13 @@ def predict_fused(cfg, split, output_root, pipeline=None, batch_pairs=None, resu
     stats['close_s'] = time.perf_counter() - tc
     stats['seconds'] = time.perf_counter() - stats.pop('t0')
     LAST_RUN_STATS.clear(); LAST_RUN_STATS.update(stats, rank=rank, world=world, scenes_computed=len(todo), decode_workers=workers, decode=decode, batch_pairs=B, loader_stats=dict(getattr(loader, 'stats', {})))
+    try:                                                    # one line per call and rank: the run's own record (pairs, seconds, stalls), next to the pose files
+        line = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in LAST_RUN_STATS.items() if isinstance(v, (int, float, str, bool, dict))}
+        line['unix_time'] = round(time.time(), 1)
+        with open(out_dir / f'run_log_rank{rank}.jsonl', 'a', encoding='utf-8') as f:
+            f.write(json.dumps(line) + '\n')
+    except OSError:
+        pass
     mine = torch.from_numpy(np.concatenate(recs) if recs else np.zeros((0, parallel.REC_W))).to(device)
     allrec = parallel.gather_records(mine, world).cpu().numpy()
     if rank != 0:

@@ -98,6 +98,11 @@ def test_predict_fused_world1_zip_layout_and_resume(tmp_path):
     submission.predict_fused(_cfg(), "test", tmp_path / "a", pipeline=pipe3, batch_pairs=4, prefetch=2)
     assert [c[0] for c in pipe3.calls] == ["s00003"]
     assert open(tmp_path / "a" / "submission.zip", "rb").read() == open(z, "rb").read()
+    # every call leaves one line in the run log beside the pose files: what it computed and how long the loop took
+    import json
+    log = [json.loads(l) for l in open(tmp_path / "a" / "poses" / "run_log_rank0.jsonl")]
+    assert [r["pairs"] for r in log] == [15, 0, 3] and [r["scenes_computed"] for r in log] == [5, 0, 1]
+    assert all(r["seconds"] >= 0 and r["world"] == 1 and r["decode"] in ("process", "thread") for r in log)
     # ... but only for the SAME configuration: pose files left by another solver / matcher / threshold are stale and recomputed
     # (the manifest beside them carries a hash of the merged configuration and the split), never mixed into the new archive
     cfg2 = _cfg()
