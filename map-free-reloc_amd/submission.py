@@ -287,8 +287,8 @@ def predict_fused(cfg, split, output_root, pipeline=None, batch_pairs=None, resu
         line = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in LAST_RUN_STATS.items() if isinstance(v, (int, float, str, bool, dict))}
         line['unix_time'] = round(time.time(), 1)
         with open(out_dir / f'run_log_rank{rank}.jsonl', 'a', encoding='utf-8') as f:
-            f.write(json.dumps(line) + '\n')
-    except OSError:
+            f.write(json.dumps(line, default=float) + '\n')
+    except (OSError, TypeError, ValueError):
         pass
     mine = torch.from_numpy(np.concatenate(recs) if recs else np.zeros((0, parallel.REC_W))).to(device)
     allrec = parallel.gather_records(mine, world).cpu().numpy()
