@@ -9,12 +9,17 @@
 // v_mfma_f32_32x32x16_bf16.  Error against an fp64 product = that of the exact-fp32 matrix instruction (tools/ubench/
 // bf16x3_probe.hip, profiles/r03_bf16x3_probe.jsonl: rms 2.4e-8 vs 2.8e-8 of sum|x||w| at K = 64 .. 2304).
 //
-// Mapping: workgroup = 128 rows x 128 output features, 4 wavefronts as 2 x 2, each 64 x 64 = 2 x 2 MFMA tiles (64 accumulator
-// registers); K in steps of 32.  W is split and packed ONCE per weight set in the exact image the workgroup stages (three terms x
-// [k group of 8][feature][8 bf16]); X is read as fp32 (coalesced 128-byte row pieces), split by the staging threads -- each
-// element once per workgroup -- and written to LDS in the same fragment order, so every MFMA operand is one conflict-free
-// ds_read_b128.  The next K step's global loads are in flight while the current one is multiplied (register staging, one LDS
-// stage of 48 KB: three workgroups per CU hide each other's barriers).  Output features run along the lanes: 128-byte stores.
+// Mapping (all kernels of this file): workgroup tile = 128 rows x 128 output features, 4 wavefronts as 2 x 2, each 64 x 64 = 2 x 2 MFMA tiles
+// (64 accumulator registers); K in steps of 32.  W is split and packed ONCE per weight set in the exact image a workgroup stages (three
+// terms x [k group of 8][feature][8 bf16]); X is read as fp32 (coalesced 128-byte row pieces), split by the staging threads -- each element
+// once per workgroup -- and written to LDS in the same fragment order, so every MFMA operand is one conflict-free ds_read_b128.  Output
+// features run along the lanes: 128-byte stores.
+//
+// Kernels, newest last; every one sums each output element in the same order (bitwise-equal results, tests/test_gpu_gemm_bf16x3.py):
+//   gemm_bf16x3_kernel      one tile per workgroup, register-staged prefetch, 3 workgroups per CU (rounds 1-3; flag 4)
+//   gemm_bf16x3_pk_kernel   persistent workgroups walking XCD-local tile lists (flag 8; 16 = with deferred tile stores); runs K % 64 != 0
+//   gemm_bf16x3_w8_kernel   256 x 128 tiles, eight wavefronts, two LDS stages, opposite-phase wavefronts (flag 32; measured no faster)
+//   gemm_bf16x3_d_kernel    persistent, W by LDS-DMA into two W stages, X two K steps ahead -- the default (K % 64 == 0)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
