@@ -323,3 +323,25 @@ def test_fused_conv1a_vs_torch_fp64():
                                                mfr._lib.stream_ptr()), "conv1a")
         torch.cuda.synchronize()
         np.testing.assert_allclose(y.cpu().numpy(), want.numpy(), rtol=0, atol=2e-6)
+
+
+@pytest.mark.parametrize("B,C,HW,deint,add,pad", [(4, 256, 6030, 0, False, 0), (6, 128, 97, 1, True, 256), (2, 65, 64, 0, True, 7), (3, 1, 1, 0, False, 0)])
+def test_nchw_to_rows_equals_permute(B, C, HW, deint, add, pad):
+    """mfr_nchw_to_rows (LDS-tiled transpose in front of the linear layers) == (x + add).permute(0, 2, 1) written at the given row / image
+    strides, pair batches de-interleaved on request; nothing outside the C columns of a row is touched"""
+    from mapfree_reloc_amd import _lib
+    lib = _lib.load(require_gpu=True)
+    g = torch.Generator().manual_seed(B * 1000 + C)
+    x = torch.randn(B, C, HW, generator=g).to(DEV)
+    a = torch.randn(C, HW, generator=g).to(DEV) if add else None
+    ldo = C + pad
+    out = torch.full((B, HW, ldo), -7.0, device=DEV)
+    if deint and (B & 1):
+        assert lib.mfr_nchw_to_rows(_lib.ptr(x), _lib.ptr(a), B, C, HW, 1, _lib.ptr(out), HW * ldo, ldo, _lib.stream_ptr()) != 0
+        return
+    _lib.check(lib.mfr_nchw_to_rows(_lib.ptr(x), _lib.ptr(a), B, C, HW, deint, _lib.ptr(out), HW * ldo, ldo, _lib.stream_ptr()), "mfr_nchw_to_rows")
+    want = (x + a[None] if add else x).permute(0, 2, 1)
+    if deint:
+        want = torch.cat([want[0::2], want[1::2]], 0)
+    assert torch.equal(out[..., :C], want)
+    assert (out[..., C:] == -7.0).all()
