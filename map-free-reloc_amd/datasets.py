@@ -127,6 +127,88 @@ def read_color_image(path, resize):
     return torch.from_numpy(a)
 
 
+_GRAY_LUT = None
+_DEPTH_LUT = None
+_HOST_LIB = False           # False = not looked for yet, None = absent (numpy expressions), else the ctypes handle of csrc/libmfr_host.so
+
+
+def _host_lib():
+    """csrc/libmfr_host.so (host_decode.c: the loaders' two per-pixel loops in C), or None -- then the numpy expressions run"""
+    global _HOST_LIB
+    if _HOST_LIB is False:
+        import ctypes
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libmfr_host.so")
+        try:
+            lib = ctypes.CDLL(path)
+            vp, sz = ctypes.c_void_p, ctypes.c_size_t
+            lib.mfr_host_gray_from_rgb.argtypes = [vp, sz, vp, vp, vp, vp]; lib.mfr_host_gray_from_rgb.restype = None
+            lib.mfr_host_depth_from_u16.argtypes = [vp, sz, vp, vp]; lib.mfr_host_depth_from_u16.restype = None
+            _HOST_LIB = lib if lib.mfr_host_abi_version() == 1 else None
+        except (OSError, AttributeError):
+            _HOST_LIB = None
+    return _HOST_LIB
+
+
+def _luts():
+    global _GRAY_LUT, _DEPTH_LUT
+    if _GRAY_LUT is None:
+        v = np.arange(256, dtype=np.float32) / np.float32(255)                    # read_color_image's float32 quotients
+        _GRAY_LUT = tuple(np.ascontiguousarray(np.float32(w) * v) for w in (0.299, 0.587, 0.114))      # to_gray's float32 products
+        _DEPTH_LUT = np.ascontiguousarray((np.arange(65536, dtype=np.float64) / 1000).astype(np.float32))   # read_depth_image's values
+    return _GRAY_LUT, _DEPTH_LUT
+
+
+def read_gray_plane(path, resize, out=None):
+    """to_gray(read_color_image(path, resize)) WITHOUT the float RGB image: the same float32 luma, bit for bit, written into `out` ([h, w]
+    float32, C-contiguous) when given.  The loaders of the fused path only ever want the gray plane; building the [3, h, w] float image first
+    (transpose + /255 + three multiplies over 1.2 M elements) costs as much as the JPEG decode.  A pixel's value is
+    (w0 * (R/255) + w1 * (G/255)) + w2 * (B/255) in float32 and R, G, B are bytes: three 256-entry tables of the rounded products and two
+    float32 additions in the same order (csrc/host_decode.c; numpy expressions when that library is not built)."""
+    from PIL import Image
+    pim = Image.open(path)
+    if pim.mode != "RGB":
+        pim = pim.convert("RGB")                                # (a JPEG opens as RGB: convert() would only copy it)
+    im = np.asarray(pim)
+    if resize is not None:
+        im = resize_bilinear_u8(im, resize)
+    h, w = im.shape[:2]
+    lib = _host_lib()
+    if lib is None:
+        a = np.ascontiguousarray(np.asarray(im, dtype=np.float32).transpose(2, 0, 1))
+        a /= np.float32(255)
+        g = np.float32(0.299) * a[0] + np.float32(0.587) * a[1] + np.float32(0.114) * a[2]
+        if out is None:
+            return g
+        out[...] = g
+        return out
+    (l0, l1, l2), _ = _luts()
+    im = np.ascontiguousarray(im)
+    if out is None:
+        out = np.empty((h, w), dtype=np.float32)
+    assert out.dtype == np.float32 and out.shape == (h, w) and out.flags["C_CONTIGUOUS"]
+    lib.mfr_host_gray_from_rgb(im.ctypes.data, h * w, l0.ctypes.data, l1.ctypes.data, l2.ctypes.data, out.ctypes.data)
+    return out
+
+
+def read_depth_plane(path, out=None):
+    """read_depth_image as a numpy array (into `out` when given): float32(v / 1000.0), tabulated once for the 65 536 possible values"""
+    from PIL import Image
+    d = np.ascontiguousarray(np.asarray(Image.open(path), dtype=np.uint16))
+    lib = _host_lib()
+    if lib is None:
+        g = (d / 1000).astype(np.float32)
+        if out is None:
+            return g
+        out[...] = g
+        return out
+    _, lut = _luts()
+    if out is None:
+        out = np.empty(d.shape, dtype=np.float32)
+    assert out.dtype == np.float32 and out.shape == d.shape and out.flags["C_CONTIGUOUS"]
+    lib.mfr_host_depth_from_u16(d.ctypes.data, d.size, lut.ctypes.data, out.ctypes.data)
+    return out
+
+
 import collections as _collections
 import threading as _threading
 
@@ -232,6 +314,51 @@ class MapFreeScene:
                 while len(_FRAME_CACHE) > 4:
                     _FRAME_CACHE.popitem(last=False)
         return img, d
+
+    def _gray_frame(self, rel, keep=False, out_g=None, out_d=None):
+        """(gray plane [h,w] f32, depth [h,w] f32 or None) of one frame as numpy arrays -- to_gray(image) / depth of _frame(rel), bit for bit,
+        without the float RGB image, decoded straight into out_g / out_d when given; keep=True: the same small least-recently-used cache as
+        _frame under its own keys (the cached arrays are copied into out_g / out_d)"""
+        path = os.path.join(self.scene_root, rel)
+        dpath = path.replace(".jpg", f".{self.estimated_depth}.png") if self.estimated_depth is not None else None
+        if not keep:
+            return read_gray_plane(path, self.resize, out_g), (read_depth_plane(dpath, out_d) if dpath else None)
+        try:
+            st = os.stat(path)
+            ident = (st.st_mtime_ns, st.st_size)
+        except OSError:
+            ident = None
+        key = ("gray", self.scene_root, rel, ident, tuple(self.resize) if self.resize is not None else None, self.estimated_depth)
+        with _FRAME_LOCK:
+            hit = _FRAME_CACHE.get(key)
+            if hit is not None:
+                _FRAME_CACHE.move_to_end(key)
+        if hit is None:
+            hit = (read_gray_plane(path, self.resize), read_depth_plane(dpath) if dpath else None)
+            with _FRAME_LOCK:
+                _FRAME_CACHE[key] = hit
+                while len(_FRAME_CACHE) > 4:
+                    _FRAME_CACHE.popitem(last=False)
+        g, d = hit
+        if out_g is not None:
+            out_g[...] = g
+        if out_d is not None and d is not None:
+            out_d[...] = d
+        return g, d
+
+    def gray_pair(self, index, want_ref=True, out=None):
+        """what the batched loaders need of sample `index`: (gray0 or None, depth0, gray1, depth1, K0, K1, pair_id, (name0, name1)), numpy arrays
+        with the values of to_gray(self[index]['image0' / 'image1']) and its depth maps.  out = (g0, d0, g1, d1) destination arrays (entries
+        may be None): the planes are then decoded / copied straight into them.  Returns None when this scene's images are not plain RGB reads
+        (black_white training transform): the caller takes the generic sample then."""
+        if self.black_white:
+            return None
+        sa, ia, sb, ib = self.pairs[index]
+        p1, p2 = f"seq{sa}/frame_{ia:05}.jpg", f"seq{sb}/frame_{ib:05}.jpg"
+        og0, od0, og1, od1 = out if out is not None else (None, None, None, None)
+        g0, d0 = self._gray_frame(p1, keep=True, out_g=og0 if want_ref else None, out_d=od0)
+        g1, d1 = self._gray_frame(p2, out_g=og1, out_d=od1)
+        return (g0 if want_ref else None, d0, g1, d1, self.K[p1].copy(), self.K[p2].copy(), index * self.sample_factor, (p1, p2))
 
     def __getitem__(self, index):
         from . import evaluation as E
@@ -421,10 +548,18 @@ def _pw_fill(task):
     import time as _t
     t0 = _t.perf_counter()
     k, p, si, i, want_ref = task
-    smp = _PW["scenes"][si][i]
+    sc = _PW["scenes"][si]
     sl = _PW["slots"][k]
-    npv = lambda t: t.numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
     im = sl["images"].numpy()
+    if hasattr(sc, "gray_pair"):                            # gray planes / depth straight from the files' bytes into the slot (MapFreeScene)
+        has_d = sl["depth0"] is not None
+        fast = sc.gray_pair(i, want_ref, out=(im[2 * p, 0], sl["depth0"].numpy()[p] if has_d else None, im[2 * p + 1, 0],
+                                              sl["depth1"].numpy()[p] if has_d else None))
+        if fast is not None:
+            _, _, _, _, K0, K1, pid, (n0, n1) = fast
+            return (np.asarray(K0), np.asarray(K1), int(pid), n1, n0, _t.perf_counter() - t0)
+    smp = sc[i]
+    npv = lambda t: t.numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
     if want_ref:
         im[2 * p, 0] = npv(to_gray(smp["image0"]))
     im[2 * p + 1, 0] = npv(to_gray(smp["image1"]))
@@ -540,6 +675,13 @@ class PairBatchLoader:
                                                                # keyframe; the tensor is held so that its id cannot be reused inside the batch
 
         def fill(p, smp=None):
+            sc_ = self.scenes[items[p][0]]
+            if smp is None and hasattr(sc_, "gray_pair"):      # gray planes / depth straight from the files' bytes into the batch buffers
+                fast = sc_.gray_pair(items[p][1], True, out=(im_np[2 * p, 0], d0_np[p] if has_depth else None, im_np[2 * p + 1, 0],
+                                                             d1_np[p] if has_depth else None))
+                if fast is not None:
+                    _, _, _, _, K0_, K1_, pid, (n0, n1) = fast
+                    return (torch.as_tensor(K0_), torch.as_tensor(K1_), int(pid), n1, n0)
             smp = get(items[p]) if smp is None else smp
             k0 = id(smp["image0"])
             hit = gray_of.get(k0)

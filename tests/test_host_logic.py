@@ -387,7 +387,13 @@ def test_pair_batch_loader_equals_the_per_sample_reader(tmp_path):
         scenes.append(MapFreeScene(sc, resize=(36, 48), sample_factor=1, estimated_depth="dptkitti"))
     ref = [(si, i, sc[i]) for si, sc in enumerate(scenes) for i in range(len(sc))]
     assert len(ref) == 21
-    for workers, decode in ((1, "thread"), (4, "thread"), (3, "process")):     # "process": worker processes writing into shared-memory batch slots
+    from mapfree_reloc_amd import datasets as D
+    # the loaders decode gray planes / depth straight from the files' bytes (read_gray_plane / read_depth_plane: csrc/libmfr_host.so, or the
+    # numpy expressions without it): both must hand out the per-sample reader's values bit for bit
+    modes = [(1, "thread", True), (4, "thread", True), (3, "process", True), (2, "thread", False), (2, "process", False)]
+    for workers, decode, use_host_lib in modes:               # "process": worker processes writing into shared-memory batch slots
+        D._HOST_LIB = False if use_host_lib else None
+        D.clear_frame_cache()
         got = 0
         ld = PairBatchLoader(scenes, batch_pairs=8, prefetch=2, pin=False, workers=workers, decode=decode)
         for b in ld:
@@ -401,6 +407,36 @@ def test_pair_batch_loader_equals_the_per_sample_reader(tmp_path):
                 got += 1
         ld.close()
         assert got == 21
+    D._HOST_LIB = False
+
+
+def test_gray_and_depth_planes_equal_the_reference_readers(tmp_path):
+    """read_gray_plane == to_gray(read_color_image) and read_depth_plane == read_depth_image, bit for bit: with and without the C helper,
+    with a real resize, for a JPEG, a gray-mode file (converted to RGB like the reference's loader) and depth values over the whole uint16 range"""
+    from PIL import Image
+    from mapfree_reloc_amd import datasets as D
+    rng = np.random.default_rng(5)
+    Image.fromarray(rng.integers(0, 256, (90, 70, 3), dtype=np.uint8)).save(tmp_path / "a.jpg", quality=90)
+    Image.fromarray(rng.integers(0, 256, (90, 70), dtype=np.uint8)).save(tmp_path / "b.png")
+    Image.fromarray(np.concatenate([np.arange(65536, dtype=np.uint16), rng.integers(0, 65536, 6464, dtype=np.uint16)]).reshape(300, 240)).save(tmp_path / "d.png")
+    try:
+        for lib in (False, None):
+            D._HOST_LIB = lib
+            if lib is False and D._host_lib() is None:
+                continue                                        # helper not built here: the numpy leg below covers the values
+            for f in ("a.jpg", "b.png"):
+                for rs in (None, (35, 45), (140, 181)):
+                    want = D.to_gray(D.read_color_image(str(tmp_path / f), rs)).numpy()
+                    got = D.read_gray_plane(str(tmp_path / f), rs)
+                    out = np.full(want.shape, -1.0, np.float32)
+                    assert got.dtype == np.float32 and np.array_equal(got, want) and np.array_equal(D.read_gray_plane(str(tmp_path / f), rs, out), want)
+            want = D.read_depth_image(str(tmp_path / "d.png")).numpy()
+            assert np.array_equal(D.read_depth_plane(str(tmp_path / "d.png")), want)
+            out = np.empty_like(want)
+            D.read_depth_plane(str(tmp_path / "d.png"), out)
+            assert np.array_equal(out, want)
+    finally:
+        D._HOST_LIB = False
 
 
 def test_bench_module_contract_pieces_importable():
