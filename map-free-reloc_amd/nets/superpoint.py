@@ -1,7 +1,7 @@
 """SuperPoint on MI355X: the 3x3 convolutions through the fused Winograd/MFMA kernel of
-csrc/winograd_conv.hip (conv1a: csrc/elementwise.hip; MFR_CONV=miopen selects the library convolution +
-epilogue kernels instead), the 1x1 heads as library GEMMs, everything after the conv heads through the
-hand-written HIP kernels of csrc/superpoint_post.hip.
+csrc/winograd_bf16x3.hip / winograd_conv.hip (conv1a: csrc/elementwise.hip; the declared option CONV = 'miopen', options.py, selects the
+library convolution + epilogue kernels instead), the 1x1 heads through csrc/elementwise.hip (convPb) and csrc/gemm_bf16x3.hip (convDb, fed by
+the NCHW -> rows transpose), everything after the conv heads through the hand-written HIP kernels of csrc/superpoint_post.hip.
 
 Reference call site: SuperGlue_matcher (etc/feature_matching_baselines/matchers.py:62-120; nms 4,
 threshold 0.005, max 1024 keypoints :65-67); network = un-vendored magicleap submodule, restated
@@ -43,7 +43,7 @@ class SuperPointHIP:
 
     def _conv(self, x, name, relu=True, pool=False):
         """3x3 layer = ONE launch of the fused Winograd/MFMA kernel (conv + bias + ReLU [+ 2x2 max-pool],
-        csrc/winograd_conv.hip).  MFR_CONV=miopen (or an unsupported shape): library conv without bias + one fused
+        csrc/winograd_conv.hip).  Option CONV = 'miopen' (or an unsupported shape): library conv without bias + one fused
         HIP epilogue pass (csrc/elementwise.hip)."""
         lib = _lib.load()
         w, b = self.w[name + ".weight"], self.w[name + ".bias"]
