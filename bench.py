@@ -239,8 +239,8 @@ def census_summary():
 class SgPnpWorkload:
     name = "sg_pnp"
     dtype = ("f32 in / f32 accumulate; matrix products of the large convolutions, attention and the transformer's linear layers as 3 x bf16 exact "
-             "operand splits (6 partial products, error = fp32 class); the 90x67 convolutions, 1x1 heads and the score matrix on the fp32 matrix "
-             "cores; f64 solver")
+             "operand splits (6 partial products, error = fp32 class; incl. SuperPoint's 1x1 descriptor head); the 90x67 convolutions and the score "
+             "matrix on the fp32 matrix cores, the 1x1 detector head as fp32 FMA chains; f64 solver")
     metric = "image-pairs/sec @ 540x720 (SuperPoint+SuperGlue + PnP w/ depth)"
     workload = "configs[1]: SuperPoint+SuperGlue matching + PnP w/ depth, 540x720"
 
