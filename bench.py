@@ -46,6 +46,12 @@ CONFIGS = ("sg_pnp", "loftr_emat", "rpr_train")
 EXP_PEAK_GOPS = 256 * 4 * 16 / 4 * 2.4
 
 
+def split_products():
+    """partial products (MFMAs) per fp32 multiply-add of the operand-splitting kernels: 3 for HIP.SPLIT = 'f16x2' (the default), 6 for 'bf16x3'"""
+    from mapfree_reloc_amd import options
+    return 3.0 if options.get("SPLIT") == "f16x2" else 6.0
+
+
 def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -284,7 +290,7 @@ class SgPnpWorkload:
         # flops it EXECUTES -- what the roofline prices against the dense bf16 MFMA peak -- are 6x the fp32 figure.
         tiles = ((H + 1) // 2) * ((W + 1) // 2)
         conv_fp32 = 16 * 2.0 * 64 * 64 * tiles * 2 * B
-        conv_flops = 6.0 * conv_fp32
+        conv_flops = split_products() * conv_fp32
         conv_direct = 2.0 * 9 * 64 * 64 * H * W * 2 * B
         achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms else None
         eq = conv_fp32 / (conv_ms * 1e-3) / 1e12 if conv_ms else None
@@ -314,11 +320,11 @@ class SgPnpWorkload:
         ms = self.gemm_timer.mean_ms()
         M = 2 * self.B * 1024
         fp32 = 2.0 * M * 512 * 512
-        ex = 6.0 * fp32 / (ms * 1e-3) / 1e12 if ms else None
+        ex = split_products() * fp32 / (ms * 1e-3) / 1e12 if ms else None
         return {"kernel": "gemm_bf16x3_d_kernel, the 512 -> 512 + ReLU layer of a GNN block (mfr_gemm_bf16x3: persistent workgroups, W by LDS-DMA, 3-way split operands)",
                 "bound": "mfma", "achieved": round(ex, 1) if ex else None, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ex / BF16_MFMA_PEAK_TFLOPS, 4) if ex else None, "fp32_equivalent_tflops": round(ex / 6.0, 2) if ex else None,
-                "avg_launch_ms": round(ms, 4) if ms else None, "launches_timed": len(self.gemm_timer.events), "flops_per_launch": 6.0 * fp32}
+                "frac": round(ex / BF16_MFMA_PEAK_TFLOPS, 4) if ex else None, "fp32_equivalent_tflops": round(ex / split_products(), 2) if ex else None,
+                "avg_launch_ms": round(ms, 4) if ms else None, "launches_timed": len(self.gemm_timer.events), "flops_per_launch": split_products() * fp32}
 
     def _sinkhorn_line(self, out):
         """log-Sinkhorn + mutual arg-max stage.  Its binding resource is the transcendental ALU, not HBM: 2 x iters x (n+1)^2
@@ -387,12 +393,12 @@ class LoftrEmatWorkload:
         # the layer runs the bf16x3 Winograd kernel (nets/conv.py: prefer_bf16x3(360, 272)): six bf16 partial products per fp32
         # multiply-add -> priced against the DENSE bf16 MFMA peak; useful flops count the 196 real channels (the kernel also
         # multiplies the zero padding: Cin 196 -> 208 = 13 K steps of 16, Cout 196 -> 256 = 4 groups of 64: x1.39 executed)
-        exe = 6.0 * achieved if achieved else None
+        exe = split_products() * achieved if achieved else None
         return {"kernel": "wino_bf16x3_p8_kernel layer1_outconv2.0 launch, 196->196 ch at 360x272 (dominant kernel: fused Winograd F(2x2,3x3) convolutions of the "
                           "ResNet-FPN backbone on the bf16 matrix cores at fp32 accuracy; 34 % of the step's GPU time, profiles/r04_bench_loftr_emat_kernel_stats.csv)",
                 "bound": "mfma", "achieved": round(exe, 1) if exe else None, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(exe / BF16_MFMA_PEAK_TFLOPS, 4) if exe else None, "traffic": _traffic("loftr_l1out2", B),
-                "avg_launch_ms": round(conv_ms, 4) if conv_ms else None, "launches_timed": len(self.conv_timer.events), "flops_per_launch": 6.0 * conv_flops,
+                "avg_launch_ms": round(conv_ms, 4) if conv_ms else None, "launches_timed": len(self.conv_timer.events), "flops_per_launch": split_products() * conv_flops,
                 "note": "achieved = useful bf16 flops (6 partial products per fp32 multiply-add of the 16 Winograd GEMMs over the 196 real channels) / launch "
                         "time against the dense bf16 peak; executed incl. channel padding = x1.39",
                 "fp32_equivalent": {"tflops": round(achieved, 2) if achieved else None, "flops_per_launch": conv_flops,

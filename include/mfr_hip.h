@@ -219,15 +219,19 @@ int mfr_sp_sample_descriptors(const float *dense_nhwc, int B, int Hc, int Wc, co
  *                          mfr_sg_sinkhorn_match_variant: 0 = one sweep over S per iteration (round 4, default when ldS % 4 == 0 and
  *                          ldS <= 1024), 1 = a row pass and a column pass per iteration (rounds 1-3); the same bits either way.
  * ------------------------------------------------------------------------------------------ */
-/*   mfr_gemm_bf16x3        the transformers' linear layers, y [M, ldy] (+)= act(x [M, ldx] W [N, K]^T + bias), fp32 in / fp32 out, on the
- *                          bf16 matrix cores at fp32 accuracy (csrc/gemm_bf16x3.hip: exact 3-way bf16 operand split, six partial products,
- *                          fp32 accumulate; rounds 1-2 called the library's fp32 GEMM here).  W is split and packed once per weight set
- *                          (mfr_gemm_bf16x3_pack, size from mfr_gemm_bf16x3_pack_bytes; 0 if K % 32 != 0).  flags: 1 = ReLU, 2 = accumulate
- *                          into y (y += x W^T + bias).  x 16-byte aligned, ldx % 4 == 0; bias may be NULL.  Kernel selection for A/B runs and
- *                          the bitwise-agreement test (every variant sums each output element in the same order): + 4 one tile per
- *                          workgroup (rounds 1-3), + 8 / 16 persistent workgroups without / with deferred tile stores, + 32 eight
- *                          wavefronts on 256 x 128 tiles; none = persistent, W by LDS-DMA (K % 64 == 0; other K run as + 8).
- *                          + 256 / 512 / 768: measurement ablations (tools/ablate_gemm.py), results undefined. */
+/*   mfr_gemm_f16x2 / mfr_gemm_bf16x3   the transformers' linear layers, y [M, ldy] (+)= act(x [M, ldx] W [N, K]^T + bias), fp32 in / fp32 out, on
+ *                          the 16-bit matrix cores at fp32 accuracy by operand splitting (csrc/gemm_split.hip; rounds 1-2 called the library's fp32
+ *                          GEMM here).  f16x2 (round 5, what nets/linear.py runs; csrc/split_f16.h): activations as two f16 terms, the weight
+ *                          pre-scaled per output feature and packed as three f16 terms, three partial products, fp32 accumulate;
+ *                          precondition |x| <= 65504.  bf16x3 (rounds 3-4): exact 3-way bf16 split of both operands, six partial products.
+ *                          W is split and packed once per weight set (mfr_gemm_*_pack, size from mfr_gemm_*_pack_bytes; 0 if K % 32 != 0;
+ *                          the two packed formats are not interchangeable).  flags: 1 = ReLU, 2 = accumulate into y (y += x W^T + bias).
+ *                          x 16-byte aligned, ldx % 4 == 0; bias may be NULL.  Kernel selection for the bitwise-agreement test (every
+ *                          kernel sums each output element in the same order): + 4 one tile per workgroup (round 3), + 8 persistent
+ *                          workgroups with register-staged W; none = persistent, W by LDS-DMA (K % 64 == 0; other K run as + 8). */
+size_t mfr_gemm_f16x2_pack_bytes(int N, int K);
+int mfr_gemm_f16x2_pack(const float *w, int N, int K, void *packed, void *stream);
+int mfr_gemm_f16x2(const float *x, int ldx, const void *packed_w, const float *bias, float *y, int ldy, int M, int N, int K, int flags, void *stream);
 size_t mfr_gemm_bf16x3_pack_bytes(int N, int K);
 int mfr_gemm_bf16x3_pack(const float *w, int N, int K, void *packed, void *stream);
 int mfr_gemm_bf16x3(const float *x, int ldx, const void *packed_w, const float *bias, float *y, int ldy, int M, int N, int K, int flags, void *stream);
@@ -416,22 +420,23 @@ int mfr_desc_ratio_match(const float *des0, const float *des1, const float *norm
  *                              convolutions of LoFTR's ResNet-FPN backbone (BatchNorm folded into w / bias).
  * f32 Winograd arithmetic: agrees with a direct f32 convolution to ~1e-6 relative (not bit-identical).
  * ------------------------------------------------------------------------------------------ */
-/* The same layer (same arguments, same epilogue) on the BF16 matrix cores at fp32 accuracy (csrc/winograd_bf16x3.hip): U = G g G^T
- * and V = B^T d B are formed in fp32 as above, then every operand is split exactly into three bf16 terms and a product is the six
- * leading partial products accumulated in fp32 (error vs fp64 = that of the exact-fp32 matrix instruction, profiles/
- * r03_bf16x3_probe.jsonl).  Any Cin, Cout (padded to multiples of 16 / 64 inside the packed filter).
- *   mfr_wino_bf16x3_filter_bytes      size of the packed, split filter (ceil(Cout/64) * ceil(Cin/16) * 96 KiB)
- *   mfr_wino_bf16x3_filter_transform  w [Cout,Cin,3,3] f32 -> upk; once per weight set
- *   mfr_conv3x3_wino_bf16x3           as mfr_conv3x3_wino */
+/* The same layer (same arguments, same epilogue) on the 16-bit matrix cores at fp32 accuracy by operand splitting (csrc/winograd_split.hip):
+ * U = G g G^T and V = B^T d B are formed in fp32 as above.  f16x2 (round 5, what nets/conv.py runs; csrc/split_f16.h): V as two f16 terms,
+ * U pre-scaled per output channel and packed as three f16 terms, three partial products; precondition |activation| < 16376.
+ * bf16x3 (rounds 3-4): every operand split exactly into three bf16 terms, six partial products.  fp32 accumulate either way; error vs fp64 =
+ * that of the exact-fp32 matrix instruction (profiles/r05_f16x2_probe.jsonl, r03_bf16x3_probe.jsonl).  Any Cin, Cout (padded to multiples
+ * of 16 / 64 inside the packed filter; the two packed formats are not interchangeable).
+ *   mfr_wino_*_filter_bytes      size of the packed, split filter (ceil(Cout/64) * ceil(Cin/16) * 96 KiB; f16x2: + the channel scales)
+ *   mfr_wino_*_filter_transform  w [Cout,Cin,3,3] f32 -> upk; once per weight set
+ *   mfr_conv3x3_wino_*           as mfr_conv3x3_wino */
+size_t mfr_wino_f16x2_filter_bytes(int Cin, int Cout);
+int mfr_wino_f16x2_filter_transform(const float *w, int Cin, int Cout, void *upk, void *stream);
+int mfr_conv3x3_wino_f16x2(const float *x, const void *upk, const float *bias, const float *residual, int B, int Cin, int Cout,
+                           int H, int W, int act, int pool, float *y, void *stream);
 size_t mfr_wino_bf16x3_filter_bytes(int Cin, int Cout);
 int mfr_wino_bf16x3_filter_transform(const float *w, int Cin, int Cout, void *upk, void *stream);
 int mfr_conv3x3_wino_bf16x3(const float *x, const void *upk, const float *bias, const float *residual, int B, int Cin, int Cout,
                             int H, int W, int act, int pool, float *y, void *stream);
-/* variant 0 = the kernel; other values = timing ablations of tools/bench_conv.py (pooled layers only; results are wrong) */
-int mfr_conv3x3_wino_bf16x3_variant(const float *x, const void *upk, const float *bias, const float *residual, int B, int Cin, int Cout,
-                                    int H, int W, int act, int pool, int variant, float *y, void *stream);
-/* debug hook of tools/ablate_conv_bf16x3.py: s_memtime stamps (4 wavefronts x 64) of one workgroup of the last variant-16 launch */
-int mfr_wino_bf16x3_profile(unsigned long long *out_host);
 size_t mfr_wino_filter_bytes(int Cin, int Cout);
 int mfr_wino_filter_transform(const float *w, int Cin, int Cout, float *upk, void *stream);
 int mfr_conv3x3_wino(const float *x, const float *upk, const float *bias, const float *residual, int B, int Cin, int Cout,

@@ -40,6 +40,9 @@ SIGNATURES = {
     "mfr_sp_nms_candidates": (_i, [_vp, _i, _i, _i, _i, C.c_float, _i, _vp, _vp, _i, _vp, _vp]),
     "mfr_sp_select_topk": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "mfr_sp_sample_descriptors": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp]),
+    "mfr_gemm_f16x2_pack_bytes": (_sz, [_i, _i]),
+    "mfr_gemm_f16x2_pack": (_i, [_vp, _i, _i, _vp, _vp]),
+    "mfr_gemm_f16x2": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "mfr_gemm_bf16x3_pack_bytes": (_sz, [_i, _i]),
     "mfr_gemm_bf16x3_pack": (_i, [_vp, _i, _i, _vp, _vp]),
     "mfr_gemm_bf16x3": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
@@ -66,8 +69,9 @@ SIGNATURES = {
     "mfr_wino_bf16x3_filter_bytes": (_sz, [_i, _i]),
     "mfr_wino_bf16x3_filter_transform": (_i, [_vp, _i, _i, _vp, _vp]),
     "mfr_conv3x3_wino_bf16x3": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
-    "mfr_conv3x3_wino_bf16x3_variant": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
-    "mfr_wino_bf16x3_profile": (_i, [_vp]),
+    "mfr_wino_f16x2_filter_bytes": (_sz, [_i, _i]),
+    "mfr_wino_f16x2_filter_transform": (_i, [_vp, _i, _i, _vp, _vp]),
+    "mfr_conv3x3_wino_f16x2": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "mfr_wino_filter_bytes": (_sz, [_i, _i]),
     "mfr_wino_filter_transform": (_i, [_vp, _i, _i, _vp, _vp]),
     "mfr_conv3x3_wino": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),

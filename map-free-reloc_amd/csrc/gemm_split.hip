@@ -1,0 +1,616 @@
+// gemm_split.hip -- Y[M, N] (+)= act(X[M, K] W[N, K]^T + bias): the linear layers of the SuperGlue / LoFTR transformers (fp32 in,
+// fp32 out) on the gfx950 16-bit matrix cores at fp32 accuracy, by operand splitting.
+//
+// Reference call site: SuperGlue_matcher / LoFTR_matcher (etc/feature_matching_baselines/matchers.py:12-120) -> the un-vendored
+// networks' Conv1d(k=1) / Linear layers; rounds 1-2 ran them as library (hipBLASLt) fp32 GEMMs.
+//
+// Two arithmetics, one kernel structure (template parameter F16):
+//   bf16x3 (rounds 3-4)  every fp32 operand is split EXACTLY into three bf16 terms x = h + m + l (truncation, 8 + 8 + 8 significand bits); a
+//                        product is the six partial products hh + hm + mh + hl + lh + mm (each exact in fp32) accumulated in fp32 by
+//                        v_mfma_f32_32x32x16_bf16.  Error = that of the exact-fp32 matrix instruction (profiles/r03_bf16x3_probe.jsonl).
+//   f16x2  (round 5, the default)  split_f16.h: activations as two f16 terms (the low one scaled by 2^11), weights pre-scaled per output
+//                        feature and packed as three f16 terms (wh, wl, wh 2^-11): THREE v_mfma_f32_32x32x16_f16 per K block, 2.5 instead of
+//                        5.5 VALU per activation element, two instead of three X term images in LDS.  Same error class for
+//                        2^-14 <= |x| <= 65504 (profiles/r05_f16x2_probe.jsonl); the epilogue multiplies by the feature's 1 / scale.
+//
+// Mapping (all kernels of this file): workgroup tile = 128 rows x 128 output features, 4 wavefronts as 2 x 2, each 64 x 64 = 2 x 2 MFMA tiles
+// (64 accumulator registers); K in steps of 32.  W is split and packed ONCE per weight set in the exact image a workgroup stages (three
+// terms x [k group of 8][feature][8 x 16 bit]); X is read as fp32 (coalesced 128-byte row pieces), split by the staging threads -- each
+// element once per workgroup -- and written to LDS in the same fragment order, so every MFMA operand is one conflict-free ds_read_b128.
+// Output features run along the lanes: 128-byte stores.
+//
+// Kernels; every one sums each output element in the same order (bitwise-equal results per arithmetic, tests/test_gpu_gemm_split.py):
+//   gemm_split_kernel      one tile per workgroup, register-staged prefetch (round 3; flag 4: the baseline of the bitwise test)
+//   gemm_split_pk_kernel   persistent workgroups walking XCD-local tile lists (flag 8); runs K % 64 != 0
+//   gemm_split_d_kernel    persistent, W by LDS-DMA into two W stages, X two K steps ahead -- the default (K % 64 == 0)
+// (Round 4's other generations -- deferred tile stores, the eight-wavefront 256 x 128 kernel, the timing ablations -- measured no faster
+// and left the library in round 5; their measurements are profiles/r04_ablate_gemm.json.)
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/mfr_hip.h"
+#include "split_f16.h"
+
+#define CHECK_LAUNCH() do { if (hipGetLastError() != hipSuccess) return MFR_E_LAUNCH; } while (0)
+
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define GB_BM 128
+#define GB_BN 128
+#define GB_BK 32
+#define GB_KG_STRIDE 129                  // 16-byte units per k group (128 rows + 1 pad: conflict-free stores)
+#define GB_TERM_UNITS (4 * GB_KG_STRIDE)  // units per X term image
+#define GB_W_TILE_UNITS 1536              // packed W tile: 3 terms x 4 k groups x 128 features, 16 bytes each (both arithmetics)
+
+union GbFrag { bf16x8 v; unsigned u[4]; uint4 q; };
+
+__device__ __forceinline__ void gb_split3(float x, unsigned &h, unsigned &m, unsigned &l)
+{
+    h = __float_as_uint(x);
+    const float r = x - __uint_as_float(h & 0xffff0000u);
+    m = __float_as_uint(r);
+    l = __float_as_uint(r - __uint_as_float(m & 0xffff0000u));
+}
+__device__ __forceinline__ unsigned gb_pack(unsigned lo, unsigned hi) { return __builtin_amdgcn_perm(hi, lo, 0x07060302u); }
+
+// eight consecutive K elements of one row -> the row's 16-byte unit of every X term image (XT = 3: h, m, l bf16; XT = 2: xh, xl f16)
+template <bool F16>
+__device__ __forceinline__ void gb_xsplit_store(uint4 *lds, const float4 &p, const float4 &q, int dst)
+{
+    if (F16) {
+        unsigned h[4], l[4];
+        sf_split2(p.x, p.y, SF_LOW_SCALE, h[0], l[0]); sf_split2(p.z, p.w, SF_LOW_SCALE, h[1], l[1]);
+        sf_split2(q.x, q.y, SF_LOW_SCALE, h[2], l[2]); sf_split2(q.z, q.w, SF_LOW_SCALE, h[3], l[3]);
+        lds[0 * GB_TERM_UNITS + dst] = make_uint4(h[0], h[1], h[2], h[3]);
+        lds[1 * GB_TERM_UNITS + dst] = make_uint4(l[0], l[1], l[2], l[3]);
+    } else {
+        const float x[8] = { p.x, p.y, p.z, p.w, q.x, q.y, q.z, q.w };
+        unsigned h[8], m[8], l[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) gb_split3(x[e], h[e], m[e], l[e]);
+        lds[0 * GB_TERM_UNITS + dst] = make_uint4(gb_pack(h[0], h[1]), gb_pack(h[2], h[3]), gb_pack(h[4], h[5]), gb_pack(h[6], h[7]));
+        lds[1 * GB_TERM_UNITS + dst] = make_uint4(gb_pack(m[0], m[1]), gb_pack(m[2], m[3]), gb_pack(m[4], m[5]), gb_pack(m[6], m[7]));
+        lds[2 * GB_TERM_UNITS + dst] = make_uint4(gb_pack(l[0], l[1]), gb_pack(l[2], l[3]), gb_pack(l[4], l[5]), gb_pack(l[6], l[7]));
+    }
+}
+
+// the partial products of one 16-wide K block into the 2 x 2 accumulator tiles, small terms first; a: X terms, b: W terms
+#define GB_MFMA_BF(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+template <bool F16>
+__device__ __forceinline__ void gb_products(f32x16 (&acc)[2][2], const GbFrag (&a)[2][3], const GbFrag (&b)[2][3])
+{
+#define GB_P4(ta, tb) do { \
+        if (F16) { acc[0][0] = SF_MFMA(a[0][ta].q, b[0][tb].q, acc[0][0]); acc[0][1] = SF_MFMA(a[0][ta].q, b[1][tb].q, acc[0][1]); \
+                   acc[1][0] = SF_MFMA(a[1][ta].q, b[0][tb].q, acc[1][0]); acc[1][1] = SF_MFMA(a[1][ta].q, b[1][tb].q, acc[1][1]); } \
+        else     { acc[0][0] = GB_MFMA_BF(a[0][ta].v, b[0][tb].v, acc[0][0]); acc[0][1] = GB_MFMA_BF(a[0][ta].v, b[1][tb].v, acc[0][1]); \
+                   acc[1][0] = GB_MFMA_BF(a[1][ta].v, b[0][tb].v, acc[1][0]); acc[1][1] = GB_MFMA_BF(a[1][ta].v, b[1][tb].v, acc[1][1]); } } while (0)
+    if (F16) { GB_P4(1, 2); GB_P4(0, 1); GB_P4(0, 0); }                              // xl wq, xh wl, xh wh
+    else     { GB_P4(1, 1); GB_P4(0, 2); GB_P4(2, 0); GB_P4(0, 1); GB_P4(1, 0); GB_P4(0, 0); }
+#undef GB_P4
+}
+#define GB_XT(F16) ((F16) ? 2 : 3)
+
+// ---- weight packing ----------------------------------------------------------------------------------------------------------------------
+// W [N, K] f32 row-major -> packed [n block][k block][term][k group][feature (128)][8 x 16 bit]; one thread per 16-byte unit.
+// f16x2: the blob ends with the per-feature 1 / scale (nnb x 128 floats, written by gb_scale_kernel BEFORE this kernel runs).
+__global__ void __launch_bounds__(64) gb_scale_kernel(const float *__restrict__ w, int N, int K, int npad, float *__restrict__ oscale)
+{
+    const int n = blockIdx.x, lane = threadIdx.x;
+    float mx = 0.f;
+    if (n < N)
+        for (int k = lane; k < K; k += 64) mx = fmaxf(mx, fabsf(w[(size_t)n * K + k]));
+#pragma unroll
+    for (int o = 32; o; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if (lane == 0 && n < npad) oscale[n] = 1.0f / sf_feature_scale(mx);              // powers of two: the reciprocal is exact
+}
+template <bool F16>
+__global__ void __launch_bounds__(256) gb_pack_kernel(const float *__restrict__ w, int N, int K, long long total, const float *__restrict__ oscale, uint4 *__restrict__ out)
+{
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    const int u = (int)(t % GB_W_TILE_UNITS);
+    const long long tile = t / GB_W_TILE_UNITS;
+    const int nkb = K / GB_BK;
+    const int kb = (int)(tile % nkb), nb = (int)(tile / nkb);
+    const int term = u / 512, kg = (u % 512) / 128, f = u % 128;
+    const int n = nb * GB_BN + f, k0 = kb * GB_BK + 8 * kg;
+    unsigned word[8];
+    const float s = F16 ? 1.0f / oscale[n] : 1.0f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float x = (n < N) ? w[(size_t)n * K + k0 + e] : 0.f;
+        if (F16) {
+            unsigned short wh, wl, wq;
+            sf_split_w(x * s, wh, wl, wq);
+            word[e] = (unsigned)(term == 0 ? wh : term == 1 ? wl : wq) << 16;        // (upper half, as the bf16 terms: gb_pack takes the upper halves)
+        } else {
+            unsigned h, m, l;
+            gb_split3(x, h, m, l);
+            word[e] = term == 0 ? h : term == 1 ? m : l;
+        }
+    }
+    out[t] = make_uint4(gb_pack(word[0], word[1]), gb_pack(word[2], word[3]), gb_pack(word[4], word[5]), gb_pack(word[6], word[7]));
+}
+
+// ---- baseline: one tile per workgroup (round 3) --------------------------------------------------------------------------------------
+// FLAGS: 1 = ReLU, 2 = accumulate into Y (Y += ...)
+template <int FLAGS, bool F16>
+__global__ void __launch_bounds__(256, 2) gemm_split_kernel(const float *__restrict__ X, int ldx, const uint4 *__restrict__ Wp, const float *__restrict__ oscale,
+                                                            const float *__restrict__ bias, float *__restrict__ Y, int ldy, int M, int N, int K, int nnb)
+{
+    constexpr int XT = GB_XT(F16);
+    __shared__ uint4 lds[(XT + 3) * GB_TERM_UNITS];       // X terms, W terms 0..2
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    // feature blocks innermost: the workgroups that share an X row block run back to back (its tiles stay in L2)
+    const int nb = blockIdx.x % nnb, mb = blockIdx.x / nnb;
+    const int m0 = mb * GB_BM;
+    const int nkb = K / GB_BK;
+
+    // staging assignment.  X: unit u = tid + 256 i -> (row = u >> 2, k group = u & 3), 8 floats = two 16-byte loads.
+    // W: unit u = tid + 256 i, i = 0..5 -> straight copy of the packed tile image.
+    const float *xrow[2];
+    int xdst[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int u = tid + 256 * i, row = u >> 2, kg = u & 3;
+        const int m = min(m0 + row, M - 1);               // rows beyond M: a valid row is read and its results are never stored
+        xrow[i] = X + (size_t)m * ldx + 8 * kg;
+        xdst[i] = kg * GB_KG_STRIDE + row;
+    }
+    int wdst[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int u = tid + 256 * i, term = u / 512, kg = (u % 512) / 128, f = u % 128;
+        wdst[i] = (XT + term) * GB_TERM_UNITS + kg * GB_KG_STRIDE + f;
+    }
+    const uint4 *wtile = Wp + (size_t)nb * nkb * GB_W_TILE_UNITS + tid;
+
+    // (named registers, not arrays: hipcc keeps a lambda-captured array that is written under a condition in scratch memory)
+    float4 xa0, xa1, xb0, xb1;
+    uint4 w0, w1, w2, w3, w4, w5;
+#define GB_GLOAD(kb) do { \
+        xa0 = *(const float4 *)(xrow[0] + (kb) * GB_BK); xa1 = *(const float4 *)(xrow[0] + (kb) * GB_BK + 4); \
+        xb0 = *(const float4 *)(xrow[1] + (kb) * GB_BK); xb1 = *(const float4 *)(xrow[1] + (kb) * GB_BK + 4); \
+        const uint4 *wt_ = wtile + (size_t)(kb) * GB_W_TILE_UNITS; \
+        w0 = wt_[0]; w1 = wt_[256]; w2 = wt_[512]; w3 = wt_[768]; w4 = wt_[1024]; w5 = wt_[1280]; } while (0)
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // fragment addresses: operand row (token / feature) = 64 w + 32 t + (lane & 31), k group = 2 ks + (lane >> 5)
+    const int arow = (lane >> 5) * GB_KG_STRIDE + 64 * wm + (lane & 31);
+    const int brow = (lane >> 5) * GB_KG_STRIDE + 64 * wn + (lane & 31);
+
+    GB_GLOAD(0);
+    for (int kb = 0; kb < nkb; ++kb) {
+        __syncthreads();                                  // the previous step's fragment reads are done
+        gb_xsplit_store<F16>(lds, xa0, xa1, xdst[0]); gb_xsplit_store<F16>(lds, xb0, xb1, xdst[1]);
+        lds[wdst[0]] = w0; lds[wdst[1]] = w1; lds[wdst[2]] = w2; lds[wdst[3]] = w3; lds[wdst[4]] = w4; lds[wdst[5]] = w5;
+        __syncthreads();
+        { const int kn = min(kb + 1, nkb - 1); GB_GLOAD(kn); }   // in flight during the MFMAs below (the last step re-reads its own tile)
+        // without this fence hipcc sinks the loads BELOW the MFMAs (ten live 16-byte registers fewer across them) and every K step
+        // pays the full memory latency before its split: load -> wait -> split -> store -> MFMA, nothing overlapped inside a workgroup
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            GbFrag a[2][3], b[2][3];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+#pragma unroll
+                for (int t = 0; t < XT; ++t) a[i][t].q = lds[t * GB_TERM_UNITS + 2 * ks * GB_KG_STRIDE + arow + 32 * i];
+#pragma unroll
+                for (int t = 0; t < 3; ++t) b[i][t].q = lds[(XT + t) * GB_TERM_UNITS + 2 * ks * GB_KG_STRIDE + brow + 32 * i];
+            }
+            gb_products<F16>(acc, a, b);
+        }
+    }
+#undef GB_GLOAD
+
+    // epilogue: accumulator register r of tile (i, j): token row 64 wm + 32 i + (r & 3) + 8 (r >> 2) + 4 (lane >> 5), feature 64 wn + 32 j + (lane & 31)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = nb * GB_BN + 64 * wn + 32 * j + (lane & 31);
+        if (n >= N) continue;
+        const float bv = bias ? bias[n] : 0.f;
+        const float os = F16 ? oscale[n] : 1.0f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + 64 * wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (m >= M) continue;
+                float *yp = Y + (size_t)m * ldy + n;
+                float v = F16 ? __builtin_fmaf(acc[i][j][r], os, bv) : acc[i][j][r] + bv;
+                if (FLAGS & 1) v = fmaxf(v, 0.f);
+                if (FLAGS & 2) v += *yp;
+                *yp = v;
+            }
+        }
+    }
+}
+
+
+// ---- round 4: PERSISTENT workgroups -------------------------------------------------------------------------------------------------------
+// Measured on the SuperGlue shapes (M = 65536; profiles/r04_bench_sg_pnp_kernel_stats.csv) the one-tile-per-workgroup kernel above takes
+// matrix-core time + HBM time + ~30 us, not their maximum: all resident workgroups start together, run the same K loop and store their
+// 64 KB tiles together, so the matrix cores idle while 50 MB of tiles drain and HBM idles while they multiply; a new workgroup waits for the
+// previous one's stores and then for its own first loads.  Here a workgroup walks over tiles: the loads of the next tile's first K step are
+// in flight during the current tile's last multiply and -- for the accumulating epilogue -- Y is fetched during the last K step.
+// Same arithmetic per output element as the kernel above, bit for bit.  Grid = 2 workgroups per CU (512: the SuperGlue shapes are
+// 1024 / 2048 / 3072 tiles); tiles are dealt per XCD so that the workgroups sharing an X row block share an L2 (row block mb lives on XCD mb % 8).
+#define GB_RSRC_FLAGS 0x00020000
+template <int FLAGS, bool F16>
+__global__ void __launch_bounds__(256, 2) gemm_split_pk_kernel(const float *__restrict__ X, int ldx, const uint4 *__restrict__ Wp, const float *__restrict__ oscale,
+                                                               const float *__restrict__ bias, float *__restrict__ Y, int ldy, int M, int N, int K, int nnb, int nmb)
+{
+    constexpr int XT = GB_XT(F16);
+    __shared__ uint4 lds[(XT + 3) * GB_TERM_UNITS];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    const int nkb = K / GB_BK;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
+    const int items = ((nmb + 7) >> 3) * nnb;               // work items of one XCD: (local row block, feature block), feature block innermost
+    // item j of this XCD -> tile; row blocks beyond nmb do not exist (they can only be the last local row block: the walk ends there)
+#define GB_TILE(j, mb_, nb_) const int nb_ = (j) % nnb, mb_ = ((j) / nnb) * 8 + xcd
+    int j = slot;
+    if (j >= items) return;
+    { GB_TILE(j, mb, nb); (void)nb; if (mb >= nmb) return; }
+
+    int xdst[2], xr[2], xk[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int u = tid + 256 * i;
+        xr[i] = u >> 2; xk[i] = 8 * (u & 3);
+        xdst[i] = (u & 3) * GB_KG_STRIDE + xr[i];
+    }
+    int wdst[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int u = tid + 256 * i, term = u / 512, kg = (u % 512) / 128, f = u % 128;
+        wdst[i] = (XT + term) * GB_TERM_UNITS + kg * GB_KG_STRIDE + f;
+    }
+    const int arow = (lane >> 5) * GB_KG_STRIDE + 64 * wm + (lane & 31);
+    const int brow = (lane >> 5) * GB_KG_STRIDE + 64 * wn + (lane & 31);
+    const unsigned rowb = (unsigned)ldy * 4u;              // bytes per row of Y
+    const __amdgpu_buffer_rsrc_t rbias = __builtin_amdgcn_make_buffer_rsrc((void *)bias, 0, bias ? N * 4 : 0, GB_RSRC_FLAGS);   // no bias: every read returns 0
+    const __amdgpu_buffer_rsrc_t rscale = __builtin_amdgcn_make_buffer_rsrc((void *)oscale, 0, F16 ? nnb * GB_BN * 4 : 0, GB_RSRC_FLAGS);
+
+    // the LOAD stream runs one K step ahead of the multiply, across tile boundaries
+    const float *lx0, *lx1;
+    const uint4 *lw;
+    int lk, lj = j;                                        // K step / item the load stream is at
+    auto load_tile_start = [&](int jj) {
+        GB_TILE(jj, mb, nb);
+        lx0 = X + (size_t)min(mb * GB_BM + xr[0], M - 1) * ldx + xk[0];      // rows beyond M: a valid row is read, its results are never stored
+        lx1 = X + (size_t)min(mb * GB_BM + xr[1], M - 1) * ldx + xk[1];
+        lw = Wp + (size_t)nb * nkb * GB_W_TILE_UNITS + tid;
+        lk = 0;
+    };
+    float4 xa0, xa1, xb0, xb1;
+    uint4 w0, w1, w2, w3, w4, w5;
+#define GB_PLOAD() do { \
+        xa0 = *(const float4 *)lx0; xa1 = *(const float4 *)(lx0 + 4); xb0 = *(const float4 *)lx1; xb1 = *(const float4 *)(lx1 + 4); \
+        w0 = lw[0]; w1 = lw[256]; w2 = lw[512]; w3 = lw[768]; w4 = lw[1024]; w5 = lw[1280]; \
+        lx0 += GB_BK; lx1 += GB_BK; lw += GB_W_TILE_UNITS; \
+        if (++lk == nkb) { int jn = lj + per_xcd; if (jn < items) { GB_TILE(jn, mbn_, nbn_); (void)nbn_; if (mbn_ >= nmb) jn = items; } \
+                           if (jn < items) lj = jn; load_tile_start(lj); } } while (0)        /* no next tile: the last load re-reads this tile's start */
+
+    f32x16 acc[2][2];
+    unsigned ov[2][2][16];                                 // FLAGS & 2: the tile of Y fetched during the last K step
+    // accumulator register r of tile (i, jj) of a wavefront: row 32 i + (r & 3) + 8 (r >> 2) (+ 64 wm + 4 (lane >> 5): the lane offset), feature + 32 jj
+#define GB_SOFF(i, r) ((unsigned)(32 * (i) + ((r) & 3) + 8 * ((r) >> 2)) * rowb)
+
+    load_tile_start(j);
+    GB_PLOAD();
+    for (;;) {
+        GB_TILE(j, mb, nb);
+        const int m0 = mb * GB_BM;
+        // this tile's rows of Y as one buffer (rows beyond M fall outside it: reads return 0, stores are dropped)
+        const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void *)(Y + (size_t)m0 * ldy), 0, (int)((unsigned)min(GB_BM, M - m0) * rowb), GB_RSRC_FLAGS);
+        const int n0 = nb * GB_BN + 64 * wn + (lane & 31);
+        const unsigned yoff = (unsigned)(64 * wm + 4 * (lane >> 5)) * rowb + 4u * (unsigned)n0;
+        const float bv0 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rbias, 4u * (unsigned)n0, 0, 0));
+        const float bv1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rbias, 4u * (unsigned)n0 + 128u, 0, 0));
+        const float os0 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rscale, 4u * (unsigned)n0, 0, 0));
+        const float os1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rscale, 4u * (unsigned)n0 + 128u, 0, 0));
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.f;
+#define GB_PSTEP(LAST) do { \
+            __syncthreads(); \
+            gb_xsplit_store<F16>(lds, xa0, xa1, xdst[0]); gb_xsplit_store<F16>(lds, xb0, xb1, xdst[1]); \
+            lds[wdst[0]] = w0; lds[wdst[1]] = w1; lds[wdst[2]] = w2; lds[wdst[3]] = w3; lds[wdst[4]] = w4; lds[wdst[5]] = w5; \
+            __syncthreads(); \
+            GB_PLOAD(); \
+            if ((LAST) && (FLAGS & 2)) { \
+                _Pragma("unroll") for (int jj = 0; jj < 2; ++jj) \
+                    _Pragma("unroll") for (int i = 0; i < 2; ++i) \
+                        _Pragma("unroll") for (int r = 0; r < 16; ++r) \
+                            ov[i][jj][r] = __builtin_amdgcn_raw_buffer_load_b32(ry, yoff + 128u * jj, GB_SOFF(i, r), 0); } \
+            __builtin_amdgcn_sched_barrier(0); \
+            _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) { \
+                GbFrag a[2][3], b[2][3]; \
+                _Pragma("unroll") for (int i = 0; i < 2; ++i) { \
+                    _Pragma("unroll") for (int t = 0; t < XT; ++t) a[i][t].q = lds[t * GB_TERM_UNITS + 2 * ks * GB_KG_STRIDE + arow + 32 * i]; \
+                    _Pragma("unroll") for (int t = 0; t < 3; ++t) b[i][t].q = lds[(XT + t) * GB_TERM_UNITS + 2 * ks * GB_KG_STRIDE + brow + 32 * i]; } \
+                gb_products<F16>(acc, a, b); } } while (0)
+        for (int kb = 0; kb < nkb - 1; ++kb) GB_PSTEP(false);
+        GB_PSTEP(true);
+
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            if (n0 + 32 * jj >= N) continue;
+            const float bv = jj ? bv1 : bv0, os = jj ? os1 : os0;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = F16 ? __builtin_fmaf(acc[i][jj][r], os, bv) : acc[i][jj][r] + bv;
+                    if (FLAGS & 1) v = fmaxf(v, 0.f);
+                    if (FLAGS & 2) v += __builtin_bit_cast(float, ov[i][jj][r]);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ry, yoff + 128u * jj, GB_SOFF(i, r), 0);
+                }
+        }
+        // next item of this workgroup
+        int jn = j + per_xcd;
+        if (jn >= items) break;
+        { GB_TILE(jn, mbn, nbn); (void)nbn; if (mbn >= nmb) break; }
+        j = jn;
+    }
+#undef GB_PSTEP
+#undef GB_PLOAD
+#undef GB_TILE
+#undef GB_SOFF
+}
+
+// ---- the default (K % 64 == 0): persistent 128 x 128 workgroups, W by LDS-DMA, X two K steps ahead -----------------------------------
+// What tools/ubench/mfma_lds_bf16.hip and the round-4 ablations measured on the persistent kernel above (profiles/r04_mfma_lds_bf16.jsonl,
+// r04_ablate_gemm.json): the step's twelve ds_write_b128 cost a fifth of the matrix-core rate (0.93 -> 0.73 of the register-only loop), the
+// X loads another 12 % (issued one K step = ~1 us ahead, less than the HBM latency under load) and the W loads 4 %.  Here
+//   * W never passes through registers: each wavefront issues six `buffer_load_dwordx4 ... lds` per step that copy the packed tile image of
+//     the NEXT step straight into the other of two W stages (unpadded: fragment reads of consecutive 16-byte units are conflict-free);
+//   * X keeps its register staging (it has to be split) but two register sets alternate, so a step's loads are issued two steps ahead;
+//   * LDS = X terms (24.2 KB bf16x3, 16.1 KB f16x2) + 2 x 24 KB W: two workgroups per CU.
+// The K loop is unrolled by two (register set / W stage = parity of the step): K % 64 == 0, other K run the kernel above.  Arithmetic per
+// output element unchanged.
+#define GD_WSTAGE 1536                    // units per W stage (one packed tile image)
+#define GD_VMCNT(n) __builtin_amdgcn_s_waitcnt(0x0F70 | ((n) & 15) | (((n) >> 4) << 14))      /* vmcnt(n) only */
+template <int FLAGS, bool F16>
+__global__ void __launch_bounds__(256, 2) gemm_split_d_kernel(const float *__restrict__ X, int ldx, const uint4 *__restrict__ Wp, unsigned wp_bytes, const float *__restrict__ oscale,
+                                                              const float *__restrict__ bias, float *__restrict__ Y, int ldy, int M, int N, int K, int nnb, int nmb)
+{
+    constexpr int XT = GB_XT(F16);
+    __shared__ uint4 lds[XT * GB_TERM_UNITS + 2 * GD_WSTAGE];
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid >> 1, wn = wid & 1;
+    const int nkb = K / GB_BK;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
+    const int items = ((nmb + 7) >> 3) * nnb;
+#define GD_TILE(j, mb_, nb_) const int nb_ = (j) % nnb, mb_ = ((j) / nnb) * 8 + xcd
+    int j = slot;
+    if (j >= items) return;
+    { GD_TILE(j, mb, nb); (void)nb; if (mb >= nmb) return; }
+    // the item after jj in this workgroup's walk, or jj itself at the end (the streams then re-read valid memory that is never used)
+    auto next_item = [&](int jj) { int jn = jj + per_xcd; if (jn < items) { GD_TILE(jn, mbn, nbn); (void)nbn; if (mbn >= nmb) jn = items; } return jn < items ? jn : jj; };
+
+    int xdst[2], xr[2], xk[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int u = tid + 256 * i;
+        xr[i] = u >> 2; xk[i] = 8 * (u & 3);
+        xdst[i] = (u & 3) * GB_KG_STRIDE + xr[i];
+    }
+    const int arow = (lane >> 5) * GB_KG_STRIDE + 64 * wm + (lane & 31);
+    const int brow = XT * GB_TERM_UNITS + (lane >> 5) * 128 + 64 * wn + (lane & 31);
+    const unsigned rowb = (unsigned)ldy * 4u;
+    const __amdgpu_buffer_rsrc_t rbias = __builtin_amdgcn_make_buffer_rsrc((void *)bias, 0, bias ? N * 4 : 0, GB_RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t rscale = __builtin_amdgcn_make_buffer_rsrc((void *)oscale, 0, F16 ? nnb * GB_BN * 4 : 0, GB_RSRC_FLAGS);
+
+    // W stream (LDS-DMA, one step ahead): descriptor over the whole packed weight, scalar offset = tile image + this wavefront's chunks
+    typedef unsigned gd_u32x4 __attribute__((ext_vector_type(4)));
+    gd_u32x4 wdesc;
+    wdesc.x = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)Wp);
+    wdesc.y = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)Wp >> 32) & 0xffffu);
+    wdesc.z = wp_bytes;
+    wdesc.w = GB_RSRC_FLAGS;
+    const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) uint4 *)lds;
+    const unsigned lane16 = 16u * (unsigned)lane;
+    int wj = j, wk = 0;                                    // item / K step the W stream is at
+    auto wdma = [&](int stage) {
+        GD_TILE(wj, mbw, nbw); (void)mbw;
+        const unsigned img = (unsigned)(nbw * nkb + wk) * (unsigned)(GD_WSTAGE * 16);
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            const unsigned so = __builtin_amdgcn_readfirstlane(img + (unsigned)(64 * (wid + 4 * q)) * 16u);
+            const unsigned m0v = __builtin_amdgcn_readfirstlane(lds0 + 16u * (unsigned)(XT * GB_TERM_UNITS + stage * GD_WSTAGE + 64 * (wid + 4 * q)));
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" :: "s"(m0v), "v"(lane16), "s"(wdesc), "s"(so) : "memory");
+        }
+        if (++wk == nkb) { wk = 0; wj = next_item(wj); }
+    };
+    // X stream (registers, two steps ahead)
+    const float *lx0, *lx1;
+    int lk = 0, lj = j;
+    auto x_tile_start = [&](int jj) {
+        GD_TILE(jj, mb, nb); (void)nb;
+        lx0 = X + (size_t)min(mb * GB_BM + xr[0], M - 1) * ldx + xk[0];
+        lx1 = X + (size_t)min(mb * GB_BM + xr[1], M - 1) * ldx + xk[1];
+    };
+    float4 xa0, xa1, xb0, xb1, xc0, xc1, xd0, xd1;         // set 0: xa (rows u >> 2), xb (+ 64 rows); set 1: xc, xd
+#define GD_XLOAD(p0, p1, q0, q1) do { \
+        p0 = *(const float4 *)lx0; p1 = *(const float4 *)(lx0 + 4); q0 = *(const float4 *)lx1; q1 = *(const float4 *)(lx1 + 4); \
+        lx0 += GB_BK; lx1 += GB_BK; \
+        if (++lk == nkb) { lk = 0; lj = next_item(lj); x_tile_start(lj); } } while (0)
+
+    f32x16 acc[2][2];
+    unsigned ov[2][2][16];                                 // FLAGS & 2: the tile of Y, fetched during the last K step
+#define GD_SOFF(i, r) ((unsigned)(32 * (i) + ((r) & 3) + 8 * ((r) >> 2)) * rowb)
+    // step of parity P: X register set P -> the X stage; W stage P (filled by the DMA of the previous step) is multiplied; the DMA of the next
+    // step's W goes to stage P ^ 1 and set P is reloaded with the X of two steps ahead.  Younger than the DMA this step waits for: the previous
+    // step's 4 X loads, this step's 6 DMAs and 4 X loads.
+#define GD_STEP(P, p0, p1, q0, q1, LAST) do { \
+        __syncthreads(); \
+        gb_xsplit_store<F16>(lds, p0, p1, xdst[0]); gb_xsplit_store<F16>(lds, q0, q1, xdst[1]); \
+        wdma((P) ^ 1); GD_XLOAD(p0, p1, q0, q1); \
+        if ((LAST) && (FLAGS & 2)) { \
+            _Pragma("unroll") for (int jj = 0; jj < 2; ++jj) \
+                _Pragma("unroll") for (int i = 0; i < 2; ++i) \
+                    _Pragma("unroll") for (int r = 0; r < 16; ++r) \
+                        ov[i][jj][r] = __builtin_amdgcn_raw_buffer_load_b32(ry, yoff + 128u * jj, GD_SOFF(i, r), 0); \
+            GD_VMCNT(63); } \
+        else GD_VMCNT(14); \
+        __syncthreads(); \
+        __builtin_amdgcn_sched_barrier(0); \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) { \
+            GbFrag a[2][3], b[2][3]; \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i) { \
+                _Pragma("unroll") for (int t = 0; t < XT; ++t) a[i][t].q = lds[t * GB_TERM_UNITS + 2 * ks * GB_KG_STRIDE + arow + 32 * i]; \
+                _Pragma("unroll") for (int t = 0; t < 3; ++t) b[i][t].q = lds[(P) * GD_WSTAGE + t * 512 + 2 * ks * 128 + brow + 32 * i]; } \
+            gb_products<F16>(acc, a, b); } } while (0)
+
+    x_tile_start(j);
+    wdma(0);
+    GD_XLOAD(xa0, xa1, xb0, xb1);
+    GD_XLOAD(xc0, xc1, xd0, xd1);
+    for (;;) {
+        GD_TILE(j, mb, nb);
+        const int m0 = mb * GB_BM;
+        const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void *)(Y + (size_t)m0 * ldy), 0, (int)((unsigned)min(GB_BM, M - m0) * rowb), GB_RSRC_FLAGS);
+        const int n0 = nb * GB_BN + 64 * wn + (lane & 31);
+        const unsigned yoff = (unsigned)(64 * wm + 4 * (lane >> 5)) * rowb + 4u * (unsigned)n0;
+        const float bv0 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rbias, 4u * (unsigned)n0, 0, 0));
+        const float bv1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rbias, 4u * (unsigned)n0 + 128u, 0, 0));
+        const float os0 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rscale, 4u * (unsigned)n0, 0, 0));
+        const float os1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rscale, 4u * (unsigned)n0 + 128u, 0, 0));
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.f;
+        for (int kb = 0; kb < nkb - 2; kb += 2) { GD_STEP(0, xa0, xa1, xb0, xb1, false); GD_STEP(1, xc0, xc1, xd0, xd1, false); }
+        GD_STEP(0, xa0, xa1, xb0, xb1, false);
+        GD_STEP(1, xc0, xc1, xd0, xd1, true);
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            if (n0 + 32 * jj >= N) continue;
+            const float bv = jj ? bv1 : bv0, os = jj ? os1 : os0;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = F16 ? __builtin_fmaf(acc[i][jj][r], os, bv) : acc[i][jj][r] + bv;
+                    if (FLAGS & 1) v = fmaxf(v, 0.f);
+                    if (FLAGS & 2) v += __builtin_bit_cast(float, ov[i][jj][r]);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ry, yoff + 128u * jj, GD_SOFF(i, r), 0);
+                }
+        }
+        const int jn = next_item(j);
+        if (jn == j) break;
+        j = jn;
+    }
+    GD_VMCNT(0);                                           // the streams' last (unused) DMA must not land in the LDS of the next workgroup
+#undef GD_STEP
+#undef GD_SOFF
+#undef GD_XLOAD
+#undef GD_TILE
+}
+
+// ---- host ------------------------------------------------------------------------------------------------------------------------------------
+static size_t gb_tile_bytes(int N, int K) { return (size_t)((N + GB_BN - 1) / GB_BN) * (K / GB_BK) * GB_W_TILE_UNITS * 16; }
+
+template <bool F16>
+static int gb_launch(const float *x, int ldx, const void *packed_w, const float *bias, float *y, int ldy, int M, int N, int K, int flags, void *stream)
+{
+    // flags: 1 = ReLU, 2 = accumulate; 4 = one tile per workgroup (the baseline of the bitwise-agreement test), 8 = persistent 128 x 128 workgroups
+    // with register-staged W; no variant flag: W by LDS-DMA (K % 64 == 0, packed weight < 4 GB), else as flag 8
+    if (!x || !packed_w || !y || M <= 0 || N <= 0 || K <= 0 || (K % GB_BK) || (ldx & 3) || ldx < K || ldy < N || flags < 0 || (flags & ~15) || (flags & 12) == 12) return MFR_E_ARG;
+    if (((uintptr_t)x & 15)) return MFR_E_ARG;
+    const int f = flags & 3, one_tile = flags & 4;
+    int pk = flags & 8;
+    const size_t tb = gb_tile_bytes(N, K);
+    if (!one_tile && !pk && ((K % 64) || tb >= 0xffffffffull)) pk = 8;
+    const int nnb = (N + GB_BN - 1) / GB_BN, nmb = (M + GB_BM - 1) / GB_BM;
+    const long long tiles = (long long)nmb * nnb;
+    if (tiles > 0x7fffffffll) return MFR_E_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const uint4 *wp = (const uint4 *)packed_w;
+    const float *oscale = F16 ? (const float *)((const char *)packed_w + tb) : nullptr;
+    // 2 workgroups per CU on 256 CUs; fewer when there are fewer tiles (multiple of 8: one share per XCD)
+    const long long per_xcd = (long long)((nmb + 7) / 8) * nnb;
+    const unsigned grid = 8u * (unsigned)(per_xcd < 64 ? per_xcd : 64);
+#define GB_SW(GO) switch (f) { case 0: GO(0); break; case 1: GO(1); break; case 2: GO(2); break; default: GO(3); break; }
+    if (one_tile) {
+#define GB_GO(F) hipLaunchKernelGGL((gemm_split_kernel<F, F16>), dim3((unsigned)tiles), dim3(256), 0, st, x, ldx, wp, oscale, bias, y, ldy, M, N, K, nnb)
+        GB_SW(GB_GO)
+#undef GB_GO
+    } else if (pk) {
+#define GB_GO(F) hipLaunchKernelGGL((gemm_split_pk_kernel<F, F16>), dim3(grid), dim3(256), 0, st, x, ldx, wp, oscale, bias, y, ldy, M, N, K, nnb, nmb)
+        GB_SW(GB_GO)
+#undef GB_GO
+    } else {
+#define GB_GO(F) hipLaunchKernelGGL((gemm_split_d_kernel<F, F16>), dim3(grid), dim3(256), 0, st, x, ldx, wp, (unsigned)tb, oscale, bias, y, ldy, M, N, K, nnb, nmb)
+        GB_SW(GB_GO)
+#undef GB_GO
+    }
+#undef GB_SW
+    CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" {
+
+size_t mfr_gemm_bf16x3_pack_bytes(int N, int K)
+{
+    if (N <= 0 || K <= 0 || (K % GB_BK)) return 0;
+    return gb_tile_bytes(N, K);
+}
+
+size_t mfr_gemm_f16x2_pack_bytes(int N, int K)
+{
+    if (N <= 0 || K <= 0 || (K % GB_BK)) return 0;
+    return gb_tile_bytes(N, K) + (size_t)((N + GB_BN - 1) / GB_BN) * GB_BN * 4;      // + the per-feature 1 / scale
+}
+
+int mfr_gemm_bf16x3_pack(const float *w, int N, int K, void *packed, void *stream)
+{
+    if (!w || !packed || N <= 0 || K <= 0 || (K % GB_BK)) return MFR_E_ARG;
+    const long long total = (long long)(gb_tile_bytes(N, K) / 16);
+    hipLaunchKernelGGL((gb_pack_kernel<false>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, N, K, total, (const float *)nullptr, (uint4 *)packed);
+    CHECK_LAUNCH();
+    return 0;
+}
+
+int mfr_gemm_f16x2_pack(const float *w, int N, int K, void *packed, void *stream)
+{
+    if (!w || !packed || N <= 0 || K <= 0 || (K % GB_BK)) return MFR_E_ARG;
+    const size_t tb = gb_tile_bytes(N, K);
+    const long long total = (long long)(tb / 16);
+    const int npad = (N + GB_BN - 1) / GB_BN * GB_BN;
+    float *oscale = (float *)((char *)packed + tb);
+    hipLaunchKernelGGL(gb_scale_kernel, dim3((unsigned)npad), dim3(64), 0, (hipStream_t)stream, w, N, K, npad, oscale);
+    hipLaunchKernelGGL((gb_pack_kernel<true>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, N, K, total, (const float *)oscale, (uint4 *)packed);
+    CHECK_LAUNCH();
+    return 0;
+}
+
+int mfr_gemm_bf16x3(const float *x, int ldx, const void *packed_w, const float *bias, float *y, int ldy, int M, int N, int K, int flags, void *stream)
+{
+    return gb_launch<false>(x, ldx, packed_w, bias, y, ldy, M, N, K, flags, stream);
+}
+
+int mfr_gemm_f16x2(const float *x, int ldx, const void *packed_w, const float *bias, float *y, int ldy, int M, int N, int K, int flags, void *stream)
+{
+    return gb_launch<true>(x, ldx, packed_w, bias, y, ldy, M, N, K, flags, stream);
+}
+
+}  // extern "C"

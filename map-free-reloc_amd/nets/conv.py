@@ -1,34 +1,41 @@
 """3x3 / stride 1 / pad 1 convolution layers of the matcher backbones: packed Winograd filters + kernel choice.
 
 Two hand-written kernels compute the same layer (include/mfr_hip.h):
-  * mfr_conv3x3_wino_bf16x3  (csrc/winograd_bf16x3.hip)  Winograd F(2x2,3x3) on the BF16 matrix cores at fp32 accuracy: exact
-                             3-way bf16 operand split, six partial products, fp32 accumulate (default);
+  * mfr_conv3x3_wino_f16x2 / _bf16x3  (csrc/winograd_split.hip)  Winograd F(2x2,3x3) on the 16-bit matrix cores at fp32 accuracy by operand
+                             splitting; the arithmetic is `HIP.SPLIT` ('f16x2', the default: three partial products; 'bf16x3': six),
+                             resolved when the layer's filters are packed;
   * mfr_conv3x3_wino         (csrc/winograd_conv.hip)    the same transform on the exact-fp32 matrix cores.
-Both meet the same parity bar (<= 2e-5 against a float64 convolution, tests/test_gpu_winograd_*.py).  The bf16x3 kernel tiles
-the image in blocks of 16 Winograd tiles along x; for the narrow odd-width maps of SuperPoint's 1/8 level (67 pixels = 34 tiles
--> 48 computed) the exact-fp32 kernel's linear tiling wastes nothing and is the faster of the two (tools/bench_conv.py,
-profiles/r03_ab_conv_*.json), so the choice is made per layer shape, once, here."""
+All meet the same parity bar (<= 2e-5 against a float64 convolution, tests/test_gpu_winograd_*.py).  The split kernel tiles the image in
+blocks of 16 Winograd tiles along x; for the narrow odd-width maps of SuperPoint's 1/8 level (67 pixels = 34 tiles -> 48 computed) the
+exact-fp32 kernel's linear tiling wastes nothing, so the choice is made per layer shape, once, here (`HIP.CONV_KERNEL` forces one)."""
 import torch
 
 from .. import _lib, options
 
+# tile-block waste along x above which the exact-fp32 kernel (linear tiling) is the faster one, per arithmetic (tools/bench_conv.py:
+# profiles/r03_ab_conv.json for bf16x3, profiles/r05_ab_conv.json for f16x2)
+WASTE_LIMIT = {"bf16x3": 0.2, "f16x2": 0.2}
 
-def prefer_bf16x3(H, W):
-    """tile-block waste of the bf16x3 kernel along x: ceil(tiles / 16) * 16 / tiles - 1; above 20 % the exact kernel wins"""
-    mode = options.get("CONV_KERNEL")                        # "bf16x3" / "exact" force one kernel (A/B runs, tests; options.py)
-    if mode == "bf16x3":
+
+def prefer_split(H, W, split=None):
+    """tile-block waste of the split kernel along x: ceil(tiles / 16) * 16 / tiles - 1; above the limit the exact kernel wins"""
+    mode = options.get("CONV_KERNEL")                        # "split" / "exact" force one kernel (A/B runs, tests; options.py)
+    if mode == "split":
         return True
     if mode == "exact":
         return False
     tiles = (W + 1) // 2
-    return (-(-tiles // 16) * 16) / tiles - 1.0 <= 0.2
+    return (-(-tiles // 16) * 16) / tiles - 1.0 <= WASTE_LIMIT[split or options.get("SPLIT")]
 
 
 class WinoConv3x3:
     """one 3x3 layer: both packed filter forms (built once per weight set) and the launch"""
 
-    def __init__(self, weight, bias):
+    def __init__(self, weight, bias, split=None):
         lib = _lib.load(require_gpu=True)
+        self.split = split or options.get("SPLIT")
+        if self.split not in ("f16x2", "bf16x3"):
+            raise ValueError(f"WinoConv3x3: unknown split {self.split!r}")
         self.w, self.b = weight.contiguous(), bias
         self.co, self.ci = int(weight.shape[0]), int(weight.shape[1])
         dev = weight.device
@@ -38,10 +45,11 @@ class WinoConv3x3:
             self.u_exact = torch.empty(nb // 4, dtype=torch.float32, device=dev)
             _lib.check(lib.mfr_wino_filter_transform(_lib.ptr(self.w), self.ci, self.co, _lib.ptr(self.u_exact), _lib.stream_ptr()),
                        "mfr_wino_filter_transform")
-        nb = lib.mfr_wino_bf16x3_filter_bytes(self.ci, self.co)
+        nb = getattr(lib, f"mfr_wino_{self.split}_filter_bytes")(self.ci, self.co)
         self.u_split = torch.empty(nb, dtype=torch.uint8, device=dev)
-        _lib.check(lib.mfr_wino_bf16x3_filter_transform(_lib.ptr(self.w), self.ci, self.co, _lib.ptr(self.u_split), _lib.stream_ptr()),
-                   "mfr_wino_bf16x3_filter_transform")
+        _lib.check(getattr(lib, f"mfr_wino_{self.split}_filter_transform")(_lib.ptr(self.w), self.ci, self.co, _lib.ptr(self.u_split), _lib.stream_ptr()),
+                   f"mfr_wino_{self.split}_filter_transform")
+        self._conv_split = getattr(lib, f"mfr_conv3x3_wino_{self.split}")
 
     def __call__(self, x, act=0, pool=False, residual=None):
         """act: 0 none, 1 ReLU, 2 LeakyReLU(0.01); pool: fused 2x2 max-pool; residual [B,Cout,H,W] added before the activation"""
@@ -50,9 +58,9 @@ class WinoConv3x3:
         B, C, H, W = x.shape
         y = torch.empty((B, self.co, H // 2, W // 2) if pool else (B, self.co, H, W), dtype=torch.float32, device=x.device)
         res = _lib.ptr(residual.contiguous()) if residual is not None else None
-        if self.u_exact is None or prefer_bf16x3(H, W):
-            _lib.check(lib.mfr_conv3x3_wino_bf16x3(_lib.ptr(x), _lib.ptr(self.u_split), _lib.ptr(self.b), res, B, C, self.co, H, W, int(act), int(pool),
-                                                   _lib.ptr(y), _lib.stream_ptr()), "mfr_conv3x3_wino_bf16x3")
+        if self.u_exact is None or prefer_split(H, W, self.split):
+            _lib.check(self._conv_split(_lib.ptr(x), _lib.ptr(self.u_split), _lib.ptr(self.b), res, B, C, self.co, H, W, int(act), int(pool),
+                                        _lib.ptr(y), _lib.stream_ptr()), f"mfr_conv3x3_wino_{self.split}")
         else:
             _lib.check(lib.mfr_conv3x3_wino(_lib.ptr(x), _lib.ptr(self.u_exact), _lib.ptr(self.b), res, B, C, self.co, H, W, int(act), int(pool),
                                             _lib.ptr(y), _lib.stream_ptr()), "mfr_conv3x3_wino")

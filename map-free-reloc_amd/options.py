@@ -3,8 +3,11 @@ does this package: every switch that picks between two implementations of the sa
 of values, and is set either from the configuration (`cfg.HIP.<NAME>`, declared in config/default.py: unknown keys are rejected on
 merge) through `apply_cfg(cfg)`, or directly by a tool / test (`options.set("CONV_KERNEL", "exact")`, `bench.py --hip-opt K=V`).
 
+  SPLIT             'f16x2' (round 5: activations as two f16 terms, weights pre-scaled and packed as three; csrc/split_f16.h) | 'bf16x3'
+                    (rounds 3-4: exact 3-way bf16 split of both operands): the arithmetic of the matrix-core kernels (linear layers,
+                    3x3 convolutions); resolved when a weight is packed
   CONV              'wino' (own Winograd kernels) | 'miopen' (library convolution + own epilogue kernels): 3x3 layers of the matchers
-  CONV_KERNEL       'auto' (per layer shape, nets/conv.py) | 'bf16x3' | 'exact': which own Winograd kernel
+  CONV_KERNEL       'auto' (per layer shape, nets/conv.py) | 'split' (the operand-splitting kernel, arithmetic = SPLIT) | 'exact': which own Winograd kernel
   FUSED_CONV_RELU   SuperPoint conv1a through the fused first-layer kernel with ReLU folded (True / False)
   RPR_CONV          'hip' (own implicit-GEMM forward of the regression decoder's 3x3 convolutions) | 'miopen'
   RPR_CONV_BWD      'lib' (torch / MIOpen backward; the measured default) | 'hip' (own d input / d weight products)
@@ -14,8 +17,9 @@ merge) through `apply_cfg(cfg)`, or directly by a tool / test (`options.set("CON
                     take their operands as they are instead of transposing every one (regression/encoder.py)
 """
 _SPEC = {
+    "SPLIT": ("f16x2", ("f16x2", "bf16x3")),
     "CONV": ("wino", ("wino", "miopen")),
-    "CONV_KERNEL": ("auto", ("auto", "bf16x3", "exact")),
+    "CONV_KERNEL": ("auto", ("auto", "split", "exact")),
     "FUSED_CONV_RELU": (False, (False, True)),
     "RPR_CONV": ("hip", ("hip", "miopen")),
     "RPR_CONV_BWD": ("lib", ("lib", "hip")),

@@ -19,14 +19,20 @@ def _mlp(out_dims, in_features=None):
 
 
 class _Trunk(nn.Module):
+    def __init__(self):
+        super().__init__()
+        # ONE persistent device flag, updated in place: a captured training step (TRAINING.GRAPH_STEP) bakes this buffer's address into
+        # the graph, so every replay ORs into the flag the reader looks at and the reader's reset is seen by the next replay
+        # (non-persistent: the reference's state_dict keys stay as they are)
+        self.register_buffer("invalid", torch.zeros((), dtype=torch.bool), persistent=False)
+
     def _flag(self, *tensors):
         ok = torch.stack([torch.isfinite(t.detach()).all() for t in tensors]).all()
         # sticky on the device: a NaN in ANY forward since the last read stays visible (the reader clears it: clear_invalid)
-        prev = getattr(self, "invalid", None)
-        self.invalid = ~ok if prev is None or prev.device != ok.device else (prev | ~ok)
+        self.invalid.logical_or_(~ok)
 
     def clear_invalid(self):
-        self.invalid = None
+        self.invalid.zero_()
 
 
 class ResBlockMLP(_Trunk):

@@ -23,10 +23,10 @@ def test_options_are_declared_validated_and_in_the_config_schema():
         cfg.HIP.CONV_KERNEL = "exact"; cfg.HIP.RPR_WGRAD_SPLITS = 8
         options.apply_cfg(cfg)
         assert options.get("CONV_KERNEL") == "exact" and options.get("RPR_WGRAD_SPLITS") == 8
-        from mapfree_reloc_amd.nets.conv import prefer_bf16x3
-        assert prefer_bf16x3(720, 540) is False
-        options.set("CONV_KERNEL", "bf16x3")
-        assert prefer_bf16x3(90, 67) is True
+        from mapfree_reloc_amd.nets.conv import prefer_split
+        assert prefer_split(720, 540) is False
+        options.set("CONV_KERNEL", "split")
+        assert prefer_split(90, 67) is True
     finally:
         options.reset()
     assert options.get("CONV_KERNEL") == "auto"

@@ -337,3 +337,23 @@ def test_siamese_batch_keeps_the_two_call_arithmetic():
             assert int(s0[n]) == int(s1[n]) and int(s0[n]) % 2 == 0, n                  # two updates per forward in both paths
         else:
             assert torch.allclose(s0[n].float(), s1[n].float(), rtol=1e-5, atol=1e-7), n
+
+
+def test_head_nan_flag_is_one_persistent_buffer_updated_in_place():
+    """the sticky NaN flag must survive a captured training step -- one buffer whose address never changes, ORed in place by
+    every forward and zeroed in place by the reader (rebinding the attribute would leave a graph replay writing into freed memory and
+    switch the check off after the first read)"""
+    import torch
+    from mapfree_reloc_amd.regression.head import _Trunk
+    t = _Trunk()
+    assert "invalid" not in t.state_dict()                   # the reference's checkpoint keys are unchanged
+    p = t.invalid.data_ptr()
+    t._flag(torch.ones(3), torch.zeros(2))
+    assert not bool(t.invalid) and t.invalid.data_ptr() == p
+    t._flag(torch.tensor([1.0, float("nan")]))
+    t._flag(torch.ones(3))                                   # sticky across later clean forwards
+    assert bool(t.invalid) and t.invalid.data_ptr() == p
+    t.clear_invalid()
+    assert not bool(t.invalid) and t.invalid.data_ptr() == p
+    t._flag(torch.tensor([float("inf")]))                    # ... and live again after the reader's reset
+    assert bool(t.invalid)

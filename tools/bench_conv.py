@@ -1,5 +1,6 @@
 """A/B timing of the 3x3 convolution kernels on the SuperPoint / LoFTR layer shapes of the bench batch: exact-fp32 Winograd
-(mfr_conv3x3_wino) vs bf16x3 Winograd (mfr_conv3x3_wino_bf16x3).  python tools/bench_conv.py [out.json] [images]"""
+(mfr_conv3x3_wino) vs the operand-splitting Winograd kernel in both arithmetics (mfr_conv3x3_wino_bf16x3, mfr_conv3x3_wino_f16x2).
+python tools/bench_conv.py [out.json] [images]"""
 import json
 import os
 import sys
@@ -26,12 +27,11 @@ for name, ci, co, H, W, pool in LAYERS:
     lib.mfr_wino_filter_transform(_lib.ptr(w), ci, co, _lib.ptr(u1), _lib.stream_ptr())
     u3 = torch.empty(lib.mfr_wino_bf16x3_filter_bytes(ci, co), dtype=torch.uint8, device=dev)
     lib.mfr_wino_bf16x3_filter_transform(_lib.ptr(w), ci, co, _lib.ptr(u3), _lib.stream_ptr())
+    u2 = torch.empty(lib.mfr_wino_f16x2_filter_bytes(ci, co), dtype=torch.uint8, device=dev)
+    lib.mfr_wino_f16x2_filter_transform(_lib.ptr(w), ci, co, _lib.ptr(u2), _lib.stream_ptr())
     rec = {}
-    def variant(v):
-        return lambda *a: lib.mfr_conv3x3_wino_bf16x3_variant(*a[:11], v, *a[11:])
-    for tag, fn, u in (("exact_fp32", lib.mfr_conv3x3_wino, u1), ("bf16x3", variant(0), u3), ("bf16x3_1wave", variant(32), u3),
-                       ("bf16x3_w2", variant(2), u3), ("bf16x3_p8", variant(3), u3), ("exact_fp32_b", lib.mfr_conv3x3_wino, u1),
-                       ("bf16x3_b", variant(0), u3), ("bf16x3_1wave_b", variant(32), u3), ("bf16x3_w2_b", variant(2), u3), ("bf16x3_p8_b", variant(3), u3)):
+    for tag, fn, u in (("exact_fp32", lib.mfr_conv3x3_wino, u1), ("bf16x3", lib.mfr_conv3x3_wino_bf16x3, u3), ("f16x2", lib.mfr_conv3x3_wino_f16x2, u2),
+                       ("exact_fp32_b", lib.mfr_conv3x3_wino, u1), ("bf16x3_b", lib.mfr_conv3x3_wino_bf16x3, u3), ("f16x2_b", lib.mfr_conv3x3_wino_f16x2, u2)):
         for _ in range(2):
             fn(_lib.ptr(x), _lib.ptr(u), _lib.ptr(b), None, n, ci, co, H, W, 1, pool, _lib.ptr(y), _lib.stream_ptr())
         torch.cuda.synchronize()
@@ -43,11 +43,11 @@ for name, ci, co, H, W, pool in LAYERS:
         rec[tag] = round(e0.elapsed_time(e1) / 5, 4)
     wino_flops = 16 * 2.0 * ci * co * ((H + 1) // 2) * ((W + 1) // 2) * n
     rec["images"] = n
+    rec["fp32_equiv_tflops_f16x2"] = round(wino_flops / min(rec["f16x2"], rec["f16x2_b"]) / 1e9, 1)
     rec["fp32_equiv_tflops_bf16x3"] = round(wino_flops / min(rec["bf16x3"], rec["bf16x3_b"]) / 1e9, 1)
     rec["fp32_tflops_exact"] = round(wino_flops / min(rec["exact_fp32"], rec["exact_fp32_b"]) / 1e9, 1)
-    rec["bf16_tflops_p8"] = round(6 * wino_flops / min(rec["bf16x3_p8"], rec["bf16x3_p8_b"]) / 1e9, 1)
-    rec["bf16_tflops_w2"] = round(6 * wino_flops / min(rec["bf16x3_w2"], rec["bf16x3_w2_b"]) / 1e9, 1)
-    rec["bf16_tflops_1wave"] = round(6 * wino_flops / min(rec["bf16x3_1wave"], rec["bf16x3_1wave_b"]) / 1e9, 1)
+    rec["f16_mfma_tflops_f16x2"] = round(3 * wino_flops / min(rec["f16x2"], rec["f16x2_b"]) / 1e9, 1)
+    rec["bf16_mfma_tflops_bf16x3"] = round(6 * wino_flops / min(rec["bf16x3"], rec["bf16x3_b"]) / 1e9, 1)
     res[name] = rec
     print(name, rec, flush=True)
 if len(sys.argv) > 1:

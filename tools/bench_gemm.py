@@ -1,4 +1,4 @@
-"""A/B timing of the SuperGlue linear-layer shapes: library fp32 GEMM (torch / hipBLASLt) vs csrc/gemm_bf16x3.hip"""
+"""A/B timing of the SuperGlue linear-layer shapes: library fp32 GEMM (torch / hipBLASLt) vs csrc/gemm_split.hip in both arithmetics"""
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -11,16 +11,16 @@ for name, K, N, relu, acc in (("qkv 256->768", 256, 768, False, False), ("mlp1 5
     m = 195840 if "loftr" in name else M
     x = torch.randn(m, K, device=dev); w = torch.randn(N, K, device=dev) / K ** 0.5; b = torch.randn(N, device=dev)
     y = torch.randn(m, N, device=dev)
-    lin = SplitLinear(w, b)
+    lin3, lin2 = SplitLinear(w, b, split="bf16x3"), SplitLinear(w, b, split="f16x2")
     wt = w.t().contiguous()
     def lib():
         if acc: y.addmm_(x, wt)
         elif relu: torch._addmm_activation(b, x, wt)
         else: torch.addmm(b, x, wt)
-    def mine():
-        lin(x, out=y, relu=relu, accumulate=acc)
     rec = {}
-    for tag, fn in (("library_fp32", lib), ("bf16x3", mine), ("library_fp32_b", lib), ("bf16x3_b", mine)):
+    for tag, fn in (("library_fp32", lib), ("bf16x3", lambda: lin3(x, out=y, relu=relu, accumulate=acc)), ("f16x2", lambda: lin2(x, out=y, relu=relu, accumulate=acc)),
+                    ("f16x2_flag8", lambda: lin2(x, out=y, relu=relu, accumulate=acc, kernel_flag=8)),
+                    ("library_fp32_b", lib), ("bf16x3_b", lambda: lin3(x, out=y, relu=relu, accumulate=acc)), ("f16x2_b", lambda: lin2(x, out=y, relu=relu, accumulate=acc))):
         for _ in range(3): fn()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -29,6 +29,7 @@ for name, K, N, relu, acc in (("qkv 256->768", 256, 768, False, False), ("mlp1 5
         e1.record(); torch.cuda.synchronize()
         rec[tag] = round(e0.elapsed_time(e1) / 10, 4)
     fl = 2.0 * m * K * N
+    rec["fp32_equiv_tflops_f16x2"] = round(fl / min(rec["f16x2"], rec["f16x2_b"]) / 1e9, 1)
     rec["fp32_equiv_tflops_bf16x3"] = round(fl / min(rec["bf16x3"], rec["bf16x3_b"]) / 1e9, 1)
     rec["tflops_library"] = round(fl / min(rec["library_fp32"], rec["library_fp32_b"]) / 1e9, 1)
     res[name] = rec
