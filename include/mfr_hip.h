@@ -203,11 +203,12 @@ int mfr_sp_sample_descriptors(const float *dense_nhwc, int B, int Hc, int Wc, co
 /* ------------------------------------------------------------------------------------------
  * SuperGlue kernels (same call site; upstream algorithm per SURVEY.md Appendix A.3).
  *   mfr_sg_attention       softmax(q k^T / 8) v, `heads` heads x 64, fp32 in / fp32 out, scores never materialised.
- *                          Both contractions run on the bf16 matrix cores at fp32 accuracy: every fp32 operand is split
- *                          exactly into three bf16 terms and a product is the six leading partial products accumulated
- *                          in fp32 (csrc/attention.hip; error vs fp64 = that of the exact-fp32 MFMA, measured in
- *                          profiles/r03_bf16x3_probe.jsonl).  mfr_sg_attention_variant: 0 = that kernel, 1 = the
- *                          exact-fp32 matrix-core kernel of rounds 1-2 (v_mfma_f32_32x32x2_f32), kept for A/B and tests.  q,k,v [B2,N,ld] (head h = channels
+ *                          Both contractions run on the 16-bit matrix cores at fp32 accuracy by operand splitting (csrc/attention.hip).
+ *                          mfr_sg_attention_variant: 0 = f16x2 (round 5, what mfr_sg_attention runs; csrc/split_f16.h: every operand as two f16
+ *                          terms, main + correction accumulators, three partial products; precondition |q|, |k|, |v| <= 65504),
+ *                          2 = bf16x3 (rounds 3-4: exact 3-way bf16 split, six partial products), 1 = the exact-fp32 matrix-core kernel of
+ *                          rounds 1-2 (v_mfma_f32_32x32x2_f32), kept for A/B and tests; error vs fp64 of all three = the fp32 class
+ *                          (tests/test_gpu_nets_parity.py).  q,k,v [B2,N,ld] (head h = channels
  *                          [64h, 64h+64) from each base pointer), out [B2,N,ldo]; keys/queries
  *                          >= n_tok[image] are masked; cross != 0 -> image b reads K/V of image b^1.
  *   mfr_sg_sinkhorn_match  log_optimal_transport(S, bin_score, iters) without materialising the

@@ -1,4 +1,5 @@
-// attention.hip -- SuperGlue multi-head softmax attention (self and cross) on gfx950, exact fp32.
+// attention.hip -- SuperGlue multi-head softmax attention (self and cross) on gfx950: the exact-fp32 kernel (rounds 1-2, kept for A/B and parity),
+// and the operand-splitting kernels on the 16-bit matrix cores at fp32 accuracy (bf16x3: rounds 3-4; f16x2: round 5, the default).
 //
 // Reference call site: SuperGlue_matcher (etc/feature_matching_baselines/matchers.py:62-120) ->
 // upstream AttentionalGNN / MultiHeadedAttention (un-vendored):
@@ -24,6 +25,7 @@
 #include <stdint.h>
 
 #include "../../include/mfr_hip.h"
+#include "split_f16.h"
 
 #define CHECK_LAUNCH() do { if (hipGetLastError() != hipSuccess) return MFR_E_LAUNCH; } while (0)
 
@@ -220,383 +222,12 @@ union Frag8 { bf16x8 v; unsigned u[4]; uint4 q; };
 
 #define MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
 
-__global__ void __launch_bounds__(256, 2) sg_attention_bf16x3_kernel(
-    const float *__restrict__ Q, const float *__restrict__ Kp, const float *__restrict__ Vp, int ld,
-    int N, int heads, int B2, const int *__restrict__ n_tok, int cross, float scale_log2e, float *__restrict__ O, int ldo)
-{
-    __shared__ __attribute__((aligned(16))) unsigned short Ks[2][3][AT_KT][AB_KS];
-    __shared__ __attribute__((aligned(16))) unsigned short Vt[2][3][AT_D][AB_VS];
-    const int nbh = heads * B2;
-    const int bh = blockIdx.x % nbh, qb = blockIdx.x / nbh;
-    const int b = bh / heads, h = bh - b * heads;
-    const int bk = cross ? (b ^ 1) : b;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int ql = lane & 31, half = lane >> 5;
-    const int nq = n_tok[b], nk = n_tok[bk];
-    const int q0 = qb * (AT_QW * AT_WAVES);
-    const int q = q0 + wid * AT_QW + ql;
-    if (q0 >= nq) {
-        if (q < N) {
-            float4 *op = (float4 *)(O + ((size_t)b * N + q) * ldo + h * AT_D + 32 * half);
-#pragma unroll
-            for (int g = 0; g < 8; ++g) op[g] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        return;
-    }
-
-    // Q^T operand, split once: step s covers d = 16 s + 8 half + (0..7); pre-scaled by log2(e)/sqrt(64)
-    Frag8 qf[4][3];
-    {
-        const bool ok = q < N;
-        const float *qp = Q + ((size_t)b * N + (ok ? q : 0)) * ld + h * AT_D + half * 8;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            float x[8];
-            float4 t0 = *(const float4 *)(qp + 16 * s), t1 = *(const float4 *)(qp + 16 * s + 4);
-            if (!ok) { t0 = make_float4(0.f, 0.f, 0.f, 0.f); t1 = t0; }
-            x[0] = t0.x * scale_log2e; x[1] = t0.y * scale_log2e; x[2] = t0.z * scale_log2e; x[3] = t0.w * scale_log2e;
-            x[4] = t1.x * scale_log2e; x[5] = t1.y * scale_log2e; x[6] = t1.z * scale_log2e; x[7] = t1.w * scale_log2e;
-            split_pack<8>(x, qf[s][0].u, qf[s][1].u, qf[s][2].u);
-        }
-    }
-    f32x16 o0, o1;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
-    float m_run = -INFINITY, l_run = 0.f;
-
-    // staging: K as before (thread -> rows sr, sr+16, 4 floats at column sc); V one d per lane, wave w -> keys 8w .. 8w+7
-    const int sr = tid >> 4, sc = (tid & 15) * 4;
-    const float *kbase = Kp + (size_t)bk * N * ld + h * AT_D + sc;
-    const float *vbase = Vp + (size_t)bk * N * ld + h * AT_D + lane;
-    const int ntiles = (nk + AT_KT - 1) / AT_KT;
-    float4 kr0, kr1;
-    float v0, v1, v2, v3, v4, v5, v6, v7;
-    auto gload = [&](int t) {
-        // out-of-range keys: load a valid row (clamped); it is zeroed when the tile is SPLIT (lstore), after the MFMAs of the current
-        // tile -- a select on the loaded value here makes the wave wait for its loads before it multiplies anything (`c ? *p : 0`
-        // would be worse still: hipcc selects between the global pointer and a private-memory zero and issues FLAT loads)
-        const int k0 = t * AT_KT + sr, k1 = k0 + 16, kl = nk - 1;
-        kr0 = *(const float4 *)(kbase + (size_t)min(k0, kl) * ld);
-        kr1 = *(const float4 *)(kbase + (size_t)min(k1, kl) * ld);
-        const int kv = t * AT_KT + 8 * wid;
-        v0 = vbase[(size_t)min(kv + 0, kl) * ld]; v1 = vbase[(size_t)min(kv + 1, kl) * ld];
-        v2 = vbase[(size_t)min(kv + 2, kl) * ld]; v3 = vbase[(size_t)min(kv + 3, kl) * ld];
-        v4 = vbase[(size_t)min(kv + 4, kl) * ld]; v5 = vbase[(size_t)min(kv + 5, kl) * ld];
-        v6 = vbase[(size_t)min(kv + 6, kl) * ld]; v7 = vbase[(size_t)min(kv + 7, kl) * ld];
-    };
-    auto gmask = [&](int t) {
-        const int k0 = t * AT_KT + sr, k1 = k0 + 16;
-        if (k0 >= nk) kr0 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (k1 >= nk) kr1 = make_float4(0.f, 0.f, 0.f, 0.f);
-        const int kv = t * AT_KT + 8 * wid;
-        if (kv + 0 >= nk) v0 = 0.f;
-        if (kv + 1 >= nk) v1 = 0.f;
-        if (kv + 2 >= nk) v2 = 0.f;
-        if (kv + 3 >= nk) v3 = 0.f;
-        if (kv + 4 >= nk) v4 = 0.f;
-        if (kv + 5 >= nk) v5 = 0.f;
-        if (kv + 6 >= nk) v6 = 0.f;
-        if (kv + 7 >= nk) v7 = 0.f;
-    };
-    auto lstore = [&](int buf) {
-        unsigned ph[2], pm[2], pl[2];
-        const float ka[4] = { kr0.x, kr0.y, kr0.z, kr0.w }, kb2[4] = { kr1.x, kr1.y, kr1.z, kr1.w };
-        split_pack<4>(ka, ph, pm, pl);
-        *(uint2 *)&Ks[buf][0][sr][sc] = make_uint2(ph[0], ph[1]); *(uint2 *)&Ks[buf][1][sr][sc] = make_uint2(pm[0], pm[1]);
-        *(uint2 *)&Ks[buf][2][sr][sc] = make_uint2(pl[0], pl[1]);
-        split_pack<4>(kb2, ph, pm, pl);
-        *(uint2 *)&Ks[buf][0][sr + 16][sc] = make_uint2(ph[0], ph[1]); *(uint2 *)&Ks[buf][1][sr + 16][sc] = make_uint2(pm[0], pm[1]);
-        *(uint2 *)&Ks[buf][2][sr + 16][sc] = make_uint2(pl[0], pl[1]);
-        // wave w holds keys 8w + j' (j' = 4 hh + j): key = 16 s + 8 g + 4 hh + j with s = w >> 1, g = w & 1 -> position 16 s + 8 hh + 4 g + j
-        unsigned vh[4], vm[4], vl[4];
-        const float vr[8] = { v0, v1, v2, v3, v4, v5, v6, v7 };
-        split_pack<8>(vr, vh, vm, vl);
-        const int p0 = 16 * (wid >> 1) + 4 * (wid & 1);
-        *(uint2 *)&Vt[buf][0][lane][p0] = make_uint2(vh[0], vh[1]); *(uint2 *)&Vt[buf][0][lane][p0 + 8] = make_uint2(vh[2], vh[3]);
-        *(uint2 *)&Vt[buf][1][lane][p0] = make_uint2(vm[0], vm[1]); *(uint2 *)&Vt[buf][1][lane][p0 + 8] = make_uint2(vm[2], vm[3]);
-        *(uint2 *)&Vt[buf][2][lane][p0] = make_uint2(vl[0], vl[1]); *(uint2 *)&Vt[buf][2][lane][p0 + 8] = make_uint2(vl[2], vl[3]);
-    };
-    if (ntiles > 0) { gload(0); gmask(0); lstore(0); }
-    __syncthreads();
-
-    for (int t = 0; t < ntiles; ++t) {
-        const int buf = t & 1;
-        if (t + 1 < ntiles) gload(t + 1);
-        __builtin_amdgcn_sched_barrier(0);                  // the loads stay ahead of the MFMAs, their consumers (mask, split) behind them
-
-        // ---- S^T = K Q^T: 4 steps of 16 channels x 6 partial products, two accumulators (small terms / leading terms)
-        f32x16 s, s2;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { s[r] = 0.f; s2[r] = 0.f; }
-#pragma unroll
-        for (int st = 0; st < 4; ++st) {
-            Frag8 kh, km, kl;
-            kh.q = *(const uint4 *)&Ks[buf][0][ql][16 * st + 8 * half];
-            km.q = *(const uint4 *)&Ks[buf][1][ql][16 * st + 8 * half];
-            kl.q = *(const uint4 *)&Ks[buf][2][ql][16 * st + 8 * half];
-            s2 = MFMA_BF16(km.v, qf[st][1].v, s2);
-            s = MFMA_BF16(kh.v, qf[st][2].v, s);
-            s2 = MFMA_BF16(kl.v, qf[st][0].v, s2);
-            s = MFMA_BF16(kh.v, qf[st][1].v, s);
-            s2 = MFMA_BF16(km.v, qf[st][0].v, s2);
-            s = MFMA_BF16(kh.v, qf[st][0].v, s);
-        }
-        // ---- online softmax over this tile's keys (rows of S^T); key = (r&3) + 8(r>>2) + 4 half
-        const int kb = t * AT_KT + 4 * half;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s[r] += s2[r];
-        if ((t + 1) * AT_KT > nk) {                         // only the last tile can hold keys >= nk (wave-uniform branch)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                if (kb + (r & 3) + 8 * (r >> 2) >= nk) s[r] = -INFINITY;
-        }
-        float mx = s[0];
-#pragma unroll
-        for (int r = 1; r < 15; r += 2) mx = fmaxf(fmaxf(mx, s[r]), s[r + 1]);      // v_max3_f32
-        mx = fmaxf(mx, s[15]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx);
-        float p[16];
-        at_f2 rs2; rs2.x = 0.f; rs2.y = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; r += 2) {                                            // two keys per packed instruction
-            at_f2 d; d.x = s[r]; d.y = s[r + 1];
-            at_f2 mm; mm.x = m_new; mm.y = m_new;
-            d = d - mm;
-            at_f2 e; e.x = __builtin_amdgcn_exp2f(d.x); e.y = __builtin_amdgcn_exp2f(d.y);
-            rs2 += e;
-            p[r] = e.x; p[r + 1] = e.y;
-        }
-        float rs = rs2.x + rs2.y;
-        rs += __shfl_xor(rs, 32, 64);
-        if (__ballot(m_new != m_run) != 0ull) {             // the running maximum moved for some query of this wavefront: rescale
-            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-            l_run *= alpha;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
-        }
-        l_run += rs;
-        m_run = m_new;
-        // ---- O^T += V^T P: 2 steps of 16 keys; slot j of step st <-> accumulator register 8 st + j
-#pragma unroll
-        for (int st = 0; st < 2; ++st) {
-            Frag8 ph, pm, pl;
-            float pp[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) pp[j] = p[8 * st + j];
-            split_pack<8>(pp, ph.u, pm.u, pl.u);
-            Frag8 v0h, v0m, v0l, v1h, v1m, v1l;
-            v0h.q = *(const uint4 *)&Vt[buf][0][ql][16 * st + 8 * half]; v1h.q = *(const uint4 *)&Vt[buf][0][32 + ql][16 * st + 8 * half];
-            v0m.q = *(const uint4 *)&Vt[buf][1][ql][16 * st + 8 * half]; v1m.q = *(const uint4 *)&Vt[buf][1][32 + ql][16 * st + 8 * half];
-            v0l.q = *(const uint4 *)&Vt[buf][2][ql][16 * st + 8 * half]; v1l.q = *(const uint4 *)&Vt[buf][2][32 + ql][16 * st + 8 * half];
-            o0 = MFMA_BF16(v0m.v, pm.v, o0); o1 = MFMA_BF16(v1m.v, pm.v, o1);
-            o0 = MFMA_BF16(v0h.v, pl.v, o0); o1 = MFMA_BF16(v1h.v, pl.v, o1);
-            o0 = MFMA_BF16(v0l.v, ph.v, o0); o1 = MFMA_BF16(v1l.v, ph.v, o1);
-            o0 = MFMA_BF16(v0h.v, pm.v, o0); o1 = MFMA_BF16(v1h.v, pm.v, o1);
-            o0 = MFMA_BF16(v0m.v, ph.v, o0); o1 = MFMA_BF16(v1m.v, ph.v, o1);
-            o0 = MFMA_BF16(v0h.v, ph.v, o0); o1 = MFMA_BF16(v1h.v, ph.v, o1);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (t + 1 < ntiles) { gmask(t + 1); lstore(buf ^ 1); }
-        __syncthreads();
-    }
-
-    if (q < N) {
-        const float inv = (l_run > 0.f && q < nq) ? 1.f / l_run : 0.f;
-        float *op = O + ((size_t)b * N + q) * ldo + h * AT_D + 4 * half;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            *(float4 *)(op + 8 * g) = make_float4(o0[4 * g] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv);
-            *(float4 *)(op + 32 + 8 * g) = make_float4(o1[4 * g] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv);
-        }
-    }
-}
-
-// ---- round 4 (variant 3): the same kernel with 256 queries (eight wavefronts) per workgroup and buffer addressing -------------------------
-// The loop above issues ~420 VALU slots per 48 MFMAs (8.8 per MFMA; tools/ubench/mfma_valu_bf16.hip: more than 5 stop being free), a third of
-// them not arithmetic: clamped row addresses, the zeroing of keys >= nk, and the operand split of the K / V tile, which every workgroup of an
-// (image, head) repeats.  Here
-//   * K / V rows are read through buffer descriptors that end at row nk: the row offset of a tile is a SCALAR (no address VALU), rows beyond
-//     nk read as zero in hardware (no clamp, no select);
-//   * a workgroup serves 256 queries, so a K / V tile is split once per 256 instead of once per 128 queries (8 instead of 16 elements per
-//     thread and tile) and read from L2 half as often.
-// One workgroup of eight wavefronts per CU (two per SIMD, as before).  Per query the arithmetic is the kernel's above, bit for bit.
+// ---- round 4 (variant 2 since round 5): eight wavefronts (256 queries) per workgroup, software-pipelined -----------------------------------------
+// K / V rows are read through buffer descriptors that end at row nk: the row offset of a tile is a SCALAR (no address VALU), rows beyond nk
+// read as zero in hardware (no clamp, no select); a K / V tile is split once per 256 queries.  (Round 3's 128-query kernel and the
+// non-pipelined eight-wavefront kernel computed the same bits and left the library in round 5: profiles/r04_bench_attention.json.)
 #define AB_WAVES 8
-__global__ void __launch_bounds__(512, 1) sg_attention_bf16x3_w8_kernel(
-    const float *__restrict__ Q, const float *__restrict__ Kp, const float *__restrict__ Vp, int ld,
-    int N, int heads, int B2, const int *__restrict__ n_tok, int cross, float scale_log2e, float *__restrict__ O, int ldo)
-{
-    __shared__ __attribute__((aligned(16))) unsigned short Ks[2][3][AT_KT][AB_KS];
-    __shared__ __attribute__((aligned(16))) unsigned short Vt[2][3][AT_D][AB_VS];
-    const int nbh = heads * B2;
-    const int bh = blockIdx.x % nbh, qb = blockIdx.x / nbh;
-    const int b = bh / heads, h = bh - b * heads;
-    const int bk = cross ? (b ^ 1) : b;
-    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ql = lane & 31, half = lane >> 5;
-    const int nq = n_tok[b], nk = n_tok[bk];
-    const int q0 = qb * (AT_QW * AB_WAVES);
-    const int q = q0 + wid * AT_QW + ql;
-    if (q0 >= nq) {
-        if (q < N) {
-            float4 *op = (float4 *)(O + ((size_t)b * N + q) * ldo + h * AT_D + 32 * half);
-#pragma unroll
-            for (int g = 0; g < 8; ++g) op[g] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        return;
-    }
-
-    Frag8 qf[4][3];
-    {
-        const bool ok = q < N;
-        const float *qp = Q + ((size_t)b * N + (ok ? q : 0)) * ld + h * AT_D + half * 8;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            float x[8];
-            float4 t0 = *(const float4 *)(qp + 16 * s), t1 = *(const float4 *)(qp + 16 * s + 4);
-            if (!ok) { t0 = make_float4(0.f, 0.f, 0.f, 0.f); t1 = t0; }
-            x[0] = t0.x * scale_log2e; x[1] = t0.y * scale_log2e; x[2] = t0.z * scale_log2e; x[3] = t0.w * scale_log2e;
-            x[4] = t1.x * scale_log2e; x[5] = t1.y * scale_log2e; x[6] = t1.z * scale_log2e; x[7] = t1.w * scale_log2e;
-            split_pack<8>(x, qf[s][0].u, qf[s][1].u, qf[s][2].u);
-        }
-    }
-    f32x16 o0, o1;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
-    float m_run = -INFINITY, l_run = 0.f;
-
-    // staging: K -- thread -> key row sr (0..31), 4 floats at column sc; V -- one d per lane, wavefront w -> keys 4 w .. 4 w + 3.
-    // Both through buffers that hold exactly the nk rows of this (image, head): base = row 0 / channel 0 of the head, the last valid byte is
-    // the end of row nk - 1's 64 channels; a row >= nk lies beyond it and reads as zero.
-    const int sr = tid >> 4, sc = (tid & 15) * 4;
-    const unsigned rowb = (unsigned)ld * 4u;
-    const unsigned span = nk > 0 ? (unsigned)(nk - 1) * rowb + AT_D * 4u : 0u;
-    const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void *)(Kp + (size_t)bk * N * ld + h * AT_D), 0, (int)span, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void *)(Vp + (size_t)bk * N * ld + h * AT_D), 0, (int)span, 0x00020000);
-    const unsigned koff = (unsigned)sr * rowb + 4u * (unsigned)sc, voff = 4u * (unsigned)lane;
-    const int ntiles = (nk + AT_KT - 1) / AT_KT;
-    float4 kr;
-    float v0, v1, v2, v3;
-    auto gload = [&](int t) {
-        const unsigned so = (unsigned)(t * AT_KT) * rowb;                            // scalar: the tile's first row
-        kr = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rk, koff, so, 0));
-        const unsigned sv = so + (unsigned)(4 * wid) * rowb;
-        v0 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rv, voff, sv, 0));
-        v1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rv, voff, sv + rowb, 0));
-        v2 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rv, voff, sv + 2u * rowb, 0));
-        v3 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rv, voff, sv + 3u * rowb, 0));
-    };
-    auto lstore = [&](int buf) {
-        unsigned ph[2], pm[2], pl[2];
-        const float ka[4] = { kr.x, kr.y, kr.z, kr.w };
-        split_pack<4>(ka, ph, pm, pl);
-        *(uint2 *)&Ks[buf][0][sr][sc] = make_uint2(ph[0], ph[1]); *(uint2 *)&Ks[buf][1][sr][sc] = make_uint2(pm[0], pm[1]);
-        *(uint2 *)&Ks[buf][2][sr][sc] = make_uint2(pl[0], pl[1]);
-        // wavefront w holds keys 4 w + j: key = 16 s + 8 g + 4 hh + j with s = w >> 2, g = (w >> 1) & 1, hh = w & 1 -> position 16 s + 8 hh + 4 g + j
-        const float vr[4] = { v0, v1, v2, v3 };
-        split_pack<4>(vr, ph, pm, pl);
-        const int p0 = 16 * (wid >> 2) + 8 * (wid & 1) + 4 * ((wid >> 1) & 1);
-        *(uint2 *)&Vt[buf][0][lane][p0] = make_uint2(ph[0], ph[1]); *(uint2 *)&Vt[buf][1][lane][p0] = make_uint2(pm[0], pm[1]);
-        *(uint2 *)&Vt[buf][2][lane][p0] = make_uint2(pl[0], pl[1]);
-    };
-    if (ntiles > 0) { gload(0); lstore(0); }
-    __syncthreads();
-
-    for (int t = 0; t < ntiles; ++t) {
-        const int buf = t & 1;
-        if (t + 1 < ntiles) gload(t + 1);
-        __builtin_amdgcn_sched_barrier(0);
-
-        // one lane-dependent LDS address per operand; stage, term, step and the second 32 channels of V are immediate offsets
-        const unsigned short *kq = &Ks[0][0][ql][8 * half] + buf * (3 * AT_KT * AB_KS);
-        const unsigned short *vq = &Vt[0][0][ql][8 * half] + buf * (3 * AT_D * AB_VS);
-        f32x16 s, s2;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { s[r] = 0.f; s2[r] = 0.f; }
-#pragma unroll
-        for (int st = 0; st < 4; ++st) {
-            Frag8 kh, km, kl;
-            kh.q = *(const uint4 *)(kq + 16 * st);
-            km.q = *(const uint4 *)(kq + AT_KT * AB_KS + 16 * st);
-            kl.q = *(const uint4 *)(kq + 2 * AT_KT * AB_KS + 16 * st);
-            s2 = MFMA_BF16(km.v, qf[st][1].v, s2);
-            s = MFMA_BF16(kh.v, qf[st][2].v, s);
-            s2 = MFMA_BF16(kl.v, qf[st][0].v, s2);
-            s = MFMA_BF16(kh.v, qf[st][1].v, s);
-            s2 = MFMA_BF16(km.v, qf[st][0].v, s2);
-            s = MFMA_BF16(kh.v, qf[st][0].v, s);
-        }
-        const int kb = t * AT_KT + 4 * half;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s[r] += s2[r];
-        if ((t + 1) * AT_KT > nk) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                if (kb + (r & 3) + 8 * (r >> 2) >= nk) s[r] = -INFINITY;
-        }
-        float mx = s[0];
-#pragma unroll
-        for (int r = 1; r < 15; r += 2) mx = fmaxf(fmaxf(mx, s[r]), s[r + 1]);      // v_max3_f32
-        mx = fmaxf(mx, s[15]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx);
-        float p[16];
-        at_f2 rs2; rs2.x = 0.f; rs2.y = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; r += 2) {                                            // two keys per packed instruction
-            at_f2 d; d.x = s[r]; d.y = s[r + 1];
-            at_f2 mm; mm.x = m_new; mm.y = m_new;
-            d = d - mm;
-            at_f2 e; e.x = __builtin_amdgcn_exp2f(d.x); e.y = __builtin_amdgcn_exp2f(d.y);
-            rs2 += e;
-            p[r] = e.x; p[r + 1] = e.y;
-        }
-        float rs = rs2.x + rs2.y;
-        rs += __shfl_xor(rs, 32, 64);
-        if (__ballot(m_new != m_run) != 0ull) {
-            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-            l_run *= alpha;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
-        }
-        l_run += rs;
-        m_run = m_new;
-#pragma unroll
-        for (int st = 0; st < 2; ++st) {
-            Frag8 ph, pm, pl;
-            float pp[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) pp[j] = p[8 * st + j];
-            split_pack<8>(pp, ph.u, pm.u, pl.u);
-            Frag8 v0h, v0m, v0l, v1h, v1m, v1l;
-            v0h.q = *(const uint4 *)(vq + 16 * st); v1h.q = *(const uint4 *)(vq + 32 * AB_VS + 16 * st);
-            v0m.q = *(const uint4 *)(vq + AT_D * AB_VS + 16 * st); v1m.q = *(const uint4 *)(vq + AT_D * AB_VS + 32 * AB_VS + 16 * st);
-            v0l.q = *(const uint4 *)(vq + 2 * AT_D * AB_VS + 16 * st); v1l.q = *(const uint4 *)(vq + 2 * AT_D * AB_VS + 32 * AB_VS + 16 * st);
-            o0 = MFMA_BF16(v0m.v, pm.v, o0); o1 = MFMA_BF16(v1m.v, pm.v, o1);
-            o0 = MFMA_BF16(v0h.v, pl.v, o0); o1 = MFMA_BF16(v1h.v, pl.v, o1);
-            o0 = MFMA_BF16(v0l.v, ph.v, o0); o1 = MFMA_BF16(v1l.v, ph.v, o1);
-            o0 = MFMA_BF16(v0h.v, pm.v, o0); o1 = MFMA_BF16(v1h.v, pm.v, o1);
-            o0 = MFMA_BF16(v0m.v, ph.v, o0); o1 = MFMA_BF16(v1m.v, ph.v, o1);
-            o0 = MFMA_BF16(v0h.v, ph.v, o0); o1 = MFMA_BF16(v1h.v, ph.v, o1);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (t + 1 < ntiles) lstore(buf ^ 1);
-        __syncthreads();
-    }
-
-    if (q < N) {
-        const float inv = (l_run > 0.f && q < nq) ? 1.f / l_run : 0.f;
-        float *op = O + ((size_t)b * N + q) * ldo + h * AT_D + 4 * half;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            *(float4 *)(op + 8 * g) = make_float4(o0[4 * g] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv);
-            *(float4 *)(op + 32 + 8 * g) = make_float4(o1[4 * g] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv);
-        }
-    }
-}
-
-// ---- round 4, the default: the eight-wavefront kernel, software-pipelined ------------------------------------------------------------------
-// In the kernels above a wavefront's tile is [24 MFMAs: S^T] -> [softmax: ~120 VALU slots, no MFMA] -> [24 MFMAs: O^T, with the split of P];
+// Without pipelining a wavefront's tile is [24 MFMAs: S^T] -> [softmax: ~120 VALU slots, no MFMA] -> [24 MFMAs: O^T, with the split of P];
 // the barrier per tile keeps all wavefronts of the CU in the same phase, so the matrix core idles through every softmax (measured: a tile
 // costs a SIMD the SUM of its two wavefronts' MFMA and VALU time, 5400 cycles for 3072 of MFMA).  Here the score product runs one tile ahead:
 // iteration t issues S^T(t+1) = K(t+1) Q^T in four steps of six MFMAs, and between them the softmax of tile t (whose scores were finished an
@@ -834,39 +465,250 @@ __global__ void __launch_bounds__(512, 1) sg_attention_bf16x3_p_kernel(
     }
 }
 
+// ---- round 5, the default: the same pipelined kernel in the f16x2 arithmetic (split_f16.h) -----------------------------------------------------
+// Both operands of both contractions are activations, so there is no packed weight to carry the 2^-11: every operand is split the activation way,
+// x -> xh = rne_f16(x), xl = rne_f16((x - xh) 2^11), and a contraction keeps TWO accumulators,
+//     main += ah bh          corr += ah bl + al bh          result = main + 2^-11 corr          (dropped: al bl 2^-22, below 2^-24 |a||b|)
+// i.e. THREE v_mfma_f32_32x32x16_f16 per block instead of six bf16 ones, 2.5 instead of 5.5 VALU per split element (K, V: once per 256 queries
+// at staging; P: per tile in registers), two instead of three term images of K / V in LDS and 32 instead of 48 registers of Q.  The S^T tile already
+// had two accumulator chains (s, s2), so "sc = s + s2" becomes one fma per score; O^T gains a correction pair (32 registers).  Every operand
+// term is good to 2^-24 relative for |x| >= 2^-12 and to an absolute 2^-36 below (P <= 1: its tiny entries are exact to 2^-36).
+#define MFMA_F16(a, b, c) SF_MFMA((a).q, (b).q, (c))
+__global__ void __launch_bounds__(512, 1) sg_attention_f16x2_p_kernel(
+    const float *__restrict__ Q, const float *__restrict__ Kp, const float *__restrict__ Vp, int ld,
+    int N, int heads, int B2, const int *__restrict__ n_tok, int cross, float scale_log2e, float *__restrict__ O, int ldo)
+{
+    __shared__ __attribute__((aligned(16))) unsigned short Ks[2][2][AT_KT][AB_KS];
+    __shared__ __attribute__((aligned(16))) unsigned short Vt[2][2][AT_D][AB_VS];
+    const int nbh = heads * B2;
+    const int bh = blockIdx.x % nbh, qb = blockIdx.x / nbh;
+    const int b = bh / heads, h = bh - b * heads;
+    const int bk = cross ? (b ^ 1) : b;
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ql = lane & 31, half = lane >> 5;
+    const int nq = n_tok[b], nk = n_tok[bk];
+    const int q0 = qb * (AT_QW * AB_WAVES);
+    const int q = q0 + wid * AT_QW + ql;
+    if (q0 >= nq) {
+        if (q < N) {
+            float4 *op = (float4 *)(O + ((size_t)b * N + q) * ldo + h * AT_D + 32 * half);
+#pragma unroll
+            for (int g = 0; g < 8; ++g) op[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        return;
+    }
+    const float LS = SF_LOW_SCALE, ILS = 1.0f / SF_LOW_SCALE;
+
+    Frag8 qf[4][2];                                          // [step][h, l]
+    {
+        const bool ok = q < N;
+        const float *qp = Q + ((size_t)b * N + (ok ? q : 0)) * ld + h * AT_D + half * 8;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            float4 t0 = *(const float4 *)(qp + 16 * s), t1 = *(const float4 *)(qp + 16 * s + 4);
+            if (!ok) { t0 = make_float4(0.f, 0.f, 0.f, 0.f); t1 = t0; }
+            sf_split2(t0.x * scale_log2e, t0.y * scale_log2e, LS, qf[s][0].u[0], qf[s][1].u[0]);
+            sf_split2(t0.z * scale_log2e, t0.w * scale_log2e, LS, qf[s][0].u[1], qf[s][1].u[1]);
+            sf_split2(t1.x * scale_log2e, t1.y * scale_log2e, LS, qf[s][0].u[2], qf[s][1].u[2]);
+            sf_split2(t1.z * scale_log2e, t1.w * scale_log2e, LS, qf[s][0].u[3], qf[s][1].u[3]);
+        }
+    }
+    f32x16 o0, o1, c0, c1;                                   // O^T main (channels 0-31 / 32-63) and correction accumulators
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; c0[r] = 0.f; c1[r] = 0.f; }
+    float m_run = -INFINITY, l_run = 0.f;
+
+    const int sr = tid >> 4, sc4 = (tid & 15) * 4;
+    const unsigned rowb = (unsigned)ld * 4u;
+    const unsigned span = nk > 0 ? (unsigned)(nk - 1) * rowb + AT_D * 4u : 0u;
+    const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void *)(Kp + (size_t)bk * N * ld + h * AT_D), 0, (int)span, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void *)(Vp + (size_t)bk * N * ld + h * AT_D), 0, (int)span, 0x00020000);
+    const unsigned koff = (unsigned)sr * rowb + 4u * (unsigned)sc4, voff = 4u * (unsigned)lane;
+    const int ntiles = (nk + AT_KT - 1) / AT_KT;
+    float4 kr;
+    float v0, v1, v2, v3;
+    auto gload_k = [&](int t) { kr = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rk, koff, (unsigned)(t * AT_KT) * rowb, 0)); };
+    auto gload_v = [&](int t) {
+        const unsigned sv = (unsigned)(t * AT_KT + 4 * wid) * rowb;
+        v0 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rv, voff, sv, 0));
+        v1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rv, voff, sv + rowb, 0));
+        v2 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rv, voff, sv + 2u * rowb, 0));
+        v3 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rv, voff, sv + 3u * rowb, 0));
+    };
+    auto lstore_k = [&](int buf) {
+        unsigned ph[2], pl[2];
+        sf_split2(kr.x, kr.y, LS, ph[0], pl[0]); sf_split2(kr.z, kr.w, LS, ph[1], pl[1]);
+        *(uint2 *)&Ks[buf][0][sr][sc4] = make_uint2(ph[0], ph[1]); *(uint2 *)&Ks[buf][1][sr][sc4] = make_uint2(pl[0], pl[1]);
+    };
+    auto lstore_v = [&](int buf) {
+        unsigned ph[2], pl[2];
+        sf_split2(v0, v1, LS, ph[0], pl[0]); sf_split2(v2, v3, LS, ph[1], pl[1]);
+        const int p0 = 16 * (wid >> 2) + 8 * (wid & 1) + 4 * ((wid >> 1) & 1);
+        *(uint2 *)&Vt[buf][0][lane][p0] = make_uint2(ph[0], ph[1]); *(uint2 *)&Vt[buf][1][lane][p0] = make_uint2(pl[0], pl[1]);
+    };
+    const unsigned short *kq0 = &Ks[0][0][ql][8 * half], *vq0 = &Vt[0][0][ql][8 * half];
+    // fragments of S^T's step st (K stage at kq): [h, l]; its three MFMAs: corr += kh ql + kl qh (s2), main += kh qh (s)
+#define AF_KLOAD(f, kq, st) do { f[0].q = *(const uint4 *)((kq) + 16 * (st)); f[1].q = *(const uint4 *)((kq) + AT_KT * AB_KS + 16 * (st)); } while (0)
+#define AF_QK3(f, st, s, s2) do { s2 = MFMA_F16(f[0], qf[st][1], s2); s = MFMA_F16(f[0], qf[st][0], s); s2 = MFMA_F16(f[1], qf[st][0], s2); } while (0)
+    // V^T fragments of 16 keys: f[0] / f[1] = h term of channels 0-31 / 32-63, f[2] / f[3] = l term; six MFMAs
+#define AF_VLOAD(f, vq, st) do { \
+        f[0].q = *(const uint4 *)((vq) + 16 * (st)); f[1].q = *(const uint4 *)((vq) + 32 * AB_VS + 16 * (st)); \
+        f[2].q = *(const uint4 *)((vq) + AT_D * AB_VS + 16 * (st)); f[3].q = *(const uint4 *)((vq) + AT_D * AB_VS + 32 * AB_VS + 16 * (st)); } while (0)
+#define AF_PV6(f, ph, pl) do { \
+        c0 = MFMA_F16(f[0], pl, c0); c1 = MFMA_F16(f[1], pl, c1); o0 = MFMA_F16(f[0], ph, o0); o1 = MFMA_F16(f[1], ph, o1); \
+        c0 = MFMA_F16(f[2], ph, c0); c1 = MFMA_F16(f[3], ph, c1); } while (0)
+
+    f32x16 sc;                                              // the scores of the tile whose softmax is due
+    gload_k(0); gload_v(0); lstore_k(0); lstore_v(0);       // (tiles beyond nk: zeros)
+    gload_k(1); lstore_k(1);
+    gload_k(2); gload_v(1);                                 // staged during iteration 0
+    __syncthreads();
+    {
+        f32x16 s, s2;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = 0.f; s2[r] = 0.f; }
+        if (ntiles > 0) {
+#pragma unroll
+            for (int st = 0; st < 4; ++st) { Frag8 kf[2]; AF_KLOAD(kf, kq0, st); AF_QK3(kf, st, s, s2); }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sc[r] = __builtin_fmaf(s2[r], ILS, s[r]);
+    }
+    __syncthreads();                                        // K stage 0 is rewritten during iteration 0
+
+    // The last iteration multiplies a K stage of zeros (tile ntiles does not exist) and stages tiles that are never used: one basic block per
+    // chunk, so that the MFMAs and the VALU work can be woven together, is worth more than the MFMAs it wastes.
+    for (int t = 0; t < ntiles; ++t) {
+        const int buf = t & 1;
+        const unsigned short *kq = kq0 + (buf ^ 1) * (2 * AT_KT * AB_KS);
+        const unsigned short *vq = vq0 + buf * (2 * AT_D * AB_VS);
+        f32x16 s, s2;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = 0.f; s2[r] = 0.f; }
+        Frag8 ka[2], kb2[2];
+        AF_KLOAD(ka, kq, 0);
+        AF_KLOAD(kb2, kq, 1);
+        const int kb = t * AT_KT + 4 * half;
+        if ((t + 1) * AT_KT > nk) {                         // only the last tile can hold keys >= nk (wave-uniform branch)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (kb + (r & 3) + 8 * (r >> 2) >= nk) sc[r] = -INFINITY;
+        }
+        // ---- S^T(t+1), step 0  ||  softmax(t): row maximum
+        AF_QK3(ka, 0, s, s2);
+        AF_KLOAD(ka, kq, 2);
+        float mx = sc[0];
+#pragma unroll
+        for (int r = 1; r < 15; r += 2) mx = fmaxf(fmaxf(mx, sc[r]), sc[r + 1]);
+        mx = fmaxf(mx, sc[15]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- step 1  ||  exponentials of keys 0 .. 7
+        AF_QK3(kb2, 1, s, s2);
+        AF_KLOAD(kb2, kq, 3);
+        float p[16];
+        at_f2 rs2; rs2.x = 0.f; rs2.y = 0.f;
+        at_f2 mm; mm.x = m_new; mm.y = m_new;
+#pragma unroll
+        for (int r = 0; r < 8; r += 2) {
+            at_f2 d; d.x = sc[r]; d.y = sc[r + 1];
+            d = d - mm;
+            at_f2 e; e.x = __builtin_amdgcn_exp2f(d.x); e.y = __builtin_amdgcn_exp2f(d.y);
+            rs2 += e;
+            p[r] = e.x; p[r + 1] = e.y;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- step 2  ||  exponentials of keys 8 .. 15
+        AF_QK3(ka, 2, s, s2);
+#pragma unroll
+        for (int r = 8; r < 16; r += 2) {
+            at_f2 d; d.x = sc[r]; d.y = sc[r + 1];
+            d = d - mm;
+            at_f2 e; e.x = __builtin_amdgcn_exp2f(d.x); e.y = __builtin_amdgcn_exp2f(d.y);
+            rs2 += e;
+            p[r] = e.x; p[r + 1] = e.y;
+        }
+        float rs = rs2.x + rs2.y;
+        rs += __shfl_xor(rs, 32, 64);
+        __builtin_amdgcn_sched_barrier(0);
+        if (__ballot(m_new != m_run) != 0ull) {             // the running maximum moved for some query of this wavefront: rescale
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            l_run *= alpha;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; c0[r] *= alpha; c1[r] *= alpha; }
+        }
+        l_run += rs;
+        m_run = m_new;
+        // ---- step 3  ||  split of P (first 16 keys), staging of K(t+2) / V(t+1)
+        AF_QK3(kb2, 3, s, s2);
+        Frag8 va[4];
+        AF_VLOAD(va, vq, 0);
+        Frag8 ph0, pl0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sf_split2(p[2 * j], p[2 * j + 1], LS, ph0.u[j], pl0.u[j]);
+        lstore_k(buf); lstore_v(buf ^ 1);
+        gload_k(t + 3); gload_v(t + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- O^T += V^T P: keys 0 .. 15  ||  split of P (last 16 keys); then keys 16 .. 31
+        AF_PV6(va, ph0, pl0);
+        Frag8 vb[4];
+        AF_VLOAD(vb, vq, 1);
+        Frag8 ph1, pl1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sf_split2(p[8 + 2 * j], p[8 + 2 * j + 1], LS, ph1.u[j], pl1.u[j]);
+        __builtin_amdgcn_sched_barrier(0);
+        AF_PV6(vb, ph1, pl1);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sc[r] = __builtin_fmaf(s2[r], ILS, s[r]);
+        __syncthreads();
+    }
+#undef AF_PV6
+#undef AF_VLOAD
+#undef AF_QK3
+#undef AF_KLOAD
+
+    if (q < N) {
+        const float inv = (l_run > 0.f && q < nq) ? 1.f / l_run : 0.f;
+        float *op = O + ((size_t)b * N + q) * ldo + h * AT_D + 4 * half;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o0[r] = __builtin_fmaf(c0[r], ILS, o0[r]) * inv; o1[r] = __builtin_fmaf(c1[r], ILS, o1[r]) * inv; }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            *(float4 *)(op + 8 * g) = make_float4(o0[4 * g], o0[4 * g + 1], o0[4 * g + 2], o0[4 * g + 3]);
+            *(float4 *)(op + 32 + 8 * g) = make_float4(o1[4 * g], o1[4 * g + 1], o1[4 * g + 2], o1[4 * g + 3]);
+        }
+    }
+}
+
 extern "C" {
 
 // q,k,v: [B2, N, ld] fp32 (row = keypoint; channels of head h at [h*64, h*64+64) from the given base
 // pointers, so a fused [.., 768] qkv buffer is passed as base, base+256, base+512 with ld = 768).
 // out: [B2, N, ldo].  cross != 0: image b attends to image b^1 (the other image of its pair).
-// variant: 0 = bf16x3, 256 queries per workgroup, score product one tile ahead of the softmax (default); 1 = exact-fp32 matrix instruction;
-// 2 = bf16x3, 128 queries per workgroup (round 3); 3 = bf16x3, 256 queries per workgroup, not pipelined
+// variant: 0 = f16x2, 256 queries per workgroup, score product one tile ahead of the softmax (default); 1 = exact-fp32 matrix instruction
+// (128 queries per workgroup); 2 = bf16x3, otherwise as 0
 int mfr_sg_attention_variant(const float *q, const float *k, const float *v, int ld, int B2, int N, int heads,
                              const int32_t *n_tok, int cross, float *out, int ldo, int variant, void *stream)
 {
     if (!q || !k || !v || !n_tok || !out || B2 <= 0 || N <= 0 || heads <= 0 || (ld & 3) || (ldo & 3)) return MFR_E_ARG;
     if (cross && (B2 & 1)) return MFR_E_ARG;
-    if (variant < 0 || variant > 3) return MFR_E_ARG;
-    // the buffer descriptors of variants 0 / 3 address an (image, head)'s rows with 32-bit offsets
-    if ((variant == 0 || variant == 3) && (size_t)N * ld * 4 >= 0x7fffffffull) variant = 2;
+    if (variant < 0 || variant > 2) return MFR_E_ARG;
+    // the buffer descriptors of variants 0 / 2 address an (image, head)'s rows with 32-bit offsets
+    if (variant != 1 && (size_t)N * ld * 4 >= 0x7fffffffull) variant = 1;
     const float scale_log2e = 1.4426950408889634f / 8.0f;          // log2(e) / sqrt(64)
-    if (variant == 0 || variant == 3) {
+    if (variant != 1) {
         const int nqb = (N + AT_QW * AB_WAVES - 1) / (AT_QW * AB_WAVES);
         if (variant == 0)
-            hipLaunchKernelGGL(sg_attention_bf16x3_p_kernel, dim3(nqb * heads * B2), dim3(512), 0, (hipStream_t)stream, q, k, v, ld, N, heads, B2, n_tok, cross,
+            hipLaunchKernelGGL(sg_attention_f16x2_p_kernel, dim3(nqb * heads * B2), dim3(512), 0, (hipStream_t)stream, q, k, v, ld, N, heads, B2, n_tok, cross,
                                scale_log2e, out, ldo);
         else
-            hipLaunchKernelGGL(sg_attention_bf16x3_w8_kernel, dim3(nqb * heads * B2), dim3(512), 0, (hipStream_t)stream, q, k, v, ld, N, heads, B2, n_tok, cross,
+            hipLaunchKernelGGL(sg_attention_bf16x3_p_kernel, dim3(nqb * heads * B2), dim3(512), 0, (hipStream_t)stream, q, k, v, ld, N, heads, B2, n_tok, cross,
                                scale_log2e, out, ldo);
     } else {
         const int nqb = (N + AT_QW * AT_WAVES - 1) / (AT_QW * AT_WAVES);
-        dim3 grid(nqb * heads * B2);
-        if (variant == 2)
-            hipLaunchKernelGGL(sg_attention_bf16x3_kernel, grid, dim3(256), 0, (hipStream_t)stream, q, k, v, ld, N, heads, B2, n_tok, cross,
-                               scale_log2e, out, ldo);
-        else
-            hipLaunchKernelGGL(sg_attention_kernel, grid, dim3(256), 0, (hipStream_t)stream, q, k, v, ld, N, heads, B2, n_tok, cross,
-                               scale_log2e, out, ldo);
+        hipLaunchKernelGGL(sg_attention_kernel, dim3(nqb * heads * B2), dim3(256), 0, (hipStream_t)stream, q, k, v, ld, N, heads, B2, n_tok, cross,
+                           scale_log2e, out, ldo);
     }
     CHECK_LAUNCH();
     return 0;

@@ -233,7 +233,7 @@ class LoFTRHIP:
         n, C2 = xm.shape
         C = C2 // 2
         x = xm[:, :C]
-        if "lq" not in Lw:        # the five bias-free projections through csrc/gemm_bf16x3.hip, weights split / packed once per layer
+        if "lq" not in Lw:        # the five bias-free projections through csrc/gemm_split.hip, weights split / packed once per layer
             from .linear import SplitLinear
             Lw["lq"], Lw["lkv"], Lw["lm"] = SplitLinear(Lw["wq"]), SplitLinear(Lw["wkv"]), SplitLinear(Lw["wm"])
             Lw["l1"], Lw["l2"] = SplitLinear(Lw["w1"]), SplitLinear(Lw["w2"])

@@ -67,12 +67,14 @@ class SuperGlueHIP:
         _lib.load(require_gpu=True)
         self.device = torch.device(device)
         self.iters, self.match_thr = int(sinkhorn_iterations), float(match_threshold)
+        from .. import options
+        self.att_variant = 0 if options.get("SPLIT") == "f16x2" else 2       # the arithmetic of the attention kernel, resolved once (options.py)
         fw = fold_weights(state_dict, n_layers)
         dev = lambda t: t.to(self.device).contiguous()
         self.kenc = [(dev(w), dev(b)) for w, b in fw["kenc"]]
         self.layers = [dict(wqkv=dev(L["wqkv"]), bqkv=dev(L["bqkv"]), w1t=dev(L["w1"]).t(), b1=dev(L["b1"]), w2t=dev(L["w2"]).t(),
                             cross=L["cross"]) for L in fw["layers"]]
-        # the three GEMMs of a layer through csrc/gemm_bf16x3.hip (weights split / packed once here); the plain tensors above stay for
+        # the three GEMMs of a layer through csrc/gemm_split.hip (weights split / packed once here); the plain tensors above stay for
         # the stage-level parity tests
         for L in self.layers:
             L["lin_qkv"] = SplitLinear(L["wqkv"], L["bqkv"])
@@ -84,10 +86,12 @@ class SuperGlueHIP:
         self._ws = None
         self._size = {}
 
-    def attention(self, qkv, n_tok, cross, out=None, ldo=256, variant=0):
+    def attention(self, qkv, n_tok, cross, out=None, ldo=256, variant=None):
         """qkv [B2,K,768] (q | k | v, each head-major) -> message [B2,K,256] (or into `out`, row stride ldo floats);
-        variant 0 = bf16x3 matrix-core kernel (fp32 accuracy), 1 = exact-fp32 matrix-core kernel (A/B, tests)"""
+        variant None = the arithmetic resolved at construction (HIP.SPLIT: 0 = f16x2, 2 = bf16x3), 1 = exact-fp32 matrix-core kernel (A/B, tests)"""
         lib = _lib.load()
+        if variant is None:
+            variant = self.att_variant
         B2, K, _ = qkv.shape
         if out is None:
             out = torch.empty(B2, K, 256, dtype=torch.float32, device=qkv.device)

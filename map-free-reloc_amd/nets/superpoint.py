@@ -1,6 +1,6 @@
 """SuperPoint on MI355X: the 3x3 convolutions through the fused Winograd/MFMA kernel of
-csrc/winograd_bf16x3.hip / winograd_conv.hip (conv1a: csrc/elementwise.hip; the declared option CONV = 'miopen', options.py, selects the
-library convolution + epilogue kernels instead), the 1x1 heads through csrc/elementwise.hip (convPb) and csrc/gemm_bf16x3.hip (convDb, fed by
+csrc/winograd_split.hip / winograd_conv.hip (conv1a: csrc/elementwise.hip; the declared option CONV = 'miopen', options.py, selects the
+library convolution + epilogue kernels instead), the 1x1 heads through csrc/elementwise.hip (convPb) and csrc/gemm_split.hip (convDb, fed by
 the NCHW -> rows transpose), everything after the conv heads through the hand-written HIP kernels of csrc/superpoint_post.hip.
 
 Reference call site: SuperGlue_matcher (etc/feature_matching_baselines/matchers.py:62-120; nms 4,

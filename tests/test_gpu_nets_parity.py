@@ -109,12 +109,12 @@ def test_descriptor_sampling(sp_pair):
         assert (got[b, n[b]:] == 0).all()
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+@pytest.mark.parametrize("variant", [0, 1, 2])
 @pytest.mark.parametrize("cross", [False, True])
 def test_attention_vs_fp64_reference(sg_pair, cross, variant):
-    """variant 0: bf16x3 on the bf16 matrix cores (3-way exact operand split, 6 partial products, fp32 accumulate), 256 queries per
-    workgroup; 2: the same with 128 queries per workgroup (round 3); 1: exact-fp32 matrix cores.  SAME tolerance for all (the
-    fp32-accuracy claim of the split kernels)."""
+    """variant 0: f16x2 on the f16 matrix cores (two-term operand split, main + correction accumulators, three partial products), 256 queries
+    per workgroup; 2: bf16x3 (3-way exact operand split, 6 partial products), same structure; 1: exact-fp32 matrix cores.  SAME tolerance
+    for all (the fp32-accuracy claim of the split kernels)."""
     ref, hip = sg_pair
     g = torch.Generator().manual_seed(4)
     B2, K = 4, 1024
@@ -132,9 +132,9 @@ def test_attention_vs_fp64_reference(sg_pair, cross, variant):
 
 
 @pytest.mark.parametrize("cross", [False, True])
-def test_attention_bf16x3_generations_agree_bitwise(sg_pair, cross):
-    """256 queries per workgroup + buffer addressing, score product one tile ahead (variant 0) / not pipelined (3) vs 128 queries per
-    workgroup (variant 2): per query the same products in the same order; keys beyond n are zeroed by the buffer range instead of a select"""
+def test_attention_split_kernels_ragged_counts(sg_pair, cross):
+    """both split kernels on ragged key / query counts (1, 33, 257 ...): finite, zero rows beyond n, and within the fp32-class tolerance of each
+    other (they are different arithmetics: no bitwise relation)"""
     ref, hip = sg_pair
     g = torch.Generator().manual_seed(43)
     B2, K = 6, 1024
@@ -142,11 +142,14 @@ def test_attention_bf16x3_generations_agree_bitwise(sg_pair, cross):
     n = torch.tensor([1024, 700, 33, 1000, 257, 1], dtype=torch.int32).to(DEV)
     a = hip.attention(qkv, n, cross, variant=0)
     b = hip.attention(qkv, n, cross, variant=2)
-    c = hip.attention(qkv, n, cross, variant=3)
-    assert torch.isfinite(a).all() and torch.equal(a, b) and torch.equal(a, c)
+    assert torch.isfinite(a).all() and torch.isfinite(b).all()
+    assert float((a - b).abs().max()) < 2e-5                 # two fp32-class results (each within rtol 1e-4 / atol 2e-5 of fp64, test above)
+    for i in range(B2):
+        assert (a[i, int(n[i]):] == 0).all()
 
 
-def test_attention_bf16x3_error_is_fp32_class(sg_pair):
+@pytest.mark.parametrize("split_variant", [0, 2])
+def test_attention_split_error_is_fp32_class(sg_pair, split_variant):
     """the split kernel's error against fp64 is no larger than 1.5x the exact-fp32 kernel's on the same inputs (max and rms),
     including badly scaled inputs (|q| ~ 1e-3 .. 30, |v| ~ 1e-4 .. 1e3)"""
     ref, hip = sg_pair
@@ -158,7 +161,7 @@ def test_attention_bf16x3_error_is_fp32_class(sg_pair):
         n = torch.tensor([1024, 999], dtype=torch.int32)
         q, k, v = [t.double().view(B2, K, 4, 64) for t in qkv.split(256, -1)]
         errs = {}
-        for variant in (0, 1):
+        for variant in (split_variant, 1):
             got = hip.attention(qkv.to(DEV), n.to(DEV), False, variant=variant).cpu().double()
             e = []
             for b in range(B2):
@@ -168,7 +171,7 @@ def test_attention_bf16x3_error_is_fp32_class(sg_pair):
                 e.append((got[b, :nq] - want) / vs)
             e = torch.cat(e)
             errs[variant] = (float(e.abs().max()), float(e.pow(2).mean().sqrt()))
-        assert errs[0][0] <= 1.5 * errs[1][0] + 1e-9 and errs[0][1] <= 1.5 * errs[1][1] + 1e-10, (qs, vs, errs)
+        assert errs[split_variant][0] <= 1.5 * errs[1][0] + 1e-9 and errs[split_variant][1] <= 1.5 * errs[1][1] + 1e-10, (qs, vs, errs)
 
 
 def test_attention_matches_upstream_head_layout(sg_pair):

@@ -1,5 +1,5 @@
 """A/B timing of the SuperGlue attention kernel variants on the bench shape (2B = 64 images x 4 heads x 1024 keypoints):
-variant 0 = bf16x3 matrix-core kernel with 256 queries per workgroup (default), 2 = with 128 (round 3), 1 = exact-fp32 matrix-core kernel.  python tools/bench_attention.py [out.json]"""
+variant 0 = f16x2 matrix-core kernel (default), 2 = bf16x3 (both 256 queries per workgroup, pipelined), 1 = exact-fp32 matrix-core kernel.  python tools/bench_attention.py [out.json]"""
 import json
 import sys
 import os
@@ -16,7 +16,7 @@ qkv = torch.randn(B2, K, 768, device=dev)
 n = torch.full((B2,), K, dtype=torch.int32, device=dev)
 out = torch.empty(B2, K, 256, device=dev)
 res = {}
-for variant in (1, 2, 3, 0, 1, 2, 3, 0):
+for variant in (1, 2, 0, 1, 2, 0):
     for cross in (False, True):
         for _ in range(3):
             sg.attention(qkv, n, cross, out=out, variant=variant)
