@@ -116,6 +116,51 @@ def resize_bilinear_u8(a, wh):
     return np.clip(np.floor(out + 0.5), 0, 255).astype(np.uint8)
 
 
+def resize_bilinear_f32(a, wh):
+    """cv2.resize(img.astype('float32'), (w, h)) (INTER_LINEAR) of a single-channel float32 [H,W] image -- SuperGlue's read_image resizes the
+    float gray image, so nothing is rounded back to uint8: the same half-pixel-centre taps as resize_bilinear_u8, float32 arithmetic"""
+    H, W = a.shape[:2]
+    w, h = int(wh[0]), int(wh[1])
+    if (w, h) == (W, H):
+        return a
+
+    def taps(n_out, n_in):
+        s = (np.arange(n_out, dtype=np.float64) + 0.5) * (n_in / n_out) - 0.5
+        i0 = np.floor(s).astype(np.int64)
+        f = (s - i0).astype(np.float32)
+        return np.clip(i0, 0, n_in - 1), np.clip(i0 + 1, 0, n_in - 1), f
+    y0, y1, fy = taps(h, H)
+    x0, x1, fx = taps(w, W)
+    af = a.astype(np.float32, copy=False)
+    top = af[y0][:, x0] * (1 - fx)[None, :] + af[y0][:, x1] * fx[None, :]
+    bot = af[y1][:, x0] * (1 - fx)[None, :] + af[y1][:, x1] * fx[None, :]
+    return (top * (1 - fy)[:, None] + bot * fy[:, None]).astype(np.float32)
+
+
+def luma_u8(rgb):
+    """[..., 3] uint8 RGB -> uint8 gray, the value an 8-bit grayscale read of the file yields (matchers.py:101-104 -> SuperGlue's read_image:
+    cv2.imread(path, GRAYSCALE)): ITU-R 601-2 luma ROUNDED to a byte.  PIL's "L" conversion, restated so that every route shares it:
+    (19595 R + 38470 G + 7471 B + 2^15) >> 16."""
+    u = rgb.astype(np.uint32)
+    return ((u[..., 0] * 19595 + u[..., 1] * 38470 + u[..., 2] * 7471 + 0x8000) >> 16).astype(np.uint8)
+
+
+def gray_plane(rgb_u8, resize=None, out=None):
+    """THE matcher input of every route (offline matchers.read_image, the batched loaders, the per-pair online plugin): uint8 luma of the
+    decoded RGB bytes, resized as a float image when a size is asked for (SuperGlue's read_image order: gray, then resize), / 255 in float32
+    -> [h, w] float32 in [0, 1], written into `out` when given"""
+    g8 = luma_u8(rgb_u8)
+    if resize is not None and (int(resize[0]), int(resize[1])) != (g8.shape[1], g8.shape[0]):
+        g = resize_bilinear_f32(g8.astype(np.float32), resize)
+        g /= np.float32(255)
+    else:
+        g = _luts()[0][g8]
+    if out is None:
+        return g
+    out[...] = g
+    return out
+
+
 def read_color_image(path, resize):
     """lib/datasets/utils.py:58-74: RGB, cv2.resize to (w, h) (INTER_LINEAR: resize_bilinear_u8 above), float /255, [3,h,w]."""
     from PIL import Image
@@ -141,9 +186,9 @@ def _host_lib():
         try:
             lib = ctypes.CDLL(path)
             vp, sz = ctypes.c_void_p, ctypes.c_size_t
-            lib.mfr_host_gray_from_rgb.argtypes = [vp, sz, vp, vp, vp, vp]; lib.mfr_host_gray_from_rgb.restype = None
+            lib.mfr_host_gray_from_rgb.argtypes = [vp, sz, vp, vp]; lib.mfr_host_gray_from_rgb.restype = None
             lib.mfr_host_depth_from_u16.argtypes = [vp, sz, vp, vp]; lib.mfr_host_depth_from_u16.restype = None
-            _HOST_LIB = lib if lib.mfr_host_abi_version() == 1 else None
+            _HOST_LIB = lib if lib.mfr_host_abi_version() == 2 else None
         except (OSError, AttributeError):
             _HOST_LIB = None
     return _HOST_LIB
@@ -152,41 +197,31 @@ def _host_lib():
 def _luts():
     global _GRAY_LUT, _DEPTH_LUT
     if _GRAY_LUT is None:
-        v = np.arange(256, dtype=np.float32) / np.float32(255)                    # read_color_image's float32 quotients
-        _GRAY_LUT = tuple(np.ascontiguousarray(np.float32(w) * v) for w in (0.299, 0.587, 0.114))      # to_gray's float32 products
+        _GRAY_LUT = np.ascontiguousarray(np.arange(256, dtype=np.float32) / np.float32(255))           # gray byte / 255 (read_image's float32 quotients)
         _DEPTH_LUT = np.ascontiguousarray((np.arange(65536, dtype=np.float64) / 1000).astype(np.float32))   # read_depth_image's values
     return _GRAY_LUT, _DEPTH_LUT
 
 
 def read_gray_plane(path, resize, out=None):
-    """to_gray(read_color_image(path, resize)) WITHOUT the float RGB image: the same float32 luma, bit for bit, written into `out` ([h, w]
-    float32, C-contiguous) when given.  The loaders of the fused path only ever want the gray plane; building the [3, h, w] float image first
-    (transpose + /255 + three multiplies over 1.2 M elements) costs as much as the JPEG decode.  A pixel's value is
-    (w0 * (R/255) + w1 * (G/255)) + w2 * (B/255) in float32 and R, G, B are bytes: three 256-entry tables of the rounded products and two
-    float32 additions in the same order (csrc/host_decode.c; numpy expressions when that library is not built)."""
+    """gray_plane() of a file -- what matchers.read_image(path, resize) returns, bit for bit -- WITHOUT any float RGB image, written into
+    `out` ([h, w] float32, C-contiguous) when given.  At the file's own size (Map-free: 540 x 720, config/mapfree.yaml) a pixel is one
+    integer luma + one 256-entry table look-up of byte / 255 (csrc/host_decode.c; the numpy expression when that library is not built)."""
     from PIL import Image
     pim = Image.open(path)
     if pim.mode != "RGB":
         pim = pim.convert("RGB")                                # (a JPEG opens as RGB: convert() would only copy it)
     im = np.asarray(pim)
-    if resize is not None:
-        im = resize_bilinear_u8(im, resize)
     h, w = im.shape[:2]
+    native = resize is None or (int(resize[0]), int(resize[1])) == (w, h)
     lib = _host_lib()
-    if lib is None:
-        a = np.ascontiguousarray(np.asarray(im, dtype=np.float32).transpose(2, 0, 1))
-        a /= np.float32(255)
-        g = np.float32(0.299) * a[0] + np.float32(0.587) * a[1] + np.float32(0.114) * a[2]
-        if out is None:
-            return g
-        out[...] = g
-        return out
-    (l0, l1, l2), _ = _luts()
+    if lib is None or not native:
+        return gray_plane(im, resize, out)
+    lut, _ = _luts()
     im = np.ascontiguousarray(im)
     if out is None:
         out = np.empty((h, w), dtype=np.float32)
     assert out.dtype == np.float32 and out.shape == (h, w) and out.flags["C_CONTIGUOUS"]
-    lib.mfr_host_gray_from_rgb(im.ctypes.data, h * w, l0.ctypes.data, l1.ctypes.data, l2.ctypes.data, out.ctypes.data)
+    lib.mfr_host_gray_from_rgb(im.ctypes.data, h * w, lut.ctypes.data, out.ctypes.data)
     return out
 
 
@@ -505,15 +540,22 @@ def usable_cpus():
 
 
 def to_gray(img):
-    """[3,H,W] or [1,H,W] float in [0,1] -> [H,W] float32 luma (BT.601 weights, what cv2.imread(GRAYSCALE) computes)"""
+    """[3,H,W] or [1,H,W] float in [0,1] -> [H,W] float32: the matcher's gray plane (gray_plane above) of the image the floats were made from.
+    A colour image of the loaders is byte / 255 per channel, so the bytes are recovered exactly (rint(x * 255)), the luma is ROUNDED to a byte
+    as an 8-bit grayscale read of the file would deliver it (matchers.py:101-104), and divided by 255: the online / fused routes then feed
+    SuperPoint the very plane the offline route (compute.py -> matchers.read_image) reads.  (Rounds 1-4 fed the unrounded float luma here --
+    up to half a grey level away from the offline route's input)  A single-channel image passes through."""
     if img.shape[0] == 1:
         return img[0]
-    if isinstance(img, torch.Tensor) and img.device.type == "cpu" and img.dtype == torch.float32:
-        # numpy on the calling thread: torch's CPU elementwise kernels fan a 1.5 MB image out over every host core (256 on the
-        # GPU boxes), which costs more in thread wake-ups than the arithmetic (measured ~20 ms vs < 1 ms per pair)
-        a = img.numpy()
-        return torch.from_numpy(np.float32(0.299) * a[0] + np.float32(0.587) * a[1] + np.float32(0.114) * a[2])
-    return 0.299 * img[0] + 0.587 * img[1] + 0.114 * img[2]
+    if isinstance(img, torch.Tensor) and img.device.type != "cpu":
+        u = (img.float() * 255.0).round().to(torch.int32)
+        g8 = (u[0] * 19595 + u[1] * 38470 + u[2] * 7471 + 0x8000) >> 16
+        return g8.to(torch.float32) / 255.0
+    # numpy on the calling thread: torch's CPU elementwise kernels fan a 1.5 MB image out over every host core (256 on the
+    # GPU boxes), which costs more in thread wake-ups than the arithmetic (measured ~20 ms vs < 1 ms per pair)
+    a = img.numpy() if isinstance(img, torch.Tensor) else np.asarray(img)
+    u8 = np.rint(a.astype(np.float32, copy=False) * np.float32(255)).astype(np.uint8)
+    return torch.from_numpy(gray_plane(np.moveaxis(u8, 0, -1)))
 
 
 # ---- decode in worker PROCESSES (PairBatchLoader(decode="process")) ------------------------------------------------------------------

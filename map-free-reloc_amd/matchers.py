@@ -3,10 +3,13 @@ class M(resize: (W, H), outdoor: bool) with match(pair_path: (str, str)) -> ndar
 (x0,y0,x1,y1) in the resized pixel frame, or np.full((1,4), nan) when there is no correspondence
 (:59, :120); registered in MATCHERS and driven by compute.py (-ds Mapfree -m SG|LoFTR).
 
-Image reading: the reference uses SuperGlue's read_image (cv2.imread GRAYSCALE, resize to (W,H),
-/255).  cv2 is not available offline, so PIL is used (L mode = the same BT.601
-luma; bilinear resize on the uint8 image rather than cv2's float resize -- sub-grey-level
-differences, documented).
+Image reading: the reference uses SuperGlue's read_image (cv2.imread GRAYSCALE, cv2.resize of the float
+image to (W,H), /255).  cv2 is not available offline: the file is decoded with PIL and the
+gray plane is datasets.gray_plane -- the ONE definition every route of this package shares (offline
+matchers, batched loaders, online plugin): ITU-R 601-2 luma rounded to a byte, cv2-style half-pixel
+bilinear resize of the float gray image when the size changes, / 255.  (Unpinned against OpenCV: libjpeg's
+own grayscale output can differ from the luma of its RGB output by a grey level; tests/external/gen_cv_golden.py
+dumps cv2's planes for three JPEGs when run off-box.)
 
 Weights: upstream checkpoints when present (same file names as matchers.py:17,70), else the seeded
 synthetic weights of nets/weights.py with a warning.
@@ -21,9 +24,8 @@ from .nets import weights as WT
 
 
 def read_image(path, resize):
-    from PIL import Image
-    im = Image.open(path).convert("L").resize((int(resize[0]), int(resize[1])), Image.BILINEAR)
-    return np.asarray(im, dtype=np.float32) / 255.0
+    from .datasets import read_gray_plane
+    return read_gray_plane(path, resize)
 
 
 def _weights(path, synth, what):

@@ -40,11 +40,11 @@ class PrecomputedMatching:
         return wire.strip_nan(self.correspondences[pair_id])
 
 
-from ..datasets import to_gray as _to_gray   # BT.601 luma, what cv2.imread(GRAYSCALE) / COLOR_RGB2GRAY compute
+from ..datasets import to_gray as _to_gray, gray_plane as _gray_plane   # the matcher's gray plane: byte-rounded BT.601 luma / 255 (datasets.gray_plane)
 
 
 class _GrayPairStage:
-    """data['image0'], data['image1'] ([1,3,H,W] or [1,1,H,W] in [0,1]) -> ONE host array [2,1,H,W] f32 of BT.601 luma, written with
+    """data['image0'], data['image1'] ([1,3,H,W] or [1,1,H,W] in [0,1]) -> ONE host array [2,1,H,W] f32 of the matcher's gray plane (datasets.to_gray), written with
     numpy on the calling thread into a persistent buffer.  No torch CPU kernel touches the images: on the GPU boxes' 256-core hosts
     a torch elementwise op / stack over a 1.5 MB image fans out over every core and costs ~20 ms in thread wake-ups per call
     (tools/diag_plugin_prof2.py), more than the whole matcher on the GPU."""
@@ -66,11 +66,9 @@ class _GrayPairStage:
             g = self.np[k, 0]
             if a.shape[0] == 1:
                 g[...] = a[0]
-            else:                                               # same products and order as datasets.to_gray
-                a = a.astype(np.float32, copy=False)
-                np.multiply(a[0], np.float32(0.299), out=g)
-                g += np.float32(0.587) * a[1]
-                g += np.float32(0.114) * a[2]
+            else:                                               # datasets.to_gray's values, written in place
+                u8 = np.rint(a.astype(np.float32, copy=False) * np.float32(255)).astype(np.uint8)
+                _gray_plane(np.moveaxis(u8, 0, -1), None, g)
         return self.buf
 
 

@@ -14,7 +14,7 @@ from .. import _lib, options
 
 # tile-block waste along x above which the exact-fp32 kernel (linear tiling) is the faster one, per arithmetic (tools/bench_conv.py:
 # profiles/r03_ab_conv.json for bf16x3, profiles/r05_ab_conv.json for f16x2)
-WASTE_LIMIT = {"bf16x3": 0.2, "f16x2": 0.2}
+WASTE_LIMIT = {"bf16x3": 0.2, "f16x2": 0.5}
 
 
 def prefer_split(H, W, split=None):

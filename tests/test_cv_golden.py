@@ -109,3 +109,19 @@ def test_hip_solvers_vs_opencv_golden():
     d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
     o = ops.PnPBatchSolver(1000, 3.0, 0.9999, 0)(d(b["pts0"]), d(b["pts1"]), d(b["n_corr"]), d(b["depth0"]), d(b["K0"]), d(b["K1"]), d(b["pair_ids"]))
     assert int(o["status"][0]) == 0 and _ang(o["R"][0].cpu().numpy(), z[f"s{seed}_R"]) < 0.15
+
+
+def test_gray_plane_vs_opencv():
+    """the matcher's input plane (datasets.gray_plane: PIL decode, byte-rounded BT.601 luma, half-pixel bilinear float resize, / 255) against
+    cv2.imread(GRAYSCALE) + cv2.resize(float) / 255 on the three committed JPEGs: at most one grey level apart anywhere (libjpeg's
+    grayscale output vs the luma of its RGB output), identical on nearly all pixels"""
+    z = _load("cv_gray.npz")
+    from mapfree_reloc_amd.matchers import read_image
+    for i in range(3):
+        path = os.path.join(GOLD, f"gray_src_{i}.jpg")
+        for (w, h) in ((120, 160), (60, 80), (200, 270)):
+            got, want = read_image(path, (w, h)), z[f"g{i}_{w}x{h}"]
+            assert got.shape == want.shape and got.dtype == np.float32
+            d = np.abs(got.astype(np.float64) - want.astype(np.float64)) * 255.0
+            assert d.max() <= 1.0 + 1e-3, (i, w, h, float(d.max()))
+            assert (d < 1e-3).mean() > 0.9, (i, w, h, float((d < 1e-3).mean()))
