@@ -218,7 +218,7 @@ def parity_leg(wl, oracle_npz, dev):
         recs.append(PR.compare_pair(ref, np.concatenate([o["pts0"][i, :n], o["pts1"][i, :n]], 1), o["R"][i], o["t"][i],
                                     o["n_inliers"][i], o["status"][i]))
     s = PR.summarize(recs)
-    s["against"] = "oracle/pipeline_ref.py (CPU restatement of the reference path) on the cpu_baseline pairs; full census: profiles/r03_parity_census_hard.json, r03_parity_census_hard2.json"
+    s["against"] = "oracle/pipeline_ref.py (CPU restatement of the reference path) on the cpu_baseline pairs; full census: profiles/r05_parity_census_hard.json, r05_parity_census_hard2.json"
     s["census"] = census_summary()
     return s
 
@@ -229,7 +229,7 @@ def census_summary():
     keep = ("pairs", "status_agree", "pose_within_bar", "inlier_count_equal", "inlier_index_sets_compared", "inlier_index_sets_identical",
             "min_inlier_set_jaccard_q64", "median_inlier_fraction", "max_rot_rad", "max_trans_m")
     out = {}
-    for tag, fn in (("hard1", "r03_parity_census_hard.json"), ("hard2", "r03_parity_census_hard2.json")):
+    for tag, fn in (("hard1", "r05_parity_census_hard.json"), ("hard2", "r05_parity_census_hard2.json")):
         try:
             d = json.load(open(os.path.join(ROOT, "profiles", fn)))
             out[tag] = {"scenes": d.get("scenes"), "file": "profiles/" + fn,
@@ -244,9 +244,18 @@ def census_summary():
 # ----------------------------------------------------------------------------------------------------------------
 class SgPnpWorkload:
     name = "sg_pnp"
-    dtype = ("f32 in / f32 accumulate; matrix products of the large convolutions, attention and the transformer's linear layers as 3 x bf16 exact "
-             "operand splits (6 partial products, error = fp32 class; incl. SuperPoint's 1x1 descriptor head); the 90x67 convolutions and the score "
-             "matrix on the fp32 matrix cores, the 1x1 detector head as fp32 FMA chains; f64 solver")
+
+    @property
+    def dtype(self):
+        if split_products() == 3.0:
+            return ("f32 in / f32 accumulate; matrix products of the 3x3 convolutions, attention and the transformer's linear layers on the f16 matrix cores with "
+                    "every fp32 operand carried as TWO f16 terms (xh = rne_f16(x), xl = rne_f16((x - xh) 2^11); weights pre-scaled per output feature; 3 partial "
+                    "products, fp32 accumulate: 2^-24 relative per operand for 2^-12 <= |x| <= 65504, error vs fp64 = the exact-fp32 MFMA's class, "
+                    "profiles/r05_f16x2_probe.jsonl; incl. SuperPoint's 1x1 descriptor head); the score matrix on the fp32 matrix cores, the 1x1 detector "
+                    "head as fp32 FMA chains; f64 solver")
+        return ("f32 in / f32 accumulate; matrix products of the 3x3 convolutions, attention and the transformer's linear layers as 3 x bf16 exact operand splits "
+                "(6 partial products, error = fp32 class; incl. SuperPoint's 1x1 descriptor head); the score matrix on the fp32 matrix cores, the 1x1 detector "
+                "head as fp32 FMA chains; f64 solver")
     metric = "image-pairs/sec @ 540x720 (SuperPoint+SuperGlue + PnP w/ depth)"
     workload = "configs[1]: SuperPoint+SuperGlue matching + PnP w/ depth, 540x720"
 
@@ -294,20 +303,22 @@ class SgPnpWorkload:
         conv_direct = 2.0 * 9 * 64 * 64 * H * W * 2 * B
         achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms else None
         eq = conv_fp32 / (conv_ms * 1e-3) / 1e12 if conv_ms else None
-        att_exec = 6.0 * att_tf if att_tf else None
-        return {"kernel": "wino_bf16x3_p8_kernel conv1b launch (dominant kernel: fused Winograd F(2x2,3x3) convolution on the bf16 matrix cores at "
-                          "fp32 accuracy, 64->64 ch, pooled output; eight wavefronts per workgroup, two per SIMD)",
+        att_exec = split_products() * att_tf if att_tf else None
+        nprod = int(split_products())
+        return {"kernel": f"wino_split_p8_kernel conv1b launch (dominant kernel: fused Winograd F(2x2,3x3) convolution on the 16-bit matrix cores at "
+                          f"fp32 accuracy, {'f16x2' if nprod == 3 else 'bf16x3'} operand split, 64->64 ch, pooled output; eight wavefronts per workgroup, two per SIMD)",
                 "bound": "mfma", "achieved": round(achieved, 1) if achieved else None, "peak": BF16_MFMA_PEAK_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4) if achieved else None,
                 "traffic": _traffic("conv1b", B), "avg_launch_ms": round(conv_ms, 4) if conv_ms else None,
                 "launches_timed": len(self.conv_timer.events), "flops_per_launch": conv_flops,
-                "note": "achieved = bf16 flops executed (6 partial products per fp32 multiply-add of the 16 Winograd GEMMs) / launch time, "
-                        "against the DENSE bf16 MFMA peak; fp32_equivalent = the same launch priced as fp32 multiply-adds",
+                "note": f"achieved = 16-bit matrix-core flops EXECUTED ({nprod} partial products per fp32 multiply-add of the 16 Winograd GEMMs) / launch time, "
+                        "against the DENSE bf16 / f16 MFMA peak; fp32_equivalent = the same launch priced as fp32 multiply-adds (what the layer delivers); "
+                        "direct_equivalent = priced as the direct 3x3 convolution's multiply-adds (SURVEY 8d's algorithmic work)",
                 "fp32_equivalent": {"tflops": round(eq, 2) if eq else None, "flops_per_launch": conv_fp32,
                                     "vs_fp32_mfma_peak": round(eq / FP32_MFMA_PEAK_TFLOPS, 4) if eq else None,
                                     "round2_exact_fp32_kernel": "8.63 ms / launch, 94.5 TFLOP/s, 0.60 of the fp32 MFMA peak (BENCH_r02)"},
                 "direct_equivalent_tflops": round(conv_direct / (conv_ms * 1e-3) / 1e12, 2) if conv_ms else None,
-                "other_kernels": [self._gemm_line(), {"kernel": "sg_attention_bf16x3_p_kernel (softmax(QK^T/8)V on the bf16 matrix cores, 3-way split operands, 256 queries per workgroup, score product one tile ahead of the softmax)", "bound": "mfma",
+                "other_kernels": [self._gemm_line(), {"kernel": ("sg_attention_f16x2_p_kernel (softmax(QK^T/8)V on the f16 matrix cores, two-term operands with main + correction accumulators" if nprod == 3 else "sg_attention_bf16x3_p_kernel (softmax(QK^T/8)V on the bf16 matrix cores, 3-way split operands") + ", 256 queries per workgroup, score product one tile ahead of the softmax)", "bound": "mfma",
                                    "achieved": round(att_exec, 1) if att_exec else None,
                                    "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(att_exec / BF16_MFMA_PEAK_TFLOPS, 4) if att_exec else None,
                                    "fp32_equivalent_tflops": round(att_tf, 2) if att_tf else None,
@@ -321,7 +332,7 @@ class SgPnpWorkload:
         M = 2 * self.B * 1024
         fp32 = 2.0 * M * 512 * 512
         ex = split_products() * fp32 / (ms * 1e-3) / 1e12 if ms else None
-        return {"kernel": "gemm_bf16x3_d_kernel, the 512 -> 512 + ReLU layer of a GNN block (mfr_gemm_bf16x3: persistent workgroups, W by LDS-DMA, 3-way split operands)",
+        return {"kernel": f"gemm_split_d_kernel, the 512 -> 512 + ReLU layer of a GNN block (mfr_gemm_{'f16x2' if split_products() == 3.0 else 'bf16x3'}: persistent workgroups, W by LDS-DMA, split operands)",
                 "bound": "mfma", "achieved": round(ex, 1) if ex else None, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(ex / BF16_MFMA_PEAK_TFLOPS, 4) if ex else None, "fp32_equivalent_tflops": round(ex / split_products(), 2) if ex else None,
                 "avg_launch_ms": round(ms, 4) if ms else None, "launches_timed": len(self.gemm_timer.events), "flops_per_launch": split_products() * fp32}
@@ -348,9 +359,13 @@ class SgPnpWorkload:
 
 class LoftrEmatWorkload:
     name = "loftr_emat"
-    dtype = ("f32 in / f32 accumulate; 3x3 stride-1 convolutions and the transformer's linear layers as 3 x bf16 exact operand splits (6 partial "
-             "products, error = fp32 class); strided / 7x7 / 1x1 convolutions, similarity products and linear attention in fp32 (library / fp32 MFMA "
-             "kernels); f64 solver")
+
+    @property
+    def dtype(self):
+        arith = ("on the f16 matrix cores with every fp32 operand carried as two f16 terms (3 partial products, fp32 accumulate, error = fp32 class: "
+                 "profiles/r05_f16x2_probe.jsonl)") if split_products() == 3.0 else "as 3 x bf16 exact operand splits (6 partial products, error = fp32 class)"
+        return (f"f32 in / f32 accumulate; 3x3 stride-1 convolutions and the transformer's linear layers {arith}; strided / 7x7 / 1x1 convolutions, similarity "
+                "products and linear attention in fp32 (library / fp32 MFMA kernels); f64 solver")
     metric = "image-pairs/sec @ 540x720 (LoFTR + E-mat RANSAC w/ scale from depth)"
     workload = "configs[2]: LoFTR coarse-to-fine matching + Essential-matrix RANSAC + metric scale, 540x720 (padded to 544)"
 
@@ -394,13 +409,13 @@ class LoftrEmatWorkload:
         # multiply-add -> priced against the DENSE bf16 MFMA peak; useful flops count the 196 real channels (the kernel also
         # multiplies the zero padding: Cin 196 -> 208 = 13 K steps of 16, Cout 196 -> 256 = 4 groups of 64: x1.39 executed)
         exe = split_products() * achieved if achieved else None
-        return {"kernel": "wino_bf16x3_p8_kernel layer1_outconv2.0 launch, 196->196 ch at 360x272 (dominant kernel: fused Winograd F(2x2,3x3) convolutions of the "
-                          "ResNet-FPN backbone on the bf16 matrix cores at fp32 accuracy; 34 % of the step's GPU time, profiles/r04_bench_loftr_emat_kernel_stats.csv)",
+        return {"kernel": "wino_split_p8_kernel layer1_outconv2.0 launch, 196->196 ch at 360x272 (dominant kernel: fused Winograd F(2x2,3x3) convolutions of the "
+                          "ResNet-FPN backbone on the 16-bit matrix cores at fp32 accuracy; a third of the step's GPU time, profiles/r05_bench_loftr_emat_kernel_stats.csv)",
                 "bound": "mfma", "achieved": round(exe, 1) if exe else None, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(exe / BF16_MFMA_PEAK_TFLOPS, 4) if exe else None, "traffic": _traffic("loftr_l1out2", B),
                 "avg_launch_ms": round(conv_ms, 4) if conv_ms else None, "launches_timed": len(self.conv_timer.events), "flops_per_launch": split_products() * conv_flops,
-                "note": "achieved = useful bf16 flops (6 partial products per fp32 multiply-add of the 16 Winograd GEMMs over the 196 real channels) / launch "
-                        "time against the dense bf16 peak; executed incl. channel padding = x1.39",
+                "note": f"achieved = useful 16-bit matrix-core flops ({int(split_products())} partial products per fp32 multiply-add of the 16 Winograd GEMMs over the 196 real channels) / launch "
+                        "time against the dense bf16 / f16 peak; executed incl. channel padding = x1.39",
                 "fp32_equivalent": {"tflops": round(achieved, 2) if achieved else None, "flops_per_launch": conv_flops,
                                     "vs_fp32_mfma_peak": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4) if achieved else None},
                 "other_kernels": [{"kernel": "dual-softmax coarse matching (similarity + row/col softmax statistics + mutual-NN selection)",
@@ -645,7 +660,7 @@ def _traffic(tag, B):
     """HBM traffic of the dominant kernel: PMC counters cannot be read inside this process, so the per-launch figure
     comes from the committed rocprofv3 --pmc passes of this same command (2 x FETCH_SIZE + WRITE_SIZE, the guide's
     gfx950 correction), profiles/r02_pmc_<tag>.json"""
-    for rnd in ("r04", "r03", "r02", "r01"):
+    for rnd in ("r05", "r04", "r03", "r02", "r01"):
         try:
             name = {"conv1b": "wino"}.get(tag, tag) if rnd == "r01" else tag
             pj = json.load(open(os.path.join(ROOT, "profiles", f"{rnd}_pmc_{name}.json")))
@@ -844,6 +859,9 @@ def main():
             # default command): configs[2] LoFTR + E-mat and configs[4] the bf16 regression training step
             line["secondary"] = [secondary_line("loftr_emat", ["--steps", "8", "--warmup", "2", "--cpu-pairs", "2"], args.secondary_budget),
                                  secondary_line("rpr_train", ["--steps", "20", "--warmup", "3", "--cpu-pairs", "4"], args.secondary_budget)]
+            # compact copy at the top level, so that a reader who keeps only scalar keys of the line still sees configs[2] / [4]
+            line["secondary_values"] = {(s_.get("config") or {}).get("workload", "?").split(":")[0].strip() + " " + str(s_.get("unit", "")): s_.get("value") for s_ in line["secondary"]}
+            line["secondary_values"] = {"loftr_emat_pairs_per_s": line["secondary"][0].get("value"), "rpr_train_pairs_per_s": line["secondary"][1].get("value")}
         print(json.dumps(line))
     if use_dist:
         dist.destroy_process_group()

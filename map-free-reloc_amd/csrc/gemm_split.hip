@@ -9,8 +9,10 @@
 //                        product is the six partial products hh + hm + mh + hl + lh + mm (each exact in fp32) accumulated in fp32 by
 //                        v_mfma_f32_32x32x16_bf16.  Error = that of the exact-fp32 matrix instruction (profiles/r03_bf16x3_probe.jsonl).
 //   f16x2  (round 5, the default)  split_f16.h: activations as two f16 terms (the low one scaled by 2^11), weights pre-scaled per output
-//                        feature and packed as three f16 terms (wh, wl, wh 2^-11): THREE v_mfma_f32_32x32x16_f16 per K block, 2.5 instead of
-//                        5.5 VALU per activation element, two instead of three X term images in LDS.  Same error class for
+//                        feature and packed as two f16 terms (wh, wl; the third, wq = wh 2^-11, is one v_pk_mul_f16 per four weights on the
+//                        fragment a wavefront has just read -- exact, and a third less W traffic through L2 and LDS than carrying it):
+//                        THREE v_mfma_f32_32x32x16_f16 per K block, 2.5 instead of 5.5 VALU per activation element, two instead of three
+//                        term images of X AND of W in LDS.  Same error class for
 //                        2^-14 <= |x| <= 65504 (profiles/r05_f16x2_probe.jsonl); the epilogue multiplies by the feature's 1 / scale.
 //
 // Mapping (all kernels of this file): workgroup tile = 128 rows x 128 output features, 4 wavefronts as 2 x 2, each 64 x 64 = 2 x 2 MFMA tiles
@@ -41,7 +43,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define GB_BK 32
 #define GB_KG_STRIDE 129                  // 16-byte units per k group (128 rows + 1 pad: conflict-free stores)
 #define GB_TERM_UNITS (4 * GB_KG_STRIDE)  // units per X term image
-#define GB_W_TILE_UNITS 1536              // packed W tile: 3 terms x 4 k groups x 128 features, 16 bytes each (both arithmetics)
+#define GB_WT(F16) ((F16) ? 2 : 3)        // W terms STORED per tile: bf16x3 h, m, l; f16x2 wh, wl (wq = wh 2^-11 is formed in registers, below)
+#define GB_W_TILE_UNITS(F16) (GB_WT(F16) * 512)   // packed W tile: terms x 4 k groups x 128 features, 16 bytes each
 
 union GbFrag { bf16x8 v; unsigned u[4]; uint4 q; };
 
@@ -53,6 +56,15 @@ __device__ __forceinline__ void gb_split3(float x, unsigned &h, unsigned &m, uns
     l = __float_as_uint(r - __uint_as_float(m & 0xffff0000u));
 }
 __device__ __forceinline__ unsigned gb_pack(unsigned lo, unsigned hi) { return __builtin_amdgcn_perm(hi, lo, 0x07060302u); }
+
+// f16x2: wq = rne_f16(wh * 2^-11), eight weights at a time (4 x v_pk_mul_f16; a power of two: exact unless the product is subnormal)
+typedef _Float16 gb_h8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ uint4 gb_wq(const uint4 &wh)
+{
+    const gb_h8 h = __builtin_bit_cast(gb_h8, wh);
+    const gb_h8 q = h * (_Float16)(1.0f / SF_LOW_SCALE);
+    return __builtin_bit_cast(uint4, q);
+}
 
 // eight consecutive K elements of one row -> the row's 16-byte unit of every X term image (XT = 3: h, m, l bf16; XT = 2: xh, xl f16)
 template <bool F16>
@@ -109,8 +121,8 @@ __global__ void __launch_bounds__(256) gb_pack_kernel(const float *__restrict__ 
 {
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
     if (t >= total) return;
-    const int u = (int)(t % GB_W_TILE_UNITS);
-    const long long tile = t / GB_W_TILE_UNITS;
+    const int u = (int)(t % GB_W_TILE_UNITS(F16));
+    const long long tile = t / GB_W_TILE_UNITS(F16);
     const int nkb = K / GB_BK;
     const int kb = (int)(tile % nkb), nb = (int)(tile / nkb);
     const int term = u / 512, kg = (u % 512) / 128, f = u % 128;
@@ -123,7 +135,8 @@ __global__ void __launch_bounds__(256) gb_pack_kernel(const float *__restrict__ 
         if (F16) {
             unsigned short wh, wl, wq;
             sf_split_w(x * s, wh, wl, wq);
-            word[e] = (unsigned)(term == 0 ? wh : term == 1 ? wl : wq) << 16;        // (upper half, as the bf16 terms: gb_pack takes the upper halves)
+            (void)wq;
+            word[e] = (unsigned)(term == 0 ? wh : wl) << 16;                         // (upper half, as the bf16 terms: gb_pack takes the upper halves)
         } else {
             unsigned h, m, l;
             gb_split3(x, h, m, l);
@@ -140,7 +153,8 @@ __global__ void __launch_bounds__(256, 2) gemm_split_kernel(const float *__restr
                                                             const float *__restrict__ bias, float *__restrict__ Y, int ldy, int M, int N, int K, int nnb)
 {
     constexpr int XT = GB_XT(F16);
-    __shared__ uint4 lds[(XT + 3) * GB_TERM_UNITS];       // X terms, W terms 0..2
+    constexpr int WT = GB_WT(F16);
+    __shared__ uint4 lds[(XT + WT) * GB_TERM_UNITS];      // X terms, W terms
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1;
     // feature blocks innermost: the workgroups that share an X row block run back to back (its tiles stay in L2)
@@ -159,13 +173,13 @@ __global__ void __launch_bounds__(256, 2) gemm_split_kernel(const float *__restr
         xrow[i] = X + (size_t)m * ldx + 8 * kg;
         xdst[i] = kg * GB_KG_STRIDE + row;
     }
-    int wdst[6];
+    int wdst[2 * WT];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
+    for (int i = 0; i < 2 * WT; ++i) {
         const int u = tid + 256 * i, term = u / 512, kg = (u % 512) / 128, f = u % 128;
         wdst[i] = (XT + term) * GB_TERM_UNITS + kg * GB_KG_STRIDE + f;
     }
-    const uint4 *wtile = Wp + (size_t)nb * nkb * GB_W_TILE_UNITS + tid;
+    const uint4 *wtile = Wp + (size_t)nb * nkb * GB_W_TILE_UNITS(F16) + tid;
 
     // (named registers, not arrays: hipcc keeps a lambda-captured array that is written under a condition in scratch memory)
     float4 xa0, xa1, xb0, xb1;
@@ -173,8 +187,8 @@ __global__ void __launch_bounds__(256, 2) gemm_split_kernel(const float *__restr
 #define GB_GLOAD(kb) do { \
         xa0 = *(const float4 *)(xrow[0] + (kb) * GB_BK); xa1 = *(const float4 *)(xrow[0] + (kb) * GB_BK + 4); \
         xb0 = *(const float4 *)(xrow[1] + (kb) * GB_BK); xb1 = *(const float4 *)(xrow[1] + (kb) * GB_BK + 4); \
-        const uint4 *wt_ = wtile + (size_t)(kb) * GB_W_TILE_UNITS; \
-        w0 = wt_[0]; w1 = wt_[256]; w2 = wt_[512]; w3 = wt_[768]; w4 = wt_[1024]; w5 = wt_[1280]; } while (0)
+        const uint4 *wt_ = wtile + (size_t)(kb) * GB_W_TILE_UNITS(F16); \
+        w0 = wt_[0]; w1 = wt_[256]; w2 = wt_[512]; w3 = wt_[768]; if (WT == 3) { w4 = wt_[1024]; w5 = wt_[1280]; } } while (0)
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -192,7 +206,8 @@ __global__ void __launch_bounds__(256, 2) gemm_split_kernel(const float *__restr
     for (int kb = 0; kb < nkb; ++kb) {
         __syncthreads();                                  // the previous step's fragment reads are done
         gb_xsplit_store<F16>(lds, xa0, xa1, xdst[0]); gb_xsplit_store<F16>(lds, xb0, xb1, xdst[1]);
-        lds[wdst[0]] = w0; lds[wdst[1]] = w1; lds[wdst[2]] = w2; lds[wdst[3]] = w3; lds[wdst[4]] = w4; lds[wdst[5]] = w5;
+        lds[wdst[0]] = w0; lds[wdst[1]] = w1; lds[wdst[2]] = w2; lds[wdst[3]] = w3;
+        if (WT == 3) { lds[wdst[2 * WT - 2]] = w4; lds[wdst[2 * WT - 1]] = w5; }
         __syncthreads();
         { const int kn = min(kb + 1, nkb - 1); GB_GLOAD(kn); }   // in flight during the MFMAs below (the last step re-reads its own tile)
         // without this fence hipcc sinks the loads BELOW the MFMAs (ten live 16-byte registers fewer across them) and every K step
@@ -206,7 +221,8 @@ __global__ void __launch_bounds__(256, 2) gemm_split_kernel(const float *__restr
 #pragma unroll
                 for (int t = 0; t < XT; ++t) a[i][t].q = lds[t * GB_TERM_UNITS + 2 * ks * GB_KG_STRIDE + arow + 32 * i];
 #pragma unroll
-                for (int t = 0; t < 3; ++t) b[i][t].q = lds[(XT + t) * GB_TERM_UNITS + 2 * ks * GB_KG_STRIDE + brow + 32 * i];
+                for (int t = 0; t < WT; ++t) b[i][t].q = lds[(XT + t) * GB_TERM_UNITS + 2 * ks * GB_KG_STRIDE + brow + 32 * i];
+                if (F16) b[i][2].q = gb_wq(b[i][0].q);
             }
             gb_products<F16>(acc, a, b);
         }
@@ -251,7 +267,8 @@ __global__ void __launch_bounds__(256, 2) gemm_split_pk_kernel(const float *__re
                                                                const float *__restrict__ bias, float *__restrict__ Y, int ldy, int M, int N, int K, int nnb, int nmb)
 {
     constexpr int XT = GB_XT(F16);
-    __shared__ uint4 lds[(XT + 3) * GB_TERM_UNITS];
+    constexpr int WT = GB_WT(F16);
+    __shared__ uint4 lds[(XT + WT) * GB_TERM_UNITS];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1;
     const int nkb = K / GB_BK;
@@ -270,9 +287,9 @@ __global__ void __launch_bounds__(256, 2) gemm_split_pk_kernel(const float *__re
         xr[i] = u >> 2; xk[i] = 8 * (u & 3);
         xdst[i] = (u & 3) * GB_KG_STRIDE + xr[i];
     }
-    int wdst[6];
+    int wdst[2 * WT];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
+    for (int i = 0; i < 2 * WT; ++i) {
         const int u = tid + 256 * i, term = u / 512, kg = (u % 512) / 128, f = u % 128;
         wdst[i] = (XT + term) * GB_TERM_UNITS + kg * GB_KG_STRIDE + f;
     }
@@ -290,15 +307,15 @@ __global__ void __launch_bounds__(256, 2) gemm_split_pk_kernel(const float *__re
         GB_TILE(jj, mb, nb);
         lx0 = X + (size_t)min(mb * GB_BM + xr[0], M - 1) * ldx + xk[0];      // rows beyond M: a valid row is read, its results are never stored
         lx1 = X + (size_t)min(mb * GB_BM + xr[1], M - 1) * ldx + xk[1];
-        lw = Wp + (size_t)nb * nkb * GB_W_TILE_UNITS + tid;
+        lw = Wp + (size_t)nb * nkb * GB_W_TILE_UNITS(F16) + tid;
         lk = 0;
     };
     float4 xa0, xa1, xb0, xb1;
     uint4 w0, w1, w2, w3, w4, w5;
 #define GB_PLOAD() do { \
         xa0 = *(const float4 *)lx0; xa1 = *(const float4 *)(lx0 + 4); xb0 = *(const float4 *)lx1; xb1 = *(const float4 *)(lx1 + 4); \
-        w0 = lw[0]; w1 = lw[256]; w2 = lw[512]; w3 = lw[768]; w4 = lw[1024]; w5 = lw[1280]; \
-        lx0 += GB_BK; lx1 += GB_BK; lw += GB_W_TILE_UNITS; \
+        w0 = lw[0]; w1 = lw[256]; w2 = lw[512]; w3 = lw[768]; if (WT == 3) { w4 = lw[1024]; w5 = lw[1280]; } \
+        lx0 += GB_BK; lx1 += GB_BK; lw += GB_W_TILE_UNITS(F16); \
         if (++lk == nkb) { int jn = lj + per_xcd; if (jn < items) { GB_TILE(jn, mbn_, nbn_); (void)nbn_; if (mbn_ >= nmb) jn = items; } \
                            if (jn < items) lj = jn; load_tile_start(lj); } } while (0)        /* no next tile: the last load re-reads this tile's start */
 
@@ -329,7 +346,8 @@ __global__ void __launch_bounds__(256, 2) gemm_split_pk_kernel(const float *__re
 #define GB_PSTEP(LAST) do { \
             __syncthreads(); \
             gb_xsplit_store<F16>(lds, xa0, xa1, xdst[0]); gb_xsplit_store<F16>(lds, xb0, xb1, xdst[1]); \
-            lds[wdst[0]] = w0; lds[wdst[1]] = w1; lds[wdst[2]] = w2; lds[wdst[3]] = w3; lds[wdst[4]] = w4; lds[wdst[5]] = w5; \
+            lds[wdst[0]] = w0; lds[wdst[1]] = w1; lds[wdst[2]] = w2; lds[wdst[3]] = w3; \
+            if (WT == 3) { lds[wdst[2 * WT - 2]] = w4; lds[wdst[2 * WT - 1]] = w5; } \
             __syncthreads(); \
             GB_PLOAD(); \
             if ((LAST) && (FLAGS & 2)) { \
@@ -342,7 +360,8 @@ __global__ void __launch_bounds__(256, 2) gemm_split_pk_kernel(const float *__re
                 GbFrag a[2][3], b[2][3]; \
                 _Pragma("unroll") for (int i = 0; i < 2; ++i) { \
                     _Pragma("unroll") for (int t = 0; t < XT; ++t) a[i][t].q = lds[t * GB_TERM_UNITS + 2 * ks * GB_KG_STRIDE + arow + 32 * i]; \
-                    _Pragma("unroll") for (int t = 0; t < 3; ++t) b[i][t].q = lds[(XT + t) * GB_TERM_UNITS + 2 * ks * GB_KG_STRIDE + brow + 32 * i]; } \
+                    _Pragma("unroll") for (int t = 0; t < WT; ++t) b[i][t].q = lds[(XT + t) * GB_TERM_UNITS + 2 * ks * GB_KG_STRIDE + brow + 32 * i]; \
+                    if (F16) b[i][2].q = gb_wq(b[i][0].q); } \
                 gb_products<F16>(acc, a, b); } } while (0)
         for (int kb = 0; kb < nkb - 1; ++kb) GB_PSTEP(false);
         GB_PSTEP(true);
@@ -383,14 +402,23 @@ __global__ void __launch_bounds__(256, 2) gemm_split_pk_kernel(const float *__re
 //   * LDS = X terms (24.2 KB bf16x3, 16.1 KB f16x2) + 2 x 24 KB W: two workgroups per CU.
 // The K loop is unrolled by two (register set / W stage = parity of the step): K % 64 == 0, other K run the kernel above.  Arithmetic per
 // output element unchanged.
-#define GD_WSTAGE 1536                    // units per W stage (one packed tile image)
+#define GD_WSTAGE(F16) GB_W_TILE_UNITS(F16)   // units per W stage (one packed tile image)
 #define GD_VMCNT(n) __builtin_amdgcn_s_waitcnt(0x0F70 | ((n) & 15) | (((n) >> 4) << 14))      /* vmcnt(n) only */
+// Measurement build only (tools/gemm_timeline.py compiles THIS file a second time with -DGD_PROF into tools/ubench/libgemm_prof.so; the product
+// library never defines it): s_memtime stamps of the four wavefronts of one mid-grid workgroup over its first 12 K steps.
+#ifdef GD_PROF
+__device__ unsigned long long gd_prof[4][64];
+#define GD_STAMP(k) do { if (blockIdx.x == (gridDim.x / 2 | 3u) && lane == 0 && pstep < 12) { __builtin_amdgcn_sched_barrier(0); gd_prof[wid][5 * pstep + (k)] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#else
+#define GD_STAMP(k) do { } while (0)
+#endif
 template <int FLAGS, bool F16>
 __global__ void __launch_bounds__(256, 2) gemm_split_d_kernel(const float *__restrict__ X, int ldx, const uint4 *__restrict__ Wp, unsigned wp_bytes, const float *__restrict__ oscale,
                                                               const float *__restrict__ bias, float *__restrict__ Y, int ldy, int M, int N, int K, int nnb, int nmb)
 {
     constexpr int XT = GB_XT(F16);
-    __shared__ uint4 lds[XT * GB_TERM_UNITS + 2 * GD_WSTAGE];
+    constexpr int WT = GB_WT(F16), WSTAGE = GD_WSTAGE(F16);
+    __shared__ uint4 lds[XT * GB_TERM_UNITS + 2 * WSTAGE];
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wid >> 1, wn = wid & 1;
     const int nkb = K / GB_BK;
@@ -428,11 +456,11 @@ __global__ void __launch_bounds__(256, 2) gemm_split_d_kernel(const float *__res
     int wj = j, wk = 0;                                    // item / K step the W stream is at
     auto wdma = [&](int stage) {
         GD_TILE(wj, mbw, nbw); (void)mbw;
-        const unsigned img = (unsigned)(nbw * nkb + wk) * (unsigned)(GD_WSTAGE * 16);
+        const unsigned img = (unsigned)(nbw * nkb + wk) * (unsigned)(WSTAGE * 16);
 #pragma unroll
-        for (int q = 0; q < 6; ++q) {
+        for (int q = 0; q < 2 * WT; ++q) {
             const unsigned so = __builtin_amdgcn_readfirstlane(img + (unsigned)(64 * (wid + 4 * q)) * 16u);
-            const unsigned m0v = __builtin_amdgcn_readfirstlane(lds0 + 16u * (unsigned)(XT * GB_TERM_UNITS + stage * GD_WSTAGE + 64 * (wid + 4 * q)));
+            const unsigned m0v = __builtin_amdgcn_readfirstlane(lds0 + 16u * (unsigned)(XT * GB_TERM_UNITS + stage * WSTAGE + 64 * (wid + 4 * q)));
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" :: "s"(m0v), "v"(lane16), "s"(wdesc), "s"(so) : "memory");
         }
         if (++wk == nkb) { wk = 0; wj = next_item(wj); }
@@ -453,29 +481,42 @@ __global__ void __launch_bounds__(256, 2) gemm_split_d_kernel(const float *__res
 
     f32x16 acc[2][2];
     unsigned ov[2][2][16];                                 // FLAGS & 2: the tile of Y, fetched during the last K step
+#ifdef GD_PROF
+    int pstep = 0;
+#define GD_PSTEP_INC ++pstep
+#else
+#define GD_PSTEP_INC (void)0
+#endif
 #define GD_SOFF(i, r) ((unsigned)(32 * (i) + ((r) & 3) + 8 * ((r) >> 2)) * rowb)
     // step of parity P: X register set P -> the X stage; W stage P (filled by the DMA of the previous step) is multiplied; the DMA of the next
     // step's W goes to stage P ^ 1 and set P is reloaded with the X of two steps ahead.  Younger than the DMA this step waits for: the previous
-    // step's 4 X loads, this step's 6 DMAs and 4 X loads.
+    // step's 4 X loads, this step's 2 WT DMAs and 4 X loads.
 #define GD_STEP(P, p0, p1, q0, q1, LAST) do { \
+        GD_STAMP(0); \
         __syncthreads(); \
+        GD_STAMP(1); \
         gb_xsplit_store<F16>(lds, p0, p1, xdst[0]); gb_xsplit_store<F16>(lds, q0, q1, xdst[1]); \
         wdma((P) ^ 1); GD_XLOAD(p0, p1, q0, q1); \
+        GD_STAMP(2); \
         if ((LAST) && (FLAGS & 2)) { \
             _Pragma("unroll") for (int jj = 0; jj < 2; ++jj) \
                 _Pragma("unroll") for (int i = 0; i < 2; ++i) \
                     _Pragma("unroll") for (int r = 0; r < 16; ++r) \
                         ov[i][jj][r] = __builtin_amdgcn_raw_buffer_load_b32(ry, yoff + 128u * jj, GD_SOFF(i, r), 0); \
             GD_VMCNT(63); } \
-        else GD_VMCNT(14); \
+        else GD_VMCNT(8 + 2 * WT); \
+        GD_STAMP(3); \
         __syncthreads(); \
+        GD_STAMP(4); \
         __builtin_amdgcn_sched_barrier(0); \
         _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) { \
             GbFrag a[2][3], b[2][3]; \
             _Pragma("unroll") for (int i = 0; i < 2; ++i) { \
                 _Pragma("unroll") for (int t = 0; t < XT; ++t) a[i][t].q = lds[t * GB_TERM_UNITS + 2 * ks * GB_KG_STRIDE + arow + 32 * i]; \
-                _Pragma("unroll") for (int t = 0; t < 3; ++t) b[i][t].q = lds[(P) * GD_WSTAGE + t * 512 + 2 * ks * 128 + brow + 32 * i]; } \
-            gb_products<F16>(acc, a, b); } } while (0)
+                _Pragma("unroll") for (int t = 0; t < WT; ++t) b[i][t].q = lds[(P) * WSTAGE + t * 512 + 2 * ks * 128 + brow + 32 * i]; \
+                if (F16) b[i][2].q = gb_wq(b[i][0].q); } \
+            gb_products<F16>(acc, a, b); } \
+        GD_PSTEP_INC; } while (0)
 
     x_tile_start(j);
     wdma(0);
@@ -526,7 +567,7 @@ __global__ void __launch_bounds__(256, 2) gemm_split_d_kernel(const float *__res
 }
 
 // ---- host ------------------------------------------------------------------------------------------------------------------------------------
-static size_t gb_tile_bytes(int N, int K) { return (size_t)((N + GB_BN - 1) / GB_BN) * (K / GB_BK) * GB_W_TILE_UNITS * 16; }
+static size_t gb_tile_bytes(int N, int K, bool f16) { return (size_t)((N + GB_BN - 1) / GB_BN) * (K / GB_BK) * GB_W_TILE_UNITS(f16) * 16; }
 
 template <bool F16>
 static int gb_launch(const float *x, int ldx, const void *packed_w, const float *bias, float *y, int ldy, int M, int N, int K, int flags, void *stream)
@@ -537,7 +578,7 @@ static int gb_launch(const float *x, int ldx, const void *packed_w, const float 
     if (((uintptr_t)x & 15)) return MFR_E_ARG;
     const int f = flags & 3, one_tile = flags & 4;
     int pk = flags & 8;
-    const size_t tb = gb_tile_bytes(N, K);
+    const size_t tb = gb_tile_bytes(N, K, F16);
     if (!one_tile && !pk && ((K % 64) || tb >= 0xffffffffull)) pk = 8;
     const int nnb = (N + GB_BN - 1) / GB_BN, nmb = (M + GB_BM - 1) / GB_BM;
     const long long tiles = (long long)nmb * nnb;
@@ -547,7 +588,10 @@ static int gb_launch(const float *x, int ldx, const void *packed_w, const float 
     const float *oscale = F16 ? (const float *)((const char *)packed_w + tb) : nullptr;
     // 2 workgroups per CU on 256 CUs; fewer when there are fewer tiles (multiple of 8: one share per XCD)
     const long long per_xcd = (long long)((nmb + 7) / 8) * nnb;
-    const unsigned grid = 8u * (unsigned)(per_xcd < 64 ? per_xcd : 64);
+    // f16x2 without the accumulating epilogue: 158 registers, 48 KB of LDS -> three workgroups per CU (0.119 -> 0.099 ms on the 256 -> 768 layer,
+    // profiles/r05_ab_gemm.json); the others: two
+    const long long cap = (F16 && !(f & 2) && !pk) ? 96 : 64;
+    const unsigned grid = 8u * (unsigned)(per_xcd < cap ? per_xcd : cap);
 #define GB_SW(GO) switch (f) { case 0: GO(0); break; case 1: GO(1); break; case 2: GO(2); break; default: GO(3); break; }
     if (one_tile) {
 #define GB_GO(F) hipLaunchKernelGGL((gemm_split_kernel<F, F16>), dim3((unsigned)tiles), dim3(256), 0, st, x, ldx, wp, oscale, bias, y, ldy, M, N, K, nnb)
@@ -569,22 +613,29 @@ static int gb_launch(const float *x, int ldx, const void *packed_w, const float 
 
 extern "C" {
 
+#ifdef GD_PROF
+int mfr_gemm_split_profile(unsigned long long *out_host)      /* the stamps of the last default-kernel launch: 4 wavefronts x 64 */
+{
+    return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(gd_prof), sizeof(unsigned long long) * 256, 0, hipMemcpyDeviceToHost) == hipSuccess ? 0 : MFR_E_LAUNCH;
+}
+#endif
+
 size_t mfr_gemm_bf16x3_pack_bytes(int N, int K)
 {
     if (N <= 0 || K <= 0 || (K % GB_BK)) return 0;
-    return gb_tile_bytes(N, K);
+    return gb_tile_bytes(N, K, false);
 }
 
 size_t mfr_gemm_f16x2_pack_bytes(int N, int K)
 {
     if (N <= 0 || K <= 0 || (K % GB_BK)) return 0;
-    return gb_tile_bytes(N, K) + (size_t)((N + GB_BN - 1) / GB_BN) * GB_BN * 4;      // + the per-feature 1 / scale
+    return gb_tile_bytes(N, K, true) + (size_t)((N + GB_BN - 1) / GB_BN) * GB_BN * 4;      // + the per-feature 1 / scale
 }
 
 int mfr_gemm_bf16x3_pack(const float *w, int N, int K, void *packed, void *stream)
 {
     if (!w || !packed || N <= 0 || K <= 0 || (K % GB_BK)) return MFR_E_ARG;
-    const long long total = (long long)(gb_tile_bytes(N, K) / 16);
+    const long long total = (long long)(gb_tile_bytes(N, K, false) / 16);
     hipLaunchKernelGGL((gb_pack_kernel<false>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, N, K, total, (const float *)nullptr, (uint4 *)packed);
     CHECK_LAUNCH();
     return 0;
@@ -593,7 +644,7 @@ int mfr_gemm_bf16x3_pack(const float *w, int N, int K, void *packed, void *strea
 int mfr_gemm_f16x2_pack(const float *w, int N, int K, void *packed, void *stream)
 {
     if (!w || !packed || N <= 0 || K <= 0 || (K % GB_BK)) return MFR_E_ARG;
-    const size_t tb = gb_tile_bytes(N, K);
+    const size_t tb = gb_tile_bytes(N, K, true);
     const long long total = (long long)(tb / 16);
     const int npad = (N + GB_BN - 1) / GB_BN * GB_BN;
     float *oscale = (float *)((char *)packed + tb);

@@ -132,6 +132,15 @@ __global__ void __launch_bounds__(256) wb_filter_kernel(const float *__restrict_
 // ---------------------------------------------------------------------------------------------------------------------
 #define WB_MFMA_BF(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
 
+// Measurement build only (tools/conv_timeline.py compiles THIS file a second time with -DWB_PROF into tools/ubench/libwino_prof.so; the product
+// library never defines it): s_memtime stamps of the eight wavefronts of one workgroup in the middle of the grid.
+#ifdef WB_PROF
+__device__ unsigned long long wb_prof[8][32];
+#define WB_STAMP(k) do { if (blockIdx.x == (gridDim.x / 2 | 5u) && lane == 0) { __builtin_amdgcn_sched_barrier(0); wb_prof[w][(k)] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#else
+#define WB_STAMP(k) do { } while (0)
+#endif
+
 // What bounds this kernel (round 4, bf16x3: profiles/r04_pmc_conv1b.json, r04_ablate_conv_p8.json): not memory (traffic 1.009 x algorithmic)
 // and not the matrix pipe (36 % busy) but the SIMD's issue port and the latencies two wavefronts per SIMD cannot hide -- 10.4 VALU per MFMA,
 // 5.5 of them the exact 3-way split of a V element.  The f16x2 arithmetic halves the MFMAs and takes 3 VALU per element out of the split.
@@ -296,11 +305,14 @@ __global__ void __launch_bounds__(512, 2) wino_split_p8_kernel(
 #define WB8_VMCNT(n) __builtin_amdgcn_s_waitcnt(0x0F70 | ((n) & 15) | (((n) >> 4) << 14))      /* vmcnt(n) only; the builtin (not inline asm) so that hipcc's own wait bookkeeping sees it */
 
     // ---- prologue
+    WB_STAMP(0);
     aload(0, 0); aload(0, 1);
     pdma(0, 0);
     WB8_VMCNT(0);
+    WB_STAMP(1);
     pfix(0);
     __syncthreads();
+    WB_STAMP(2);
     f32x16 acc[2][2][2];
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj)
@@ -327,6 +339,7 @@ __global__ void __launch_bounds__(512, 2) wino_split_p8_kernel(
     wread(0, 0);
     vmake(vfA, 0);
     int c = 0;
+    WB_STAMP(3);
     for (; c + 1 < nks; ++c) {
         WB8_VMCNT(0);
         pdma(c + 1, (c + 1) & 1);
@@ -338,14 +351,18 @@ __global__ void __launch_bounds__(512, 2) wino_split_p8_kernel(
         vmake(vfB, 1);
         WB8_PHASE(0, 1, vfA);
         aload(c + 1, 0);
+        WB_STAMP(4 + 3 * (c & 3));
         WB8_VMCNT(6);                                                     // the four DMAs are older than the six fragment loads
         pfix((c + 1) & 1);
+        WB_STAMP(5 + 3 * (c & 3));
         __syncthreads();
+        WB_STAMP(6 + 3 * (c & 3));
         wread((c + 1) & 1, 0);
         vmake(vfA, 0);
         WB8_PHASE(1, 1, vfB);
         aload(c + 1, 1);
     }
+    WB_STAMP(16);
     WB8_VMCNT(0);
     vmake(vfB, 1);
     WB8_PHASE(0, 0, vfA);
@@ -355,6 +372,7 @@ __global__ void __launch_bounds__(512, 2) wino_split_p8_kernel(
     vmake(vfB, 1);
     WB8_PHASE(0, 1, vfA);
     WB8_PHASE(1, 1, vfB);
+    WB_STAMP(17);
 #undef WB8_PHASE
 #undef WB8_PROD
 #undef WB8_VMCNT
@@ -371,6 +389,7 @@ __global__ void __launch_bounds__(512, 2) wino_split_p8_kernel(
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb) {
         __syncthreads();                                    // patch stages (mb = 0) / the previous round's partials (mb = 1) are dead
+        WB_STAMP(18 + 4 * mb);
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
@@ -393,7 +412,9 @@ __global__ void __launch_bounds__(512, 2) wino_split_p8_kernel(
             bv[k] = bias ? bias[min(co0 + k, Cout - 1)] : 0.f;
             os[k] = F16 ? oscale[co0 + k] : 1.0f;                   // (padded to ncg * 64 entries)
         }
+        WB_STAMP(19 + 4 * mb);
         __syncthreads();
+        WB_STAMP(20 + 4 * mb);
         const float4 *pq = part + (qnb * 4 + qr4) * 64 + lane;      // + ((row * 2 + jp) * 2 + ab) * 8 * 64
         float4 P[4][2];
 #pragma unroll
@@ -414,6 +435,7 @@ __global__ void __launch_bounds__(512, 2) wino_split_p8_kernel(
             if (F16) { Y[k][0] = __builtin_fmaf(y0, os[k], bv[k]); Y[k][1] = __builtin_fmaf(y1, os[k], bv[k]); Y[k][2] = __builtin_fmaf(y2, os[k], bv[k]); Y[k][3] = __builtin_fmaf(y3, os[k], bv[k]); }
             else     { Y[k][0] = y0 + bv[k]; Y[k][1] = y1 + bv[k]; Y[k][2] = y2 + bv[k]; Y[k][3] = y3 + bv[k]; }
         }
+        WB_STAMP(21 + 4 * mb);
         float *yb = y + ((size_t)b * Cout + co0) * cstride;
         const bool allco = cg * 64 + mb * 32 + 32 <= Cout;
         if (POOL) {
@@ -481,6 +503,7 @@ __global__ void __launch_bounds__(512, 2) wino_split_p8_kernel(
             }
         }
     }
+    WB_STAMP(26);
 }
 
 // ---- host ------------------------------------------------------------------------------------------------------------------------------------
@@ -527,6 +550,13 @@ static int wb_conv(const float *x, const void *upk, const float *bias, const flo
 }
 
 extern "C" {
+
+#ifdef WB_PROF
+int mfr_wino_split_profile(unsigned long long *out_host)      /* the stamps of the last launch: 8 wavefronts x 32 */
+{
+    return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(wb_prof), sizeof(unsigned long long) * 256, 0, hipMemcpyDeviceToHost) == hipSuccess ? 0 : MFR_E_LAUNCH;
+}
+#endif
 
 size_t mfr_wino_bf16x3_filter_bytes(int Cin, int Cout) { return (Cin <= 0 || Cout <= 0) ? 0 : wb_frag_bytes(Cin, Cout); }
 size_t mfr_wino_f16x2_filter_bytes(int Cin, int Cout) { return (Cin <= 0 || Cout <= 0) ? 0 : wb_frag_bytes(Cin, Cout) + (size_t)((Cout + 63) / 64) * 64 * 4; }

@@ -476,6 +476,7 @@ def test_bench_module_contract_pieces_importable():
     a = b.parse([])
     assert a.gpus == 1 and a.config == "sg_pnp" and a.steps > 0 and a.rpr_opts == "siamese,graph"
     for wl in (b.SgPnpWorkload, b.LoftrEmatWorkload):
-        assert isinstance(wl.dtype, str) and "bf16" in wl.dtype and isinstance(wl.metric, str) and isinstance(wl.workload, str)
+        dt = wl.dtype.fget(None)                            # (a property: the string names the arithmetic HIP.SPLIT selects)
+        assert isinstance(dt, str) and "f16" in dt and isinstance(wl.metric, str) and isinstance(wl.workload, str)
     c = b.census_summary()
     assert c["hard2"]["sg_pnp"]["pose_within_bar"] == c["hard2"]["sg_pnp"]["pairs"] and c["hard1"]["sg_pnp"]["inlier_index_sets_identical"] == 64
