@@ -381,6 +381,8 @@ class MapFreeScene:
             out_d[...] = d
         return g, d
 
+    has_gray_pair = True        # the loaders' fast path (an explicit capability: subclasses whose pairs are not (frame, frame) switch it off)
+
     def gray_pair(self, index, want_ref=True, out=None):
         """what the batched loaders need of sample `index`: (gray0 or None, depth0, gray1, depth1, K0, K1, pair_id, (name0, name1)), numpy arrays
         with the values of to_gray(self[index]['image0' / 'image1']) and its depth maps.  out = (g0, d0, g1, d1) destination arrays (entries
@@ -420,6 +422,7 @@ class MapFreeSceneMultiFrame(MapFreeScene):
       map frame does not fall inside that window (different sequence, or before the window, or after the query frame) -- the valid
       frame lists are taken BEFORE the overlap window is applied, like upstream.
     The device-tracking poses (poses_device.txt) only feed upstream's debug plot and are not read."""
+    has_gray_pair = False       # a pair's query is a TUPLE of frames here: the batched loaders take the generic per-sample route (ADVICE r4)
 
     def __init__(self, scene_root, resize, query_frames=9, estimated_depth=None, overlap_limits=None, black_white=False):
         import re
@@ -427,6 +430,7 @@ class MapFreeSceneMultiFrame(MapFreeScene):
         if T < 2:
             raise ValueError("query_frames must be >= 2 (use MapFreeScene for single-frame queries)")
         super().__init__(scene_root, resize, 1, estimated_depth, None, black_white)
+        self.shared_reference = False                           # (the single-frame pair list it was computed from is replaced below)
         self.query_frames, self.sample_factor = T, T + 1
         ov = os.path.join(self.scene_root, "overlaps.npz")
         if os.path.exists(ov):
@@ -593,7 +597,7 @@ def _pw_fill(task):
     sc = _PW["scenes"][si]
     sl = _PW["slots"][k]
     im = sl["images"].numpy()
-    if hasattr(sc, "gray_pair"):                            # gray planes / depth straight from the files' bytes into the slot (MapFreeScene)
+    if getattr(sc, "has_gray_pair", False):                 # gray planes / depth straight from the files' bytes into the slot (MapFreeScene)
         has_d = sl["depth0"] is not None
         fast = sc.gray_pair(i, want_ref, out=(im[2 * p, 0], sl["depth0"].numpy()[p] if has_d else None, im[2 * p + 1, 0],
                                               sl["depth1"].numpy()[p] if has_d else None))
@@ -686,8 +690,27 @@ class PairBatchLoader:
         else:
             self.batches = [[(si, i) for i in range(lo, min(lo + self.B, len(sc)))] for si, sc in enumerate(self.scenes) for lo in range(0, len(sc), self.B)]
 
+    _ref_ident = None
+
     def __len__(self):
         return len(self.batches)
+
+    def _ref_key(self, si, frame):
+        """(scene_root, reference frame, file identity): a scene regenerated at the same path (st_mtime_ns / st_size change) must not be served
+        the features cached for its previous content; scenes without files (synthetic stand-ins) key on the names alone"""
+        root = self.scenes[si].scene_root
+        k = (root, frame)
+        if self._ref_ident is None:
+            self._ref_ident = {}
+        ident = self._ref_ident.get(k)
+        if ident is None:
+            try:
+                st = os.stat(os.path.join(root, frame))
+                ident = (st.st_mtime_ns, st.st_size)
+            except (OSError, TypeError):
+                ident = ()
+            self._ref_ident[k] = ident
+        return (root, frame) + ident
 
     def _load(self, items):
         """decode the pairs of one batch STRAIGHT INTO the batch's (pinned) buffers: every worker thread decodes its pair, converts to
@@ -718,7 +741,7 @@ class PairBatchLoader:
 
         def fill(p, smp=None):
             sc_ = self.scenes[items[p][0]]
-            if smp is None and hasattr(sc_, "gray_pair"):      # gray planes / depth straight from the files' bytes into the batch buffers
+            if smp is None and getattr(sc_, "has_gray_pair", False):      # gray planes / depth straight from the files' bytes into the batch buffers
                 fast = sc_.gray_pair(items[p][1], True, out=(im_np[2 * p, 0], d0_np[p] if has_depth else None, im_np[2 * p + 1, 0],
                                                              d1_np[p] if has_depth else None))
                 if fast is not None:
@@ -758,7 +781,7 @@ class PairBatchLoader:
                     # identity of every pair's REFERENCE view (a val / test scene pairs one keyframe with all its queries, mapfree.py:148-165):
                     # what FusedPosePipeline keys its reference-view feature cache on
                     # -- only for scenes that DECLARE the sharing (`shared_reference`: MapFreeScene val / test); None = do not cache
-                    ref_keys=[(self.scenes[si].scene_root, m[4]) if getattr(self.scenes[si], "shared_reference", False) else None
+                    ref_keys=[self._ref_key(si, m[4]) if getattr(self.scenes[si], "shared_reference", False) else None
                               for (si, _), m in zip(items, meta)],
                     scene_id=sc.scene_id, scene_root=sc.scene_root, scene_index=items[-1][0], last_of_scene=bool(done and done[-1] == sc.scene_id))
 
@@ -807,7 +830,7 @@ class PairBatchLoader:
                     global_ids=torch.tensor([self.offsets[si] + i for si, i in items], dtype=torch.int64),
                     names=[m[3] for m in meta], scene_ids=[self.scenes[si].scene_id for si, _ in items],
                     scene_roots=[self.scenes[si].scene_root for si, _ in items], scenes_done=done,
-                    ref_keys=[(self.scenes[si].scene_root, m[4]) if getattr(self.scenes[si], "shared_reference", False) else None
+                    ref_keys=[self._ref_key(si, m[4]) if getattr(self.scenes[si], "shared_reference", False) else None
                               for (si, _), m in zip(items, meta)],
                     scene_id=sc.scene_id, scene_root=sc.scene_root, scene_index=items[-1][0], last_of_scene=bool(done and done[-1] == sc.scene_id),
                     _slot=(pr, k))

@@ -272,6 +272,15 @@ def predict_fused(cfg, split, output_root, pipeline=None, batch_pairs=None, resu
         land(True)
         for rows in host_rows.values():                     # (likewise: rows whose scene never reported its end)
             recs.extend(rows)
+    except BaseException:
+        # the pipeline or the loader raised: release the forked decode pool and the registered shared-memory ring, and land what finished scenes
+        # already produced (their pose files are this run's resume markers) before the error propagates
+        try:
+            land(True)
+        except Exception:
+            pass
+        loader.close()
+        raise
     finally:
         sys.setswitchinterval(old_switch)
     stats['loop_s'] = time.perf_counter() - stats['t0']   # (includes landing the last scenes' records)

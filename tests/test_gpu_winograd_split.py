@@ -64,7 +64,9 @@ def _ref(x, w, b, act, pool, residual=None):
     (1, 16, 64, 6, 33, 1, 1, 1, 0), (2, 8, 128, 5, 1, 1, 0, 1, 0), (1, 64, 64, 31, 35, 1, 1, 0, 0),
     # LoFTR backbone shapes: 196-channel stages, LeakyReLU, residual
     (1, 196, 196, 23, 34, 1, 0, 1, 1), (2, 196, 128, 20, 17, 2, 0, 1, 0), (1, 128, 128, 30, 44, 1, 0, 1, 1), (2, 8, 5, 9, 10, 2, 0, 1, 1),
-    (1, 256, 196, 45, 34, 2, 1, 1, 0), (1, 12, 40, 7, 9, 0, 0, 1, 1), (1, 128, 196, 136, 180, 1, 0, 1, 1)])
+    (1, 256, 196, 45, 34, 2, 1, 1, 0), (1, 12, 40, 7, 9, 0, 0, 1, 1), (1, 128, 196, 136, 180, 1, 0, 1, 1),
+    # more than 64 output channels with an ODD number of 64-channel groups (the 128-channel workgroup of the f16x2 kernel reads one group beyond the packed filter)
+    (1, 16, 160, 9, 33, 1, 0, 1, 0), (2, 32, 136, 8, 10, 1, 1, 1, 0), (1, 64, 192, 21, 70, 2, 0, 1, 1)])
 @pytest.mark.parametrize("split", SPLITS)
 def test_split_conv_vs_float64(B, ci, co, H, W, act, pool, bias, res, split):
     g = torch.Generator().manual_seed(B * 1000 + ci + H)

@@ -403,7 +403,9 @@ def test_pair_batch_loader_equals_the_per_sample_reader(tmp_path):
                 assert torch.equal(b["images"][2 * p, 0], to_gray(smp["image0"])) and torch.equal(b["images"][2 * p + 1, 0], to_gray(smp["image1"]))
                 assert torch.equal(b["depth0"][p], smp["depth0"]) and torch.equal(b["depth1"][p], smp["depth1"])
                 assert b["K0"].dtype == torch.float64 and torch.equal(b["K0"][p], smp["K_color0"]) and torch.equal(b["K1"][p], smp["K_color1"])
-                assert b["ref_keys"][p] == (scenes[si].scene_root, smp["pair_names"][0])      # every pair of these scenes shares its keyframe
+                assert b["ref_keys"][p][:2] == (scenes[si].scene_root, smp["pair_names"][0])  # every pair of these scenes shares its keyframe
+                st = os.stat(os.path.join(scenes[si].scene_root, smp["pair_names"][0]))
+                assert b["ref_keys"][p][2:] == (st.st_mtime_ns, st.st_size)                   # ... identified by its file, not only by its name
                 got += 1
         ld.close()
         assert got == 21
