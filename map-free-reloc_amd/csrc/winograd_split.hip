@@ -143,32 +143,27 @@ __device__ unsigned long long wb_prof[8][32];
 
 // What bounds this kernel (profiles/r05_pmc_conv1b.json, r05_conv1b_timeline.json): not memory (traffic 1.01 x algorithmic) and not the matrix pipe
 // (20 % busy with f16x2) but the SIMD's issue port -- a VALU / LDS / VMEM instruction costs ~4 cycles of the SIMD whichever wavefront issues it
-// and does NOT overlap an MFMA's 32: a K step costs a wavefront 24 x 32 + ~300 x 4 cycles, two wavefronts per SIMD, 3.7 - 4.6 k cycles measured.
-// So the lever is the instruction count per MFMA, and what sets it is how many output channels share one produced V:
-//   MB = 2 (round 4): 64 tiles x 64 output channels per workgroup, a wavefront = 2 positions x 2 channel blocks x 2 tile blocks;
-//   MB = 4 (round 5, f16x2, layers with more than 64 output channels): 32 tiles x 128 output channels -- the same 128 accumulators and the
-//          same 24 MFMAs per K step and wavefront, but ONE tile block: half the patch reads, row combinations and V splits per MFMA.  The
-//          filter fragments of four channel blocks do not fit beside the accumulators as three terms, so uq = uh 2^-11 is formed in
-//          registers (v_pk_mul_f16, exact) from the uh fragment instead of being loaded.
-template <bool POOL, bool F16, int MB>
+// and does NOT overlap an MFMA's 32: a K step costs a wavefront 24 x 32 + ~300 x 4 cycles, two wavefronts per SIMD, 3.7 - 4.6 k cycles measured
+// (219 VALU + 72 LDS + 16 VMEM instructions per 24 MFMAs in the loop body).  Around the loop: 17 % of a conv1b workgroup's time is the wait for
+// the first patches (HBM latency, nothing else resident on the CU) and 23 % the output transform, whose exchange is bound by the LDS store path
+// (128 KB per round through ds_write_b128).
+// Tried in round 5 and dropped (profiles/r05_ab_conv_128ch_workgroup.json): a 32-tile x 128-channel workgroup for layers with more than 64 output
+// channels (one tile block per wavefront instead of two: half the patch reads, row combinations and V splits per MFMA, uq formed in registers so
+// that four channel blocks of fragments fit).  Parity-green on every shape, but 6 - 11 % SLOWER on every layer (LoFTR 128 -> 128 at 360x272:
+// 2.55 -> 2.83 ms, 196 -> 196: 6.94 -> 7.38): twice the filter fragments per MFMA from L2, 2.25 x instead of 1.9 x patch read amplification and
+// four output rounds instead of two cost more than the saved VALU.
+template <bool POOL, bool F16>
 __global__ void __launch_bounds__(512, 2) wino_split_p8_kernel(
     const float *__restrict__ x, const uint4 *__restrict__ upk, const float *__restrict__ oscale, const float *__restrict__ bias, float *__restrict__ y,
-    const float *__restrict__ residual, int Cin, int Cout, int H, int W, int nbx, int nby, int S, int Sx, int ncg, int ncg64, int nks, int act, int chunk)
+    const float *__restrict__ residual, int Cin, int Cout, int H, int W, int nbx, int nby, int S, int Sx, int ncg, int nks, int act, int chunk)
 {
-    static_assert(MB == 2 || (MB == 4 && F16), "the 128-channel workgroup exists for the f16x2 arithmetic only");
-    constexpr int NB = 4 / MB;                              // tile blocks (32 tiles = 16 x 2) per workgroup
-    constexpr int ROWS = 4 * NB + 2, HR = ROWS / 2;         // staged input rows (output rows + 2 halo); rows per DMA instruction
-    constexpr int CH = ROWS * WB_RS, STAGE = 16 * CH;       // floats per staged channel / K step
-    constexpr int FT = (MB == 4) ? 2 : 3;                   // filter terms LOADED per fragment
-    constexpr int NCH = (NB == 2) ? 4 : 2;                  // output channels a lane finishes per round
-    // [2][STAGE] patch staging during the K loop (60 / 36 KB), the partials of one output round afterwards (128 / 64 KB)
-    __shared__ __attribute__((aligned(16))) float lds[NB * 16384];
-    // workgroup -> (spatial block, output group of 32 MB channels): every XCD walks its own contiguous raster range of Sx spatial blocks in
+    __shared__ __attribute__((aligned(16))) float lds[32768];
+    // workgroup -> (spatial block, 64-channel output group): every XCD walks its own contiguous raster range of Sx spatial blocks in
     // chunks of `chunk` blocks, and inside a chunk all blocks of one output group before the next group.  chunk = 1 is "output groups
     // innermost" (the groups of a block run back to back and share its patches in L2) -- right while the packed filters of ALL groups
     // fit the XCD's 4 MB L2 beside them; for the 196- / 256-channel layers they do not (5 - 6 MB: every fragment request missed L2,
     // 32 GB of fabric reads per launch against 4.9 GB algorithmic, profiles/r04_pmc_loftr_l1out2.json), so there a chunk is 8
-    // blocks: one group's fragments stay L2-resident for 8 workgroups and the chunk's patches (~2 MB) for all groups.
+    // blocks: one group's fragments (1.2 - 1.5 MB) stay L2-resident for 8 workgroups and the chunk's patches (~2 MB) for all groups.
     const int id = blockIdx.x;
     const int xcd = id & 7, jq = id >> 3;
     const int per = chunk * ncg;
@@ -186,16 +181,16 @@ __global__ void __launch_bounds__(512, 2) wino_split_p8_kernel(
     const int col = lane & 15, tysub = (lane >> 4) & 1, kg = lane >> 5;
     const int HW = H * W;
 
-    // ---- patch staging by LDS-DMA: per K step and channel a ROWS-row x 48-column window (columns 32 bx - 1 + cx, rows 4 NB by - 1 + r; 34 columns
-    // are used), fetched as 16-byte pieces: piece = lane, HR rows x 12 pieces per instruction, two instructions per channel; this wavefront
-    // stages input channels 2 w, 2 w + 1 of the step's 16
-    const int prow = lane / 12, pk = lane - 12 * prow;      // lanes >= 12 HR: no piece
+    // ---- patch staging by LDS-DMA: per K step and channel a 10-row x 48-column window (columns 32 bx - 1 + cx, rows 8 by - 1 + r; 34 x 10
+    // are used), fetched as 16-byte pieces: piece = lane (60 of 64 lanes), 5 rows x 12 pieces per instruction, two instructions per
+    // channel; this wavefront stages input channels 2 w, 2 w + 1 of the step's 16
+    const int prow = lane / 12, pk = lane - 12 * prow;      // lanes 60..63: prow = 5 -> no piece
     const int pix = 32 * bx - 1 + 4 * pk;                   // first column of this lane's piece
     unsigned voff[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-        const int iy = 4 * NB * by - 1 + HR * h + prow;
-        const bool ok = prow < HR && pk < 9 && iy >= 0 && iy < H && pix < W && pix + 3 >= 0;
+        const int iy = 8 * by - 1 + 5 * h + prow;
+        const bool ok = prow < 5 && pk < 9 && iy >= 0 && iy < H && pix < W && pix + 3 >= 0;
         voff[h] = ok ? (unsigned)(iy * W + max(pix, 0)) * 4u : WB_OOB;   // the piece that starts at column -1 is fetched from column 0 and shifted right by one in LDS (pfix)
     }
     const bool fixl = pix < 0;
@@ -214,23 +209,23 @@ __global__ void __launch_bounds__(512, 2) wino_split_p8_kernel(
     }
     const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) float *)lds;
     auto pdma = [&](int c, int buf) {
-        if (prow < HR) {
+        if (prow < 5) {
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const unsigned so = (unsigned)(16 * c + 2 * w + q) * (unsigned)HW * 4u;
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
-                    const unsigned m0v = lds0 + 4u * (unsigned)(buf * STAGE + (2 * w + q) * CH + (HR * h) * WB_RS);
+                    const unsigned m0v = lds0 + 4u * (unsigned)(buf * WB_STAGE + (2 * w + q) * WB_CH + (5 * h) * WB_RS);
                     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" :: "s"(m0v), "v"(voff[h]), "s"(xdesc), "s"(so) : "memory");
                 }
             }
         }
     };
     auto pfix = [&](int buf) {
-        if (edge && prow < HR && (fixl || keep != 0xfu)) {
+        if (edge && prow < 5 && (fixl || keep != 0xfu)) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                uint4 *pp = (uint4 *)(lds + buf * STAGE + (2 * w + (k >> 1)) * CH + (HR * (k & 1)) * WB_RS + lane * 4);
+                uint4 *pp = (uint4 *)(lds + buf * WB_STAGE + (2 * w + (k >> 1)) * WB_CH + (5 * (k & 1)) * WB_RS + lane * 4);
                 uint4 v = *pp;
                 if (fixl) v = make_uint4(0u, v.x, v.y, v.z);
                 v.x = (keep & 1u) ? v.x : 0u; v.y = (keep & 2u) ? v.y : 0u; v.z = (keep & 4u) ? v.z : 0u; v.w = (keep & 8u) ? v.w : 0u;
@@ -249,14 +244,14 @@ __global__ void __launch_bounds__(512, 2) wino_split_p8_kernel(
     const int ofa = (2 * tysub + ra) * WB_RS + 2 * col, ofb = (2 * tysub + rb) * WB_RS + 2 * col;    // tile block nb: + 4 nb WB_RS
     float wX[8], wY[8], wZ[8];
     auto wread = [&](int buf, int nb) {
-        const wb_lds_f32 *st = (const wb_lds_f32 *)lds + buf * STAGE + (8 * kg) * CH + 4 * nb * WB_RS;
+        const wb_lds_f32 *st = (const wb_lds_f32 *)lds + buf * WB_STAGE + (8 * kg) * WB_CH + 4 * nb * WB_RS;
 #pragma unroll
         for (int e0 = 0; e0 < 8; e0 += 4) {
             wb_f32x2 a2[4], b2[4];
             float a1[4], b1[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const wb_lds_f32 *ch = st + (e0 + e) * CH;
+                const wb_lds_f32 *ch = st + (e0 + e) * WB_CH;
                 // volatile: keeps hipcc from fusing the reads of a row into ds_read2_b64, which the LDS serves at a quarter of the rate of two
                 // ds_read_b64 (MI355X_MICROARCH.md, LDS table: 16 vs 2 + 2 cycles per wavefront)
                 a2[e] = *(const volatile wb_lds_f32x2 *)(ch + ofa + cX); a1[e] = *(const volatile wb_lds_f32 *)(ch + ofa + cZ);
@@ -293,50 +288,28 @@ __global__ void __launch_bounds__(512, 2) wino_split_p8_kernel(
         }
     };
 
-    // ---- filter fragments of positions (wi, 2 jp), (wi, 2 jp + 1): [jj][channel block][term]; the packed layout keeps 64-channel groups of
-    // [mb][term], a 128-channel workgroup spans two of them.  Buffer loads: the fragment index is wave-uniform (scalar offset), the only
-    // vector address is lane * 16; groups beyond the packed filter (an odd number of 64-groups) read as zeros.
-    const __amdgpu_buffer_rsrc_t rsF = __builtin_amdgcn_make_buffer_rsrc((void *)upk, 0, (int)(ncg64 * nks * WB_FRAGS_PER_KSTEP * 1024), WB_RSRC_FLAGS);
-    unsigned fbase[MB / 2];
-#pragma unroll
-    for (int g = 0; g < MB / 2; ++g) {
-        const int g64 = cg * (MB / 2) + g;
-        fbase[g] = g64 < ncg64 ? (unsigned)((g64 * nks * WB_FRAGS_PER_KSTEP + wi * 24 + jp * 12) * 1024) : WB_OOB;
-    }
+    // ---- filter fragments of positions (wi, 2 jp), (wi, 2 jp + 1): [jj][mb][term], 12 consecutive fragments of the packed layout.
+    // Buffer loads: the fragment index is wave-uniform (scalar offset), the only vector address is lane * 16.
+    const __amdgpu_buffer_rsrc_t rsF = __builtin_amdgcn_make_buffer_rsrc((void *)upk, 0, (int)(ncg * nks * WB_FRAGS_PER_KSTEP * 1024), WB_RSRC_FLAGS);
+    const unsigned fbase = (unsigned)((cg * nks * WB_FRAGS_PER_KSTEP + wi * 24 + jp * 12) * 1024);
     const unsigned lane16 = (unsigned)lane * 16u;
-    WbFrag F[2][MB][FT];
+    WbFrag F[2][2][3];
     auto aload = [&](int c, int jj) {
+        const unsigned so = fbase + (unsigned)((c * WB_FRAGS_PER_KSTEP + jj * 6) * 1024);
 #pragma unroll
-        for (int mb = 0; mb < MB; ++mb) {
-            const unsigned so = fbase[mb >> 1] + (unsigned)((c * WB_FRAGS_PER_KSTEP + jj * 6 + (mb & 1) * 3) * 1024);
+        for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-            for (int t = 0; t < FT; ++t)
-                F[jj][mb][t].q = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsF, lane16, so + (unsigned)(t * 1024), 0));
-        }
+            for (int t = 0; t < 3; ++t)
+                F[jj][mb][t].q = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsF, lane16, so + (unsigned)((mb * 3 + t) * 1024), 0));
     };
-    // partial products of one (position, tile block), small terms first; the channel blocks alternate
-    f32x16 acc[2][MB][NB];
-    auto phase = [&](int jj, int nb, const WbFrag (&vf)[3]) {
-        if (F16) {
-#pragma unroll
-            for (int mb = 0; mb < MB; ++mb) {               // uq vl
-                typedef _Float16 wb_h8 __attribute__((ext_vector_type(8)));
-                const uint4 uq = (FT == 3) ? F[jj][mb][FT - 1].q
-                                           : __builtin_bit_cast(uint4, __builtin_bit_cast(wb_h8, F[jj][mb][0].q) * (_Float16)(1.0f / SF_LOW_SCALE));
-                acc[jj][mb][nb] = SF_MFMA(uq, vf[1].q, acc[jj][mb][nb]);
-            }
-#pragma unroll
-            for (int mb = 0; mb < MB; ++mb) acc[jj][mb][nb] = SF_MFMA(F[jj][mb][1].q, vf[0].q, acc[jj][mb][nb]);      // ul vh
-#pragma unroll
-            for (int mb = 0; mb < MB; ++mb) acc[jj][mb][nb] = SF_MFMA(F[jj][mb][0].q, vf[0].q, acc[jj][mb][nb]);      // uh vh
-        } else {
-            constexpr int TA[6] = { 1, 0, 2, 0, 1, 0 }, TB[6] = { 1, 2, 0, 1, 0, 0 };
-#pragma unroll
-            for (int p = 0; p < 6; ++p)
-#pragma unroll
-                for (int mb = 0; mb < MB; ++mb) acc[jj][mb][nb] = WB_MFMA_BF(F[jj][mb][TA[p] < FT ? TA[p] : 0].v, vf[TB[p]].v, acc[jj][mb][nb]);
-        }
-    };
+    // partial products, small terms first (ta: filter term, tb: V term); the two channel blocks alternate
+#define WB8_PROD(jj, nb, vf, ta, tb) do { \
+        if (F16) { acc[jj][0][nb] = SF_MFMA(F[jj][0][ta].q, vf[tb].q, acc[jj][0][nb]); acc[jj][1][nb] = SF_MFMA(F[jj][1][ta].q, vf[tb].q, acc[jj][1][nb]); } \
+        else     { acc[jj][0][nb] = WB_MFMA_BF(F[jj][0][ta].v, vf[tb].v, acc[jj][0][nb]); acc[jj][1][nb] = WB_MFMA_BF(F[jj][1][ta].v, vf[tb].v, acc[jj][1][nb]); } } while (0)
+#define WB8_PHASE(jj, nb, vf) do { \
+        if (F16) { WB8_PROD(jj, nb, vf, 2, 1); WB8_PROD(jj, nb, vf, 1, 0); WB8_PROD(jj, nb, vf, 0, 0); }      /* uq vl, ul vh, uh vh */ \
+        else     { WB8_PROD(jj, nb, vf, 1, 1); WB8_PROD(jj, nb, vf, 0, 2); WB8_PROD(jj, nb, vf, 2, 0); \
+                   WB8_PROD(jj, nb, vf, 0, 1); WB8_PROD(jj, nb, vf, 1, 0); WB8_PROD(jj, nb, vf, 0, 0); } } while (0)
 #define WB8_VMCNT(n) __builtin_amdgcn_s_waitcnt(0x0F70 | ((n) & 15) | (((n) >> 4) << 14))      /* vmcnt(n) only; the builtin (not inline asm) so that hipcc's own wait bookkeeping sees it */
 
     // ---- prologue
@@ -348,25 +321,28 @@ __global__ void __launch_bounds__(512, 2) wino_split_p8_kernel(
     pfix(0);
     __syncthreads();
     WB_STAMP(2);
+    f32x16 acc[2][2][2];
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
-        for (int mb = 0; mb < MB; ++mb)
+        for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb)
+            for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[jj][mb][nb][r] = 0.f;
 
-    // ---- K loop, software-pipelined.  V is double-buffered (vfA / vfB) and every block of MFMAs is written together with the production of
-    // the NEXT block's V (NB = 2; NB = 1 drops S2 / S3):
+    // ---- K loop, software-pipelined.  A wavefront that alternates "produce V" and "its MFMAs" is blocked at the MFMA issue while the
+    // matrix pipe drains -- and with the barrier its SIMD partner is in the same phase at the same time, so nothing overlaps.
+    // tools/ubench/mfma_valu_bf16.hip: five VALU instructions per MFMA are free when they sit BETWEEN the MFMAs in program order.  So V is
+    // double-buffered (vfA / vfB) and every block of MFMAs is written together with the production of the NEXT block's V:
     //     S1  products (jj 0, nb 0; vfA)   +  V(jj 1, nb 0) -> vfB
     //     S2  products (jj 1, nb 0; vfB)   +  row combinations of tile block 1, V(jj 0, nb 1) -> vfA
     //     S3  products (jj 0, nb 1; vfA)   +  V(jj 1, nb 1) -> vfB;   fragments (jj 0) of the next step requested
     //     -- vmcnt: the next step's patches are in; border fix-up; barrier --
-    //     S4  products (jj 1, last nb; vfB) +  row combinations of tile block 0 of the NEXT step, V(jj 0, nb 0) -> vfA;
+    //     S4  products (jj 1, nb 1; vfB)   +  row combinations of tile block 0 of the NEXT step, V(jj 0, nb 0) -> vfA;
     //         fragments (jj 1) of the next step requested
     // Top of a step: vmcnt(0) (the step's fragments are in; hipcc would otherwise wait vmcnt(0) at their first use, i.e. for
-    // the DMAs it cannot see), then the patch DMAs of the step after go out: the rest of the step to land.
+    // the DMAs it cannot see), then the patch DMAs of the step after go out: three blocks of time to land.
     WbFrag vfA[3], vfB[3];
     wread(0, 0);
     vmake(vfA, 0);
@@ -376,57 +352,54 @@ __global__ void __launch_bounds__(512, 2) wino_split_p8_kernel(
         WB8_VMCNT(0);
         pdma(c + 1, (c + 1) & 1);
         vmake(vfB, 1);
-        phase(0, 0, vfA);
-        if (NB == 2) {
-            wread(c & 1, 1);
-            vmake(vfA, 0);
-            phase(1, 0, vfB);
-            vmake(vfB, 1);
-            phase(0, NB - 1, vfA);
-        }
+        WB8_PHASE(0, 0, vfA);
+        wread(c & 1, 1);
+        vmake(vfA, 0);
+        WB8_PHASE(1, 0, vfB);
+        vmake(vfB, 1);
+        WB8_PHASE(0, 1, vfA);
         aload(c + 1, 0);
         WB_STAMP(4 + 3 * (c & 3));
-        WB8_VMCNT(MB * FT);                                               // the four DMAs are older than the fragment loads just issued
+        WB8_VMCNT(6);                                                     // the four DMAs are older than the six fragment loads
         pfix((c + 1) & 1);
         WB_STAMP(5 + 3 * (c & 3));
         __syncthreads();
         WB_STAMP(6 + 3 * (c & 3));
         wread((c + 1) & 1, 0);
         vmake(vfA, 0);
-        phase(1, NB - 1, vfB);
+        WB8_PHASE(1, 1, vfB);
         aload(c + 1, 1);
     }
     WB_STAMP(16);
     WB8_VMCNT(0);
     vmake(vfB, 1);
-    phase(0, 0, vfA);
-    if (NB == 2) {
-        wread(c & 1, 1);
-        vmake(vfA, 0);
-        phase(1, 0, vfB);
-        vmake(vfB, 1);
-        phase(0, NB - 1, vfA);
-    }
-    phase(1, NB - 1, vfB);
+    WB8_PHASE(0, 0, vfA);
+    wread(c & 1, 1);
+    vmake(vfA, 0);
+    WB8_PHASE(1, 0, vfB);
+    vmake(vfB, 1);
+    WB8_PHASE(0, 1, vfA);
+    WB8_PHASE(1, 1, vfB);
     WB_STAMP(17);
+#undef WB8_PHASE
+#undef WB8_PROD
 #undef WB8_VMCNT
 
     // ---- output transform.  Row partials over j: pa = M0 + M1 + M2, pb = M1 - M2 - M3; wavefront (wi, 0) contributes (M0 + M1, M1),
-    // wavefront (wi, 1) contributes (M2, -(M2 + M3)).  One round per 32-channel block: part[row][jp][ab][nb][r4][lane] (float4 = registers
-    // 4 r4 .. 4 r4 + 3), 8 NB x 16 KB; wavefront q then finishes register group q >> 1 of the round -- NB = 2: tile block q & 1, all four
-    // channels of the group; NB = 1: channels 2 (q & 1), 2 (q & 1) + 1 of the group.
-    const int qnb = (NB == 2) ? (w & 1) : 0, qr4 = w >> 1, qk0 = (NB == 2) ? 0 : 2 * (w & 1);
+    // wavefront (wi, 1) contributes (M2, -(M2 + M3)).  Round mb: part[row][jp][ab][nb][r4][lane] (float4 = registers 4 r4 .. 4 r4 + 3),
+    // 8 x 16 KB; wavefront q then finishes tile block q & 1, register group q >> 1 (four channels) of the round.
+    const int qnb = w & 1, qr4 = w >> 1;
     const int tr = 2 * qnb + tysub;
-    const int ty = 2 * NB * by + tr, tx = 16 * bx + col;
+    const int ty = 4 * by + tr, tx = 16 * bx + col;
     const int Ho = POOL ? (H >> 1) : H, Wo = POOL ? (W >> 1) : W;
     const size_t cstride = (size_t)Ho * Wo;
     float4 *part = (float4 *)lds;
 #pragma unroll
-    for (int mb = 0; mb < MB; ++mb) {
-        __syncthreads();                                    // patch stages (mb = 0) / the previous round's partials are dead
-        WB_STAMP(18 + 4 * (mb & 1));
+    for (int mb = 0; mb < 2; ++mb) {
+        __syncthreads();                                    // patch stages (mb = 0) / the previous round's partials (mb = 1) are dead
+        WB_STAMP(18 + 4 * mb);
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
+        for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) {
                 float pa[4], pb[4];
@@ -437,51 +410,46 @@ __global__ void __launch_bounds__(512, 2) wino_split_p8_kernel(
                     pa[k] = jp ? acc[0][mb][nb][r] : sum;
                     pb[k] = jp ? -sum : acc[1][mb][nb][r];
                 }
-                part[((((wi * 2 + jp) * 2 + 0) * NB + nb) * 4 + r4) * 64 + lane] = make_float4(pa[0], pa[1], pa[2], pa[3]);
-                part[((((wi * 2 + jp) * 2 + 1) * NB + nb) * 4 + r4) * 64 + lane] = make_float4(pb[0], pb[1], pb[2], pb[3]);
+                part[((((wi * 2 + jp) * 2 + 0) * 2 + nb) * 4 + r4) * 64 + lane] = make_float4(pa[0], pa[1], pa[2], pa[3]);
+                part[((((wi * 2 + jp) * 2 + 1) * 2 + nb) * 4 + r4) * 64 + lane] = make_float4(pb[0], pb[1], pb[2], pb[3]);
             }
-        const int cob = cg * (32 * MB) + mb * 32;                   // first channel of the round's block
-        const int co0 = cob + 4 * kg + 8 * qr4 + qk0;               // this lane's channels of the round: co0 + k, k < NCH
-        float bv[NCH], os[NCH];
+        const int co0 = cg * 64 + mb * 32 + 4 * kg + 8 * qr4;       // this lane's four channels of the round: co0 + k
+        float bv[4], os[4];
 #pragma unroll
-        for (int k = 0; k < NCH; ++k) {
+        for (int k = 0; k < 4; ++k) {
             bv[k] = bias ? bias[min(co0 + k, Cout - 1)] : 0.f;
-            os[k] = (F16 && co0 + k < ncg64 * 64) ? oscale[co0 + k] : 1.0f;      // (padded to ncg64 * 64 entries)
+            os[k] = F16 ? oscale[co0 + k] : 1.0f;                   // (padded to ncg * 64 entries)
         }
-        WB_STAMP(19 + 4 * (mb & 1));
+        WB_STAMP(19 + 4 * mb);
         __syncthreads();
-        WB_STAMP(20 + 4 * (mb & 1));
-        const float *pq = (const float *)(part + (qnb * 4 + qr4) * 64 + lane) + qk0;      // + ((row * 2 + jp) * 2 + ab) * NB * 4 * 64 float4s
-        float P[4][2][NCH];
+        WB_STAMP(20 + 4 * mb);
+        const float4 *pq = part + (qnb * 4 + qr4) * 64 + lane;      // + ((row * 2 + jp) * 2 + ab) * 8 * 64
+        float4 P[4][2];
 #pragma unroll
         for (int row = 0; row < 4; ++row)
 #pragma unroll
             for (int ab = 0; ab < 2; ++ab) {
-                const float *pu = pq + (size_t)(((row * 2 + 0) * 2 + ab) * NB * 4 * 64) * 4, *pv = pq + (size_t)(((row * 2 + 1) * 2 + ab) * NB * 4 * 64) * 4;
-                if (NCH == 4) {
-                    const float4 u = *(const float4 *)pu, v = *(const float4 *)pv;
-                    P[row][ab][0] = u.x + v.x; P[row][ab][1] = u.y + v.y; P[row][ab][NCH - 2] = u.z + v.z; P[row][ab][NCH - 1] = u.w + v.w;
-                } else {
-                    const float2 u = *(const float2 *)pu, v = *(const float2 *)pv;
-                    P[row][ab][0] = u.x + v.x; P[row][ab][1] = u.y + v.y;
-                }
+                const float4 u = pq[(((row * 2 + 0) * 2 + ab) * 8) * 64], v = pq[(((row * 2 + 1) * 2 + ab) * 8) * 64];
+                P[row][ab] = make_float4(u.x + v.x, u.y + v.y, u.z + v.z, u.w + v.w);
             }
-        float Y[NCH][4];
+        float Y[4][4];
 #pragma unroll
-        for (int k = 0; k < NCH; ++k) {
+        for (int k = 0; k < 4; ++k) {
+#define WB_EL(v) (k == 0 ? (v).x : k == 1 ? (v).y : k == 2 ? (v).z : (v).w)
             // A^T applied along i:  Y[0][.] = P0 + P1 + P2,  Y[1][.] = P1 - P2 - P3
-            const float y0 = (P[0][0][k] + P[1][0][k]) + P[2][0][k], y1 = (P[0][1][k] + P[1][1][k]) + P[2][1][k];
-            const float y2 = (P[1][0][k] - P[2][0][k]) - P[3][0][k], y3 = (P[1][1][k] - P[2][1][k]) - P[3][1][k];
+            const float y0 = (WB_EL(P[0][0]) + WB_EL(P[1][0])) + WB_EL(P[2][0]), y1 = (WB_EL(P[0][1]) + WB_EL(P[1][1])) + WB_EL(P[2][1]);
+            const float y2 = (WB_EL(P[1][0]) - WB_EL(P[2][0])) - WB_EL(P[3][0]), y3 = (WB_EL(P[1][1]) - WB_EL(P[2][1])) - WB_EL(P[3][1]);
+#undef WB_EL
             if (F16) { Y[k][0] = __builtin_fmaf(y0, os[k], bv[k]); Y[k][1] = __builtin_fmaf(y1, os[k], bv[k]); Y[k][2] = __builtin_fmaf(y2, os[k], bv[k]); Y[k][3] = __builtin_fmaf(y3, os[k], bv[k]); }
             else     { Y[k][0] = y0 + bv[k]; Y[k][1] = y1 + bv[k]; Y[k][2] = y2 + bv[k]; Y[k][3] = y3 + bv[k]; }
         }
-        WB_STAMP(21 + 4 * (mb & 1));
+        WB_STAMP(21 + 4 * mb);
         float *yb = y + ((size_t)b * Cout + co0) * cstride;
-        const bool allco = cob + 32 <= Cout;
+        const bool allco = cg * 64 + mb * 32 + 32 <= Cout;
         if (POOL) {
-            float m[NCH];
+            float m[4];
 #pragma unroll
-            for (int k = 0; k < NCH; ++k) {
+            for (int k = 0; k < 4; ++k) {
                 m[k] = fmaxf(fmaxf(Y[k][0], Y[k][1]), fmaxf(Y[k][2], Y[k][3]));     // the activations are monotone: act(max) = max(act)
                 if (act == 1) m[k] = fmaxf(m[k], 0.f);
                 else if (act == 2) m[k] = m[k] > 0.f ? m[k] : 0.01f * m[k];
@@ -489,7 +457,7 @@ __global__ void __launch_bounds__(512, 2) wino_split_p8_kernel(
             if (ty < Ho && tx < Wo) {
                 float *yo = yb + (size_t)ty * Wo + tx;
 #pragma unroll
-                for (int k = 0; k < NCH; ++k)
+                for (int k = 0; k < 4; ++k)
                     if (allco || co0 + k < Cout) yo[(size_t)k * cstride] = m[k];
             }
         } else {
@@ -498,7 +466,7 @@ __global__ void __launch_bounds__(512, 2) wino_split_p8_kernel(
             if (residual) {
                 const float *rb0 = residual + ((size_t)b * Cout + co0) * cstride + (size_t)oy * W + ox;
 #pragma unroll
-                for (int k = 0; k < NCH; ++k)
+                for (int k = 0; k < 4; ++k)
                     if (allco || co0 + k < Cout) {
                         const float *ro = rb0 + (size_t)k * cstride;
                         if (r0 && c0) Y[k][0] += ro[0];
@@ -508,7 +476,7 @@ __global__ void __launch_bounds__(512, 2) wino_split_p8_kernel(
                     }
             }
 #pragma unroll
-            for (int k = 0; k < NCH; ++k)
+            for (int k = 0; k < 4; ++k)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     if (act == 1) Y[k][q] = fmaxf(Y[k][q], 0.f);
@@ -518,14 +486,14 @@ __global__ void __launch_bounds__(512, 2) wino_split_p8_kernel(
             const bool interior = allco && r0 && r1 && c1 && !(W & 1);     // per lane; the common case: two float2 stores per channel
             if (interior) {
 #pragma unroll
-                for (int k = 0; k < NCH; ++k) {
+                for (int k = 0; k < 4; ++k) {
                     float *yo = yo0 + (size_t)k * cstride;
                     *(float2 *)yo = make_float2(Y[k][0], Y[k][1]);
                     *(float2 *)(yo + W) = make_float2(Y[k][2], Y[k][3]);
                 }
             } else
 #pragma unroll
-            for (int k = 0; k < NCH; ++k) {
+            for (int k = 0; k < 4; ++k) {
                 if (!(allco || co0 + k < Cout)) continue;
                 float *yo = yo0 + (size_t)k * cstride;
                 if (c1) {
@@ -574,10 +542,8 @@ static int wb_conv(const float *x, const void *upk, const float *bias, const flo
     if (!x || !upk || !y || B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || act < 0 || act > 2) return MFR_E_ARG;
     if (pool && (H < 2 || W < 2 || residual)) return MFR_E_ARG;
     if ((size_t)4 * Cin * H * W >= 0x7fffffffull) return MFR_E_ARG;    // one image must fit a 2 GB buffer descriptor
-    // f16x2, more than 64 output channels: 32 tiles x 128 channels per workgroup (MB = 4); else 64 tiles x 64 channels
-    const bool wide = F16 && Cout > 64;
-    const int nbx = ((W + 1) / 2 + 15) / 16, nby = wide ? ((H + 1) / 2 + 1) / 2 : ((H + 1) / 2 + 3) / 4;
-    const int ncg64 = (Cout + 63) / 64, ncg = wide ? (Cout + 127) / 128 : ncg64, nks = (Cin + 15) / 16;
+    const int nbx = ((W + 1) / 2 + 15) / 16, nby = ((H + 1) / 2 + 3) / 4;
+    const int ncg = (Cout + 63) / 64, nks = (Cin + 15) / 16;
     const long long S = (long long)nbx * nby * B, Sx = (S + 7) / 8;
     const size_t fb = wb_frag_bytes(Cin, Cout);
     const int chunk = (fb > (size_t)(2u << 20)) ? 8 : 1;               // packed filters of all groups vs half an XCD's L2
@@ -585,14 +551,8 @@ static int wb_conv(const float *x, const void *upk, const float *bias, const flo
     if (grid > 0x7fffffffll || fb >= 0x7fffffffull) return MFR_E_ARG;
     const float *oscale = F16 ? (const float *)((const char *)upk + fb) : nullptr;
     hipStream_t st = (hipStream_t)stream;
-#define WB_GO(P, M) hipLaunchKernelGGL((wino_split_p8_kernel<P, F16, M>), dim3((unsigned)grid), dim3(512), 0, st, x, (const uint4 *)upk, oscale, bias, y, residual, Cin, Cout, H, W, nbx, nby, (int)S, (int)Sx, ncg, ncg64, nks, act, chunk)
-    if constexpr (F16) {
-        if (wide) { if (pool) WB_GO(true, 4); else WB_GO(false, 4); }
-        else      { if (pool) WB_GO(true, 2); else WB_GO(false, 2); }
-    } else {
-        if (pool) WB_GO(true, 2); else WB_GO(false, 2);
-    }
-#undef WB_GO
+    if (pool) hipLaunchKernelGGL((wino_split_p8_kernel<true, F16>), dim3((unsigned)grid), dim3(512), 0, st, x, (const uint4 *)upk, oscale, bias, y, residual, Cin, Cout, H, W, nbx, nby, (int)S, (int)Sx, ncg, nks, act, chunk);
+    else      hipLaunchKernelGGL((wino_split_p8_kernel<false, F16>), dim3((unsigned)grid), dim3(512), 0, st, x, (const uint4 *)upk, oscale, bias, y, residual, Cin, Cout, H, W, nbx, nby, (int)S, (int)Sx, ncg, nks, act, chunk);
     CHECK_LAUNCH();
     return 0;
 }
