@@ -233,6 +233,15 @@ int mfr_sp_sample_descriptors(const float *dense_nhwc, int B, int Hc, int Wc, co
 size_t mfr_gemm_f16x2_pack_bytes(int N, int K);
 int mfr_gemm_f16x2_pack(const float *w, int N, int K, void *packed, void *stream);
 int mfr_gemm_f16x2(const float *x, int ldx, const void *packed_w, const float *bias, float *y, int ldy, int M, int N, int K, int flags, void *stream);
+/*   mfr_conv_igemm_f16x2   implicit-GEMM convolution on NCHW images in the f16x2 arithmetic (csrc/gemm_split.hip): the strided / 1x1 / 7x7
+ *                          convolutions of the matcher backbones (LoFTR's conv1, the stride-2 3x3 and 1x1 of layer2.0 / layer3.0, the FPN's 1x1
+ *                          lateral and output convolutions; rounds 1-4: MIOpen / hipBLASLt).  y [B,Cout,Ho,Wo] = act(conv(x [B,Cin,H,W], w, stride,
+ *                          pad) + bias), Ho = (H + 2 pad - KH) / stride + 1; relu != 0: ReLU; bias may be NULL.  packed_w = mfr_gemm_f16x2_pack of
+ *                          the [Cout, K] matrix with K = mfr_conv_igemm_k(Cin, KH, KW) and k = (dy KW + dx) * Cpad + ci, Cpad = Cin rounded up to 32
+ *                          (zero columns for ci >= Cin); Cin == 1: k = dy KW + dx, zero columns up to K. */
+int mfr_conv_igemm_k(int Cin, int KH, int KW);
+int mfr_conv_igemm_f16x2(const float *x, const void *packed_w, const float *bias, float *y, int B, int Cin, int H, int W, int Cout, int KH, int KW,
+                         int stride, int pad, int relu, void *stream);
 size_t mfr_gemm_bf16x3_pack_bytes(int N, int K);
 int mfr_gemm_bf16x3_pack(const float *w, int N, int K, void *packed, void *stream);
 int mfr_gemm_bf16x3(const float *x, int ldx, const void *packed_w, const float *bias, float *y, int ldy, int M, int N, int K, int flags, void *stream);

@@ -566,6 +566,162 @@ __global__ void __launch_bounds__(256, 2) gemm_split_d_kernel(const float *__res
 #undef GD_TILE
 }
 
+// ---- implicit-GEMM convolution on NCHW images (round 5): what the matcher backbones' strided / 1x1 / 7x7 convolutions run ----------------------
+// Reference call site: LoFTR_matcher (etc/feature_matching_baselines/matchers.py:16-19,50) -> the un-vendored ResNet-FPN backbone: conv1 (7x7, stride 2,
+// 1 -> 128), the first 3x3 convolution and the 1x1 downsample of layer2.0 / layer3.0 (stride 2), the 1x1 lateral / output convolutions of the FPN
+// (SURVEY.md Appendix A.4); rounds 1-4 ran them as library convolutions / batched GEMMs (MIOpen, hipBLASLt: 16 % of the LoFTR step).
+//     out[b, co, oy, ox] = act( sum_k W[co, k] X_k(b, oy, ox) + bias[co] ),       f16x2 arithmetic (split_f16.h), fp32 accumulate
+// K order -- MODE 0 (Cin >= 2): k = tap * Cpad + ci, Cpad = Cin rounded up to 32, X_k = in[b, ci, s oy + dy - pad, s ox + dx - pad]  (a K step = one tap,
+//            32 consecutive input channels);  MODE 1 (Cin == 1): k = tap, X_k = in[b, 0, s oy + dy - pad, s ox + dx - pad]  (a K step = 32 taps).
+// Zero padding and channels / taps beyond the real ones come out of the buffer range check (offset beyond the image -> 0).
+// The weight matrix [Cout, K] is packed by mfr_gemm_f16x2_pack (same tile images as the linear layers, per-output-channel scale).
+// Mapping: workgroup = 128 output channels x 128 consecutive output pixels (raster order) of ONE image, 4 wavefronts as 2 x 2 of 64 x 64.  The MFMA's
+// first operand is the WEIGHT fragment, so an accumulator holds 32 pixels along the lanes and channels along its registers: NCHW stores of 128
+// bytes.  X staging: a thread owns (pixel, k group of 8) -- eight 4-byte loads whose lanes are consecutive pixels (coalesced along x, half the
+// sectors used at stride 2), split in registers, one 16-byte LDS unit per term; W through registers.  One tile per workgroup, loads one K step ahead.
+template <int MODE, bool RELU>
+__global__ void __launch_bounds__(256, 2) conv_igemm_f16x2_kernel(const float *__restrict__ X, const uint4 *__restrict__ Wp, const float *__restrict__ oscale,
+                                                                  const float *__restrict__ bias, float *__restrict__ Y, int B, int Cin, int H, int W, int Cout,
+                                                                  int Ho, int Wo, int KH, int KW, int stride, int pad, int nkb, int cblocks, int nnb, int npt)
+{
+    constexpr int XT = 2, WT = 2;
+    __shared__ uint4 lds[(XT + WT) * GB_TERM_UNITS];
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid >> 1, wn = wid & 1;                  // channel half, pixel half
+    // channel blocks innermost: the workgroups that share a pixel tile run back to back (its input stays in L2)
+    const int nb = blockIdx.x % nnb;
+    const int pt = (blockIdx.x / nnb) % npt, b = blockIdx.x / (nnb * npt);
+    const int HW = H * W, HoWo = Ho * Wo;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)(X + (size_t)b * Cin * HW), 0, Cin * HW * 4, GB_RSRC_FLAGS);
+
+    // X staging: unit u = tid + 256 i -> pixel u & 127 of the tile, k group u >> 7 (wave-uniform)
+    int xdst[2], kg[2];
+    int iy0[2], ix0[2];                                     // input coordinates of tap (0, 0) for this thread's pixel (the same pixel for both units)
+    {
+        const int p = pt * 128 + (tid & 127);
+        const int oy = p / Wo, ox = p - oy * Wo;
+        const bool pv = p < HoWo;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            kg[i] = __builtin_amdgcn_readfirstlane((tid >> 7) + 2 * i);
+            xdst[i] = kg[i] * GB_KG_STRIDE + (tid & 127);
+            iy0[i] = pv ? oy * stride - pad : -(1 << 20);   // pixels beyond the image: every tap out of range
+            ix0[i] = ox * stride - pad;
+        }
+    }
+    int wdst[2 * WT];
+#pragma unroll
+    for (int i = 0; i < 2 * WT; ++i) {
+        const int u = tid + 256 * i, term = u / 512, kgw = (u % 512) / 128, f = u % 128;
+        wdst[i] = (XT + term) * GB_TERM_UNITS + kgw * GB_KG_STRIDE + f;
+    }
+    const uint4 *wtile = Wp + (size_t)nb * nkb * GB_W_TILE_UNITS(true) + tid;
+
+    float xr[2][8];
+    uint4 w0, w1, w2, w3;
+    auto gload = [&](int kb) {
+        if (MODE == 0) {
+            const int tap = kb / cblocks, c0 = (kb - tap * cblocks) * 32;
+            const int dy = tap / KW, dx = tap - dy * KW;
+            const int iy = iy0[0] + dy, ix = ix0[0] + dx;
+            const unsigned vo = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? (unsigned)(iy * W + ix) * 4u : 0x80000000u;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int e = 0; e < 8; ++e)                  // channels >= Cin: the scalar offset is beyond the image's range -> 0
+                    xr[i][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, vo, (unsigned)(c0 + 8 * kg[i] + e) * (unsigned)HW * 4u, 0));
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int tap = kb * 32 + 8 * kg[i] + e;
+                    const int dy = tap / KW, dx = tap - dy * KW;
+                    const int iy = iy0[0] + dy, ix = ix0[0] + dx;
+                    const unsigned vo = (tap < KH * KW && iy >= 0 && iy < H && ix >= 0 && ix < W) ? (unsigned)(iy * W + ix) * 4u : 0x80000000u;
+                    xr[i][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, vo, 0, 0));
+                }
+        }
+        const uint4 *wt_ = wtile + (size_t)kb * GB_W_TILE_UNITS(true);
+        w0 = wt_[0]; w1 = wt_[256]; w2 = wt_[512]; w3 = wt_[768];
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            unsigned h[4], l[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) sf_split2(xr[i][2 * q], xr[i][2 * q + 1], SF_LOW_SCALE, h[q], l[q]);
+            lds[0 * GB_TERM_UNITS + xdst[i]] = make_uint4(h[0], h[1], h[2], h[3]);
+            lds[1 * GB_TERM_UNITS + xdst[i]] = make_uint4(l[0], l[1], l[2], l[3]);
+        }
+        lds[wdst[0]] = w0; lds[wdst[1]] = w1; lds[wdst[2]] = w2; lds[wdst[3]] = w3;
+    };
+
+    f32x16 acc[2][2];                                       // [channel block i][pixel block j]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int wrow = (lane >> 5) * GB_KG_STRIDE + 64 * wm + (lane & 31);      // weight fragment rows (channels)
+    const int prow = (lane >> 5) * GB_KG_STRIDE + 64 * wn + (lane & 31);      // X fragment rows (pixels)
+
+    gload(0);
+    for (int kb = 0; kb < nkb; ++kb) {
+        __syncthreads();                                    // the previous step's fragment reads are done
+        lstore();
+        __syncthreads();
+        gload(min(kb + 1, nkb - 1));                        // in flight during the MFMAs below (the last step re-reads its own tile)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            uint4 wh[2], wl[2], xh[2], xl[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                wh[i] = lds[(XT + 0) * GB_TERM_UNITS + 2 * ks * GB_KG_STRIDE + wrow + 32 * i];
+                wl[i] = lds[(XT + 1) * GB_TERM_UNITS + 2 * ks * GB_KG_STRIDE + wrow + 32 * i];
+                xh[i] = lds[0 * GB_TERM_UNITS + 2 * ks * GB_KG_STRIDE + prow + 32 * i];
+                xl[i] = lds[1 * GB_TERM_UNITS + 2 * ks * GB_KG_STRIDE + prow + 32 * i];
+            }
+            // small terms first: wq xl, wl xh, wh xh; the four accumulators alternate
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const uint4 wq = gb_wq(wh[i]);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = SF_MFMA(wq, xl[j], acc[i][j]);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = SF_MFMA(wl[i], xh[j], acc[i][j]);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = SF_MFMA(wh[i], xh[j], acc[i][j]);
+        }
+    }
+
+    // epilogue: register r of tile (i, j): channel 64 wm + 32 i + (r & 3) + 8 (r >> 2) + 4 (lane >> 5), pixel 64 wn + 32 j + (lane & 31)
+    float *yb = Y + (size_t)b * Cout * HoWo;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = nb * GB_BN + 64 * wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (co >= Cout) continue;
+            const float os = oscale[co], bv = bias ? bias[co] : 0.f;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int p = pt * 128 + 64 * wn + 32 * j + (lane & 31);
+                if (p >= HoWo) continue;
+                float v = __builtin_fmaf(acc[i][j][r], os, bv);
+                if (RELU) v = fmaxf(v, 0.f);
+                yb[(size_t)co * HoWo + p] = v;
+            }
+        }
+}
+
 // ---- host ------------------------------------------------------------------------------------------------------------------------------------
 static size_t gb_tile_bytes(int N, int K, bool f16) { return (size_t)((N + GB_BN - 1) / GB_BN) * (K / GB_BK) * GB_W_TILE_UNITS(f16) * 16; }
 
@@ -662,6 +818,34 @@ int mfr_gemm_bf16x3(const float *x, int ldx, const void *packed_w, const float *
 int mfr_gemm_f16x2(const float *x, int ldx, const void *packed_w, const float *bias, float *y, int ldy, int M, int N, int K, int flags, void *stream)
 {
     return gb_launch<true>(x, ldx, packed_w, bias, y, ldy, M, N, K, flags, stream);
+}
+
+int mfr_conv_igemm_k(int Cin, int KH, int KW)
+{
+    if (Cin <= 0 || KH <= 0 || KW <= 0) return 0;
+    return Cin == 1 ? (KH * KW + 31) / 32 * 32 : KH * KW * ((Cin + 31) / 32 * 32);
+}
+
+int mfr_conv_igemm_f16x2(const float *x, const void *packed_w, const float *bias, float *y, int B, int Cin, int H, int W, int Cout, int KH, int KW,
+                         int stride, int pad, int relu, void *stream)
+{
+    if (!x || !packed_w || !y || B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0 || KH <= 0 || KW <= 0 || stride <= 0 || pad < 0) return MFR_E_ARG;
+    if ((size_t)4 * Cin * H * W >= 0x7fffffffull) return MFR_E_ARG;    // one image must fit a 2 GB buffer descriptor
+    const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
+    if (Ho <= 0 || Wo <= 0) return MFR_E_ARG;
+    const int K = mfr_conv_igemm_k(Cin, KH, KW), nkb = K / GB_BK, cblocks = (Cin + 31) / 32;
+    const int nnb = (Cout + GB_BN - 1) / GB_BN, npt = (Ho * Wo + 127) / 128;
+    const long long grid = (long long)B * npt * nnb;
+    if (grid > 0x7fffffffll) return MFR_E_ARG;
+    const size_t tb = gb_tile_bytes(Cout, K, true);
+    const float *oscale = (const float *)((const char *)packed_w + tb);
+    hipStream_t st = (hipStream_t)stream;
+#define GB_GO(M_, R_) hipLaunchKernelGGL((conv_igemm_f16x2_kernel<M_, R_>), dim3((unsigned)grid), dim3(256), 0, st, x, (const uint4 *)packed_w, oscale, bias, y, B, Cin, H, W, Cout, Ho, Wo, KH, KW, stride, pad, nkb, cblocks, nnb, npt)
+    if (Cin == 1) { if (relu) GB_GO(1, true); else GB_GO(1, false); }
+    else          { if (relu) GB_GO(0, true); else GB_GO(0, false); }
+#undef GB_GO
+    CHECK_LAUNCH();
+    return 0;
 }
 
 }  // extern "C"

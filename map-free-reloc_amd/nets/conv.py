@@ -65,3 +65,40 @@ class WinoConv3x3:
             _lib.check(lib.mfr_conv3x3_wino(_lib.ptr(x), _lib.ptr(self.u_exact), _lib.ptr(self.b), res, B, C, self.co, H, W, int(act), int(pool),
                                             _lib.ptr(y), _lib.stream_ptr()), "mfr_conv3x3_wino")
         return y
+
+
+class IgemmConv:
+    """any other convolution of the backbones (strided 3x3, 1x1, 7x7) as ONE launch of the implicit-GEMM kernel (csrc/gemm_split.hip,
+    mfr_conv_igemm_f16x2): the weight is laid out as the [Cout, K] matrix the kernel contracts over -- k = (dy KW + dx) * Cpad + ci with the input
+    channels padded to a multiple of 32 (Cin == 1: k = dy KW + dx) -- and packed once with the linear layers' packer."""
+
+    def __init__(self, weight, bias, stride=1, padding=None):
+        lib = _lib.load(require_gpu=True)
+        co, ci, kh, kw = (int(v) for v in weight.shape)
+        self.co, self.ci, self.kh, self.kw = co, ci, kh, kw
+        self.stride, self.pad = int(stride), (kh // 2 if padding is None else int(padding))
+        K = lib.mfr_conv_igemm_k(ci, kh, kw)
+        w = weight.detach().float()
+        if ci == 1:
+            m = torch.zeros(co, K, dtype=torch.float32, device=w.device)
+            m[:, :kh * kw] = w.reshape(co, kh * kw)
+        else:
+            cpad = K // (kh * kw)
+            m = torch.zeros(co, kh * kw, cpad, dtype=torch.float32, device=w.device)
+            m[:, :, :ci] = w.permute(0, 2, 3, 1).reshape(co, kh * kw, ci)
+            m = m.reshape(co, K)
+        nb = lib.mfr_gemm_f16x2_pack_bytes(co, K)
+        self.packed = torch.empty(nb, dtype=torch.uint8, device=w.device)
+        _lib.check(lib.mfr_gemm_f16x2_pack(_lib.ptr(m.contiguous()), co, K, _lib.ptr(self.packed), _lib.stream_ptr()), "mfr_gemm_f16x2_pack")
+        self.b = None if bias is None else bias.contiguous().float()
+
+    def __call__(self, x, relu=False):
+        lib = _lib.load()
+        x = x.contiguous()
+        B, C, H, W = x.shape
+        assert C == self.ci and x.dtype == torch.float32
+        Ho, Wo = (H + 2 * self.pad - self.kh) // self.stride + 1, (W + 2 * self.pad - self.kw) // self.stride + 1
+        y = torch.empty(B, self.co, Ho, Wo, dtype=torch.float32, device=x.device)
+        _lib.check(lib.mfr_conv_igemm_f16x2(_lib.ptr(x), _lib.ptr(self.packed), _lib.ptr(self.b), _lib.ptr(y), B, C, H, W, self.co, self.kh, self.kw,
+                                            self.stride, self.pad, 1 if relu else 0, _lib.stream_ptr()), "mfr_conv_igemm_f16x2")
+        return y

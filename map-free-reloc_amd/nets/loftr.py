@@ -64,13 +64,18 @@ class LoFTRHIP:
         # stride-1 3x3 convolutions go through the fused Winograd/MFMA kernel (csrc/winograd_conv.hip): transformed
         # filters packed once here; BatchNorm is already folded into (w, b).  options CONV = "miopen" keeps the library path.
         self.upk = {}
+        self.igemm = {}
         lib = _lib.load()
         if options.get("CONV") == "wino":
-            from .conv import WinoConv3x3
+            from .conv import IgemmConv, WinoConv3x3
+            own_rest = options.get("SPLIT") == "f16x2"                   # the implicit-GEMM kernel exists in the f16x2 arithmetic
+            strides = {"conv1": 2, "layer2.0.c1": 2, "layer2.0.ds": 2, "layer3.0.c1": 2, "layer3.0.ds": 2}
             for name, (cw, cb) in w.items():
-                if tuple(cw.shape[2:]) != (3, 3) or name.endswith(".ds") or name == "conv1":
-                    continue
-                self.upk[name] = WinoConv3x3(cw, cb)                     # both packed filter forms; kernel chosen per shape (nets/conv.py)
+                if tuple(cw.shape[2:]) == (3, 3) and name not in strides:
+                    self.upk[name] = WinoConv3x3(cw, cb)                 # both packed filter forms; kernel chosen per shape (nets/conv.py)
+                elif own_rest:
+                    # strided 3x3, 7x7 and every 1x1 convolution: one launch of the implicit-GEMM kernel each (rounds 1-4: MIOpen / hipBLASLt)
+                    self.igemm[name] = IgemmConv(cw, cb, strides.get(name, 1))
 
         def encoder(prefix, n):
             layers = []
@@ -95,6 +100,9 @@ class LoFTRHIP:
         cw, cb = self.w[name]
         if stride == 1 and name in self.upk:
             return self.upk[name](x, act={None: 0, "relu": 1, "leaky": 2}[act], residual=residual)
+        if name in self.igemm and residual is None and act in (None, "relu"):
+            assert self.igemm[name].stride == stride
+            return self.igemm[name](x, relu=act == "relu")
         if cw.shape[-1] == 1:
             # 1x1 convolutions (FPN lateral / output convs, the stride-2 downsample of a BasicBlock) are plain matrix products:
             # one batched library GEMM [Cout,Cin] x [Cin,HW] per image; stride 2 = the same on the even-pixel sub-grid
