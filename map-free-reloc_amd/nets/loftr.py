@@ -92,6 +92,7 @@ class LoFTRHIP:
         self.down_proj = (dev(sd["fine_preprocess.down_proj.weight"]), dev(sd["fine_preprocess.down_proj.bias"]))
         self.merge_feat = (dev(sd["fine_preprocess.merge_feat.weight"]), dev(sd["fine_preprocess.merge_feat.bias"]))
         self._ws_la = self._ws_cm = None
+        self._fine_lin = None
         self._pe = {}
 
     # ------------------------------------------------------------------ backbone (torch / MIOpen)
@@ -337,13 +338,20 @@ class LoFTRHIP:
             win = torch.empty(2 * M, WW, 128, dtype=torch.float32, device=dev)
             self.gather_windows(ff_nhwc, (2 * b_ids).int(), mi.int(), wc, stride, out=win[:M])
             self.gather_windows(ff_nhwc, (2 * b_ids + 1).int(), mj.int(), wc, stride, out=win[M:])
-            fcw = F.linear(torch.cat([f0[b_ids, mi], f1[b_ids, mj]], 0), *self.down_proj)
-            # merge_feat(cat[window, coarse]) = window Wa^T + (coarse Wb^T + b): the coarse half is constant over the 25 taps
-            wmf, bmf = self.merge_feat
-            cw = torch.addmm(bmf, fcw, wmf[:, 128:].t())
+            # down_proj on the matched coarse features, merge_feat(cat[window, coarse]) = window Wa^T + (coarse Wb^T + b): the coarse half is
+            # constant over the 25 taps.  All three products through csrc/gemm_split.hip (rounds 1-4: library GEMMs); the window product lands
+            # in the left half of the fine transformer's [x | message] operand, the per-window constant is added in place.
+            if self._fine_lin is None:
+                from .linear import SplitLinear
+                wmf, bmf = self.merge_feat
+                self._fine_lin = (SplitLinear(self.down_proj[0], self.down_proj[1]), SplitLinear(wmf[:, 128:].contiguous(), bmf),
+                                  SplitLinear(wmf[:, :128].contiguous()))
+            lin_down, lin_coarse, lin_win = self._fine_lin
+            cw = lin_coarse(lin_down(torch.cat([f0[b_ids, mi], f1[b_ids, mj]], 0)))
             xf = torch.empty(2, M * WW, 256, dtype=torch.float32, device=dev)
-            torch.add(torch.mm(win.view(2 * M * WW, 128), wmf[:, :128].t()).view(2 * M, WW, 128), cw[:, None, :],
-                      out=xf.view(2 * M, WW, 256)[..., :128])
+            lin_win(win.view(2 * M * WW, 128), out=xf.view(2 * M * WW, 256)[:, :128])
+            xw = xf.view(2 * M, WW, 256)[..., :128]
+            xw += cw[:, None, :]
             self._transformer(self.fine, xf, self.fine_attention if self.W == 5 else self._torch_linear_attention(8), M, WW)
             # FineMatching: centre-feature correlation, softmax, spatial expectation and the sub-pixel update in one kernel
             self.fine_match(xf, M, (b_ids * L0 + slot).int(), k1, pts1, float((self.W // 2) * (H // Hf)))

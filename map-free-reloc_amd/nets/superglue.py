@@ -72,6 +72,7 @@ class SuperGlueHIP:
         fw = fold_weights(state_dict, n_layers)
         dev = lambda t: t.to(self.device).contiguous()
         self.kenc = [(dev(w), dev(b)) for w, b in fw["kenc"]]
+        self.kenc_lin = [SplitLinear(w, b) for w, b in self.kenc[1:]]
         self.layers = [dict(wqkv=dev(L["wqkv"]), bqkv=dev(L["bqkv"]), w1t=dev(L["w1"]).t(), b1=dev(L["b1"]), w2t=dev(L["w2"]).t(),
                             cross=L["cross"]) for L in fw["layers"]]
         # the three GEMMs of a layer through csrc/gemm_split.hip (weights split / packed once here); the plain tensors above stay for
@@ -130,11 +131,13 @@ class SuperGlueHIP:
             self._size[key] = torch.tensor([float(W), float(H)], device=kpts.device)
         size = self._size[key]
         kn = (kpts - size / 2) / (float(max(W, H)) * 0.7)                             # normalize_keypoints
-        h = torch.cat([kn, scores.unsqueeze(-1)], -1)
-        for i, (w, b) in enumerate(self.kenc):
-            h = F.linear(h, w, b)
-            if i < len(self.kenc) - 1:
-                h = F.relu_(h)
+        # keypoint encoder MLP(3 -> 32 -> 64 -> 128 -> 256).  First layer (K = 3): three broadcast multiply-adds in a fixed order; the others
+        # through csrc/gemm_split.hip -- no library GEMM, and every row's sums are independent of the batch size
+        w0, b0 = self.kenc[0]
+        h = (kn[..., 0:1] * w0[:, 0] + kn[..., 1:2] * w0[:, 1]) + (scores.unsqueeze(-1) * w0[:, 2] + b0)
+        h = F.relu_(h).reshape(B2 * K, -1)
+        for i, lin in enumerate(self.kenc_lin):
+            h = lin(h, relu=i < len(self.kenc_lin) - 1)
         # xa = [x~ | a]: the running descriptors (minus the folded bias offset) and the attention output side by side
         xa = torch.empty(B2 * K, 512, dtype=torch.float32, device=kpts.device)
         xv, av = xa[:, :256], xa[:, 256:]
