@@ -42,8 +42,11 @@
 extern "C" {
 #endif
 
-#define MFR_ABI_VERSION 3   /* 2: intrinsics as (const void *K, int k_dtype) instead of const float *; 3: mfr_emat_solve_batch takes the
-                             * model-quality method (MAGSAC++ / count) and its table */
+#define MFR_ABI_VERSION 4   /* 2: intrinsics as (const void *K, int k_dtype) instead of const float *; 3: mfr_emat_solve_batch takes the
+                             * model-quality method (MAGSAC++ / count) and its table; 4 (round 5): the f16x2 entry points (mfr_gemm_f16x2*,
+                             * mfr_wino_f16x2_*, mfr_conv3x3_wino_f16x2, mfr_conv_igemm_f16x2), mfr_sg_attention_variant renumbered (0 f16x2,
+                             * 1 exact fp32, 2 bf16x3), the measurement-only entry points (mfr_conv3x3_wino_bf16x3_variant,
+                             * mfr_wino_bf16x3_profile, the GEMM ablation flags) removed */
 
 /* intrinsics dtype tags */
 #define MFR_K_F32 0
