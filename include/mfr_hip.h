@@ -446,6 +446,11 @@ size_t mfr_wino_f16x2_filter_bytes(int Cin, int Cout);
 int mfr_wino_f16x2_filter_transform(const float *w, int Cin, int Cout, void *upk, void *stream);
 int mfr_conv3x3_wino_f16x2(const float *x, const void *upk, const float *bias, const float *residual, int B, int Cin, int Cout,
                            int H, int W, int act, int pool, float *y, void *stream);
+/*   mfr_sp_conv1ab_f16x2         SuperPoint's first two layers in ONE kernel (round 5): y [B,64,H/2,W/2] = max_pool2(relu(conv1b(relu(conv1a(gray))))) for
+ *                                gray [B,1,H,W]; w1a [64,1,3,3] / b1a [64] as they are, upk1b = mfr_wino_f16x2_filter_transform of conv1b's [64,64,3,3].
+ *                                Bit-identical to mfr_conv3x3_c1_relu followed by mfr_conv3x3_wino_f16x2(..., act 1, pool 1): the 64-channel
+ *                                intermediate (6.4 GB per 64 images) never exists in memory. */
+int mfr_sp_conv1ab_f16x2(const float *gray, const float *w1a, const float *b1a, const void *upk1b, const float *bias1b, int B, int H, int W, float *y, void *stream);
 size_t mfr_wino_bf16x3_filter_bytes(int Cin, int Cout);
 int mfr_wino_bf16x3_filter_transform(const float *w, int Cin, int Cout, void *upk, void *stream);
 int mfr_conv3x3_wino_bf16x3(const float *x, const void *upk, const float *bias, const float *residual, int B, int Cin, int Cout,

@@ -71,6 +71,7 @@ SIGNATURES = {
     "mfr_wino_bf16x3_filter_bytes": (_sz, [_i, _i]),
     "mfr_wino_bf16x3_filter_transform": (_i, [_vp, _i, _i, _vp, _vp]),
     "mfr_conv3x3_wino_bf16x3": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "mfr_sp_conv1ab_f16x2": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "mfr_wino_f16x2_filter_bytes": (_sz, [_i, _i]),
     "mfr_wino_f16x2_filter_transform": (_i, [_vp, _i, _i, _vp, _vp]),
     "mfr_conv3x3_wino_f16x2": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),

@@ -514,6 +514,244 @@ __global__ void __launch_bounds__(512, 2) wino_split_p8_kernel(
     WB_STAMP(26);
 }
 
+// ---- round 5: SuperPoint's conv1a FUSED into conv1b (f16x2) -------------------------------------------------------------------------------------
+// conv1a (1 -> 64 channels) writes 6.4 GB per 64 images that conv1b reads straight back: 1.25 ms of HBM-bound writing, and in conv1b 17 % of a
+// workgroup's time waiting for its first patches plus 0.8-1.7 k cycles per K step for the next ones (profiles/r05_conv1b_timeline.json).  Here a
+// conv1b workgroup makes its own input: the 12 x 38 gray window of its 8 x 32 output block goes to LDS (one 4-byte load per thread), every wavefront
+// evaluates conv1a + ReLU for eight of the 64 channels on the 10 x 34 patch (weights wave-uniform in scalar registers, a lane = one patch row x six
+// columns, its 3 x 8 gray taps in registers for all eight channels) -- the SAME nine fused multiply-adds in the same order, + bias, max 0, as
+// conv3x3_c1_relu_kernel (elementwise.hip), so the patch is that kernel's output bit for bit; positions outside the image are conv1b's zero padding
+// -- and all four K steps' patches (120 KB) sit in LDS before the first MFMA.  The K loop then has no DMA, no border fix-up and no barrier: the
+// wavefronts run free.  Everything from the row combinations to the output transform is the kernel's above (Cin = Cout = 64, pooled, ReLU).
+__global__ void __launch_bounds__(512, 2) wino_split_c1_kernel(
+    const float *__restrict__ gray, const float *__restrict__ w1a, const float *__restrict__ b1a, const uint4 *__restrict__ upk, const float *__restrict__ oscale,
+    const float *__restrict__ bias, float *__restrict__ y, int H, int W, int nbx, int nby, int S, int Sx)
+{
+    constexpr int GS = 40;                                  // gray window row stride (38 columns used)
+    __shared__ __attribute__((aligned(16))) float lds[32768];
+    float *gwin = lds + 4 * WB_STAGE;                       // [12][GS] behind the four patch stages (30 720 floats)
+    const int id = blockIdx.x;
+    const int xcd = id & 7, sl = id >> 3;
+    const int s = xcd * Sx + sl;
+    if (sl >= Sx || s >= S) return;
+    const int bx = s % nbx, by = (s / nbx) % nby, b = s / (nbx * nby);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wi = w >> 1, jp = w & 1;
+    const int col = lane & 15, tysub = (lane >> 4) & 1, kg = lane >> 5;
+
+    // ---- filter fragments of step 0 first (they land while the patch is computed)
+    const __amdgpu_buffer_rsrc_t rsF = __builtin_amdgcn_make_buffer_rsrc((void *)upk, 0, (int)(4 * WB_FRAGS_PER_KSTEP * 1024), WB_RSRC_FLAGS);
+    const unsigned fbase = (unsigned)((wi * 24 + jp * 12) * 1024);
+    const unsigned lane16 = (unsigned)lane * 16u;
+    WbFrag F[2][2][3];
+    auto aload = [&](int c, int jj) {
+        const unsigned so = fbase + (unsigned)((c * WB_FRAGS_PER_KSTEP + jj * 6) * 1024);
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+                F[jj][mb][t].q = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsF, lane16, so + (unsigned)((mb * 3 + t) * 1024), 0));
+    };
+    aload(0, 0); aload(0, 1);
+
+    // ---- gray window: rows 8 by - 2 .. 8 by + 9, columns 32 bx - 2 .. 32 bx + 35; outside the image: 0 (conv1a's zero padding)
+    if (tid < 12 * 38) {
+        const int r = tid / 38, c = tid - 38 * r;
+        const int iy = 8 * by - 2 + r, ix = 32 * bx - 2 + c;
+        gwin[r * GS + c] = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? gray[((size_t)b * H + iy) * W + ix] : 0.f;
+    }
+    __syncthreads();
+    // ---- conv1a + ReLU on the patch: lane = (patch row pr < 10, column segment ps < 6): patch columns 6 ps .. 6 ps + 5 (34, 35 are never read)
+    {
+        const int pr = lane / 6, ps = lane - 6 * pr;
+        if (pr < 10) {
+            float g[3][8];
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float2 v = *(const float2 *)(gwin + (pr + dy) * GS + 6 * ps + 2 * q);
+                    g[dy][2 * q] = v.x; g[dy][2 * q + 1] = v.y;
+                }
+            // patch position (row 8 by - 1 + pr, column 32 bx - 1 + 6 ps + j) inside the image?  outside: conv1b's zero padding
+            const int py = 8 * by - 1 + pr, px0 = 32 * bx - 1 + 6 * ps;
+            float msk[6];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) msk[j] = (py >= 0 && py < H && px0 + j >= 0 && px0 + j < W) ? 1.0f : 0.0f;
+            const bool all_in = __all(msk[0] * msk[1] * msk[2] * msk[3] * msk[4] * msk[5] != 0.0f);      // wave-uniform: interior workgroups skip the masking
+#pragma unroll 1
+            for (int t = 0; t < 8; ++t) {
+                const int c = __builtin_amdgcn_readfirstlane(w + 8 * t);
+                const float *k = w1a + 9 * c;
+                float kk[9];
+#pragma unroll
+                for (int q = 0; q < 9; ++q) kk[q] = k[q];
+                const float bv = b1a[c];
+                float o[6];
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    float a = 0.f;
+#pragma unroll
+                    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                        for (int dx = 0; dx < 3; ++dx) a = __builtin_fmaf(kk[3 * dy + dx], g[dy][j + dx], a);
+                    o[j] = fmaxf(a + bv, 0.f);
+                }
+                if (!all_in) {
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) o[j] *= msk[j];
+                }
+                float *dst = lds + c * WB_CH + pr * WB_RS + 6 * ps;
+                *(float2 *)dst = make_float2(o[0], o[1]); *(float2 *)(dst + 2) = make_float2(o[2], o[3]); *(float2 *)(dst + 4) = make_float2(o[4], o[5]);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- from here on: wino_split_p8_kernel<true, true> with the K step's stage = its 16 channels in place (no DMA, no fix-up, no barrier)
+    const int ra = (wi == 0) ? 0 : (wi == 2) ? 2 : 1;
+    const int rb = (wi == 0) ? 2 : (wi == 2) ? 1 : (wi == 1) ? 2 : 3;
+    const float sg = (wi == 1) ? 1.0f : -1.0f;
+    const float beta = jp ? -1.0f : 1.0f;
+    const int cX = jp ? 2 : 0, cZ = jp ? 1 : 2;
+    const int ofa = (2 * tysub + ra) * WB_RS + 2 * col, ofb = (2 * tysub + rb) * WB_RS + 2 * col;
+    float wX[8], wY[8], wZ[8];
+    auto wread = [&](int buf, int nb) {
+        const wb_lds_f32 *st = (const wb_lds_f32 *)lds + buf * WB_STAGE + (8 * kg) * WB_CH + 4 * nb * WB_RS;
+#pragma unroll
+        for (int e0 = 0; e0 < 8; e0 += 4) {
+            wb_f32x2 a2[4], b2[4];
+            float a1[4], b1[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const wb_lds_f32 *ch = st + (e0 + e) * WB_CH;
+                a2[e] = *(const volatile wb_lds_f32x2 *)(ch + ofa + cX); a1[e] = *(const volatile wb_lds_f32 *)(ch + ofa + cZ);
+                b2[e] = *(const volatile wb_lds_f32x2 *)(ch + ofb + cX); b1[e] = *(const volatile wb_lds_f32 *)(ch + ofb + cZ);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                wX[e0 + e] = __builtin_fmaf(sg, b2[e].x, a2[e].x); wY[e0 + e] = __builtin_fmaf(sg, b2[e].y, a2[e].y);
+                wZ[e0 + e] = __builtin_fmaf(sg, b1[e], a1[e]);
+            }
+            asm volatile("" : "+v"(wX[e0]), "+v"(wY[e0]), "+v"(wZ[e0]), "+v"(wX[e0 + 1]), "+v"(wY[e0 + 1]), "+v"(wZ[e0 + 1]),
+                              "+v"(wX[e0 + 2]), "+v"(wY[e0 + 2]), "+v"(wZ[e0 + 2]), "+v"(wX[e0 + 3]), "+v"(wY[e0 + 3]), "+v"(wZ[e0 + 3]) :: "memory");
+        }
+    };
+    auto vmake = [&](WbFrag (&vf)[3], int jj) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float v[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int q = 2 * k + e;
+                v[e] = jj ? __builtin_fmaf(beta, wY[q], wZ[q]) : wX[q] - wZ[q];
+            }
+            sf_split2(v[0], v[1], SF_LOW_SCALE, vf[0].u[k], vf[1].u[k]);
+        }
+    };
+    f32x16 acc[2][2][2];
+#define WC1_PROD(jj, nb, vf, ta, tb) do { \
+        acc[jj][0][nb] = SF_MFMA(F[jj][0][ta].q, vf[tb].q, acc[jj][0][nb]); acc[jj][1][nb] = SF_MFMA(F[jj][1][ta].q, vf[tb].q, acc[jj][1][nb]); } while (0)
+#define WC1_PHASE(jj, nb, vf) do { WC1_PROD(jj, nb, vf, 2, 1); WC1_PROD(jj, nb, vf, 1, 0); WC1_PROD(jj, nb, vf, 0, 0); } while (0)
+#define WC1_VMCNT0() __builtin_amdgcn_s_waitcnt(0x0F70)
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[jj][mb][nb][r] = 0.f;
+    WbFrag vfA[3], vfB[3];
+    wread(0, 0);
+    vmake(vfA, 0);
+#pragma unroll 1
+    for (int c = 0; c < 3; ++c) {
+        WC1_VMCNT0();
+        vmake(vfB, 1);
+        WC1_PHASE(0, 0, vfA);
+        wread(c, 1);
+        vmake(vfA, 0);
+        WC1_PHASE(1, 0, vfB);
+        vmake(vfB, 1);
+        WC1_PHASE(0, 1, vfA);
+        aload(c + 1, 0);
+        wread(c + 1, 0);
+        vmake(vfA, 0);
+        WC1_PHASE(1, 1, vfB);
+        aload(c + 1, 1);
+    }
+    WC1_VMCNT0();
+    vmake(vfB, 1);
+    WC1_PHASE(0, 0, vfA);
+    wread(3, 1);
+    vmake(vfA, 0);
+    WC1_PHASE(1, 0, vfB);
+    vmake(vfB, 1);
+    WC1_PHASE(0, 1, vfA);
+    WC1_PHASE(1, 1, vfB);
+#undef WC1_VMCNT0
+#undef WC1_PHASE
+#undef WC1_PROD
+
+    // ---- output transform, pooled + ReLU (as above)
+    const int qnb = w & 1, qr4 = w >> 1;
+    const int tr = 2 * qnb + tysub;
+    const int ty = 4 * by + tr, tx = 16 * bx + col;
+    const int Ho = H >> 1, Wo = W >> 1;
+    const size_t cstride = (size_t)Ho * Wo;
+    float4 *part = (float4 *)lds;
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+        __syncthreads();
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                float pa[4], pb[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int r = 4 * r4 + k;
+                    const float sum = acc[0][mb][nb][r] + acc[1][mb][nb][r];
+                    pa[k] = jp ? acc[0][mb][nb][r] : sum;
+                    pb[k] = jp ? -sum : acc[1][mb][nb][r];
+                }
+                part[((((wi * 2 + jp) * 2 + 0) * 2 + nb) * 4 + r4) * 64 + lane] = make_float4(pa[0], pa[1], pa[2], pa[3]);
+                part[((((wi * 2 + jp) * 2 + 1) * 2 + nb) * 4 + r4) * 64 + lane] = make_float4(pb[0], pb[1], pb[2], pb[3]);
+            }
+        const int co0 = mb * 32 + 4 * kg + 8 * qr4;
+        float bv[4], os[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { bv[k] = bias ? bias[co0 + k] : 0.f; os[k] = oscale[co0 + k]; }
+        __syncthreads();
+        const float4 *pq = part + (qnb * 4 + qr4) * 64 + lane;
+        float4 P[4][2];
+#pragma unroll
+        for (int row = 0; row < 4; ++row)
+#pragma unroll
+            for (int ab = 0; ab < 2; ++ab) {
+                const float4 u = pq[(((row * 2 + 0) * 2 + ab) * 8) * 64], v = pq[(((row * 2 + 1) * 2 + ab) * 8) * 64];
+                P[row][ab] = make_float4(u.x + v.x, u.y + v.y, u.z + v.z, u.w + v.w);
+            }
+        float m[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+#define WB_EL(v) (k == 0 ? (v).x : k == 1 ? (v).y : k == 2 ? (v).z : (v).w)
+            const float y0 = (WB_EL(P[0][0]) + WB_EL(P[1][0])) + WB_EL(P[2][0]), y1 = (WB_EL(P[0][1]) + WB_EL(P[1][1])) + WB_EL(P[2][1]);
+            const float y2 = (WB_EL(P[1][0]) - WB_EL(P[2][0])) - WB_EL(P[3][0]), y3 = (WB_EL(P[1][1]) - WB_EL(P[2][1])) - WB_EL(P[3][1]);
+#undef WB_EL
+            const float Y0 = __builtin_fmaf(y0, os[k], bv[k]), Y1 = __builtin_fmaf(y1, os[k], bv[k]), Y2 = __builtin_fmaf(y2, os[k], bv[k]), Y3 = __builtin_fmaf(y3, os[k], bv[k]);
+            m[k] = fmaxf(fmaxf(fmaxf(Y0, Y1), fmaxf(Y2, Y3)), 0.f);
+        }
+        if (ty < Ho && tx < Wo) {
+            float *yo = y + ((size_t)b * 64 + co0) * cstride + (size_t)ty * Wo + tx;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) yo[(size_t)k * cstride] = m[k];
+        }
+    }
+}
+
 // ---- host ------------------------------------------------------------------------------------------------------------------------------------
 static size_t wb_frag_bytes(int Cin, int Cout)
 {
@@ -582,6 +820,19 @@ int mfr_conv3x3_wino_f16x2(const float *x, const void *upk, const float *bias, c
                            int act, int pool, float *y, void *stream)
 {
     return wb_conv<true>(x, upk, bias, residual, B, Cin, Cout, H, W, act, pool, y, stream);
+}
+
+int mfr_sp_conv1ab_f16x2(const float *gray, const float *w1a, const float *b1a, const void *upk1b, const float *bias1b, int B, int H, int W, float *y, void *stream)
+{
+    if (!gray || !w1a || !b1a || !upk1b || !y || B <= 0 || H < 2 || W < 2) return MFR_E_ARG;
+    const int nbx = ((W + 1) / 2 + 15) / 16, nby = ((H + 1) / 2 + 3) / 4;
+    const long long S = (long long)nbx * nby * B, Sx = (S + 7) / 8, grid = Sx * 8;
+    if (grid > 0x7fffffffll) return MFR_E_ARG;
+    const float *oscale = (const float *)((const char *)upk1b + wb_frag_bytes(64, 64));
+    hipLaunchKernelGGL(wino_split_c1_kernel, dim3((unsigned)grid), dim3(512), 0, (hipStream_t)stream, gray, w1a, b1a, (const uint4 *)upk1b, oscale, bias1b, y,
+                       H, W, nbx, nby, (int)S, (int)Sx);
+    CHECK_LAUNCH();
+    return 0;
 }
 
 }  // extern "C"

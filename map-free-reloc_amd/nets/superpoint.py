@@ -27,6 +27,7 @@ class SuperPointHIP:
         self.nms_radius, self.thr = int(nms_radius), float(keypoint_threshold)
         self.K, self.border = int(max_keypoints), int(remove_borders)
         self.fused_conv_relu = bool(options.get("FUSED_CONV_RELU"))
+        self.fused_conv1 = bool(options.get("FUSED_CONV1"))
         self.use_wino = options.get("CONV") == "wino"                     # "miopen": library conv + epilogue kernels (options.py)
         self.w = {k: v.to(self.device, torch.float32).contiguous() for k, v in state_dict.items()}
         # 1x1 heads as plain matrices
@@ -85,8 +86,24 @@ class SuperPointHIP:
                                            _lib.stream_ptr()), "mfr_conv3x3_c1_relu")
         return y
 
+    def _conv1ab(self, image):
+        """conv1a + ReLU + conv1b + ReLU + 2x2 max-pool in ONE kernel (csrc/winograd_split.hip mfr_sp_conv1ab_f16x2, option FUSED_CONV1): the
+        64-channel full-resolution intermediate never reaches memory; bit-identical to the two launches it replaces"""
+        lib = _lib.load()
+        B, C, H, W = image.shape
+        cv = self.upk.get("conv1b")
+        if (not self.fused_conv1 or cv is None or cv.split != "f16x2" or C != 1 or H < 2 or W < 2
+                or tuple(self.w["conv1a.weight"].shape) != (64, 1, 3, 3) or (cv.ci, cv.co) != (64, 64)):
+            return None
+        y = torch.empty(B, 64, H // 2, W // 2, dtype=torch.float32, device=image.device)
+        _lib.check(lib.mfr_sp_conv1ab_f16x2(_lib.ptr(image.contiguous()), _lib.ptr(self.w["conv1a.weight"]), _lib.ptr(self.w["conv1a.bias"]),
+                                            _lib.ptr(cv.u_split), _lib.ptr(cv.b), B, H, W, _lib.ptr(y), _lib.stream_ptr()), "mfr_sp_conv1ab_f16x2")
+        return y
+
     def encode(self, image):
-        x = self._conv1a(image); x = self._conv(x, "conv1b", pool=True)
+        x = self._conv1ab(image) if self.use_wino else None
+        if x is None:
+            x = self._conv1a(image); x = self._conv(x, "conv1b", pool=True)
         x = self._conv(x, "conv2a"); x = self._conv(x, "conv2b", pool=True)
         x = self._conv(x, "conv3a"); x = self._conv(x, "conv3b", pool=True)
         x = self._conv(x, "conv4a"); x = self._conv(x, "conv4b")

@@ -8,6 +8,8 @@ merge) through `apply_cfg(cfg)`, or directly by a tool / test (`options.set("CON
                     3x3 convolutions); resolved when a weight is packed
   CONV              'wino' (own Winograd kernels) | 'miopen' (library convolution + own epilogue kernels): 3x3 layers of the matchers
   CONV_KERNEL       'auto' (per layer shape, nets/conv.py) | 'split' (the operand-splitting kernel, arithmetic = SPLIT) | 'exact': which own Winograd kernel
+  FUSED_CONV1       SuperPoint conv1a + conv1b (+ ReLUs, max-pool) as ONE kernel that builds conv1b's input patches in LDS (True, f16x2 only) or as
+                    two launches through the 6.4 GB intermediate (False); the same bits either way
   FUSED_CONV_RELU   SuperPoint conv1a through the fused first-layer kernel with ReLU folded (True / False)
   RPR_CONV          'hip' (own implicit-GEMM forward of the regression decoder's 3x3 convolutions) | 'miopen'
   RPR_CONV_BWD      'lib' (torch / MIOpen backward; the measured default) | 'hip' (own d input / d weight products)
@@ -20,6 +22,7 @@ _SPEC = {
     "SPLIT": ("f16x2", ("f16x2", "bf16x3")),
     "CONV": ("wino", ("wino", "miopen")),
     "CONV_KERNEL": ("auto", ("auto", "split", "exact")),
+    "FUSED_CONV1": (True, (False, True)),
     "FUSED_CONV_RELU": (False, (False, True)),
     "RPR_CONV": ("hip", ("hip", "miopen")),
     "RPR_CONV_BWD": ("lib", ("lib", "hip")),

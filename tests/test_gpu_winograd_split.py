@@ -133,3 +133,35 @@ def test_split_rejects_unsupported(split):
     assert fn(_lib.ptr(x), _lib.ptr(x), None, None, 1, 4, 32, 1, 1, 0, 1, _lib.ptr(x), None) != 0      # pool needs H, W >= 2
     assert fn(_lib.ptr(x), _lib.ptr(x), None, _lib.ptr(x), 1, 4, 32, 4, 4, 0, 1, _lib.ptr(x), None) != 0  # residual + pool
     assert fn(_lib.ptr(x), _lib.ptr(x), None, None, 1, 4, 32, 4, 4, 3, 0, _lib.ptr(x), None) != 0      # unknown act
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 720, 540), (1, 64, 96), (3, 37, 45), (1, 8, 32), (2, 2, 2), (1, 131, 33)])
+def test_fused_conv1a_conv1b_equals_the_two_launches_bitwise(B, H, W):
+    """mfr_sp_conv1ab_f16x2 (conv1a + ReLU computed into conv1b's LDS patches) == mfr_conv3x3_c1_relu followed by mfr_conv3x3_wino_f16x2(act 1,
+    pool 1), bit for bit: interior and border workgroups, odd sizes, images smaller than one workgroup block"""
+    lib = _lib.load(require_gpu=True)
+    g = torch.Generator().manual_seed(H * 7 + W)
+    x = torch.rand(B, 1, H, W, generator=g).to(DEV)
+    w1 = (torch.randn(64, 1, 3, 3, generator=g) / 3.0).to(DEV); b1 = (torch.randn(64, generator=g) * 0.3).to(DEV)
+    w2 = (torch.randn(64, 64, 3, 3, generator=g) / 24.0).to(DEV); b2 = torch.randn(64, generator=g).to(DEV)
+    u = _pack(w2, "f16x2")
+    fused = torch.full((B, 64, H // 2, W // 2), float("nan"), dtype=torch.float32, device=DEV)
+    _lib.check(lib.mfr_sp_conv1ab_f16x2(_lib.ptr(x), _lib.ptr(w1), _lib.ptr(b1), _lib.ptr(u), _lib.ptr(b2), B, H, W, _lib.ptr(fused), _lib.stream_ptr()), "fused")
+    if W % 4 == 0:
+        mid = torch.empty(B, 64, H, W, dtype=torch.float32, device=DEV)
+        _lib.check(lib.mfr_conv3x3_c1_relu(_lib.ptr(x), _lib.ptr(w1), _lib.ptr(b1), B, H, W, 64, _lib.ptr(mid), _lib.stream_ptr()), "conv1a")
+    else:                                                   # the stand-alone first-layer kernel wants W % 4 == 0: the same chain of fmas in torch
+        xp = F.pad(x[:, 0], (1, 1, 1, 1))
+        mid = torch.zeros(B, 64, H, W, dtype=torch.float32, device=DEV)
+        for dy in range(3):
+            for dx in range(3):
+                mid = torch.addcmul(mid, w1[:, 0, dy, dx].view(1, 64, 1, 1), xp[:, None, dy:dy + H, dx:dx + W])      # fma per tap, dy-major like the kernel
+        mid = (mid + b1.view(1, 64, 1, 1)).relu()
+    two = _conv(mid, w2, b2, 1, 1, None, "f16x2")
+    assert torch.isfinite(fused).all()
+    if W % 4 == 0:
+        assert torch.equal(fused, two)
+    else:                                                   # (torch's addcmul is not guaranteed to contract into one fma: tolerance instead of bits)
+        assert (fused - two).abs().max().item() < 1e-4
+    want = _ref(_ref(x, w1, b1, 1, 0).float().to(DEV), w2, b2, 1, 1)
+    assert (fused.double().cpu() - want).abs().max().item() < 1e-4
