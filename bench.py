@@ -272,6 +272,11 @@ class SgPnpWorkload:
             self.pipe.sg.sinkhorn_match = self.sk_timer.wrap(self.pipe.sg.sinkhorn_match)
             sp_conv, timed_conv = self.pipe.sp._conv, self.conv_timer.wrap(self.pipe.sp._conv)
             self.pipe.sp._conv = lambda x, name, **kw: (timed_conv if name == "conv1b" else sp_conv)(x, name, **kw)
+            # round 5: conv1a is fused into the conv1b launch (options FUSED_CONV1): that launch is the dominant kernel then
+            fused = self.pipe.sp._conv1ab
+            timed_fused = self.conv_timer.wrap(fused)
+            self.pipe.sp._conv1ab = lambda im: (timed_fused(im) if self.fused_c1 else fused(im))
+        self.fused_c1 = bool(getattr(self.pipe.sp, "fused_conv1", False)) and getattr(self.pipe.sp.upk.get("conv1b"), "split", "") == "f16x2"
         self.kp_sum, self.kp_cnt = 0.0, 0
 
     def timers(self):
@@ -295,8 +300,9 @@ class SgPnpWorkload:
         att_tf = att_flops / (att_ms * 1e-3) / 1e12 if att_ms else None
         # Winograd F(2x2,3x3) conv1b (64 -> 64 channels, 2B images, HxW): 16 GEMMs of [Cout x Cin] x [Cin x tiles] = the fp32
         # multiply-adds of the layer in the Winograd domain (a direct 3x3 convolution is 2.25x that).  The kernel evaluates each
-        # fp32 product as SIX bf16 partial products on the bf16 matrix cores (exact 3-way operand split, fp32 accumulate), so the
-        # flops it EXECUTES -- what the roofline prices against the dense bf16 MFMA peak -- are 6x the fp32 figure.
+        # fp32 product as THREE f16 (f16x2) or SIX bf16 (bf16x3) partial products on the 16-bit matrix cores, fp32 accumulate, so the
+        # flops it EXECUTES -- what the roofline prices against the dense 16-bit MFMA peak -- are 3x / 6x the fp32 figure.  (With conv1a fused
+        # in, the launch also does that layer's 9 fp32 FMAs per output on the vector ALU: 1.4 % of the fp32-equivalent work, not counted.)
         tiles = ((H + 1) // 2) * ((W + 1) // 2)
         conv_fp32 = 16 * 2.0 * 64 * 64 * tiles * 2 * B
         conv_flops = split_products() * conv_fp32
@@ -305,11 +311,12 @@ class SgPnpWorkload:
         eq = conv_fp32 / (conv_ms * 1e-3) / 1e12 if conv_ms else None
         att_exec = split_products() * att_tf if att_tf else None
         nprod = int(split_products())
-        return {"kernel": f"wino_split_p8_kernel conv1b launch (dominant kernel: fused Winograd F(2x2,3x3) convolution on the 16-bit matrix cores at "
+        kname = ("wino_split_c1_kernel: SuperPoint conv1a (1->64 ch, computed into LDS) + conv1b launch" if self.fused_c1 else "wino_split_p8_kernel conv1b launch")
+        return {"kernel": f"{kname} (dominant kernel: fused Winograd F(2x2,3x3) convolution on the 16-bit matrix cores at "
                           f"fp32 accuracy, {'f16x2' if nprod == 3 else 'bf16x3'} operand split, 64->64 ch, pooled output; eight wavefronts per workgroup, two per SIMD)",
                 "bound": "mfma", "achieved": round(achieved, 1) if achieved else None, "peak": BF16_MFMA_PEAK_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4) if achieved else None,
-                "traffic": _traffic("conv1b", B), "avg_launch_ms": round(conv_ms, 4) if conv_ms else None,
+                "traffic": _traffic("conv1ab" if self.fused_c1 else "conv1b", B), "avg_launch_ms": round(conv_ms, 4) if conv_ms else None,
                 "launches_timed": len(self.conv_timer.events), "flops_per_launch": conv_flops,
                 "note": f"achieved = 16-bit matrix-core flops EXECUTED ({nprod} partial products per fp32 multiply-add of the 16 Winograd GEMMs) / launch time, "
                         "against the DENSE bf16 / f16 MFMA peak; fp32_equivalent = the same launch priced as fp32 multiply-adds (what the layer delivers); "

@@ -530,17 +530,35 @@ __global__ void __launch_bounds__(512, 2) wino_split_c1_kernel(
     constexpr int GS = 40;                                  // gray window row stride (38 columns used)
     __shared__ __attribute__((aligned(16))) float lds[32768];
     float *gwin = lds + 4 * WB_STAGE;                       // [12][GS] behind the four patch stages (30 720 floats)
+    // PERSISTENT: one workgroup per CU walks the spatial blocks of its XCD's contiguous raster range (block = xcd Sx + slot + k per_xcd); the gray
+    // window of the NEXT block (one value per thread) is requested before this block's patch is computed and lands during the block, so only the
+    // first block of a workgroup pays the memory latency in front of its patch (3.5 k of a block's 30 k cycles, profiles/r05_conv1ab_timeline_nonpersistent.json)
     const int id = blockIdx.x;
-    const int xcd = id & 7, sl = id >> 3;
-    const int s = xcd * Sx + sl;
-    if (sl >= Sx || s >= S) return;
-    const int bx = s % nbx, by = (s / nbx) % nby, b = s / (nbx * nby);
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int xcd = id & 7, slot = id >> 3, per_xcd = gridDim.x >> 3;
+    const int tid = threadIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wi = w >> 1, jp = w & 1;
+    auto gray_of = [&](int sl_) -> float {                  // this thread's element (tid < 456) of the 12 x 38 gray window: rows 8 by - 2 .. 8 by + 9, columns 32 bx - 2 .. 32 bx + 35; outside the image: 0 (conv1a's zero padding)
+        const int s_ = xcd * Sx + sl_;
+        if (tid >= 12 * 38 || sl_ >= Sx || s_ >= S) return 0.f;
+        const int gr = tid / 38, gc = tid - 38 * gr;
+        const int bx_ = s_ % nbx, by_ = (s_ / nbx) % nby, b_ = s_ / (nbx * nby);
+        const int iy = 8 * by_ - 2 + gr, ix = 32 * bx_ - 2 + gc;
+        return (iy >= 0 && iy < H && ix >= 0 && ix < W) ? gray[((size_t)b_ * H + iy) * W + ix] : 0.f;
+    };
+    float gnext = gray_of(slot);
+    for (int sl = slot; sl < Sx; sl += per_xcd) {
+    const int s = xcd * Sx + sl;
+    if (s >= S) break;
+    const int bx = s % nbx, by = (s / nbx) % nby, b = s / (nbx * nby);
+    // (the lane-derived offsets are re-derived per block from an opaque copy of the thread index: hoisted out of the block loop they are two
+    // dozen loop-invariant registers that the K loop has no room for -- hipcc spilled them to scratch)
+    int tid_ = tid;
+    asm volatile("" : "+v"(tid_));
+    const int lane = tid_ & 63;
     const int col = lane & 15, tysub = (lane >> 4) & 1, kg = lane >> 5;
 
-    // ---- filter fragments of step 0 first (they land while the patch is computed)
+    // ---- filter fragments (requested below, once the gray window is in LDS: they land while the patch is computed)
     const __amdgpu_buffer_rsrc_t rsF = __builtin_amdgcn_make_buffer_rsrc((void *)upk, 0, (int)(4 * WB_FRAGS_PER_KSTEP * 1024), WB_RSRC_FLAGS);
     const unsigned fbase = (unsigned)((wi * 24 + jp * 12) * 1024);
     const unsigned lane16 = (unsigned)lane * 16u;
@@ -553,33 +571,39 @@ __global__ void __launch_bounds__(512, 2) wino_split_c1_kernel(
             for (int t = 0; t < 3; ++t)
                 F[jj][mb][t].q = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsF, lane16, so + (unsigned)((mb * 3 + t) * 1024), 0));
     };
-    aload(0, 0); aload(0, 1);
+    WB_STAMP(0);
 
-    // ---- gray window: rows 8 by - 2 .. 8 by + 9, columns 32 bx - 2 .. 32 bx + 35; outside the image: 0 (conv1a's zero padding)
-    if (tid < 12 * 38) {
-        const int r = tid / 38, c = tid - 38 * r;
-        const int iy = 8 * by - 2 + r, ix = 32 * bx - 2 + c;
-        gwin[r * GS + c] = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? gray[((size_t)b * H + iy) * W + ix] : 0.f;
-    }
+    // ---- gray window of this block -> LDS (the previous block's output rounds are done with the memory: barrier), the next block's requested
     __syncthreads();
+    if (tid < 12 * 38) gwin[(tid / 38) * GS + (tid - 38 * (tid / 38))] = gnext;
+    gnext = gray_of(sl + per_xcd);
+    aload(0, 0); aload(0, 1);                               // (after the window is written: vmcnt retires in order, the write would wait for these too)
+    __syncthreads();
+    WB_STAMP(1);
     // ---- conv1a + ReLU on the patch: lane = (patch row pr < 10, column segment ps < 6): patch columns 6 ps .. 6 ps + 5 (34, 35 are never read)
     {
         const int pr = lane / 6, ps = lane - 6 * pr;
         if (pr < 10) {
-            float g[3][8];
+            // the lane's 3 x 8 gray taps as PAIRS, once aligned on even and once on odd columns: the nine multiply-adds of two adjacent outputs are
+            // one v_pk_fma_f32 each (no MFMA runs beside this phase, so packed fp32 is worth its two passes: half the instructions); every output
+            // still sees its nine fmas in conv3x3_c1_relu_kernel's order
+            wb_f32x2 ge[3][4], go[3][3];
 #pragma unroll
-            for (int dy = 0; dy < 3; ++dy)
+            for (int dy = 0; dy < 3; ++dy) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float2 v = *(const float2 *)(gwin + (pr + dy) * GS + 6 * ps + 2 * q);
-                    g[dy][2 * q] = v.x; g[dy][2 * q + 1] = v.y;
-                }
+                for (int q = 0; q < 4; ++q) { const float2 v = *(const float2 *)(gwin + (pr + dy) * GS + 6 * ps + 2 * q); ge[dy][q] = wb_f32x2{v.x, v.y}; }
+#pragma unroll
+                for (int q = 0; q < 3; ++q) go[dy][q] = wb_f32x2{ge[dy][q].y, ge[dy][q + 1].x};
+            }
             // patch position (row 8 by - 1 + pr, column 32 bx - 1 + 6 ps + j) inside the image?  outside: conv1b's zero padding
             const int py = 8 * by - 1 + pr, px0 = 32 * bx - 1 + 6 * ps;
-            float msk[6];
+            wb_f32x2 msk[3];
 #pragma unroll
-            for (int j = 0; j < 6; ++j) msk[j] = (py >= 0 && py < H && px0 + j >= 0 && px0 + j < W) ? 1.0f : 0.0f;
-            const bool all_in = __all(msk[0] * msk[1] * msk[2] * msk[3] * msk[4] * msk[5] != 0.0f);      // wave-uniform: interior workgroups skip the masking
+            for (int j = 0; j < 3; ++j) {
+                msk[j].x = (py >= 0 && py < H && px0 + 2 * j >= 0 && px0 + 2 * j < W) ? 1.0f : 0.0f;
+                msk[j].y = (py >= 0 && py < H && px0 + 2 * j + 1 >= 0 && px0 + 2 * j + 1 < W) ? 1.0f : 0.0f;
+            }
+            const bool all_in = __all(msk[0].x * msk[0].y * msk[1].x * msk[1].y * msk[2].x * msk[2].y != 0.0f);      // wave-uniform: interior workgroups skip the masking
 #pragma unroll 1
             for (int t = 0; t < 8; ++t) {
                 const int c = __builtin_amdgcn_readfirstlane(w + 8 * t);
@@ -588,26 +612,31 @@ __global__ void __launch_bounds__(512, 2) wino_split_c1_kernel(
 #pragma unroll
                 for (int q = 0; q < 9; ++q) kk[q] = k[q];
                 const float bv = b1a[c];
-                float o[6];
+                wb_f32x2 o[3];
 #pragma unroll
-                for (int j = 0; j < 6; ++j) {
-                    float a = 0.f;
+                for (int j = 0; j < 3; ++j) {
+                    wb_f32x2 a = { 0.f, 0.f };
 #pragma unroll
-                    for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-                        for (int dx = 0; dx < 3; ++dx) a = __builtin_fmaf(kk[3 * dy + dx], g[dy][j + dx], a);
-                    o[j] = fmaxf(a + bv, 0.f);
+                    for (int dy = 0; dy < 3; ++dy) {
+                        a = __builtin_elementwise_fma(wb_f32x2{kk[3 * dy], kk[3 * dy]}, ge[dy][j], a);
+                        a = __builtin_elementwise_fma(wb_f32x2{kk[3 * dy + 1], kk[3 * dy + 1]}, go[dy][j], a);
+                        a = __builtin_elementwise_fma(wb_f32x2{kk[3 * dy + 2], kk[3 * dy + 2]}, ge[dy][j + 1], a);
+                    }
+                    a = a + wb_f32x2{bv, bv};
+                    o[j] = __builtin_elementwise_max(a, wb_f32x2{0.f, 0.f});
                 }
                 if (!all_in) {
 #pragma unroll
-                    for (int j = 0; j < 6; ++j) o[j] *= msk[j];
+                    for (int j = 0; j < 3; ++j) o[j] = o[j] * msk[j];
                 }
                 float *dst = lds + c * WB_CH + pr * WB_RS + 6 * ps;
-                *(float2 *)dst = make_float2(o[0], o[1]); *(float2 *)(dst + 2) = make_float2(o[2], o[3]); *(float2 *)(dst + 4) = make_float2(o[4], o[5]);
+                *(float2 *)dst = make_float2(o[0].x, o[0].y); *(float2 *)(dst + 2) = make_float2(o[1].x, o[1].y); *(float2 *)(dst + 4) = make_float2(o[2].x, o[2].y);
             }
         }
     }
+    WB_STAMP(2);
     __syncthreads();
+    WB_STAMP(3);
 
     // ---- from here on: wino_split_p8_kernel<true, true> with the K step's stage = its 16 channels in place (no DMA, no fix-up, no barrier)
     const int ra = (wi == 0) ? 0 : (wi == 2) ? 2 : 1;
@@ -677,11 +706,13 @@ __global__ void __launch_bounds__(512, 2) wino_split_c1_kernel(
         vmake(vfB, 1);
         WC1_PHASE(0, 1, vfA);
         aload(c + 1, 0);
+        WB_STAMP(4 + 3 * c);
         wread(c + 1, 0);
         vmake(vfA, 0);
         WC1_PHASE(1, 1, vfB);
         aload(c + 1, 1);
     }
+    WB_STAMP(16);
     WC1_VMCNT0();
     vmake(vfB, 1);
     WC1_PHASE(0, 0, vfA);
@@ -691,6 +722,7 @@ __global__ void __launch_bounds__(512, 2) wino_split_c1_kernel(
     vmake(vfB, 1);
     WC1_PHASE(0, 1, vfA);
     WC1_PHASE(1, 1, vfB);
+    WB_STAMP(17);
 #undef WC1_VMCNT0
 #undef WC1_PHASE
 #undef WC1_PROD
@@ -705,6 +737,7 @@ __global__ void __launch_bounds__(512, 2) wino_split_c1_kernel(
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb) {
         __syncthreads();
+        WB_STAMP(18 + 4 * mb);
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
@@ -724,7 +757,9 @@ __global__ void __launch_bounds__(512, 2) wino_split_c1_kernel(
         float bv[4], os[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) { bv[k] = bias ? bias[co0 + k] : 0.f; os[k] = oscale[co0 + k]; }
+        WB_STAMP(19 + 4 * mb);
         __syncthreads();
+        WB_STAMP(20 + 4 * mb);
         const float4 *pq = part + (qnb * 4 + qr4) * 64 + lane;
         float4 P[4][2];
 #pragma unroll
@@ -749,7 +784,10 @@ __global__ void __launch_bounds__(512, 2) wino_split_c1_kernel(
 #pragma unroll
             for (int k = 0; k < 4; ++k) yo[(size_t)k * cstride] = m[k];
         }
+        WB_STAMP(21 + 4 * mb);
     }
+    WB_STAMP(26);
+    }   // next block of this workgroup
 }
 
 // ---- host ------------------------------------------------------------------------------------------------------------------------------------
@@ -826,8 +864,9 @@ int mfr_sp_conv1ab_f16x2(const float *gray, const float *w1a, const float *b1a, 
 {
     if (!gray || !w1a || !b1a || !upk1b || !y || B <= 0 || H < 2 || W < 2) return MFR_E_ARG;
     const int nbx = ((W + 1) / 2 + 15) / 16, nby = ((H + 1) / 2 + 3) / 4;
-    const long long S = (long long)nbx * nby * B, Sx = (S + 7) / 8, grid = Sx * 8;
-    if (grid > 0x7fffffffll) return MFR_E_ARG;
+    const long long S = (long long)nbx * nby * B, Sx = (S + 7) / 8;
+    if (S > 0x7fffffffll) return MFR_E_ARG;
+    const long long grid = 8 * (Sx < 32 ? Sx : 32);                    // persistent: one workgroup (128 KB of LDS) per CU, 32 CUs per XCD
     const float *oscale = (const float *)((const char *)upk1b + wb_frag_bytes(64, 64));
     hipLaunchKernelGGL(wino_split_c1_kernel, dim3((unsigned)grid), dim3(512), 0, (hipStream_t)stream, gray, w1a, b1a, (const uint4 *)upk1b, oscale, bias1b, y,
                        H, W, nbx, nby, (int)S, (int)Sx);

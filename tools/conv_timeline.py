@@ -1,7 +1,7 @@
 """In-kernel timeline of the operand-splitting Winograd kernel (csrc/winograd_split.hip) on one layer: s_memtime stamps of the eight wavefronts
 of one mid-grid workgroup, from a MEASUREMENT build of the same source (-DWB_PROF -> tools/ubench/libwino_prof.so; build it on the CPU box:
 `python tools/conv_timeline.py --build`), so the product library carries no instrumentation.
-    python tools/conv_timeline.py [--layer conv1b|conv2a|l1out2] [--split f16x2|bf16x3] [out.json]"""
+    python tools/conv_timeline.py [--layer conv1ab|conv1b|conv2a|l1out2] [--split f16x2|bf16x3] [out.json]"""
 import ctypes as C
 import json
 import os
@@ -19,7 +19,7 @@ if "--build" in sys.argv:
 import torch  # noqa: E402
 arg = lambda k, d: sys.argv[sys.argv.index(k) + 1] if k in sys.argv else d
 layer, split = arg("--layer", "conv1b"), arg("--split", "f16x2")
-B, ci, co, H, W, pool, act = {"conv1b": (64, 64, 64, 720, 540, 1, 1), "conv2a": (64, 64, 64, 360, 270, 0, 1), "l1out2": (32, 196, 196, 360, 272, 0, 2)}[layer]
+B, ci, co, H, W, pool, act = {"conv1ab": (64, 64, 64, 720, 540, 1, 1), "conv1b": (64, 64, 64, 720, 540, 1, 1), "conv2a": (64, 64, 64, 360, 270, 0, 1), "l1out2": (32, 196, 196, 360, 272, 0, 2)}[layer]
 lib = C.CDLL(SO)
 vp, i = C.c_void_p, C.c_int
 getattr(lib, f"mfr_wino_{split}_filter_bytes").restype = C.c_size_t
@@ -31,6 +31,9 @@ assert getattr(lib, f"mfr_wino_{split}_filter_transform")(vp(w.data_ptr()), i(ci
 y = torch.empty((B, co, H // 2, W // 2) if pool else (B, co, H, W), device=dev)
 conv = getattr(lib, f"mfr_conv3x3_wino_{split}")
 run = lambda: conv(vp(x.data_ptr()), vp(u.data_ptr()), vp(b.data_ptr()), None, i(B), i(ci), i(co), i(H), i(W), i(act), i(pool), vp(y.data_ptr()), vp(st))
+if layer == "conv1ab":          # SuperPoint's fused first two layers: stamps 1 = gray window in LDS, 2 = this wavefront's conv1a channels done, 3 = patch barrier passed
+    gray = torch.rand(B, 1, H, W, device=dev); w1 = torch.randn(64, 1, 3, 3, device=dev) / 3.0; b1 = torch.randn(64, device=dev) * 0.3
+    run = lambda: lib.mfr_sp_conv1ab_f16x2(vp(gray.data_ptr()), vp(w1.data_ptr()), vp(b1.data_ptr()), vp(u.data_ptr()), vp(b.data_ptr()), i(B), i(H), i(W), vp(y.data_ptr()), vp(st))
 for _ in range(3):
     assert run() == 0
 torch.cuda.synchronize()

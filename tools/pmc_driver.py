@@ -1,5 +1,5 @@
 """One isolated kernel, launched a few times, for `rocprofv3 --pmc` passes (tools/pmc_kernel.sh): python tools/pmc_driver.py <what> [split]
-what: gemm (the 512 -> 512 + ReLU layer at M = 65536), gemm_qkv (256 -> 768), conv1b (64 -> 64 channels, 64 images 720x540, pooled), attention (64 images x 4 heads x 1024),
+what: conv1ab (SuperPoint conv1a fused into conv1b, 64 images 720x540), gemm (the 512 -> 512 + ReLU layer at M = 65536), gemm_qkv (256 -> 768), conv1b (64 -> 64 channels, 64 images 720x540, pooled), attention (64 images x 4 heads x 1024),
       loftr_l1out2 (196 -> 196 at 360x272, 32 images), loftr_gemm (256 -> 256 at M = 195840)"""
 import os
 import sys
@@ -25,6 +25,12 @@ elif what in ("conv1b", "loftr_l1out2"):
     options.set("CONV_KERNEL", "split")
     cv = WinoConv3x3(w, b)
     fn = lambda: cv(x, act=act, pool=pool)
+elif what == "conv1ab":
+    from mapfree_reloc_amd.nets.superpoint import SuperPointHIP
+    from mapfree_reloc_amd.nets import weights as WT
+    sp = SuperPointHIP(WT.superpoint_state_dict(), dev)
+    img = torch.rand(64, 1, 720, 540, device=dev)
+    fn = lambda: sp._conv1ab(img)
 elif what == "attention":
     from mapfree_reloc_amd.nets.superglue import SuperGlueHIP
     from mapfree_reloc_amd.nets import weights as WT

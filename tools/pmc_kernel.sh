@@ -37,7 +37,7 @@ if "SQ_INSTS_MFMA" in d and d["SQ_INSTS_MFMA"]:
     o["per_mfma"] = {"valu": d.get("SQ_INSTS_VALU", 0) / d["SQ_INSTS_MFMA"], "lds": d.get("SQ_INSTS_LDS", 0) / d["SQ_INSTS_MFMA"], "vmem_rd": d.get("SQ_INSTS_VMEM_RD", 0) / d["SQ_INSTS_MFMA"]}
 if "SQ_VALU_MFMA_BUSY_CYCLES" in d and "SQ_BUSY_CYCLES" in d and d["SQ_BUSY_CYCLES"]:
     o["mfma_pipe_busy_over_sq_busy_x4simd"] = d["SQ_VALU_MFMA_BUSY_CYCLES"] / (4 * d["SQ_BUSY_CYCLES"])
-ALG = {"conv1b": (64 * 64 * 720 * 540 * 4 + 64 * 64 * 360 * 270 * 4, 32), "loftr_l1out2": (32 * 196 * 360 * 272 * 4 * 2, 16)}
+ALG = {"conv1b": (64 * 64 * 720 * 540 * 4 + 64 * 64 * 360 * 270 * 4, 32), "conv1ab": (64 * 1 * 720 * 540 * 4 + 64 * 64 * 360 * 270 * 4, 32), "loftr_l1out2": (32 * 196 * 360 * 272 * 4 * 2, 16)}
 if what in ALG and "FETCH_SIZE" in d and "WRITE_SIZE" in d:       # the per-launch record bench.py quotes as roofline.traffic
     o["hbm_bytes_per_launch"] = 2 * d["FETCH_SIZE"] * 1024 + d["WRITE_SIZE"] * 1024
     o["algorithmic_bytes_per_launch"], o["pairs_per_step"] = ALG[what]
