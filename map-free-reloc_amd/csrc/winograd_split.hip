@@ -528,8 +528,8 @@ __global__ void __launch_bounds__(512, 2) wino_split_c1_kernel(
     const float *__restrict__ bias, float *__restrict__ y, int H, int W, int nbx, int nby, int S, int Sx)
 {
     constexpr int GS = 40;                                  // gray window row stride (38 columns used)
-    __shared__ __attribute__((aligned(16))) float lds[32768];
-    float *gwin = lds + 4 * WB_STAGE;                       // [12][GS] behind the four patch stages (30 720 floats)
+    __shared__ __attribute__((aligned(16))) float lds[32768 + 12 * GS];
+    float *gwin = lds + 32768;                              // [12][GS] BEHIND the 128 KB the patch stages / output rounds use: it lives across blocks
     // PERSISTENT: one workgroup per CU walks the spatial blocks of its XCD's contiguous raster range (block = xcd Sx + slot + k per_xcd); the gray
     // window of the NEXT block (one value per thread) is requested before this block's patch is computed and lands during the block, so only the
     // first block of a workgroup pays the memory latency in front of its patch (3.5 k of a block's 30 k cycles, profiles/r05_conv1ab_timeline_nonpersistent.json)
@@ -546,7 +546,11 @@ __global__ void __launch_bounds__(512, 2) wino_split_c1_kernel(
         const int iy = 8 * by_ - 2 + gr, ix = 32 * bx_ - 2 + gc;
         return (iy >= 0 && iy < H && ix >= 0 && ix < W) ? gray[((size_t)b_ * H + iy) * W + ix] : 0.f;
     };
-    float gnext = gray_of(slot);
+    // the window is double-staged: LDS holds the CURRENT block's, a register per thread the NEXT block's (requested a whole block ahead and written
+    // to LDS right after the current patch is done -- not at the top of the next block, where the wait for it would also drain this block's
+    // output stores: gfx950 counts loads and stores in one in-order counter)
+    if (tid < 12 * 38) gwin[(tid / 38) * GS + (tid - 38 * (tid / 38))] = gray_of(slot);
+    float gnext = gray_of(slot + per_xcd);
     for (int sl = slot; sl < Sx; sl += per_xcd) {
     const int s = xcd * Sx + sl;
     if (s >= S) break;
@@ -573,12 +577,10 @@ __global__ void __launch_bounds__(512, 2) wino_split_c1_kernel(
     };
     WB_STAMP(0);
 
-    // ---- gray window of this block -> LDS (the previous block's output rounds are done with the memory: barrier), the next block's requested
+    // ---- this block's gray window is in LDS (written during the previous block); the patch stages are free once every wavefront is past
+    // the previous block's last output round
     __syncthreads();
-    if (tid < 12 * 38) gwin[(tid / 38) * GS + (tid - 38 * (tid / 38))] = gnext;
-    gnext = gray_of(sl + per_xcd);
-    aload(0, 0); aload(0, 1);                               // (after the window is written: vmcnt retires in order, the write would wait for these too)
-    __syncthreads();
+    aload(0, 0); aload(0, 1);
     WB_STAMP(1);
     // ---- conv1a + ReLU on the patch: lane = (patch row pr < 10, column segment ps < 6): patch columns 6 ps .. 6 ps + 5 (34, 35 are never read)
     {
@@ -637,6 +639,9 @@ __global__ void __launch_bounds__(512, 2) wino_split_c1_kernel(
     WB_STAMP(2);
     __syncthreads();
     WB_STAMP(3);
+    // every wavefront is done with this block's window: the next block's goes in, the one after that is requested
+    if (tid < 12 * 38) gwin[(tid / 38) * GS + (tid - 38 * (tid / 38))] = gnext;
+    gnext = gray_of(sl + 2 * per_xcd);
 
     // ---- from here on: wino_split_p8_kernel<true, true> with the K step's stage = its 16 channels in place (no DMA, no fix-up, no barrier)
     const int ra = (wi == 0) ? 0 : (wi == 2) ? 2 : 1;
