@@ -236,6 +236,15 @@ int mfr_sp_sample_descriptors(const float *dense_nhwc, int B, int Hc, int Wc, co
 size_t mfr_gemm_f16x2_pack_bytes(int N, int K);
 int mfr_gemm_f16x2_pack(const float *w, int N, int K, void *packed, void *stream);
 int mfr_gemm_f16x2(const float *x, int ldx, const void *packed_w, const float *bias, float *y, int ldy, int M, int N, int K, int flags, void *stream);
+/*   mfr_gemm_f16x2_batched   nbatch products of one shape in one launch, y_b [M, ldy] = x_b [M, ldx] w_b [N, K]^T * out_mul: the matchers' score /
+ *                          similarity matrices (SuperGlue's S = mdesc0 mdesc1^T / 16, models/superglue.py:278-279 of the submodule; LoFTR's
+ *                          feat_c0 feat_c1^T / C, coarse_matching.py:104-106), which rounds 1-4 left to the library's batched fp32 GEMM.  The second
+ *                          operand of each product is packed per launch into caller scratch (mfr_gemm_f16x2_pack_batched: nbatch blobs of
+ *                          mfr_gemm_f16x2_pack_bytes(N, K) each, consecutive; row stride ldw and batch stride in elements), with out_mul -- a power
+ *                          of two, so exact -- folded into the per-row scale; batch strides of x and y in elements (x's a multiple of 4). */
+int mfr_gemm_f16x2_pack_batched(const float *w, int ldw, int nbatch, long long w_batch_stride, int N, int K, float out_mul, void *packed, void *stream);
+int mfr_gemm_f16x2_batched(const float *x, int ldx, long long x_batch_stride, const void *packed_w, const float *bias, float *y, int ldy, long long y_batch_stride,
+                           int nbatch, int M, int N, int K, int flags, void *stream);
 /*   mfr_conv_igemm_f16x2   implicit-GEMM convolution on NCHW images in the f16x2 arithmetic (csrc/gemm_split.hip): the strided / 1x1 / 7x7
  *                          convolutions of the matcher backbones (LoFTR's conv1, the stride-2 3x3 and 1x1 of layer2.0 / layer3.0, the FPN's 1x1
  *                          lateral and output convolutions; rounds 1-4: MIOpen / hipBLASLt).  y [B,Cout,Ho,Wo] = act(conv(x [B,Cin,H,W], w, stride,

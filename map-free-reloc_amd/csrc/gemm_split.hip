@@ -102,23 +102,31 @@ __device__ __forceinline__ void gb_products(f32x16 (&acc)[2][2], const GbFrag (&
 #undef GB_P4
 }
 #define GB_XT(F16) ((F16) ? 2 : 3)
+// batched launches (gridDim.y problems that share shapes: the matchers' score / similarity products, one packed "weight" per pair): element
+// strides of X and Y, 16-byte-unit stride of the packed operand (its 1 / scale tail moves with it)
+#define GB_BATCH_OFFSETS() do { const size_t bz_ = blockIdx.y; X += bz_ * (size_t)xs; Wp += bz_ * (size_t)ws; Y += bz_ * (size_t)ys; if (F16) oscale += bz_ * (size_t)ws * 4; } while (0)
 
 // ---- weight packing ----------------------------------------------------------------------------------------------------------------------
 // W [N, K] f32 row-major -> packed [n block][k block][term][k group][feature (128)][8 x 16 bit]; one thread per 16-byte unit.
 // f16x2: the blob ends with the per-feature 1 / scale (nnb x 128 floats, written by gb_scale_kernel BEFORE this kernel runs).
-__global__ void __launch_bounds__(64) gb_scale_kernel(const float *__restrict__ w, int N, int K, int npad, float *__restrict__ oscale)
+__global__ void __launch_bounds__(64) gb_scale_kernel(const float *__restrict__ w, int N, int K, int npad, float *__restrict__ oscale, float out_mul,
+                                                      int ldw, long long w_stride, long long p_stride_f)
 {
+    w += (size_t)blockIdx.y * (size_t)w_stride; oscale += (size_t)blockIdx.y * (size_t)p_stride_f;
     const int n = blockIdx.x, lane = threadIdx.x;
     float mx = 0.f;
     if (n < N)
-        for (int k = lane; k < K; k += 64) mx = fmaxf(mx, fabsf(w[(size_t)n * K + k]));
+        for (int k = lane; k < K; k += 64) mx = fmaxf(mx, fabsf(w[(size_t)n * ldw + k]));
 #pragma unroll
     for (int o = 32; o; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-    if (lane == 0 && n < npad) oscale[n] = 1.0f / sf_feature_scale(mx);              // powers of two: the reciprocal is exact
+    if (lane == 0 && n < npad) oscale[n] = out_mul / sf_feature_scale(mx);           // powers of two: the reciprocal is exact (out_mul: a power of two the caller wants folded into the product)
 }
 template <bool F16>
-__global__ void __launch_bounds__(256) gb_pack_kernel(const float *__restrict__ w, int N, int K, long long total, const float *__restrict__ oscale, uint4 *__restrict__ out)
+__global__ void __launch_bounds__(256) gb_pack_kernel(const float *__restrict__ w, int N, int K, long long total, const float *__restrict__ oscale, uint4 *__restrict__ out,
+                                                      float out_mul, int ldw, long long w_stride, long long p_stride_u)
 {
+    w += (size_t)blockIdx.y * (size_t)w_stride; out += (size_t)blockIdx.y * (size_t)p_stride_u;
+    if (F16) oscale += (size_t)blockIdx.y * (size_t)p_stride_u * 4;
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
     if (t >= total) return;
     const int u = (int)(t % GB_W_TILE_UNITS(F16));
@@ -128,10 +136,10 @@ __global__ void __launch_bounds__(256) gb_pack_kernel(const float *__restrict__ 
     const int term = u / 512, kg = (u % 512) / 128, f = u % 128;
     const int n = nb * GB_BN + f, k0 = kb * GB_BK + 8 * kg;
     unsigned word[8];
-    const float s = F16 ? 1.0f / oscale[n] : 1.0f;
+    const float s = F16 ? out_mul / oscale[n] : 1.0f;            // (oscale = out_mul / scale)
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        const float x = (n < N) ? w[(size_t)n * K + k0 + e] : 0.f;
+        const float x = (n < N) ? w[(size_t)n * ldw + k0 + e] : 0.f;
         if (F16) {
             unsigned short wh, wl, wq;
             sf_split_w(x * s, wh, wl, wq);
@@ -150,8 +158,10 @@ __global__ void __launch_bounds__(256) gb_pack_kernel(const float *__restrict__ 
 // FLAGS: 1 = ReLU, 2 = accumulate into Y (Y += ...)
 template <int FLAGS, bool F16>
 __global__ void __launch_bounds__(256, 2) gemm_split_kernel(const float *__restrict__ X, int ldx, const uint4 *__restrict__ Wp, const float *__restrict__ oscale,
-                                                            const float *__restrict__ bias, float *__restrict__ Y, int ldy, int M, int N, int K, int nnb)
+                                                            const float *__restrict__ bias, float *__restrict__ Y, int ldy, int M, int N, int K, int nnb,
+                                                            long long xs, long long ws, long long ys)
 {
+    GB_BATCH_OFFSETS();
     constexpr int XT = GB_XT(F16);
     constexpr int WT = GB_WT(F16);
     __shared__ uint4 lds[(XT + WT) * GB_TERM_UNITS];      // X terms, W terms
@@ -264,8 +274,10 @@ __global__ void __launch_bounds__(256, 2) gemm_split_kernel(const float *__restr
 #define GB_RSRC_FLAGS 0x00020000
 template <int FLAGS, bool F16>
 __global__ void __launch_bounds__(256, 2) gemm_split_pk_kernel(const float *__restrict__ X, int ldx, const uint4 *__restrict__ Wp, const float *__restrict__ oscale,
-                                                               const float *__restrict__ bias, float *__restrict__ Y, int ldy, int M, int N, int K, int nnb, int nmb)
+                                                               const float *__restrict__ bias, float *__restrict__ Y, int ldy, int M, int N, int K, int nnb, int nmb,
+                                                               long long xs, long long ws, long long ys)
 {
+    GB_BATCH_OFFSETS();
     constexpr int XT = GB_XT(F16);
     constexpr int WT = GB_WT(F16);
     __shared__ uint4 lds[(XT + WT) * GB_TERM_UNITS];
@@ -414,8 +426,10 @@ __device__ unsigned long long gd_prof[4][64];
 #endif
 template <int FLAGS, bool F16>
 __global__ void __launch_bounds__(256, 2) gemm_split_d_kernel(const float *__restrict__ X, int ldx, const uint4 *__restrict__ Wp, unsigned wp_bytes, const float *__restrict__ oscale,
-                                                              const float *__restrict__ bias, float *__restrict__ Y, int ldy, int M, int N, int K, int nnb, int nmb)
+                                                              const float *__restrict__ bias, float *__restrict__ Y, int ldy, int M, int N, int K, int nnb, int nmb,
+                                                              long long xs, long long ws, long long ys)
 {
+    GB_BATCH_OFFSETS();
     constexpr int XT = GB_XT(F16);
     constexpr int WT = GB_WT(F16), WSTAGE = GD_WSTAGE(F16);
     __shared__ uint4 lds[XT * GB_TERM_UNITS + 2 * WSTAGE];
@@ -726,8 +740,11 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_f16x2_kernel(const float *_
 static size_t gb_tile_bytes(int N, int K, bool f16) { return (size_t)((N + GB_BN - 1) / GB_BN) * (K / GB_BK) * GB_W_TILE_UNITS(f16) * 16; }
 
 template <bool F16>
-static int gb_launch(const float *x, int ldx, const void *packed_w, const float *bias, float *y, int ldy, int M, int N, int K, int flags, void *stream)
+static int gb_launch(const float *x, int ldx, const void *packed_w, const float *bias, float *y, int ldy, int M, int N, int K, int flags, void *stream,
+                     int nbatch = 1, long long xs = 0, long long ws_bytes = 0, long long ys = 0)
 {
+    if (nbatch <= 0 || nbatch > 65535 || (ws_bytes & 15) || (xs & 3) || xs < 0 || ys < 0) return MFR_E_ARG;
+    const long long ws = ws_bytes / 16;
     // flags: 1 = ReLU, 2 = accumulate; 4 = one tile per workgroup (the baseline of the bitwise-agreement test), 8 = persistent 128 x 128 workgroups
     // with register-staged W; no variant flag: W by LDS-DMA (K % 64 == 0, packed weight < 4 GB), else as flag 8
     if (!x || !packed_w || !y || M <= 0 || N <= 0 || K <= 0 || (K % GB_BK) || (ldx & 3) || ldx < K || ldy < N || flags < 0 || (flags & ~15) || (flags & 12) == 12) return MFR_E_ARG;
@@ -750,15 +767,15 @@ static int gb_launch(const float *x, int ldx, const void *packed_w, const float 
     const unsigned grid = 8u * (unsigned)(per_xcd < cap ? per_xcd : cap);
 #define GB_SW(GO) switch (f) { case 0: GO(0); break; case 1: GO(1); break; case 2: GO(2); break; default: GO(3); break; }
     if (one_tile) {
-#define GB_GO(F) hipLaunchKernelGGL((gemm_split_kernel<F, F16>), dim3((unsigned)tiles), dim3(256), 0, st, x, ldx, wp, oscale, bias, y, ldy, M, N, K, nnb)
+#define GB_GO(F) hipLaunchKernelGGL((gemm_split_kernel<F, F16>), dim3((unsigned)tiles, (unsigned)nbatch), dim3(256), 0, st, x, ldx, wp, oscale, bias, y, ldy, M, N, K, nnb, xs, ws, ys)
         GB_SW(GB_GO)
 #undef GB_GO
     } else if (pk) {
-#define GB_GO(F) hipLaunchKernelGGL((gemm_split_pk_kernel<F, F16>), dim3(grid), dim3(256), 0, st, x, ldx, wp, oscale, bias, y, ldy, M, N, K, nnb, nmb)
+#define GB_GO(F) hipLaunchKernelGGL((gemm_split_pk_kernel<F, F16>), dim3(grid, (unsigned)nbatch), dim3(256), 0, st, x, ldx, wp, oscale, bias, y, ldy, M, N, K, nnb, nmb, xs, ws, ys)
         GB_SW(GB_GO)
 #undef GB_GO
     } else {
-#define GB_GO(F) hipLaunchKernelGGL((gemm_split_d_kernel<F, F16>), dim3(grid), dim3(256), 0, st, x, ldx, wp, (unsigned)tb, oscale, bias, y, ldy, M, N, K, nnb, nmb)
+#define GB_GO(F) hipLaunchKernelGGL((gemm_split_d_kernel<F, F16>), dim3(grid, (unsigned)nbatch), dim3(256), 0, st, x, ldx, wp, (unsigned)tb, oscale, bias, y, ldy, M, N, K, nnb, nmb, xs, ws, ys)
         GB_SW(GB_GO)
 #undef GB_GO
     }
@@ -792,22 +809,30 @@ int mfr_gemm_bf16x3_pack(const float *w, int N, int K, void *packed, void *strea
 {
     if (!w || !packed || N <= 0 || K <= 0 || (K % GB_BK)) return MFR_E_ARG;
     const long long total = (long long)(gb_tile_bytes(N, K, false) / 16);
-    hipLaunchKernelGGL((gb_pack_kernel<false>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, N, K, total, (const float *)nullptr, (uint4 *)packed);
+    hipLaunchKernelGGL((gb_pack_kernel<false>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, N, K, total, (const float *)nullptr, (uint4 *)packed,
+                       1.0f, K, 0ll, 0ll);
+    CHECK_LAUNCH();
+    return 0;
+}
+
+int mfr_gemm_f16x2_pack_batched(const float *w, int ldw, int nbatch, long long w_batch_stride, int N, int K, float out_mul, void *packed, void *stream)
+{
+    if (ldw < K || !w || !packed || N <= 0 || K <= 0 || (K % GB_BK) || nbatch <= 0 || nbatch > 65535 || !(out_mul > 0.f)) return MFR_E_ARG;
+    const size_t tb = gb_tile_bytes(N, K, true);
+    const long long total = (long long)(tb / 16);
+    const int npad = (N + GB_BN - 1) / GB_BN * GB_BN;
+    const size_t pbytes = tb + (size_t)npad * 4;                       // one problem's packed operand (a multiple of 16)
+    float *oscale = (float *)((char *)packed + tb);
+    hipLaunchKernelGGL(gb_scale_kernel, dim3((unsigned)npad, (unsigned)nbatch), dim3(64), 0, (hipStream_t)stream, w, N, K, npad, oscale, out_mul, ldw, w_batch_stride, (long long)(pbytes / 4));
+    hipLaunchKernelGGL((gb_pack_kernel<true>), dim3((unsigned)((total + 255) / 256), (unsigned)nbatch), dim3(256), 0, (hipStream_t)stream, w, N, K, total, (const float *)oscale,
+                       (uint4 *)packed, out_mul, ldw, w_batch_stride, (long long)(pbytes / 16));
     CHECK_LAUNCH();
     return 0;
 }
 
 int mfr_gemm_f16x2_pack(const float *w, int N, int K, void *packed, void *stream)
 {
-    if (!w || !packed || N <= 0 || K <= 0 || (K % GB_BK)) return MFR_E_ARG;
-    const size_t tb = gb_tile_bytes(N, K, true);
-    const long long total = (long long)(tb / 16);
-    const int npad = (N + GB_BN - 1) / GB_BN * GB_BN;
-    float *oscale = (float *)((char *)packed + tb);
-    hipLaunchKernelGGL(gb_scale_kernel, dim3((unsigned)npad), dim3(64), 0, (hipStream_t)stream, w, N, K, npad, oscale);
-    hipLaunchKernelGGL((gb_pack_kernel<true>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, N, K, total, (const float *)oscale, (uint4 *)packed);
-    CHECK_LAUNCH();
-    return 0;
+    return mfr_gemm_f16x2_pack_batched(w, K, 1, 0, N, K, 1.0f, packed, stream);
 }
 
 int mfr_gemm_bf16x3(const float *x, int ldx, const void *packed_w, const float *bias, float *y, int ldy, int M, int N, int K, int flags, void *stream)
@@ -818,6 +843,12 @@ int mfr_gemm_bf16x3(const float *x, int ldx, const void *packed_w, const float *
 int mfr_gemm_f16x2(const float *x, int ldx, const void *packed_w, const float *bias, float *y, int ldy, int M, int N, int K, int flags, void *stream)
 {
     return gb_launch<true>(x, ldx, packed_w, bias, y, ldy, M, N, K, flags, stream);
+}
+
+int mfr_gemm_f16x2_batched(const float *x, int ldx, long long x_batch_stride, const void *packed_w, const float *bias, float *y, int ldy, long long y_batch_stride,
+                           int nbatch, int M, int N, int K, int flags, void *stream)
+{
+    return gb_launch<true>(x, ldx, packed_w, bias, y, ldy, M, N, K, flags, stream, nbatch, x_batch_stride, (long long)mfr_gemm_f16x2_pack_bytes(N, K), y_batch_stride);
 }
 
 int mfr_conv_igemm_k(int Cin, int KH, int KW)

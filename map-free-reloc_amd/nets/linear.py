@@ -38,3 +38,33 @@ class SplitLinear:
         _lib.check(self._gemm(x.data_ptr(), x.stride(0), _lib.ptr(self.packed), _lib.ptr(self.bias), out.data_ptr(), out.stride(0),
                               M, self.N, self.K, (1 if relu else 0) | (2 if accumulate else 0) | kernel_flag, _lib.stream_ptr()), f"mfr_gemm_{self.split}")
         return out
+
+
+class SplitBatchedNT:
+    """out[b] = x[b] @ w[b]^T * out_mul for a batch of same-shape products (mfr_gemm_f16x2_batched): the matchers' score / similarity
+    matrices.  w is packed per call into scratch this object keeps (one allocation per shape); out_mul must be a power of two."""
+
+    def __init__(self):
+        self.lib = _lib.load(require_gpu=True)
+        self.scratch = {}
+
+    def __call__(self, x, w, out_mul=1.0, out=None):
+        assert x.dim() == 3 and w.dim() == 3 and x.shape[0] == w.shape[0] and x.shape[2] == w.shape[2] and x.dtype == w.dtype == torch.float32
+        nb, M, K = x.shape
+        N = w.shape[1]
+        assert x.stride(2) == 1 and w.stride(2) == 1
+        per = self.lib.mfr_gemm_f16x2_pack_bytes(N, K)
+        if per == 0:
+            raise ValueError(f"SplitBatchedNT: K = {K} must be a multiple of 32")
+        key = (nb, N, K, x.device)
+        if key not in self.scratch:
+            self.scratch[key] = torch.empty(nb * per, dtype=torch.uint8, device=x.device)
+        pk = self.scratch[key]
+        if out is None:
+            out = torch.empty(nb, M, N, dtype=torch.float32, device=x.device)
+        assert out.shape == (nb, M, N) and out.stride(2) == 1
+        st = _lib.stream_ptr()
+        _lib.check(self.lib.mfr_gemm_f16x2_pack_batched(w.data_ptr(), w.stride(1), nb, w.stride(0), N, K, float(out_mul), _lib.ptr(pk), st), "mfr_gemm_f16x2_pack_batched")
+        _lib.check(self.lib.mfr_gemm_f16x2_batched(x.data_ptr(), x.stride(1), x.stride(0), _lib.ptr(pk), None, out.data_ptr(), out.stride(1), out.stride(0),
+                                                   nb, M, N, K, 0, st), "mfr_gemm_f16x2_batched")
+        return out

@@ -93,6 +93,12 @@ class LoFTRHIP:
         self.merge_feat = (dev(sd["fine_preprocess.merge_feat.weight"]), dev(sd["fine_preprocess.merge_feat.bias"]))
         self._ws_la = self._ws_cm = None
         self._fine_lin = None
+        # the coarse similarity matrix feat_c0 feat_c1^T / C as one batched f16x2 launch (csrc/gemm_split.hip); the bf16x3 arithmetic keeps the library's GEMM
+        if options.get("SPLIT") == "f16x2":
+            from .linear import SplitBatchedNT
+            self.sim_gemm = SplitBatchedNT()
+        else:
+            self.sim_gemm = None
         self._pe = {}
 
     # ------------------------------------------------------------------ backbone (torch / MIOpen)
@@ -208,7 +214,9 @@ class LoFTRHIP:
         C = f0.shape[-1]
         # (f0 / sqrt C) . (f1 / sqrt C): for C a power of two (256) scaling the 6 MB operand is EXACT and commutes with the
         # contraction bit for bit, so the 150 MB/pair similarity matrix is written once and never rescaled in place
-        if C & (C - 1) == 0:
+        if C & (C - 1) == 0 and self.sim_gemm is not None:
+            S = self.sim_gemm(f0, f1, out_mul=1.0 / C)               # one batched f16x2 launch, 1 / C folded into the packed operand's row scales
+        elif C & (C - 1) == 0:
             S = torch.bmm(f0 * (1.0 / C), f1.transpose(1, 2))        # strided operands are fine for the batched GEMM
         else:
             S = torch.bmm(f0, f1.transpose(1, 2))

@@ -13,7 +13,7 @@ import torch
 import torch.nn.functional as F
 
 from .. import _lib
-from .linear import SplitLinear
+from .linear import SplitBatchedNT, SplitLinear
 
 
 def _fold_bn(w, b, sd, bn):
@@ -83,6 +83,7 @@ class SuperGlueHIP:
             L["lin2"] = SplitLinear(L["w2t"].t())
         self.wf, self.bf = dev(fw["wf"]), dev(fw["bf"])
         self.lin_final = SplitLinear(self.wf, self.bf)
+        self.score_gemm = SplitBatchedNT() if self.lin_final.split == "f16x2" else None      # (the bf16x3 arithmetic keeps the library's batched fp32 GEMM)
         self.bin_score = fw["bin_score"]
         self._ws = None
         self._size = {}
@@ -157,6 +158,10 @@ class SuperGlueHIP:
         n_corr [B], matches0, matching_scores0)"""
         kpts, scores, desc, n = sp_out["kpts"], sp_out["scores"], sp_out["desc"], sp_out["n"]
         md = self.final_descriptors(kpts, scores, desc, n, image_hw)
-        S = torch.bmm(md[0::2], md[1::2].transpose(1, 2)) * (1.0 / 16.0)
+        # scores = mdesc0 . mdesc1 / sqrt(256): one batched f16x2 launch, 1/16 folded (exactly) into the per-row scale of the packed operand
+        if self.score_gemm is not None:
+            S = self.score_gemm(md[0::2], md[1::2], out_mul=1.0 / 16.0)
+        else:
+            S = torch.bmm(md[0::2], md[1::2].transpose(1, 2)) * (1.0 / 16.0)
         return self.sinkhorn_match(S, n[0::2].contiguous(), n[1::2].contiguous(),
                                    kpts[0::2].contiguous(), kpts[1::2].contiguous(), maxN)

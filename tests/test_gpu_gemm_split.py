@@ -118,3 +118,31 @@ def test_f16x2_small_and_zero_operands():
 def test_split_linear_rejects():
     with pytest.raises(ValueError):
         SplitLinear(torch.zeros(8, 48, device=DEV))
+
+
+@pytest.mark.parametrize("nb,M,N,K,ldx,ldw,mul", [(32, 1024, 1024, 256, 256, 256, 1.0 / 16.0), (3, 1200, 1100, 256, 512, 512, 1.0 / 256.0), (2, 77, 130, 64, 64, 96, 1.0),
+                                                  (1, 4800, 4800, 256, 512, 512, 1.0 / 256.0), (5, 1, 1, 32, 32, 32, 2.0)])
+def test_batched_products_equal_the_per_problem_launches_and_float64(nb, M, N, K, ldx, ldw, mul):
+    """the matchers' score / similarity matrices (SuperGlue S = mdesc0 mdesc1^T / 16 on interleaved pairs, LoFTR feat_c0 feat_c1^T / C on the row-strided
+    halves of the [x | message] buffer): one batched launch == SplitLinear on every problem with the same out_mul applied afterwards (a power of two:
+    bit for bit), and the fp32-class error against a float64 product"""
+    from mapfree_reloc_amd.nets.linear import SplitBatchedNT
+    g = torch.Generator().manual_seed(nb * 131 + M + N)
+    xa = (torch.randn(2 * nb, M, ldx, generator=g) * 3.0).to(DEV)
+    wa = (torch.randn(2 * nb, N, ldw, generator=g) * torch.rand(2 * nb, N, 1, generator=g) * 4.0).to(DEV)
+    x, w = xa[0::2, :, :K], wa[1::2, :, :K]                                  # batch stride 2 x, row stride > K
+    bg = SplitBatchedNT()
+    y = bg(x, w, out_mul=mul)
+    assert y.shape == (nb, M, N) and torch.isfinite(y).all()
+    for b in range(nb):
+        one = SplitLinear(w[b].contiguous(), None, split="f16x2")(x[b])
+        assert torch.equal(one * mul, y[b])
+        want = (x[b].double() @ w[b].double().t()) * mul
+        err = (y[b].double() - want).abs()
+        ref = (x[b] @ w[b].t() * mul).double()
+        assert err.max().item() <= 4e-6 * want.abs().max().item() + 1e-12
+        assert err.pow(2).mean().sqrt().item() <= 2.0 * (ref - want).pow(2).mean().sqrt().item() + 1e-12
+    # the strided output form (written inside a wider buffer) and a second call on the same object (scratch reuse)
+    big = torch.full((nb, M, N + 8), 7.0, device=DEV)
+    bg(x, w, out_mul=mul, out=big[:, :, :N])
+    assert torch.equal(big[:, :, :N], y) and (big[:, :, N:] == 7.0).all()
