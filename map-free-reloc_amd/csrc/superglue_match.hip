@@ -50,6 +50,62 @@ static __device__ __forceinline__ void lse_merge(Lse &a, float m, float s)
     a.m = keep ? a.m : nm;
 }
 static __device__ __forceinline__ float lse_val(const Lse &a) { return a.m + __logf(a.s); }
+// round 5: four terms at once -- the block's maximum first, then ONE rescale of the running sum per four terms instead of one per term
+// (1.5 exponentials per term instead of 2).  x0 is finite; x1 .. x3 may be -inf (absent: exp(-inf) = 0).
+static __device__ __forceinline__ void lse_add4(Lse &a, float x0, float x1, float x2, float x3)
+{
+    const float bm = fmaxf(fmaxf(x0, x1), fmaxf(x2, x3));
+    const float bs = ((__expf(x0 - bm) + __expf(x1 - bm)) + __expf(x2 - bm)) + __expf(x3 - bm);
+    const float nm = fmaxf(a.m, bm);
+    a.s = __builtin_fmaf(a.s, __expf(a.m - nm), bs * __expf(bm - nm));
+    a.m = nm;
+}
+// wavefront-wide max / sum that leave the SAME bits in all 64 lanes (every step pairs two groups and a + b == b + a): DPP inside a row of
+// 16 lanes (quad_perm xor 1, xor 2, row_half_mirror, row_mirror), then gfx950's v_permlane16_swap / v_permlane32_swap across rows and halves
+// (two copies of x go in; one comes back holding the even rows' / lower half's values everywhere, the other the odd rows' / upper half's) --
+// no LDS round trip.  Inline asm: the builtin, given the same value twice, was compiled to x + x (hipcc 7.2).
+static __device__ __forceinline__ void sg_swap16(float &a, float &b) { asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+static __device__ __forceinline__ void sg_swap32(float &a, float &b) { asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+template <int CTRL> static __device__ __forceinline__ float sg_dpp(float x)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, false));
+}
+static __device__ __forceinline__ float sg_wave_max(float x)
+{
+    x = fmaxf(x, sg_dpp<0xB1>(x)); x = fmaxf(x, sg_dpp<0x4E>(x)); x = fmaxf(x, sg_dpp<0x141>(x)); x = fmaxf(x, sg_dpp<0x140>(x));
+    float y = x; sg_swap16(x, y); x = fmaxf(x, y);
+    y = x; sg_swap32(x, y); x = fmaxf(x, y);
+    return x;
+}
+static __device__ __forceinline__ float sg_wave_sum(float x)
+{
+    x += sg_dpp<0xB1>(x); x += sg_dpp<0x4E>(x); x += sg_dpp<0x141>(x); x += sg_dpp<0x140>(x);
+    float y = x; sg_swap16(x, y); x += y;
+    y = x; sg_swap32(x, y); x += y;
+    return x;
+}
+// u_i of a row on the 16-byte fast path: x[k] = S_ij + v_j of this lane's 16 columns (-inf beyond n), vn = alpha + v_n (the dustbin column, a
+// 1025th term that lane 0 adds).  Round 5: the row's maximum first (wavefront-wide), then one exponential per term against it and a plain
+// wavefront sum -- rounds 1-4 merged 64 (max, sum) pairs in a butterfly of six rescaling steps, 84 instructions a row.
+static __device__ __forceinline__ float sg_row_u(const float (&x)[16], float vn, float log_mu, int lane)
+{
+    float mx = x[0];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) mx = fmaxf(mx, x[k]);
+    mx = fmaxf(sg_wave_max(mx), vn);
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) sum += __expf(x[k] - mx);
+    const float sd = sum + __expf(vn - mx);
+    sum = sg_wave_sum(lane == 0 ? sd : sum);
+    return log_mu - (mx + __logf(sum));
+}
+// rows of accumulator r (0 .. 3) of row group g (= i mod 16), in the order they are added: whole quads first (row g + 64 t + 16 r while
+// g + 64 t + 48 < m), then -- accumulator 0 only -- the group's left-over rows (step 16); blocks of four consecutive entries of this list go
+// through lse_add4.  Shared by sg_col_kernel and sg_sweep_kernel: the same sums in the same order.
+static __device__ __forceinline__ int sg_nq(int m, int g) { return (m - 48 - g > 0) ? (m - 48 - g + 63) / 64 : 0; }
+static __device__ __forceinline__ int sg_ntail(int m, int g, int nq) { return max(0, (m - (g + 64 * nq) + 15) / 16); }
+static __device__ __forceinline__ int sg_row_of(int g, int r, int nq, int t) { return t < nq ? g + 64 * t + 16 * r : g + 64 * nq + 16 * (t - nq); }
 
 // rows 0..m (row m = dustbin row).  S: [B, ldS, ldS] raw scores (already / sqrt(256)).  One wavefront per row; a lane takes
 // float4 pieces (16-byte loads of the row and of v, all issued before the first use), reduces them with max-then-sum (no
@@ -79,15 +135,9 @@ __global__ void __launch_bounds__(256) sg_row_kernel(const float *__restrict__ S
             x[4 * k + 2] = (4 * j4 + 2 < n) ? r.z + w.z : -INFINITY;
             x[4 * k + 3] = (4 * j4 + 3 < n) ? r.w + w.w : -INFINITY;
         }
-        float mx = x[0];
-#pragma unroll
-        for (int k = 1; k < 16; ++k) mx = fmaxf(mx, x[k]);
-        if (mx > -INFINITY) {
-            float sum = 0.f;
-#pragma unroll
-            for (int k = 0; k < 16; ++k) sum += __expf(x[k] - mx);
-            a.m = mx; a.s = sum;
-        }
+        const float ui = sg_row_u(x, alpha + vb[n], norm, lane);
+        if (lane == 0) u[(size_t)b * SG_LDV(ldS) + i] = ui;
+        return;
     } else if (i < m) {
         const float *row = S + ((size_t)b * ldS + i) * ldS;
         for (int j = lane; j < n; j += 64) lse_add(a, row[j] + vb[j]);
@@ -124,13 +174,21 @@ __global__ void __launch_bounds__(1024) sg_col_kernel(const float *__restrict__ 
         const bool dust = j == n;
         const float *col = S + (size_t)b * ldS * ldS + (dust ? 0 : j);
         Lse a1 = { -INFINITY, 0.f }, a2 = a1, a3 = a1;
-        int i = g;
-        for (; i + 48 < m; i += 64) {
-            const float s0 = dust ? alpha : col[(size_t)i * ldS], s1 = dust ? alpha : col[(size_t)(i + 16) * ldS];
-            const float s2 = dust ? alpha : col[(size_t)(i + 32) * ldS], s3 = dust ? alpha : col[(size_t)(i + 48) * ldS];
-            lse_add(a, s0 + ub[i]); lse_add(a1, s1 + ub[i + 16]); lse_add(a2, s2 + ub[i + 32]); lse_add(a3, s3 + ub[i + 48]);
-        }
-        for (; i < m; i += 16) lse_add(a, (dust ? alpha : col[(size_t)i * ldS]) + ub[i]);
+        const int nq = sg_nq(m, g), ntail = sg_ntail(m, g, nq);
+        auto run = [&](Lse &ar, int r) {
+            const int nr = nq + (r == 0 ? ntail : 0);
+            for (int t = 0; t < nr; t += 4) {
+                float x[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int i = sg_row_of(g, r, nq, min(t + q, nr - 1));
+                    const float xv = (dust ? alpha : col[(size_t)i * ldS]) + ub[i];
+                    x[q] = (t + q < nr) ? xv : -INFINITY;
+                }
+                lse_add4(ar, x[0], x[1], x[2], x[3]);
+            }
+        };
+        run(a, 0); run(a1, 1); run(a2, 2); run(a3, 3);
         lse_merge(a, a1.m, a1.s); lse_merge(a2, a3.m, a3.s); lse_merge(a, a2.m, a2.s);
         if (g == 0) lse_add(a, alpha + ub[m]);                     // dustbin row
     }
@@ -156,11 +214,15 @@ __global__ void __launch_bounds__(1024) sg_col_kernel(const float *__restrict__ 
 // in sg_col_kernel's order (k = 1 .. 15) into v.  The dustbin column is a 17th column of every lane (its entries are all alpha), and the
 // dustbin row's u_m is computed by workgroup 0 before its rows.  Requires the 16-byte fast path of sg_row_kernel (ldS % 4 == 0, ldS <= 1024); other shapes keep
 // the two-pass kernels.
-__global__ void __launch_bounds__(256) sg_sweep_kernel(const float *__restrict__ S, int ldS, const int *__restrict__ n0, const int *__restrict__ n1,
+__global__ void __launch_bounds__(256, 2) sg_sweep_kernel(const float *__restrict__ S, int ldS, const int *__restrict__ n0, const int *__restrict__ n1,
                                                        float alpha, const float *__restrict__ v, float *__restrict__ u,
                                                        float *__restrict__ part_m /*[B, 16, SG_LDV]*/, float *__restrict__ part_s)
 {
-    __shared__ float xm[2][17][64], xs[2][17][64];
+    __shared__ float xm[1][17][64], xs[1][17][64];
+    // the column partials of the four wavefronts (17 per lane: 16 columns + the dustbin column) live in LDS between blocks of rows: the two row
+    // sets (128 registers) and the partials (34) do not fit 256 registers together, and one read + one write per FOUR rows is cheap
+    __shared__ float4 am4[4][4][64], as4[4][4][64];
+    __shared__ float amd[4][64], asd[4][64];
     __shared__ float um_s;
     const int b = blockIdx.y, g = blockIdx.x, lane = threadIdx.x & 63, r = threadIdx.x >> 6;
     const int m = n0[b], n = n1[b];
@@ -188,92 +250,106 @@ __global__ void __launch_bounds__(256) sg_sweep_kernel(const float *__restrict__
         __syncthreads();
     }
 
-    Lse acc[17];                                                      // [16]: the dustbin column (every lane the same value)
 #pragma unroll
-    for (int k = 0; k < 17; ++k) { acc[k].m = -INFINITY; acc[k].s = 0.f; }
-    // whole quads of rows of this group: rows g + 64 q + 16 r while g + 64 q + 48 < m; then the left-over rows (step 16) on wavefront 0
-    const int nq = (m - 48 - g > 0) ? (m - 48 - g + 63) / 64 : 0;
-    const int ntail = (r == 0) ? max(0, (m - (g + 64 * nq) + 15) / 16) : 0;
-    const int nrows = nq + ntail;
-    auto row_of = [&](int t) { return t < nq ? g + 64 * t + 16 * r : g + 64 * nq + 16 * (t - nq); };
-    // four rows in flight per wavefront (a row is 4 KB; one row ahead left the sweep bound by the cache latency): ring of four register sets
-    float4 rb0[4], rb1[4], rb2[4], rb3[4];
+    for (int k = 0; k < 4; ++k) { am4[r][k][lane] = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY); as4[r][k][lane] = make_float4(0.f, 0.f, 0.f, 0.f); }
+    amd[r][lane] = -INFINITY; asd[r][lane] = 0.f;                     // the dustbin column (every lane the same value)
+    // this wavefront = accumulator r of row group g: its rows t = 0 .. nrows - 1 (sg_row_of), four at a time
+    const int nq = sg_nq(m, g);
+    const int nrows = nq + (r == 0 ? sg_ntail(m, g, nq) : 0);
     // No per-element branches: every lane loads its four 16-byte pieces (index clamped into the row), columns >= n are masked to -inf by
     // selects for the row sum and simply accumulate into column partials that nobody reads (a column's partial never mixes with another's).
     const int j4max = (ldS >> 2) - 1;
     bool ok[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) ok[k] = 4 * (lane + 64 * (k >> 2)) + (k & 3) < n;
-    auto load_row = [&](float4 (&d)[4], int t) {
+    // two register sets of four rows (a row is 4 KB): the next block's 16 KB are requested before this block's arithmetic starts
+    auto load_block = [&](float4 (&d)[4][4], int t) {
         if (t >= nrows) return;
-        const float4 *row4 = (const float4 *)(S + ((size_t)b * ldS + row_of(t)) * ldS);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) d[k] = row4[min(lane + 64 * k, j4max)];
+        for (int q = 0; q < 4; ++q) {
+            if (t + q < nrows) {
+                const float4 *row4 = (const float4 *)(S + ((size_t)b * ldS + sg_row_of(g, r, nq, t + q)) * ldS);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) d[q][k] = row4[min(lane + 64 * k, j4max)];
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) d[q][k] = make_float4(0.f, 0.f, 0.f, 0.f);     // absent row: finite filler, its u is -inf below
+            }
+        }
     };
     float4 w[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) w[k] = v4[min(lane + 64 * k, j4max)];
-    auto do_row = [&](const float4 (&cur)[4], int t) {
+    auto do_block = [&](const float4 (&cur)[4][4], int t) {
         if (t >= nrows) return;
-        const int i = row_of(t);
-        // ---- u_i: sg_row_kernel's fast path (same sums in the same order)
-        float x[16];
+        float ui[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            ui[q] = -INFINITY;
+            if (t + q < nrows) {
+                // ---- u_i: sg_row_kernel's fast path (same sums in the same order)
+                float x[16];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float4 wk = w[k];
+                    x[4 * k] = ok[4 * k] ? cur[q][k].x + wk.x : -INFINITY;
+                    x[4 * k + 1] = ok[4 * k + 1] ? cur[q][k].y + wk.y : -INFINITY;
+                    x[4 * k + 2] = ok[4 * k + 2] ? cur[q][k].z + wk.z : -INFINITY;
+                    x[4 * k + 3] = ok[4 * k + 3] ? cur[q][k].w + wk.w : -INFINITY;
+                }
+                ui[q] = sg_row_u(x, vn, norm, lane);
+                if (lane == 0) ub[sg_row_of(g, r, nq, t + q)] = ui[q];
+            }
+            if (q & 1) __builtin_amdgcn_sched_barrier(0);          // two rows' reductions interleave (their cross-lane latencies overlap); all four would not fit the registers
+        }
+        // ---- column partials of this lane's 16 columns + the dustbin column: sg_col_kernel's lse_add4 over the same four rows
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            x[4 * k] = ok[4 * k] ? cur[k].x + w[k].x : -INFINITY;
-            x[4 * k + 1] = ok[4 * k + 1] ? cur[k].y + w[k].y : -INFINITY;
-            x[4 * k + 2] = ok[4 * k + 2] ? cur[k].z + w[k].z : -INFINITY;
-            x[4 * k + 3] = ok[4 * k + 3] ? cur[k].w + w[k].w : -INFINITY;
+            const float4 pm = am4[r][k][lane], ps = as4[r][k][lane];
+            Lse a0 = { pm.x, ps.x }, a1 = { pm.y, ps.y }, a2 = { pm.z, ps.z }, a3 = { pm.w, ps.w };
+            lse_add4(a0, cur[0][k].x + ui[0], cur[1][k].x + ui[1], cur[2][k].x + ui[2], cur[3][k].x + ui[3]);
+            lse_add4(a1, cur[0][k].y + ui[0], cur[1][k].y + ui[1], cur[2][k].y + ui[2], cur[3][k].y + ui[3]);
+            lse_add4(a2, cur[0][k].z + ui[0], cur[1][k].z + ui[1], cur[2][k].z + ui[2], cur[3][k].z + ui[3]);
+            lse_add4(a3, cur[0][k].w + ui[0], cur[1][k].w + ui[1], cur[2][k].w + ui[2], cur[3][k].w + ui[3]);
+            am4[r][k][lane] = make_float4(a0.m, a1.m, a2.m, a3.m); as4[r][k][lane] = make_float4(a0.s, a1.s, a2.s, a3.s);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        float mx = x[0];
-#pragma unroll
-        for (int k = 1; k < 16; ++k) mx = fmaxf(mx, x[k]);
-        const float mxs = (mx > -INFINITY) ? mx : 0.f;              // a lane without valid columns: every term exp(-inf - 0) = 0, (m, s) = (-inf, 0)
-        float sum = 0.f;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) sum += __expf(x[k] - mxs);
-        Lse a = { mx, sum };
-        {
-            Lse a0 = a;
-            lse_add(a0, vn);                                        // dustbin column: lane 0 only
-            a.m = lane == 0 ? a0.m : a.m; a.s = lane == 0 ? a0.s : a.s;
-        }
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            const float om = __shfl_xor(a.m, off, 64), os = __shfl_xor(a.s, off, 64);
-            lse_merge(a, om, os);
-        }
-        const float ui = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, norm - lse_val(a))));   // lane 0's, as stored
-        if (lane == 0) ub[i] = ui;
-        // ---- column partials of this lane's 16 columns: sg_col_kernel's lse_add(S_ij + u_i), rows in ascending order per accumulator
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            lse_add(acc[4 * k], cur[k].x + ui); lse_add(acc[4 * k + 1], cur[k].y + ui);
-            lse_add(acc[4 * k + 2], cur[k].z + ui); lse_add(acc[4 * k + 3], cur[k].w + ui);
-        }
-        lse_add(acc[16], alpha + ui);
+        Lse ad = { amd[r][lane], asd[r][lane] };
+        lse_add4(ad, alpha + ui[0], alpha + ui[1], alpha + ui[2], alpha + ui[3]);
+        amd[r][lane] = ad.m; asd[r][lane] = ad.s;
     };
-    load_row(rb0, 0); load_row(rb1, 1); load_row(rb2, 2); load_row(rb3, 3);
-    for (int t = 0; t < nrows; t += 4) {
-        do_row(rb0, t);     load_row(rb0, t + 4);
-        do_row(rb1, t + 1); load_row(rb1, t + 5);
-        do_row(rb2, t + 2); load_row(rb2, t + 6);
-        do_row(rb3, t + 3); load_row(rb3, t + 7);
+    float4 rbA[4][4], rbB[4][4];
+    load_block(rbA, 0);
+    for (int t = 0; t < nrows; t += 8) {
+        load_block(rbB, t + 4);
+        do_block(rbA, t);
+        load_block(rbA, t + 8);
+        do_block(rbB, t + 4);
     }
-    // ---- a += a1, a2 += a3 (wavefronts 1 and 3 hand over), then a += a2
-    if (r & 1) {
-#pragma unroll
-        for (int k = 0; k < 17; ++k) { xm[r >> 1][k][lane] = acc[k].m; xs[r >> 1][k][lane] = acc[k].s; }
-    }
+    // ---- a += a1, a2 += a3, then a += a2 (sg_col_kernel's order): wavefront 2 folds wavefront 3's partials into its own, wavefront 0 folds
+    // wavefront 1's and then wavefront 2's -- all through the LDS copies
     __syncthreads();
-    if (!(r & 1)) {
+    Lse acc[17];
+    auto fetch = [&](Lse (&d)[17], int rr) {
 #pragma unroll
-        for (int k = 0; k < 17; ++k) lse_merge(acc[k], xm[r >> 1][k][lane], xs[r >> 1][k][lane]);
-    }
-    __syncthreads();
+        for (int k = 0; k < 4; ++k) {
+            const float4 pm = am4[rr][k][lane], ps = as4[rr][k][lane];
+            d[4 * k] = { pm.x, ps.x }; d[4 * k + 1] = { pm.y, ps.y }; d[4 * k + 2] = { pm.z, ps.z }; d[4 * k + 3] = { pm.w, ps.w };
+        }
+        d[16] = { amd[rr][lane], asd[rr][lane] };
+    };
     if (r == 2) {
+        Lse o[17];
+        fetch(acc, 2); fetch(o, 3);
+#pragma unroll
+        for (int k = 0; k < 17; ++k) lse_merge(acc[k], o[k].m, o[k].s);
 #pragma unroll
         for (int k = 0; k < 17; ++k) { xm[0][k][lane] = acc[k].m; xs[0][k][lane] = acc[k].s; }
+    } else if (r == 0) {
+        Lse o[17];
+        fetch(acc, 0); fetch(o, 1);
+#pragma unroll
+        for (int k = 0; k < 17; ++k) lse_merge(acc[k], o[k].m, o[k].s);
     }
     __syncthreads();
     if (r == 0) {
