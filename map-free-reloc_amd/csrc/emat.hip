@@ -80,10 +80,14 @@ __global__ void __launch_bounds__(64) emat_hyp_kernel(
     double *o = Es + ((size_t)b * max_iters + it) * 90;
     if (n >= 5 && (n > 5 || it == 0)) {
         int s[5];
-        if (n == 5) { for (int k = 0; k < 5; ++k) s[k] = k; }
+        if (n == 5) {
+#pragma unroll
+            for (int k = 0; k < 5; ++k) s[k] = k;
+        }
         else sample_distinct<5>(seed, (uint64_t)pair_ids[b], (uint32_t)it, n, s);
         double a[10], c[10];
         const double *p0 = x0 + (size_t)b * maxN * 2, *p1 = x1 + (size_t)b * maxN * 2;
+#pragma unroll
         for (int k = 0; k < 5; ++k) {
             a[2 * k] = p0[2 * s[k]]; a[2 * k + 1] = p0[2 * s[k] + 1];
             c[2 * k] = p1[2 * s[k]]; c[2 * k + 1] = p1[2 * s[k] + 1];
@@ -220,10 +224,14 @@ static __device__ __forceinline__ void quat_right_update(const double *R, const 
 static __device__ __forceinline__ int chol_solve6(const double *A, const double *bvec, double *x)
 {
     double L[36];
+#pragma unroll
     for (int i = 0; i < 36; ++i) L[i] = 0.0;
+#pragma unroll
     for (int i = 0; i < 6; ++i)
+#pragma unroll
         for (int j = 0; j <= i; ++j) {
             double s = A[6 * i + j];
+#pragma unroll
             for (int k = 0; k < j; ++k) s = s - L[6 * i + k] * L[6 * j + k];
             if (i == j) {
                 if (!(s > 0.0)) return -1;
@@ -231,13 +239,17 @@ static __device__ __forceinline__ int chol_solve6(const double *A, const double 
             } else L[6 * i + j] = s / L[6 * j + j];
         }
     double y[6];
+#pragma unroll
     for (int i = 0; i < 6; ++i) {
         double s = bvec[i];
+#pragma unroll
         for (int k = 0; k < i; ++k) s = s - L[6 * i + k] * y[k];
         y[i] = s / L[6 * i + i];
     }
+#pragma unroll
     for (int i = 5; i >= 0; --i) {
         double s = y[i];
+#pragma unroll
         for (int k = i + 1; k < 6; ++k) s = s - L[6 * k + i] * x[k];
         x[i] = s / L[6 * i + i];
     }
@@ -258,7 +270,7 @@ static __device__ __forceinline__ double emat_cost(const double *p0, const doubl
 }
 
 // LM polish of (R, unit t) on the Sampson cost (wave-parallel, wave64-ordered reductions)
-static __device__ __noinline__ int emat_refine(const double *p0, const double *p1, const int32_t *idx, int n,
+static __device__ __forceinline__ int emat_refine(const double *p0, const double *p1, const int32_t *idx, int n,
                                                int max_iter, double *R, double *t)
 {
     double lambda = 1e-3;
@@ -380,7 +392,7 @@ struct Magsac { const double *lut; int M; double cut, scale, thr2; };     // lut
 
 // total MAGSAC++ loss + tentative inlier count of one model, one wavefront: per-lane sums over a tile of 1024 points, butterfly,
 // tiles added in sequence (the order emat_score_kernel and the oracle use)
-static __device__ __noinline__ double magsac_score_wave(const Magsac &ms, const double *E, const double *p0, const double *p1, int n,
+static __device__ __forceinline__ double magsac_score_wave(const Magsac &ms, const double *E, const double *p0, const double *p1, int n,
                                                         int *cnt_out)
 {
     double L = 0.0;
@@ -407,7 +419,7 @@ static __device__ __noinline__ double magsac_score_wave(const Magsac &ms, const 
 
 // sigma-consensus++: iteratively re-weighted least squares with the MAGSAC++ weights (= d loss / d r^2) on (R, unit t); one damped
 // Gauss-Newton step per re-weighting round, accepted when the MAGSAC++ loss decreases.  0 + optimised E / loss / count, or -1.
-static __device__ __noinline__ int magsac_lo_wave(const Magsac &ms, const double *p0, const double *p1, int n, const double *Ein,
+static __device__ __forceinline__ int magsac_lo_wave(const Magsac &ms, const double *p0, const double *p1, int n, const double *Ein,
                                                   double *Eout, double *loss_out, int *cnt_out)
 {
     double R[9], Rb[9], t[3];
@@ -649,6 +661,7 @@ __global__ void __launch_bounds__(64) emat_select_kernel(
         if (emat_decompose(Eb, Ra, Rc, tu)) st = MFR_ST_NO_MODEL;
         else {
             int bestc = -1;
+#pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const double *Rk = (c < 2) ? Ra : Rc;
                 const double tk[3] = { (c & 1) ? -tu[0] : tu[0], (c & 1) ? -tu[1] : tu[1], (c & 1) ? -tu[2] : tu[2] };

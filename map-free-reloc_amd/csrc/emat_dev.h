@@ -211,12 +211,15 @@ MFR_DEV int emat_decompose(const double *E, double *Ra, double *Rb, double *tu)
     double bb[9];
     for (int i = 0; i < 9; ++i) bb[i] = -EEt[i];
     bb[0] = bb[0] + htr; bb[4] = bb[4] + htr; bb[8] = bb[8] + htr;
+    // column k of bb with the largest diagonal entry -- by selects, not by an index into the local array (a run-time index puts bb in scratch)
     int k = 0;
-    if (bb[4] > bb[0]) k = 1;
-    if (bb[8] > bb[4 * k]) k = 2;
-    if (!(bb[4 * k] > 0.0)) return -1;
-    const double s = sqrt(bb[4 * k]);
-    const double b[3] = { bb[k] / s, bb[3 + k] / s, bb[6 + k] / s };
+    double dk = bb[0];
+    if (bb[4] > dk) { k = 1; dk = bb[4]; }
+    if (bb[8] > dk) { k = 2; dk = bb[8]; }
+    if (!(dk > 0.0)) return -1;
+    const double s = sqrt(dk);
+    const double c0 = k == 0 ? bb[0] : k == 1 ? bb[1] : bb[2], c1 = k == 0 ? bb[3] : k == 1 ? bb[4] : bb[5], c2 = k == 0 ? bb[6] : k == 1 ? bb[7] : bb[8];
+    const double b[3] = { c0 / s, c1 / s, c2 / s };
     double C[9];
     C[0] = E[4] * E[8] - E[5] * E[7]; C[1] = -(E[3] * E[8] - E[5] * E[6]); C[2] = E[3] * E[7] - E[4] * E[6];
     C[3] = -(E[1] * E[8] - E[2] * E[7]); C[4] = E[0] * E[8] - E[2] * E[6]; C[5] = -(E[0] * E[7] - E[1] * E[6]);

@@ -221,10 +221,11 @@ MFR_DEV void lds_p_mul21_perm(LdsArr a, LdsArr b, LdsArr o)
 // S = this lane's LDS window (FP_LDS_DOUBLES doubles, stride 64), colp = this lane's int window (9 ints, stride 64).
 // front_only: stop after the degree-10 polynomial and hand {Ep[36], Bx[12], By[12], B1[15], P[11]} (86 doubles) to the caller in
 // Es[0..86) (return -1); the root stage then runs in emat_roots_kernel with 8 lanes per hypothesis.
-MFR_DEV_NOINLINE int fivept_lds(const double *x0, const double *x1, double *Es, double *lds_lane, int *colp_lane, bool front_only = false)
+MFR_DEV int fivept_lds(const double *x0, const double *x1, double *Es, double *lds_lane, int *colp_lane, bool front_only = false)
 {
     const LdsArr S{ lds_lane };
     const LdsArr Ep = S, A = S.at(36), M = S.at(36), m = S.at(236), neg = S.at(246), EE = S.at(250), tr = S.at(280);
+#pragma unroll
     for (int i = 0; i < 5; ++i) {
         const double a = x0[2 * i], b = x0[2 * i + 1], c = x1[2 * i], d = x1[2 * i + 1];
         const LdsArr Ai = A.at(9 * i);

@@ -168,26 +168,18 @@ def _wgrad(x, gy, splits=None):
     return dw.view(3, 3, C, N).permute(3, 2, 0, 1)
 
 
-_LIB_OK = None
-
-
-def _library_usable():
-    """the HIP library loads and a GPU is visible (probed once): otherwise the caller keeps the library convolution instead of raising
-    from inside the autograd Function"""
-    global _LIB_OK
-    if _LIB_OK is None:
-        try:
-            load(require_gpu=True)
-            _LIB_OK = True
-        except Exception:
-            _LIB_OK = False
-    return _LIB_OK
+def _require_library():
+    """the HIP library must load when a device tensor arrives: a missing / unloadable libmfr_hip.so raises here (round 4 swallowed the
+    error -- and with it a NameError of this very function -- and silently trained through the library convolution)"""
+    from .._lib import load
+    load(require_gpu=True)
+    return True
 
 
 def supported(x, weight, stride=1, padding=1):
     N, C, kh, kw = weight.shape
-    return (_enabled() and x.is_cuda and _library_usable() and kh == 3 and kw == 3 and stride in (1, (1, 1)) and padding in (1, (1, 1))
-            and C % 32 == 0 and N % 32 == 0 and x.dim() == 4)
+    return (_enabled() and x.is_cuda and kh == 3 and kw == 3 and stride in (1, (1, 1)) and padding in (1, (1, 1))
+            and C % 32 == 0 and N % 32 == 0 and x.dim() == 4 and _require_library())
 
 
 class _Conv3x3BF16(torch.autograd.Function):

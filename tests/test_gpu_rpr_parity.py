@@ -102,6 +102,17 @@ def test_bf16_autocast_training_step_runs_and_tracks_fp32():
             low = model.encoder(d["image0"])
     assert low.dtype == torch.bfloat16
     assert ((low.float() - ref).norm() / ref.norm()).item() < 0.05
+    # the decoder's four 3x3 convolutions ran csrc/conv_gemm_bf16.hip, not the library (round 4 fell back silently: a swallowed NameError)
+    import mapfree_reloc_amd as mfr
+    lib = mfr._lib.load(require_gpu=True)
+    real, calls = lib.mfr_conv_gemm_bf16, []
+    lib.mfr_conv_gemm_bf16 = lambda *a: (calls.append(1), real(*a))[1]
+    try:
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+            model.encoder(d["image0"])
+    finally:
+        lib.mfr_conv_gemm_bf16 = real
+    assert len(calls) >= 4, f"own bf16 convolution launched {len(calls)} times in one encoder pass"
     with torch.autocast("cuda", dtype=torch.bfloat16):
         agg = model.aggregator(low, low)
         assert agg.dtype == torch.float32
