@@ -25,7 +25,9 @@
 
 using namespace mfr;
 
-#define EM_HYP_PER_WG 64
+// hypotheses per workgroup of emat_score_kernel (4 wavefronts, 4 hypotheses each).  Round 5: 64 -> 16 -- at 1000 iterations x 16 pairs the grid
+// was 256 workgroups = ONE wavefront per SIMD of latency-bound fp64 work; a hypothesis' result does not depend on the grouping
+#define EM_HYP_PER_WG 16
 #define EM_TILE 1024
 #define CHECK_LAUNCH() do { if (hipGetLastError() != hipSuccess) return MFR_E_LAUNCH; } while (0)
 
@@ -123,7 +125,7 @@ static __device__ __forceinline__ double magsac_interp(const double *lut, int st
     return a + f * (b - a);
 }
 
-// grid (ceil(iters/64), B), 4 wavefronts; wavefront w scores hypotheses w, w+4, ... of the block's 64
+// grid (ceil(iters / EM_HYP_PER_WG), B), 4 wavefronts; wavefront w scores hypotheses w, w+4, ... of the block's EM_HYP_PER_WG
 template <bool MAGSAC>
 __global__ void __launch_bounds__(256) emat_score_kernel(
     const double *__restrict__ x0, const double *__restrict__ x1, const int32_t *__restrict__ n_corr, int maxN,
@@ -256,25 +258,66 @@ static __device__ __forceinline__ int chol_solve6(const double *A, const double 
     return 0;
 }
 
-static __device__ __forceinline__ double emat_cost(const double *p0, const double *p1, const int32_t *idx, int n,
+// emat_select_kernel runs one workgroup of EM_SEL_WAVES wavefronts per pair (round 5; rounds 1-4: ONE wavefront per pair -- 16 wavefronts on the
+// whole GPU for LoFTR's 16 pairs, 1.85 ms of pure latency).  Sums over points: point i belongs to thread i mod (64 EM_SEL_WAVES), a wavefront's
+// 64 partials merge in the xor butterfly (wave_sum), the wavefront totals are added in sequence -- the order oracle/mfr_oracle_emat.c's
+// wacc_finish restates.  Every thread ends up with the same value, so all control flow stays uniform over the workgroup.
+// 4 wavefronts: the kernel needs ~340 registers per lane (the 6 x 6 normal equations and their Cholesky factor are register-resident);
+// 8 wavefronts would cap it at 256 and spill 1.5 KB per lane
+#define EM_SEL_WAVES 4
+#define EM_SEL_THREADS (64 * EM_SEL_WAVES)
+struct SelRed { double d[EM_SEL_WAVES][27]; int i[EM_SEL_WAVES]; };
+template <int N>
+static __device__ __forceinline__ void block_sum(SelRed &rd, double (&acc)[N])
+{
+    const int wv = (int)(threadIdx.x >> 6);
+#pragma unroll
+    for (int q = 0; q < N; ++q) acc[q] = wave_sum(acc[q]);
+    if (lane_id() == 0) {
+#pragma unroll
+        for (int q = 0; q < N; ++q) rd.d[wv][q] = acc[q];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < N; ++q) {
+        double s = rd.d[0][q];
+#pragma unroll
+        for (int w = 1; w < EM_SEL_WAVES; ++w) s = s + rd.d[w][q];
+        acc[q] = s;
+    }
+    __syncthreads();
+}
+static __device__ __forceinline__ int block_isum(SelRed &rd, int c)      // c: wave-uniform partial count
+{
+    if (lane_id() == 0) rd.i[threadIdx.x >> 6] = c;
+    __syncthreads();
+    int s = 0;
+#pragma unroll
+    for (int w = 0; w < EM_SEL_WAVES; ++w) s += rd.i[w];
+    __syncthreads();
+    return s;
+}
+
+static __device__ __forceinline__ double emat_cost(SelRed &rd, const double *p0, const double *p1, const int32_t *idx, int n,
                                                    const double *R, const double *t)
 {
     double E[9];
     skew_mul(t, R, E);
-    double acc = 0.0;
-    for (int i = lane_id(); i < n; i += 64) {
+    double acc[1] = { 0.0 };
+    for (int i = (int)threadIdx.x; i < n; i += EM_SEL_THREADS) {
         const int j = idx[i];
-        acc = acc + sampson2(E, p0[2 * (size_t)j], p0[2 * (size_t)j + 1], p1[2 * (size_t)j], p1[2 * (size_t)j + 1]);
+        acc[0] = acc[0] + sampson2(E, p0[2 * (size_t)j], p0[2 * (size_t)j + 1], p1[2 * (size_t)j], p1[2 * (size_t)j + 1]);
     }
-    return wave_sum(acc);
+    block_sum(rd, acc);
+    return acc[0];
 }
 
-// LM polish of (R, unit t) on the Sampson cost (wave-parallel, wave64-ordered reductions)
-static __device__ __forceinline__ int emat_refine(const double *p0, const double *p1, const int32_t *idx, int n,
+// LM polish of (R, unit t) on the Sampson cost (workgroup-parallel, block_sum-ordered reductions)
+static __device__ __forceinline__ int emat_refine(SelRed &rd, const double *p0, const double *p1, const int32_t *idx, int n,
                                                int max_iter, double *R, double *t)
 {
     double lambda = 1e-3;
-    double cost = emat_cost(p0, p1, idx, n, R, t);
+    double cost = emat_cost(rd, p0, p1, idx, n, R, t);
     if (!(cost == cost)) return -1;
     for (int it = 0; it < max_iter; ++it) {
         double E[9];
@@ -282,7 +325,7 @@ static __device__ __forceinline__ int emat_refine(const double *p0, const double
         double acc[27];
 #pragma unroll
         for (int q = 0; q < 27; ++q) acc[q] = 0.0;
-        for (int i = lane_id(); i < n; i += 64) {
+        for (int i = (int)threadIdx.x; i < n; i += EM_SEL_THREADS) {
             const int j = idx[i];
             const double a = p0[2 * (size_t)j], b = p0[2 * (size_t)j + 1], c = p1[2 * (size_t)j], d = p1[2 * (size_t)j + 1];
             const double Ex0 = (E[0] * a + E[1] * b) + E[2], Ex1 = (E[3] * a + E[4] * b) + E[5], Ex2 = (E[6] * a + E[7] * b) + E[8];
@@ -309,8 +352,7 @@ static __device__ __forceinline__ int emat_refine(const double *p0, const double
 #pragma unroll
             for (int rr = 0; rr < 6; ++rr, ++qq) acc[qq] = acc[qq] + J[rr] * r;
         }
-#pragma unroll
-        for (int q = 0; q < 27; ++q) acc[q] = wave_sum(acc[q]);
+        block_sum(rd, acc);
         double H[36], g[6];
         {
             int qq = 0;
@@ -337,7 +379,7 @@ static __device__ __forceinline__ int emat_refine(const double *p0, const double
             continue;
         }
         tn[0] = tn[0] / nt; tn[1] = tn[1] / nt; tn[2] = tn[2] / nt;
-        const double cn = emat_cost(p0, p1, idx, n, Rn, tn);
+        const double cn = emat_cost(rd, p0, p1, idx, n, Rn, tn);
         double mx = 0.0;
         for (int k = 0; k < 6; ++k) { const double v = dl[k] < 0.0 ? -dl[k] : dl[k]; if (v > mx) mx = v; }
         if (cn < cost) {
@@ -358,16 +400,16 @@ static __device__ __forceinline__ int emat_refine(const double *p0, const double
     return 0;
 }
 
-// wave-wide count of a per-point predicate over all n points
+// workgroup-wide count of a per-point predicate over all n points
 template <typename F>
-static __device__ __forceinline__ int wave_count(int n, F pred)
+static __device__ __forceinline__ int block_count(SelRed &rd, int n, F pred)
 {
     int c = 0;
-    for (int i0 = 0; i0 < n; i0 += 64) {
-        const int i = i0 + lane_id();
+    for (int i0 = 0; i0 < n; i0 += EM_SEL_THREADS) {
+        const int i = i0 + (int)threadIdx.x;
         c += __popcll(__ballot(i < n && pred(i)));
     }
-    return c;
+    return block_isum(rd, c);
 }
 
 // two Newton-Schulz steps towards the orthogonal polar factor, R <- R (3 I - R^T R) / 2: Horn's closed-form R inherits E's distance
@@ -390,16 +432,20 @@ static __device__ __forceinline__ void orthonormalize(double *R)
 
 struct Magsac { const double *lut; int M; double cut, scale, thr2; };     // lut: LDS image, entry j = (loss, weight)
 
-// total MAGSAC++ loss + tentative inlier count of one model, one wavefront: per-lane sums over a tile of 1024 points, butterfly,
-// tiles added in sequence (the order emat_score_kernel and the oracle use)
-static __device__ __forceinline__ double magsac_score_wave(const Magsac &ms, const double *E, const double *p0, const double *p1, int n,
-                                                        int *cnt_out)
+// total MAGSAC++ loss + tentative inlier count of one model, one workgroup: a wavefront takes a tile of 1024 points (per-lane sums, butterfly),
+// EM_SEL_WAVES tiles at a time, and the tile totals are added in sequence (the order emat_score_kernel and the oracle use)
+static __device__ __forceinline__ double magsac_score_block(SelRed &rd, const Magsac &ms, const double *E, const double *p0, const double *p1, int n,
+                                                            int *cnt_out)
 {
     double L = 0.0;
     int c = 0;
-    for (int base = 0; base < n; base += EM_TILE) {
-        const int tn = min(EM_TILE, n - base);
+    const int wv = (int)(threadIdx.x >> 6);
+    const int ntiles = (n + EM_TILE - 1) / EM_TILE;
+    for (int tb = 0; tb < ntiles; tb += EM_SEL_WAVES) {
+        const int base = (tb + wv) * EM_TILE;
+        const int tn = min(EM_TILE, n - base);               // <= 0: no tile for this wavefront in this round
         double acc = 0.0;
+        int cw = 0;
         for (int i0 = 0; i0 < tn; i0 += 64) {
             const int i = i0 + lane_id();
             bool in = false;
@@ -409,9 +455,13 @@ static __device__ __forceinline__ double magsac_score_wave(const Magsac &ms, con
                 in = r2 < ms.thr2;
                 if (r2 < ms.cut) acc = acc + magsac_interp(ms.lut, 2, ms.M, ms.scale, r2);
             }
-            c += __popcll(__ballot(in));
+            cw += __popcll(__ballot(in));
         }
-        L = L + wave_sum(acc);
+        acc = wave_sum(acc);
+        if (lane_id() == 0) { rd.d[wv][0] = acc; rd.i[wv] = cw; }
+        __syncthreads();
+        for (int w = 0; w < EM_SEL_WAVES && tb + w < ntiles; ++w) { L = L + rd.d[w][0]; c += rd.i[w]; }
+        __syncthreads();
     }
     *cnt_out = c;
     return L;
@@ -419,7 +469,7 @@ static __device__ __forceinline__ double magsac_score_wave(const Magsac &ms, con
 
 // sigma-consensus++: iteratively re-weighted least squares with the MAGSAC++ weights (= d loss / d r^2) on (R, unit t); one damped
 // Gauss-Newton step per re-weighting round, accepted when the MAGSAC++ loss decreases.  0 + optimised E / loss / count, or -1.
-static __device__ __forceinline__ int magsac_lo_wave(const Magsac &ms, const double *p0, const double *p1, int n, const double *Ein,
+static __device__ __forceinline__ int magsac_lo_block(SelRed &rd, const Magsac &ms, const double *p0, const double *p1, int n, const double *Ein,
                                                   double *Eout, double *loss_out, int *cnt_out)
 {
     double R[9], Rb[9], t[3];
@@ -428,14 +478,14 @@ static __device__ __forceinline__ int magsac_lo_wave(const Magsac &ms, const dou
     double E[9];
     skew_mul(t, R, E);
     int cnt;
-    double loss = magsac_score_wave(ms, E, p0, p1, n, &cnt);
+    double loss = magsac_score_block(rd, ms, E, p0, p1, n, &cnt);
     if (!(loss == loss)) return -1;
     double lambda = 1e-3;
     for (int it = 0; it < MAGSAC_LO_ITERS; ++it) {
         double acc[27];
 #pragma unroll
         for (int q = 0; q < 27; ++q) acc[q] = 0.0;
-        for (int i = lane_id(); i < n; i += 64) {
+        for (int i = (int)threadIdx.x; i < n; i += EM_SEL_THREADS) {
             const double a = p0[2 * (size_t)i], b = p0[2 * (size_t)i + 1], c = p1[2 * (size_t)i], d = p1[2 * (size_t)i + 1];
             const double Ex0 = (E[0] * a + E[1] * b) + E[2], Ex1 = (E[3] * a + E[4] * b) + E[5], Ex2 = (E[6] * a + E[7] * b) + E[8];
             const double Et0 = (E[0] * c + E[3] * d) + E[6], Et1 = (E[1] * c + E[4] * d) + E[7];
@@ -466,8 +516,7 @@ static __device__ __forceinline__ int magsac_lo_wave(const Magsac &ms, const dou
 #pragma unroll
             for (int rr = 0; rr < 6; ++rr, ++qq) acc[qq] = acc[qq] + (pw * J[rr]) * r;
         }
-#pragma unroll
-        for (int q = 0; q < 27; ++q) acc[q] = wave_sum(acc[q]);
+        block_sum(rd, acc);
         double H[36], g[6];
         {
             int qq = 0;
@@ -496,7 +545,7 @@ static __device__ __forceinline__ int magsac_lo_wave(const Magsac &ms, const dou
         tn[0] = tn[0] / nt; tn[1] = tn[1] / nt; tn[2] = tn[2] / nt;
         skew_mul(tn, Rn, En);
         int cn;
-        const double ln = magsac_score_wave(ms, En, p0, p1, n, &cn);
+        const double ln = magsac_score_block(rd, ms, En, p0, p1, n, &cn);
         double mx = 0.0;
         for (int k = 0; k < 6; ++k) { const double v = dl[k] < 0.0 ? -dl[k] : dl[k]; if (v > mx) mx = v; }
         if (ln < loss) {
@@ -520,7 +569,7 @@ static __device__ __forceinline__ int magsac_lo_wave(const Magsac &ms, const dou
 }
 
 template <bool MAGSAC>
-__global__ void __launch_bounds__(64) emat_select_kernel(
+__global__ void __launch_bounds__(EM_SEL_THREADS) emat_select_kernel(
     const double *__restrict__ x0, const double *__restrict__ x1, const int32_t *__restrict__ n_corr, int maxN,
     int max_iters, const double *__restrict__ thr2p, double conf, const double *__restrict__ Es,
     const int32_t *__restrict__ counts, const int32_t *__restrict__ bestm, const double *__restrict__ losses,
@@ -530,7 +579,8 @@ __global__ void __launch_bounds__(64) emat_select_kernel(
     int32_t *__restrict__ best_iter, int32_t *__restrict__ iters_run, int32_t *__restrict__ lo_runs)
 {
     __shared__ double lutl[MAGSAC ? 2 * (MAGSAC_MAX_M + 1) : 1];
-    const int b = blockIdx.x, lane = threadIdx.x;
+    __shared__ SelRed rd;
+    const int b = blockIdx.x, tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
     int n = n_corr[b];
     if (n > maxN) n = maxN;
     const double *p0 = x0 + (size_t)b * maxN * 2, *p1 = x1 + (size_t)b * maxN * 2;
@@ -539,10 +589,10 @@ __global__ void __launch_bounds__(64) emat_select_kernel(
     uint8_t *rm = rmask_ws + (size_t)b * maxN;
     uint8_t *mo = mask_out ? mask_out + (size_t)b * maxN : nullptr;
     const double qnan = __longlong_as_double(0x7ff8000000000000LL);
-    if (mo) for (int i = lane; i < maxN; i += 64) mo[i] = 0;
+    if (mo) for (int i = tid; i < maxN; i += EM_SEL_THREADS) mo[i] = 0;
     Magsac ms;
     if (MAGSAC) {
-        for (int i = lane; i < 2 * (lut_m + 1); i += 64) lutl[i] = lut[i];
+        for (int i = tid; i < 2 * (lut_m + 1); i += EM_SEL_THREADS) lutl[i] = lut[i];
         __syncthreads();
         ms.lut = lutl; ms.M = lut_m; ms.thr2 = thr2; ms.cut = ratio2 * thr2; ms.scale = (double)lut_m / ms.cut;
     }
@@ -558,6 +608,8 @@ __global__ void __launch_bounds__(64) emat_select_kernel(
             run = 1;
             if (ls[0] < 0.0) { best = cnt[0]; bit = 0; best_loss = ls[0]; }
         } else {
+            // (every wavefront replays the loop on the same values: uniform control flow over the workgroup, the local optimisation inside is
+            // workgroup-parallel)
             // replay of the sequential loop: the next hypothesis that beats the best loss so far becomes the best model, goes through
             // the local optimisation (from iteration MAGSAC_LO_START on) and lowers the iteration cap
             int niters = max_iters;
@@ -580,7 +632,7 @@ __global__ void __launch_bounds__(64) emat_select_kernel(
                         int cl;
                         for (int k = 0; k < 9; ++k) Ein[k] = src[k];
                         ++nlo;
-                        if (magsac_lo_wave(ms, p0, p1, n, Ein, El, &ll, &cl) == 0 && ll < best_loss) {
+                        if (magsac_lo_block(rd, ms, p0, p1, n, Ein, El, &ll, &cl) == 0 && ll < best_loss) {
                             for (int k = 0; k < 9; ++k) Eb[k] = El[k];
                             best_loss = ll; best = cl; best_is_lo = true;
                         }
@@ -638,25 +690,31 @@ __global__ void __launch_bounds__(64) emat_select_kernel(
             double El[9], ll;
             int cl;
             ++nlo;
-            if (magsac_lo_wave(ms, p0, p1, n, Eb, El, &ll, &cl) == 0 && ll < best_loss) {
+            if (magsac_lo_block(rd, ms, p0, p1, n, Eb, El, &ll, &cl) == 0 && ll < best_loss) {
                 for (int k = 0; k < 9; ++k) Eb[k] = El[k];
                 best_loss = ll; best = cl;
             }
         }
-        // RANSAC inlier set of the best model (ascending index order); USAC compares strictly
-        for (int i0 = 0; i0 < n; i0 += 64) {
-            const int i = i0 + lane;
-            bool in = false;
-            if (i < n) {
-                const double r2 = sampson2(Eb, p0[2 * (size_t)i], p0[2 * (size_t)i + 1], p1[2 * (size_t)i], p1[2 * (size_t)i + 1]);
-                in = MAGSAC ? (r2 < thr2) : (r2 <= thr2);
+        // RANSAC inlier set of the best model (ascending index order); USAC compares strictly.  Ordered compaction: wavefront 0 alone
+        if (wv == 0) {
+            for (int i0 = 0; i0 < n; i0 += 64) {
+                const int i = i0 + lane;
+                bool in = false;
+                if (i < n) {
+                    const double r2 = sampson2(Eb, p0[2 * (size_t)i], p0[2 * (size_t)i + 1], p1[2 * (size_t)i], p1[2 * (size_t)i + 1]);
+                    in = MAGSAC ? (r2 < thr2) : (r2 <= thr2);
+                }
+                const unsigned long long bal = __ballot(in);
+                if (in) idx[m + __popcll(bal & ((1ull << lane) - 1ull))] = i;
+                if (i < n) rm[i] = in ? 1 : 0;
+                m += __popcll(bal);
             }
-            const unsigned long long bal = __ballot(in);
-            if (in) idx[m + __popcll(bal & ((1ull << lane) - 1ull))] = i;
-            if (i < n) rm[i] = in ? 1 : 0;
-            m += __popcll(bal);
+            if (lane == 0) rd.i[0] = m;
         }
         __threadfence();
+        __syncthreads();
+        m = rd.i[0];
+        __syncthreads();
         double Ra[9], Rc[9], tu[3];
         if (emat_decompose(Eb, Ra, Rc, tu)) st = MFR_ST_NO_MODEL;
         else {
@@ -665,7 +723,7 @@ __global__ void __launch_bounds__(64) emat_select_kernel(
             for (int c = 0; c < 4; ++c) {
                 const double *Rk = (c < 2) ? Ra : Rc;
                 const double tk[3] = { (c & 1) ? -tu[0] : tu[0], (c & 1) ? -tu[1] : tu[1], (c & 1) ? -tu[2] : tu[2] };
-                const int cc = wave_count(m, [&](int q) {
+                const int cc = block_count(rd, m, [&](int q) {
                     const int i = idx[q];
                     return cheirality(Rk, tk, p0[2 * (size_t)i], p0[2 * (size_t)i + 1], p1[2 * (size_t)i], p1[2 * (size_t)i + 1]);
                 });
@@ -681,16 +739,16 @@ __global__ void __launch_bounds__(64) emat_select_kernel(
             double Rr[9], tr[3];
             for (int k = 0; k < 9; ++k) Rr[k] = R[k];
             for (int k = 0; k < 3; ++k) tr[k] = t[k];
-            if (emat_refine(p0, p1, idx, m, 20, Rr, tr) == 0) {
+            if (emat_refine(rd, p0, p1, idx, m, 20, Rr, tr) == 0) {
                 double Er[9];
                 skew_mul(tr, Rr, Er);
-                const int m2 = wave_count(n, [&](int i) {
+                const int m2 = block_count(rd, n, [&](int i) {
                     return sampson2(Er, p0[2 * (size_t)i], p0[2 * (size_t)i + 1], p1[2 * (size_t)i], p1[2 * (size_t)i + 1]) <= thr2;
                 });
                 if (m2 >= m) {
                     for (int k = 0; k < 9; ++k) R[k] = Rr[k];
                     for (int k = 0; k < 3; ++k) t[k] = tr[k];
-                    for (int i = lane; i < n; i += 64)
+                    for (int i = tid; i < n; i += EM_SEL_THREADS)
                         rm[i] = (sampson2(Er, p0[2 * (size_t)i], p0[2 * (size_t)i + 1], p1[2 * (size_t)i], p1[2 * (size_t)i + 1]) <= thr2) ? 1 : 0;
                 }
             }
@@ -700,20 +758,24 @@ __global__ void __launch_bounds__(64) emat_select_kernel(
     if (st == MFR_ST_OK) {
         orthonormalize(R);
         __threadfence();
-        for (int i0 = 0; i0 < n; i0 += 64) {
-            const int i = i0 + lane;
+        __syncthreads();                                    // rm: written by other wavefronts
+        int cw = 0;
+        for (int i0 = 0; i0 < n; i0 += EM_SEL_THREADS) {
+            const int i = i0 + tid;
             bool in = false;
             if (i < n) in = rm[i] && cheirality(R, t, p0[2 * (size_t)i], p0[2 * (size_t)i + 1], p1[2 * (size_t)i], p1[2 * (size_t)i + 1]);
             if (mo && i < n) mo[i] = in ? 1 : 0;
-            cntf += __popcll(__ballot(in));
+            cw += __popcll(__ballot(in));
         }
+        cntf = block_isum(rd, cw);
         if (cntf <= 0) st = MFR_ST_NO_MODEL;
     }
     if (st != MFR_ST_OK && mo) {
         __threadfence();
-        for (int i = lane; i < maxN; i += 64) mo[i] = 0;
+        __syncthreads();
+        for (int i = tid; i < maxN; i += EM_SEL_THREADS) mo[i] = 0;
     }
-    if (lane == 0) {
+    if (tid == 0) {
         for (int k = 0; k < 9; ++k) Rout[9 * b + k] = (st == MFR_ST_OK) ? R[k] : qnan;
         for (int k = 0; k < 3; ++k) tout[3 * b + k] = (st == MFR_ST_OK) ? t[k] : qnan;
         n_inliers[b] = (st == MFR_ST_OK) ? cntf : 0;
@@ -806,24 +868,24 @@ int mfr_emat_solve_batch(const float *pts0, const float *pts1, const int32_t *n_
     hipLaunchKernelGGL(emat_prep_kernel, dim3((maxN + 255) / 256, B), dim3(256), 0, s, pts0, pts1, n_corr, maxN, K0, K1, k_dtype,
                        pix_thr, x0, x1, thr2);
     CHECK_LAUNCH();
-    const dim3 hgrid((max_iters + 63) / 64, B);
+    const dim3 hgrid((max_iters + 63) / 64, B), sgrid((max_iters + EM_HYP_PER_WG - 1) / EM_HYP_PER_WG, B);
     hipLaunchKernelGGL(emat_hyp_kernel, hgrid, dim3(64), 0, s, x0, x1, n_corr, maxN, max_iters, seed, pair_ids, Es, nsol);
     CHECK_LAUNCH();
     const int total = B * max_iters;
     hipLaunchKernelGGL(emat_roots_kernel, dim3((total + FPR_HYP_PER_WG - 1) / FPR_HYP_PER_WG), dim3(256), 0, s, Es, nsol, total);
     CHECK_LAUNCH();
     if (magsac) {
-        hipLaunchKernelGGL(emat_score_kernel<true>, hgrid, dim3(256), 0, s, x0, x1, n_corr, maxN, max_iters, thr2, Es, nsol,
+        hipLaunchKernelGGL(emat_score_kernel<true>, sgrid, dim3(256), 0, s, x0, x1, n_corr, maxN, max_iters, thr2, Es, nsol,
                            magsac_lut, lut_m, ratio2, counts, bestm, losses);
         CHECK_LAUNCH();
-        hipLaunchKernelGGL(emat_select_kernel<true>, dim3(B), dim3(64), 0, s, x0, x1, n_corr, maxN, max_iters, thr2, confidence, Es,
+        hipLaunchKernelGGL(emat_select_kernel<true>, dim3(B), dim3(EM_SEL_THREADS), 0, s, x0, x1, n_corr, maxN, max_iters, thr2, confidence, Es,
                            counts, bestm, losses, magsac_lut, lut_m, ratio2, idx, rm, R, t, n_inliers, status, inlier_mask,
                            best_iter, iters_run, lo_runs);
     } else {
-        hipLaunchKernelGGL(emat_score_kernel<false>, hgrid, dim3(256), 0, s, x0, x1, n_corr, maxN, max_iters, thr2, Es, nsol,
+        hipLaunchKernelGGL(emat_score_kernel<false>, sgrid, dim3(256), 0, s, x0, x1, n_corr, maxN, max_iters, thr2, Es, nsol,
                            (const double *)nullptr, 2, 1.0, counts, bestm, losses);
         CHECK_LAUNCH();
-        hipLaunchKernelGGL(emat_select_kernel<false>, dim3(B), dim3(64), 0, s, x0, x1, n_corr, maxN, max_iters, thr2, confidence, Es,
+        hipLaunchKernelGGL(emat_select_kernel<false>, dim3(B), dim3(EM_SEL_THREADS), 0, s, x0, x1, n_corr, maxN, max_iters, thr2, confidence, Es,
                            counts, bestm, losses, (const double *)nullptr, 2, 1.0, idx, rm, R, t, n_inliers, status, inlier_mask,
                            best_iter, iters_run, lo_runs);
     }

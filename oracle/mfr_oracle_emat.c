@@ -260,15 +260,27 @@ static inline int cheirality(const double *R, const double *t, double a, double 
 }
 
 #define NACC 28
-typedef struct { double a[64][NACC]; } wacc_t;
+/* Sums over points in the order the GPU workgroup forms them (csrc/emat.hip emat_select_kernel, EM_SEL_WAVES = 4 wavefronts of 64 lanes): point i
+ * goes to virtual lane i mod 256; the 64 lanes of a wavefront merge in an xor butterfly, the 4 wavefront totals are added in sequence.
+ * (Rounds 1-4: one wavefront, lane = i mod 64.) */
+#define EM_SEL_WAVES 4
+#define EM_SEL_LANES (64 * EM_SEL_WAVES)
+typedef struct { double a[EM_SEL_LANES][NACC]; } wacc_t;
 static void wacc_finish(wacc_t *w, int nacc, double *out)
 {
-    for (int off = 32; off >= 1; off >>= 1) {
-        double tmp[64][NACC];
-        for (int l = 0; l < 64; ++l) for (int k = 0; k < nacc; ++k) tmp[l][k] = w->a[l][k] + w->a[l ^ off][k];
-        memcpy(w->a, tmp, sizeof(tmp));
+    for (int g = 0; g < EM_SEL_WAVES; ++g) {
+        double (*a)[NACC] = w->a + 64 * g;
+        for (int off = 32; off >= 1; off >>= 1) {
+            double tmp[64][NACC];
+            for (int l = 0; l < 64; ++l) for (int k = 0; k < nacc; ++k) tmp[l][k] = a[l][k] + a[l ^ off][k];
+            memcpy(a, tmp, sizeof(tmp));
+        }
     }
-    for (int k = 0; k < nacc; ++k) out[k] = w->a[0][k];
+    for (int k = 0; k < nacc; ++k) {
+        double s = w->a[0][k];
+        for (int g = 1; g < EM_SEL_WAVES; ++g) s = s + w->a[64 * g][k];
+        out[k] = s;
+    }
 }
 
 static void quat_right(const double *R, const double *dw, double *Rn)
@@ -305,7 +317,7 @@ static double emat_cost(const double *x0, const double *x1, const int32_t *idx, 
     wacc_t *w = (wacc_t *)calloc(1, sizeof(wacc_t));
     for (int i = 0; i < n; ++i) {
         int j = idx[i];
-        w->a[i & 63][0] = w->a[i & 63][0] + sampson2(E, x0[2 * j], x0[2 * j + 1], x1[2 * j], x1[2 * j + 1]);
+        w->a[i % EM_SEL_LANES][0] = w->a[i % EM_SEL_LANES][0] + sampson2(E, x0[2 * j], x0[2 * j + 1], x1[2 * j], x1[2 * j + 1]);
     }
     double c; wacc_finish(w, 1, &c); free(w);
     return c;
@@ -342,7 +354,7 @@ int mfr_ref_emat_refine(const double *x0, const double *x1, const int32_t *idx, 
             J[0] = (p[1] * u[2] - p[2] * u[1]) * wgt; J[1] = (p[2] * u[0] - p[0] * u[2]) * wgt; J[2] = (p[0] * u[1] - p[1] * u[0]) * wgt;
             J[3] = (Rp[1] * q[2] - Rp[2] * q[1]) * wgt; J[4] = (Rp[2] * q[0] - Rp[0] * q[2]) * wgt; J[5] = (Rp[0] * q[1] - Rp[1] * q[0]) * wgt;
             double r = num * wgt;
-            double *acc = w->a[i & 63];
+            double *acc = w->a[i % EM_SEL_LANES];
             int qq = 0;
             for (int rr = 0; rr < 6; ++rr) for (int cc = rr; cc < 6; ++cc, ++qq) acc[qq] = acc[qq] + J[rr] * J[cc];
             for (int rr = 0; rr < 6; ++rr, ++qq) acc[qq] = acc[qq] + J[rr] * r;
@@ -540,7 +552,7 @@ static int magsac_lo(const magsac_t *ms, const double *x0, const double *x1, int
             J[0] = (p[1] * u[2] - p[2] * u[1]) * wgt; J[1] = (p[2] * u[0] - p[0] * u[2]) * wgt; J[2] = (p[0] * u[1] - p[1] * u[0]) * wgt;
             J[3] = (Rp[1] * q[2] - Rp[2] * q[1]) * wgt; J[4] = (Rp[2] * q[0] - Rp[0] * q[2]) * wgt; J[5] = (Rp[0] * q[1] - Rp[1] * q[0]) * wgt;
             double r = num * wgt;
-            double *acc = w->a[i & 63];
+            double *acc = w->a[i % EM_SEL_LANES];
             int qq = 0;
             for (int rr = 0; rr < 6; ++rr) { double wj = pw * J[rr]; for (int cc = rr; cc < 6; ++cc, ++qq) acc[qq] = acc[qq] + wj * J[cc]; }
             for (int rr = 0; rr < 6; ++rr, ++qq) acc[qq] = acc[qq] + (pw * J[rr]) * r;
