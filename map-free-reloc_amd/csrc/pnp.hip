@@ -28,7 +28,11 @@
 using namespace mfr;
 
 #define MFR_NSEG 16          // depth-min partial segments per image
-#define HYP_BLOCK 256        // hypotheses (threads) per workgroup in pnp_hyp_score_kernel
+// pnp_hyp_score_kernel: hypotheses per workgroup / threads per workgroup.  Round 5: 256 / 256 -> 64 / 256 -- a wavefront scored the 64 hypotheses its own
+// lanes had solved, one after the other (500 wavefronts on 1024 SIMDs at 1000 iterations x 32 pairs); now wavefront 0 solves a workgroup's 64
+// hypotheses and all four wavefronts score 16 each.  A hypothesis' count does not depend on the grouping.
+#define HYP_BLOCK 64
+#define HYP_THREADS 256
 #define PT_TILE 768          // points staged in LDS per tile (24 KB models + 30 KB points < 64 KB)
 
 // ------------------------------------------------------------------------------------------
@@ -119,17 +123,17 @@ __global__ void __launch_bounds__(256) pnp_lift_kernel(
 // grid (ceil(iters/256), B).  Phase 1: one lane per hypothesis (sample + P3P + 4th-point
 // disambiguation) -> model in LDS.  Phase 2: one wavefront per hypothesis, lanes stride over the
 // LDS-staged points, ballot/popcount inlier counting.
-__global__ void __launch_bounds__(HYP_BLOCK) pnp_hyp_score_kernel(
+__global__ void __launch_bounds__(HYP_THREADS) pnp_hyp_score_kernel(
     const double *__restrict__ xyz, const double *__restrict__ obs, const int32_t *__restrict__ n_valid,
     int maxN, const void *__restrict__ K1, int k_dtype, int max_iters, double thr2, uint64_t seed,
     const int64_t *__restrict__ pair_ids, int32_t *__restrict__ counts)
 {
     const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int n = n_valid[b];
-    const int it = blockIdx.x * HYP_BLOCK + tid;
+    const int it = blockIdx.x * HYP_BLOCK + tid;                 // tid < HYP_BLOCK: this thread's hypothesis
     int32_t *cnt_out = counts + (size_t)b * max_iters;
     if (n <= 4) {                      // n < 4: no RANSAC; n == 4: handled by the select kernel
-        if (it < max_iters) cnt_out[it] = -1;
+        if (tid < HYP_BLOCK && it < max_iters) cnt_out[it] = -1;
         return;
     }
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -143,7 +147,7 @@ __global__ void __launch_bounds__(HYP_BLOCK) pnp_hyp_score_kernel(
     double Kd[4];
     kparams(K1, k_dtype, b, Kd);
 
-    {   // phase 1
+    if (tid < HYP_BLOCK) {   // phase 1 (wavefront 0)
         double R[9], t[3];
         int ok = 0;
         if (it < max_iters) {
@@ -164,14 +168,13 @@ __global__ void __launch_bounds__(HYP_BLOCK) pnp_hyp_score_kernel(
     for (int base = 0; base < n; base += PT_TILE) {
         const int tn = min(PT_TILE, n - base);
         __syncthreads();
-        for (int i = tid; i < tn; i += HYP_BLOCK) {
+        for (int i = tid; i < tn; i += HYP_THREADS) {
             const double *p = X + 3 * (size_t)(base + i);
             const double *o = O + 2 * (size_t)(base + i);
             px[i] = p[0]; py[i] = p[1]; pz[i] = p[2]; pu[i] = o[0]; pv[i] = o[1];
         }
         __syncthreads();
-        for (int h = 0; h < 64; ++h) {
-            const int hi = wid * 64 + h;
+        for (int hi = wid; hi < HYP_BLOCK; hi += HYP_THREADS / 64) {
             if (!mvalid[hi]) continue;                         // wave-uniform
             double R[9], t[3];
 #pragma unroll
@@ -193,7 +196,7 @@ __global__ void __launch_bounds__(HYP_BLOCK) pnp_hyp_score_kernel(
         }
     }
     __syncthreads();
-    if (it < max_iters) cnt_out[it] = mvalid[tid] ? cnt[tid] : 0;
+    if (tid < HYP_BLOCK && it < max_iters) cnt_out[it] = mvalid[tid] ? cnt[tid] : 0;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -551,7 +554,7 @@ static int launch_ransac(const double *xyz, const double *obs, const int32_t *n_
                          int32_t *iters_run, hipStream_t s)
 {
     const double thr2 = thr * thr;
-    hipLaunchKernelGGL(pnp_hyp_score_kernel, dim3((max_iters + HYP_BLOCK - 1) / HYP_BLOCK, B), dim3(HYP_BLOCK),
+    hipLaunchKernelGGL(pnp_hyp_score_kernel, dim3((max_iters + HYP_BLOCK - 1) / HYP_BLOCK, B), dim3(HYP_THREADS),
                        hyp_smem_bytes(), s, xyz, obs, n_valid, maxN, K1, k_dtype, max_iters, thr2, seed, pair_ids, counts);
     CHECK_LAUNCH();
     hipLaunchKernelGGL(pnp_select_kernel, dim3(B), dim3(64), 0, s, xyz, obs, n_valid, pre_status, maxN, K1, k_dtype, max_iters,
