@@ -352,7 +352,7 @@ class SgPnpWorkload:
         iters = 20
         n0 = out["n_kpts"][0::2].double() + 1 if "n_kpts" in out else torch.full((self.B,), 1025.0)
         n1 = out["n_kpts"][1::2].double() + 1 if "n_kpts" in out else torch.full((self.B,), 1025.0)
-        n_exp = float((2.0 * iters * n0 * n1).sum())         # algorithmic: one per entry for the row sums, one for the column sums (the branch-free column update executes two)
+        n_exp = float((2.0 * iters * n0 * n1).sum())         # algorithmic: one per entry for the row sums, one for the column sums (round 5's four-row column update executes 1.5)
         alg_bytes = float((4.0 * (n0 - 1) * (n1 - 1)).sum())
         g = n_exp / (sk_ms * 1e-3) / 1e9 if sk_ms else None
         return {"kernel": "(sg_sweep_kernel + sg_colmerge_kernel) x iters + sg_match (mfr_sg_sinkhorn_match: log-Sinkhorn, one sweep over S per iteration, mutual arg-max, threshold, compaction)",
