@@ -585,6 +585,12 @@ def _slot_views(flat, n_slots, B, Hh, Ww, has_depth):
 
 
 def _pw_init(scenes, flat, layout):
+    # Everything inherited from the parent becomes permanent in this process: a garbage-collection pass of the child must never finalise the
+    # PARENT's objects -- a dead multiprocessing.Pool of an earlier loader among them, whose __del__ writes to a queue under a lock that a
+    # thread of the parent may have held at fork time (the child then waits for it for ever: round 5's first full CPU test run hung exactly
+    # there, in the middle of an allocation inside gray_plane)
+    import gc
+    gc.freeze()
     torch.set_num_threads(1)
     _PW["scenes"], _PW["slots"] = scenes, _slot_views(flat, *layout)
 
@@ -633,6 +639,11 @@ class _ProcessDecoder:
         self.pinned = False
         if pin and torch.cuda.is_available():
             self.pinned = int(torch.cuda.cudart().cudaHostRegister(self.flat.data_ptr(), self.flat.numel() * 4, 0)) == 0
+        # the look-up tables and the C helper are set up BEFORE the fork (inherited, not rebuilt per worker), and cyclic garbage of earlier
+        # loaders (their pools) is finalised here, in the parent, not in a child (see _pw_init)
+        import gc
+        _luts(); _host_lib()
+        gc.collect()
         # FORK, like torch's DataLoader workers: the children inherit the scene objects and the shared segment without re-importing anything
         # (spawned workers each re-imported torch: 36 s to start 32 of them under a 16-CPU container quota, tools/bench_fused_split.py) and
         # never touch the HIP runtime -- they run PIL / zlib / numpy only
@@ -651,6 +662,8 @@ class _ProcessDecoder:
     def close(self):
         if self.pool is not None:
             self.pool.terminate(); self.pool.join(); self.pool = None
+            import gc
+            gc.collect()                                       # the pool's cycles die in THIS process, now
         if self.pinned:
             torch.cuda.cudart().cudaHostUnregister(self.flat.data_ptr())
             self.pinned = False
@@ -785,6 +798,16 @@ class PairBatchLoader:
                               for (si, _), m in zip(items, meta)],
                     scene_id=sc.scene_id, scene_root=sc.scene_root, scene_index=items[-1][0], last_of_scene=bool(done and done[-1] == sc.scene_id))
 
+    POOL_ANSWER_S = 600.0            # a batch is < 1 s of decode; a pool that stays silent this long is dead (never wait for it for ever)
+
+    def _pool_map(self, fn, tasks):
+        import multiprocessing as _mp
+        try:
+            return self._proc.pool.map_async(fn, list(tasks), chunksize=1).get(timeout=self.POOL_ANSWER_S)
+        except _mp.TimeoutError:
+            self.close()
+            raise RuntimeError(f"PairBatchLoader: the decode workers did not answer within {self.POOL_ANSWER_S:.0f} s (pool closed)") from None
+
     def _load_process(self, items):
         """the same batch through the process pool: workers write into a shared-memory slot; the first pair of the loader's life is
         decoded here once to learn the shapes"""
@@ -796,7 +819,7 @@ class PairBatchLoader:
             first = self.scenes[items[0][0]][items[0][1]]
             Hh, Ww = first["image0"].shape[-2:]
             self._proc = _ProcessDecoder(self.scenes, self.B, Hh, Ww, first["depth0"].numel() > 0, self.workers, max(self.prefetch, 0) + 4, self.pin)
-            self._proc.pool.map(_pw_ping, range(self.workers * 2), chunksize=1)        # every worker has started and imported its modules
+            self._pool_map(_pw_ping, range(self.workers * 2))                          # every worker has started and imported its modules
             st["process_pool_start_s"] = _t.perf_counter() - t0
         pr = self._proc
         t0 = _t.perf_counter()
@@ -810,7 +833,7 @@ class PairBatchLoader:
             key = si if getattr(self.scenes[si], "shared_reference", False) else ("pair", p)
             want.append(key not in first_of)
             first_of.setdefault(key, p)
-        meta = pr.pool.map(_pw_fill, [(k, p, si, i, want[p]) for p, (si, i) in enumerate(items)], chunksize=1)
+        meta = self._pool_map(_pw_fill, [(k, p, si, i, want[p]) for p, (si, i) in enumerate(items)])
         st["decode_map_s"] = st.get("decode_map_s", 0.0) + _t.perf_counter() - t0
         st["worker_task_s"] = st.get("worker_task_s", 0.0) + sum(m[5] for m in meta)
         st["batches"] = st.get("batches", 0) + 1
