@@ -83,35 +83,45 @@ static __device__ __forceinline__ void strip_max9(const float v[16], float o[8])
     for (int i = 0; i < 8; ++i) o[i] = fmaxf(m8[i], v[i + 8]);      // window [i, i+8] = outputs centred at i+4
 }
 
-static __device__ __forceinline__ void pool9(const float *src, float *tmp, float *dst)
+// m_in: margin (from the LDS tile's edge) inside which `src` is valid, m_out = m_in + R: margin inside which `dst` is needed.  Round 5: every
+// pool works on ITS region only -- the k-th of the five pools is needed R k inside the tile edge and reads what the (k - 1)-th left valid --
+// instead of on the whole 104 x 72 tile: 5 768 instead of 9 360 strips per tile, the same values wherever a value is used.
+static __device__ __forceinline__ void pool9(const float *src, float *tmp, float *dst, int m_in, int m_out)
 {
-    // row pass: strip = 8 outputs x0..x0+7 of row y, inputs x0-4..x0+11
+    // row pass: strip = 8 outputs x0..x0+7 of row y, inputs x0-4..x0+11; rows m_in .. LH - m_in (what the column pass reads)
     // (consecutive lanes -> consecutive rows: stride 105 floats = conflict-free)
-    for (int t = threadIdx.x; t < NMS_LH * (NMS_LW / 8); t += NMS_THREADS) {
-        const int st = t / NMS_LH, y = t - st * NMS_LH, x0 = st * 8;
-        float v[16], o[8];
+    {
+        const int st0 = m_out / 8, nst = (NMS_LW - m_out + 7) / 8 - st0, nrows = NMS_LH - 2 * m_in;
+        for (int t = threadIdx.x; t < nrows * nst; t += NMS_THREADS) {
+            const int st = t / nrows, y = m_in + (t - st * nrows), x0 = (st0 + st) * 8;
+            float v[16], o[8];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int xx = x0 - NMS_R + i;
-            v[i] = (xx >= 0 && xx < NMS_LW) ? src[y * NMS_LS + xx] : -INFINITY;
+            for (int i = 0; i < 16; ++i) {
+                const int xx = x0 - NMS_R + i;
+                v[i] = (xx >= 0 && xx < NMS_LW) ? src[y * NMS_LS + xx] : -INFINITY;
+            }
+            strip_max9(v, o);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) tmp[y * NMS_LS + x0 + i] = o[i];
         }
-        strip_max9(v, o);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) tmp[y * NMS_LS + x0 + i] = o[i];
     }
     __syncthreads();
-    // column pass: strip = 8 outputs y0..y0+7 of column x (consecutive threads -> consecutive x)
-    for (int t = threadIdx.x; t < (NMS_LH / 8) * NMS_LW; t += NMS_THREADS) {
-        const int ys = t / NMS_LW, x = t - ys * NMS_LW, y0 = ys * 8;
-        float v[16], o[8];
+    // column pass: strip = 8 outputs y0..y0+7 of column x (consecutive threads -> consecutive x); columns m_out .. LW - m_out
+    {
+        const int ys0 = m_out / 8, nys = (NMS_LH - m_out + 7) / 8 - ys0, ncols = NMS_LW - 2 * m_out;
+        for (int t = threadIdx.x; t < nys * ncols; t += NMS_THREADS) {
+            const int ys = t / ncols, x = m_out + (t - ys * ncols), y0 = (ys0 + ys) * 8;
+            float v[16], o[8];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int yy = y0 - NMS_R + i;
-            v[i] = (yy >= 0 && yy < NMS_LH) ? tmp[yy * NMS_LS + x] : -INFINITY;
+            for (int i = 0; i < 16; ++i) {
+                const int yy = y0 - NMS_R + i;
+                // rows outside [m_in, LH - m_in) were not produced by the row pass: they only reach outputs outside the needed region
+                v[i] = (yy >= m_in && yy < NMS_LH - m_in) ? tmp[yy * NMS_LS + x] : -INFINITY;
+            }
+            strip_max9(v, o);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) dst[(y0 + i) * NMS_LS + x] = o[i];
         }
-        strip_max9(v, o);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) dst[(y0 + i) * NMS_LS + x] = o[i];
     }
     __syncthreads();
 }
@@ -136,12 +146,12 @@ __global__ void __launch_bounds__(NMS_THREADS) sp_nms_kernel(const float *__rest
         s[i] = (lx < NMS_LW && gx >= 0 && gx < W && gy >= 0 && gy < H) ? img[(size_t)gy * W + gx] : -INFINITY;
     }
     __syncthreads();
-    pool9(s, t, a);                                             // a = max_pool(scores)
+    pool9(s, t, a, 0, NMS_R);                                   // a = max_pool(scores)
     for (int i = threadIdx.x; i < NMS_N; i += NMS_THREADS)                  // max_mask (in-image cells only)
         mk[i] = (s[i] != -INFINITY && s[i] == a[i]) ? 1.f : 0.f;
     __syncthreads();
     for (int round = 0; round < 2; ++round) {
-        pool9(mk, t, a);                                        // a = max_pool(max_mask) (>0 = supp_mask)
+        pool9(mk, t, a, (2 * round + 1) * NMS_R, (2 * round + 2) * NMS_R);      // a = max_pool(max_mask) (>0 = supp_mask)
         // a <- supp_scores = supp ? 0 : scores   (keep supp flag in t? t is pool scratch -> recompute)
         for (int i = threadIdx.x; i < NMS_N; i += NMS_THREADS) {
             const bool supp = a[i] > 0.f;
@@ -151,7 +161,7 @@ __global__ void __launch_bounds__(NMS_THREADS) sp_nms_kernel(const float *__rest
             mk[i] = mk[i] + (supp ? 2.f : 0.f);
         }
         __syncthreads();
-        pool9(a, t, p5);                                        // p5 = max_pool(supp_scores)
+        pool9(a, t, p5, (2 * round + 2) * NMS_R, (2 * round + 3) * NMS_R);      // p5 = max_pool(supp_scores)
         for (int i = threadIdx.x; i < NMS_N; i += NMS_THREADS) {
             const float m = p5[i];
             // new_max_mask = supp_scores == max_pool(supp_scores); max_mask |= new & ~supp
