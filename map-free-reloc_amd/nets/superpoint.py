@@ -34,6 +34,13 @@ class SuperPointHIP:
         self.w["convDb.mat"] = self.w["convDb.weight"].reshape(256, 256).contiguous()
         from .linear import SplitLinear
         self.convDb = SplitLinear(self.w["convDb.mat"], self.w["convDb.bias"])
+        # detector head convPb (256 -> 65, 1x1) through the implicit-GEMM kernel in the f16x2 arithmetic (round 5; a workgroup = 128 pixels of ONE
+        # image, so a pixel's logits do not depend on the batch it is in -- what the reference-view feature cache needs); the bf16x3 option keeps
+        # round 4's fp32 FMA-chain kernel
+        self.head_pb = None
+        if self.use_wino and self.convDb.split == "f16x2":
+            from .conv import IgemmConv
+            self.head_pb = IgemmConv(self.w["convPb.weight"], self.w["convPb.bias"], 1, 0)
         # Winograd-transformed 3x3 filters, packed in MFMA operand order (csrc/winograd_conv.hip), once per weight set
         self.upk = {}
         for name in ("conv1b", "conv2a", "conv2b", "conv3a", "conv3b", "conv4a", "conv4b", "convPa", "convDa"):
@@ -52,6 +59,8 @@ class SuperPointHIP:
         if self.use_wino and relu and name in self.upk:
             return self.upk[name](x, act=1, pool=pool)
         if not relu:
+            if w.shape[-1] == 1 and name == "convPb" and self.head_pb is not None:
+                return self.head_pb(x)
             if w.shape[-1] == 1 and self.use_wino:   # 1x1 head (convPb): own kernel, one ascending FMA chain per logit (batch-size independent bits)
                 B, C, H, W = x.shape
                 x = x.contiguous()
