@@ -235,6 +235,33 @@ __global__ void __launch_bounds__(1024) dsm_colbest_kernel(const float *__restri
 #define DSM_CB 1024
 #define DSM_RU 4
 
+// Round 5: the two tile kernels in the arithmetic the Sinkhorn sweep got (csrc/superglue_match.hip) -- rounds 2-4 spent ~50 instructions per
+// matrix element here (an IEEE division by the temperature, four precise expf in two online log-sum-exp updates, a butterfly of rescaling merges
+// per row; the arg-max sweep two expf and two divisions): 1.65 + 1.20 ms per 16 pairs at 0.9 TB/s.  Now: s * (1 / temperature); a row's
+// wavefront-wide maximum first and ONE v_exp_f32 per term; column partials over the four rows in flight at once (1.5 per term); the
+// confidences from two v_exp_f32 and the reciprocals of the sums (per column: registers, per row: LDS).  The four-sweep kernels (variant 1)
+// keep the round-1 arithmetic; the two agree to round-off (tests/test_gpu_loftr_parity.py).
+template <int CTRL> static __device__ __forceinline__ float dsm_dpp(float x)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, false));
+}
+static __device__ __forceinline__ void dsm_swap16(float &a, float &b) { asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+static __device__ __forceinline__ void dsm_swap32(float &a, float &b) { asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+static __device__ __forceinline__ float dsm_wave_max(float x)
+{
+    x = fmaxf(x, dsm_dpp<0xB1>(x)); x = fmaxf(x, dsm_dpp<0x4E>(x)); x = fmaxf(x, dsm_dpp<0x141>(x)); x = fmaxf(x, dsm_dpp<0x140>(x));
+    float y = x; dsm_swap16(x, y); x = fmaxf(x, y);
+    y = x; dsm_swap32(x, y); x = fmaxf(x, y);
+    return x;
+}
+static __device__ __forceinline__ float dsm_wave_sum(float x)
+{
+    x += dsm_dpp<0xB1>(x); x += dsm_dpp<0x4E>(x); x += dsm_dpp<0x141>(x); x += dsm_dpp<0x140>(x);
+    float y = x; dsm_swap16(x, y); x += y;
+    y = x; dsm_swap32(x, y); x += y;
+    return x;
+}
+
 static __device__ __forceinline__ void dsm_load4(const float *__restrict__ row, int j0, int nval, bool vec, float x[4])
 {
     if (nval == 4 && vec) {
@@ -260,34 +287,35 @@ __global__ void __launch_bounds__(256) dsm_stats_tile_kernel(const float *__rest
     Lse c[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) c[k] = { -INFINITY, 0.f };
+    const float itemp = 1.0f / temp;
     for (int r0 = 0; r0 < nrows; r0 += DSM_RU) {
         float x[DSM_RU][4];
 #pragma unroll
         for (int u = 0; u < DSM_RU; ++u)
             if (r0 + u < nrows) dsm_load4(base + (size_t)(r0 + u) * L1, j0, nval, vec, x[u]);
-        Lse a[DSM_RU];
+        float t[DSM_RU][4];
+#pragma unroll
+        for (int u = 0; u < DSM_RU; ++u)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) t[u][k] = (r0 + u < nrows && k < nval) ? x[u][k] * itemp : -INFINITY;
+        // rows: the wavefront's maximum first, one exponential per term (an all-absent lane / row contributes exp(-inf) = 0)
 #pragma unroll
         for (int u = 0; u < DSM_RU; ++u) {
-            a[u] = { -INFINITY, 0.f };
-            if (r0 + u < nrows) {
+            const float mx = dsm_wave_max(fmaxf(fmaxf(t[u][0], t[u][1]), fmaxf(t[u][2], t[u][3])));
+            const float ms = (mx > -INFINITY) ? mx : 0.f;
+            const float sm = dsm_wave_sum(((__expf(t[u][0] - ms) + __expf(t[u][1] - ms)) + __expf(t[u][2] - ms)) + __expf(t[u][3] - ms));
+            if (lane == 0 && r0 + u < nrows) { wm[r0 + u][wid] = mx; wsum[r0 + u][wid] = sm; }
+        }
+        // columns: the four rows at once (row r0 exists; absent rows are -inf)
 #pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    if (k < nval) { const float t = x[u][k] / temp; lse_add(a[u], t); lse_add(c[k], t); }
+        for (int k = 0; k < 4; ++k)
+            if (k < nval) {
+                const float bm = fmaxf(fmaxf(t[0][k], t[1][k]), fmaxf(t[2][k], t[3][k]));
+                const float bs = ((__expf(t[0][k] - bm) + __expf(t[1][k] - bm)) + __expf(t[2][k] - bm)) + __expf(t[3][k] - bm);
+                const float nm = fmaxf(c[k].m, bm);
+                c[k].s = c[k].s * __expf(c[k].m - nm) + bs * __expf(bm - nm);
+                c[k].m = nm;
             }
-        }
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-#pragma unroll
-            for (int u = 0; u < DSM_RU; ++u) {
-                const float om = __shfl_xor(a[u].m, off, 64), os = __shfl_xor(a[u].s, off, 64);
-                lse_merge(a[u], om, os);
-            }
-        }
-        if (lane == 0) {
-#pragma unroll
-            for (int u = 0; u < DSM_RU; ++u)
-                if (r0 + u < nrows) { wm[r0 + u][wid] = a[u].m; wsum[r0 + u][wid] = a[u].s; }
-        }
     }
     __syncthreads();
     if (tid < nrows) {
@@ -339,12 +367,13 @@ __global__ void __launch_bounds__(256) dsm_best_tile_kernel(const float *__restr
     const int i0 = st * DSM_RS, nrows = min(DSM_RS, L0 - i0);
     const bool vec = (L1 & 3) == 0;
     const float *base = S + ((size_t)b * L0 + i0) * L1;
-    if (tid < nrows) { rm_s[tid] = rmax[(size_t)b * L0 + i0 + tid]; rs_s[tid] = rsum[(size_t)b * L0 + i0 + tid]; }
+    if (tid < nrows) { rm_s[tid] = rmax[(size_t)b * L0 + i0 + tid]; rs_s[tid] = 1.0f / rsum[(size_t)b * L0 + i0 + tid]; }      // (reciprocal of the row sum)
+    const float itemp = 1.0f / temp;
     float cm[4], cs[4], cbest[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         cm[k] = k < nval ? cmax[(size_t)b * L1 + j0 + k] : 0.f;
-        cs[k] = k < nval ? csum[(size_t)b * L1 + j0 + k] : 1.f;
+        cs[k] = k < nval ? 1.0f / csum[(size_t)b * L1 + j0 + k] : 1.f;                                                              // (reciprocal of the column sum)
         cbest[k] = -1.f;
     }
     __syncthreads();
@@ -362,7 +391,8 @@ __global__ void __launch_bounds__(256) dsm_best_tile_kernel(const float *__restr
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
                     if (k < nval) {
-                        const float cf = conf_val(x[u][k] / temp, rm, rs, cm[k], cs[k]);
+                        const float tt = x[u][k] * itemp;
+                        const float cf = (__expf(tt - cm[k]) * cs[k]) * (__expf(tt - rm) * rs);      // conf_val with v_exp_f32 and the reciprocal sums
                         if (cf > best[u]) { best[u] = cf; bj[u] = j0 + k; }
                         if (cf > cbest[k]) cbest[k] = cf;
                     }
