@@ -519,6 +519,21 @@ __global__ void __launch_bounds__(256) fine_gather_kernel(const float *__restric
     const int img = img_ids[m], cell = cell_ids[m];
     const int cy = (cell / wc) * stride - win / 2, cx = (cell % wc) * stride - win / 2;
     const int total = win * win * C;
+    if (!(C & 3) && !(((size_t)feat | (size_t)out) & 15)) {
+        // 16-byte pieces (round 5; a window is win^2 runs of C contiguous floats on both sides): one division per PIECE by the piece count of a
+        // run instead of two per element -- the element loop below spent most of its time on them (0.44 -> 0.15 ms per launch)
+        const int c4 = C >> 2, total4 = win * win * c4;
+        const float4 *f4 = (const float4 *)feat;
+        float4 *o4 = (float4 *)out + (size_t)m * total4;
+        for (int e = threadIdx.x; e < total4; e += 256) {
+            const int k = e / c4, q = e - k * c4;
+            const int ky = k / win, y = cy + ky, x = cx + (k - ky * win);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (y >= 0 && y < Hf && x >= 0 && x < Wf) v = f4[(((size_t)img * Hf + y) * Wf + x) * c4 + q];
+            o4[e] = v;
+        }
+        return;
+    }
     for (int e = threadIdx.x; e < total; e += 256) {
         const int k = e / C, ch = e - k * C;
         const int y = cy + k / win, x = cx + k % win;
