@@ -52,13 +52,22 @@ static __device__ __forceinline__ void lse_merge(Lse &a, float m, float s)
 static __device__ __forceinline__ float lse_val(const Lse &a) { return a.m + __logf(a.s); }
 // round 5: four terms at once -- the block's maximum first, then ONE rescale of the running sum per four terms instead of one per term
 // (1.5 exponentials per term instead of 2).  x0 is finite; x1 .. x3 may be -inf (absent: exp(-inf) = 0).
-static __device__ __forceinline__ void lse_add4(Lse &a, float x0, float x1, float x2, float x3)
+static __device__ __forceinline__ void lse_block4(float x0, float x1, float x2, float x3, float &bm, float &bs)
 {
-    const float bm = fmaxf(fmaxf(x0, x1), fmaxf(x2, x3));
-    const float bs = ((__expf(x0 - bm) + __expf(x1 - bm)) + __expf(x2 - bm)) + __expf(x3 - bm);
+    bm = fmaxf(fmaxf(x0, x1), fmaxf(x2, x3));
+    bs = ((__expf(x0 - bm) + __expf(x1 - bm)) + __expf(x2 - bm)) + __expf(x3 - bm);
+}
+static __device__ __forceinline__ void lse_merge_block(Lse &a, float bm, float bs)        // bm finite
+{
     const float nm = fmaxf(a.m, bm);
     a.s = __builtin_fmaf(a.s, __expf(a.m - nm), bs * __expf(bm - nm));
     a.m = nm;
+}
+static __device__ __forceinline__ void lse_add4(Lse &a, float x0, float x1, float x2, float x3)
+{
+    float bm, bs;
+    lse_block4(x0, x1, x2, x3, bm, bs);
+    lse_merge_block(a, bm, bs);
 }
 // wavefront-wide max / sum that leave the SAME bits in all 64 lanes (every step pairs two groups and a + b == b + a): DPP inside a row of
 // 16 lanes (quad_perm xor 1, xor 2, row_half_mirror, row_mirror), then gfx950's v_permlane16_swap / v_permlane32_swap across rows and halves
@@ -214,7 +223,7 @@ __global__ void __launch_bounds__(1024) sg_col_kernel(const float *__restrict__ 
 // in sg_col_kernel's order (k = 1 .. 15) into v.  The dustbin column is a 17th column of every lane (its entries are all alpha), and the
 // dustbin row's u_m is computed by workgroup 0 before its rows.  Requires the 16-byte fast path of sg_row_kernel (ldS % 4 == 0, ldS <= 1024); other shapes keep
 // the two-pass kernels.
-__global__ void __launch_bounds__(256, 2) sg_sweep_kernel(const float *__restrict__ S, int ldS, const int *__restrict__ n0, const int *__restrict__ n1,
+__global__ void __launch_bounds__(512, 2) sg_sweep_kernel(const float *__restrict__ S, int ldS, const int *__restrict__ n0, const int *__restrict__ n1,
                                                        float alpha, const float *__restrict__ v, float *__restrict__ u,
                                                        float *__restrict__ part_m /*[B, 16, SG_LDV]*/, float *__restrict__ part_s)
 {
@@ -224,7 +233,13 @@ __global__ void __launch_bounds__(256, 2) sg_sweep_kernel(const float *__restric
     __shared__ float4 am4[4][4][64], as4[4][4][64];
     __shared__ float amd[4][64], asd[4][64];
     __shared__ float um_s;
-    const int b = blockIdx.y, g = blockIdx.x, lane = threadIdx.x & 63, r = threadIdx.x >> 6;
+    __shared__ float4 wsh[256];
+    // round 5: EIGHT wavefronts -- accumulator r's blocks of four rows alternate between wavefronts (r, 0) and (r, 1); a block's sums (maximum,
+    // sum of exponentials: lse_block4) are formed by whichever owns it, the merges into the accumulator happen in block order (lse_merge_block:
+    // the even block's wavefront first, a barrier, the odd block's) -- exactly lse_add4's arithmetic, so nothing downstream changes a bit -- and a
+    // SIMD holds four wavefronts of ~110 registers instead of two of 204: their dependent exponential chains and row loads fill each other's gaps
+    // (profiles/r05_pmc_sinkhorn.json: the four-wavefront kernel spent 34 % of its wave cycles blocked at issue, 28 % parked on loads)
+    const int b = blockIdx.y, g = blockIdx.x, lane = threadIdx.x & 63, w8 = threadIdx.x >> 6, r = w8 & 3, hb = w8 >> 2;
     const int m = n0[b], n = n1[b];
     if (m == 0 || n == 0) return;
     const int ldv = SG_LDV(ldS);
@@ -236,7 +251,7 @@ __global__ void __launch_bounds__(256, 2) sg_sweep_kernel(const float *__restric
 
     // the dustbin row's u (row m: every entry alpha), by wavefront 0 of workgroup 0 -- sg_row_kernel's third branch
     if (g == 0) {
-        if (r == 0) {
+        if (w8 == 0) {
             Lse a = { -INFINITY, 0.f };
             for (int j = lane; j < n; j += 64) lse_add(a, alpha + vb[j]);
             if (lane == 0) lse_add(a, vn);
@@ -250,9 +265,11 @@ __global__ void __launch_bounds__(256, 2) sg_sweep_kernel(const float *__restric
         __syncthreads();
     }
 
+    if (hb == 0) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { am4[r][k][lane] = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY); as4[r][k][lane] = make_float4(0.f, 0.f, 0.f, 0.f); }
-    amd[r][lane] = -INFINITY; asd[r][lane] = 0.f;                     // the dustbin column (every lane the same value)
+        for (int k = 0; k < 4; ++k) { am4[r][k][lane] = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY); as4[r][k][lane] = make_float4(0.f, 0.f, 0.f, 0.f); }
+        amd[r][lane] = -INFINITY; asd[r][lane] = 0.f;                 // the dustbin column (every lane the same value)
+    }
     // this wavefront = accumulator r of row group g: its rows t = 0 .. nrows - 1 (sg_row_of), four at a time
     const int nq = sg_nq(m, g);
     const int nrows = nq + (r == 0 ? sg_ntail(m, g, nq) : 0);
@@ -262,69 +279,77 @@ __global__ void __launch_bounds__(256, 2) sg_sweep_kernel(const float *__restric
     bool ok[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) ok[k] = 4 * (lane + 64 * (k >> 2)) + (k & 3) < n;
-    // two register sets of four rows (a row is 4 KB): the next block's 16 KB are requested before this block's arithmetic starts
-    auto load_block = [&](float4 (&d)[4][4], int t) {
-        if (t >= nrows) return;
+    // v of the pair's columns: one LDS copy for the workgroup (16 registers per wavefront otherwise, and the budget is 128)
+    if (threadIdx.x < 256) wsh[threadIdx.x] = v4[min((int)threadIdx.x, j4max)];
+    // the loop count is the workgroup's (barriers inside): accumulator 0 has the most rows (it takes the group's left-over rows)
+    const int nblk0 = (nq + sg_ntail(m, g, nq) + 3) >> 2;
+    __syncthreads();                                                  // accumulators initialised
+    for (int it = 0; 2 * it < nblk0; ++it) {
+        const int t = 4 * (2 * it + hb);
+        const bool have = t < nrows;                                  // (wave-uniform)
+        float bm[17], bs[17];
+        if (have) {
+            float4 cur[4][4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            if (t + q < nrows) {
-                const float4 *row4 = (const float4 *)(S + ((size_t)b * ldS + sg_row_of(g, r, nq, t + q)) * ldS);
+            for (int q = 0; q < 4; ++q) {
+                if (t + q < nrows) {
+                    const float4 *row4 = (const float4 *)(S + ((size_t)b * ldS + sg_row_of(g, r, nq, t + q)) * ldS);
 #pragma unroll
-                for (int k = 0; k < 4; ++k) d[q][k] = row4[min(lane + 64 * k, j4max)];
-            } else {
+                    for (int k = 0; k < 4; ++k) cur[q][k] = row4[min(lane + 64 * k, j4max)];
+                } else {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) d[q][k] = make_float4(0.f, 0.f, 0.f, 0.f);     // absent row: finite filler, its u is -inf below
+                    for (int k = 0; k < 4; ++k) cur[q][k] = make_float4(0.f, 0.f, 0.f, 0.f);     // absent row: finite filler, its u is -inf below
+                }
             }
+            float ui[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                ui[q] = -INFINITY;
+                if (t + q < nrows) {
+                    // ---- u_i: sg_row_kernel's fast path (same sums in the same order)
+                    float x[16];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float4 wk = wsh[lane + 64 * k];
+                        x[4 * k] = ok[4 * k] ? cur[q][k].x + wk.x : -INFINITY;
+                        x[4 * k + 1] = ok[4 * k + 1] ? cur[q][k].y + wk.y : -INFINITY;
+                        x[4 * k + 2] = ok[4 * k + 2] ? cur[q][k].z + wk.z : -INFINITY;
+                        x[4 * k + 3] = ok[4 * k + 3] ? cur[q][k].w + wk.w : -INFINITY;
+                    }
+                    ui[q] = sg_row_u(x, vn, norm, lane);
+                    if (lane == 0) ub[sg_row_of(g, r, nq, t + q)] = ui[q];
+                }
+                __builtin_amdgcn_sched_barrier(0);                    // one row's 16 terms at a time: the budget is 128 registers
+            }
+            // ---- this block's sums of this lane's 16 columns + the dustbin column (sg_col_kernel's lse_add4, first half)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                lse_block4(cur[0][k].x + ui[0], cur[1][k].x + ui[1], cur[2][k].x + ui[2], cur[3][k].x + ui[3], bm[4 * k], bs[4 * k]);
+                lse_block4(cur[0][k].y + ui[0], cur[1][k].y + ui[1], cur[2][k].y + ui[2], cur[3][k].y + ui[3], bm[4 * k + 1], bs[4 * k + 1]);
+                lse_block4(cur[0][k].z + ui[0], cur[1][k].z + ui[1], cur[2][k].z + ui[2], cur[3][k].z + ui[3], bm[4 * k + 2], bs[4 * k + 2]);
+                lse_block4(cur[0][k].w + ui[0], cur[1][k].w + ui[1], cur[2][k].w + ui[2], cur[3][k].w + ui[3], bm[4 * k + 3], bs[4 * k + 3]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            lse_block4(alpha + ui[0], alpha + ui[1], alpha + ui[2], alpha + ui[3], bm[16], bs[16]);
         }
-    };
-    float4 w[4];
+        // ---- merges in block order (second half of lse_add4): the even block, a barrier, the odd block
 #pragma unroll
-    for (int k = 0; k < 4; ++k) w[k] = v4[min(lane + 64 * k, j4max)];
-    auto do_block = [&](const float4 (&cur)[4][4], int t) {
-        if (t >= nrows) return;
-        float ui[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            ui[q] = -INFINITY;
-            if (t + q < nrows) {
-                // ---- u_i: sg_row_kernel's fast path (same sums in the same order)
-                float x[16];
+        for (int ph = 0; ph < 2; ++ph) {
+            if (have && hb == ph) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const float4 wk = w[k];
-                    x[4 * k] = ok[4 * k] ? cur[q][k].x + wk.x : -INFINITY;
-                    x[4 * k + 1] = ok[4 * k + 1] ? cur[q][k].y + wk.y : -INFINITY;
-                    x[4 * k + 2] = ok[4 * k + 2] ? cur[q][k].z + wk.z : -INFINITY;
-                    x[4 * k + 3] = ok[4 * k + 3] ? cur[q][k].w + wk.w : -INFINITY;
+                    const float4 pm = am4[r][k][lane], ps = as4[r][k][lane];
+                    Lse a0 = { pm.x, ps.x }, a1 = { pm.y, ps.y }, a2 = { pm.z, ps.z }, a3 = { pm.w, ps.w };
+                    lse_merge_block(a0, bm[4 * k], bs[4 * k]); lse_merge_block(a1, bm[4 * k + 1], bs[4 * k + 1]);
+                    lse_merge_block(a2, bm[4 * k + 2], bs[4 * k + 2]); lse_merge_block(a3, bm[4 * k + 3], bs[4 * k + 3]);
+                    am4[r][k][lane] = make_float4(a0.m, a1.m, a2.m, a3.m); as4[r][k][lane] = make_float4(a0.s, a1.s, a2.s, a3.s);
                 }
-                ui[q] = sg_row_u(x, vn, norm, lane);
-                if (lane == 0) ub[sg_row_of(g, r, nq, t + q)] = ui[q];
+                Lse ad = { amd[r][lane], asd[r][lane] };
+                lse_merge_block(ad, bm[16], bs[16]);
+                amd[r][lane] = ad.m; asd[r][lane] = ad.s;
             }
-            if (q & 1) __builtin_amdgcn_sched_barrier(0);          // two rows' reductions interleave (their cross-lane latencies overlap); all four would not fit the registers
+            __syncthreads();
         }
-        // ---- column partials of this lane's 16 columns + the dustbin column: sg_col_kernel's lse_add4 over the same four rows
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const float4 pm = am4[r][k][lane], ps = as4[r][k][lane];
-            Lse a0 = { pm.x, ps.x }, a1 = { pm.y, ps.y }, a2 = { pm.z, ps.z }, a3 = { pm.w, ps.w };
-            lse_add4(a0, cur[0][k].x + ui[0], cur[1][k].x + ui[1], cur[2][k].x + ui[2], cur[3][k].x + ui[3]);
-            lse_add4(a1, cur[0][k].y + ui[0], cur[1][k].y + ui[1], cur[2][k].y + ui[2], cur[3][k].y + ui[3]);
-            lse_add4(a2, cur[0][k].z + ui[0], cur[1][k].z + ui[1], cur[2][k].z + ui[2], cur[3][k].z + ui[3]);
-            lse_add4(a3, cur[0][k].w + ui[0], cur[1][k].w + ui[1], cur[2][k].w + ui[2], cur[3][k].w + ui[3]);
-            am4[r][k][lane] = make_float4(a0.m, a1.m, a2.m, a3.m); as4[r][k][lane] = make_float4(a0.s, a1.s, a2.s, a3.s);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        Lse ad = { amd[r][lane], asd[r][lane] };
-        lse_add4(ad, alpha + ui[0], alpha + ui[1], alpha + ui[2], alpha + ui[3]);
-        amd[r][lane] = ad.m; asd[r][lane] = ad.s;
-    };
-    float4 rbA[4][4], rbB[4][4];
-    load_block(rbA, 0);
-    for (int t = 0; t < nrows; t += 8) {
-        load_block(rbB, t + 4);
-        do_block(rbA, t);
-        load_block(rbA, t + 8);
-        do_block(rbB, t + 4);
     }
     // ---- a += a1, a2 += a3, then a += a2 (sg_col_kernel's order): wavefront 2 folds wavefront 3's partials into its own, wavefront 0 folds
     // wavefront 1's and then wavefront 2's -- all through the LDS copies
@@ -338,21 +363,21 @@ __global__ void __launch_bounds__(256, 2) sg_sweep_kernel(const float *__restric
         }
         d[16] = { amd[rr][lane], asd[rr][lane] };
     };
-    if (r == 2) {
+    if (w8 == 2) {
         Lse o[17];
         fetch(acc, 2); fetch(o, 3);
 #pragma unroll
         for (int k = 0; k < 17; ++k) lse_merge(acc[k], o[k].m, o[k].s);
 #pragma unroll
         for (int k = 0; k < 17; ++k) { xm[0][k][lane] = acc[k].m; xs[0][k][lane] = acc[k].s; }
-    } else if (r == 0) {
+    } else if (w8 == 0) {
         Lse o[17];
         fetch(acc, 0); fetch(o, 1);
 #pragma unroll
         for (int k = 0; k < 17; ++k) lse_merge(acc[k], o[k].m, o[k].s);
     }
     __syncthreads();
-    if (r == 0) {
+    if (w8 == 0) {
 #pragma unroll
         for (int k = 0; k < 17; ++k) lse_merge(acc[k], xm[0][k][lane], xs[0][k][lane]);
         if (g == 0) {
@@ -552,7 +577,7 @@ int mfr_sg_sinkhorn_match_variant(const float *S, int B, int ldS, const int32_t 
     const dim3 rgrid((ldS + 1 + 3) / 4, B), cgrid((ldS + 1 + 63) / 64, B);
     for (int it = 0; it < iters; ++it) {
         if (sweep) {
-            hipLaunchKernelGGL(sg_sweep_kernel, dim3(16, B), dim3(256), 0, s, S, ldS, n0, n1, bin_score, v, u, part_m, part_s);
+            hipLaunchKernelGGL(sg_sweep_kernel, dim3(16, B), dim3(512), 0, s, S, ldS, n0, n1, bin_score, v, u, part_m, part_s);
             hipLaunchKernelGGL(sg_colmerge_kernel, cgrid, dim3(64), 0, s, ldS, n0, n1, part_m, part_s, v);
         } else {
             hipLaunchKernelGGL(sg_row_kernel, rgrid, dim3(256), 0, s, S, ldS, n0, n1, bin_score, v, u);

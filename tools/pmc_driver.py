@@ -1,6 +1,6 @@
 """One isolated kernel, launched a few times, for `rocprofv3 --pmc` passes (tools/pmc_kernel.sh): python tools/pmc_driver.py <what> [split]
 what: conv1ab (SuperPoint conv1a fused into conv1b, 64 images 720x540), gemm (the 512 -> 512 + ReLU layer at M = 65536), gemm_qkv (256 -> 768), conv1b (64 -> 64 channels, 64 images 720x540, pooled), attention (64 images x 4 heads x 1024),
-      loftr_l1out2 (196 -> 196 at 360x272, 32 images), loftr_gemm (256 -> 256 at M = 195840)"""
+      loftr_l1out2 (196 -> 196 at 360x272, 32 images), loftr_gemm (256 -> 256 at M = 195840), sinkhorn (32 pairs x 1024^2, 20 sweeps)"""
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -37,6 +37,15 @@ elif what == "attention":
     sg = SuperGlueHIP(WT.superglue_state_dict(), dev)
     qkv = torch.randn(64, 1024, 768, device=dev); n = torch.full((64,), 1024, dtype=torch.int32, device=dev); out = torch.empty(64, 1024, 256, device=dev)
     fn = lambda: sg.attention(qkv, n, False, out=out)
+elif what == "sinkhorn":        # 32 pairs x 1024 x 1024 scores, 20 iterations (the bench step's shape at full keypoint counts)
+    from mapfree_reloc_amd.nets.superglue import SuperGlueHIP
+    from mapfree_reloc_amd.nets import weights as WT
+    sg = SuperGlueHIP(WT.superglue_state_dict(), dev)
+    g = torch.Generator().manual_seed(1)
+    S = (torch.randn(32, 1024, 1024, generator=g) * 2).to(dev)
+    n = torch.full((32,), 1024, dtype=torch.int32, device=dev)
+    k0 = torch.rand(32, 1024, 2, device=dev) * 500; k1 = torch.rand(32, 1024, 2, device=dev) * 500
+    fn = lambda: sg.sinkhorn_match(S, n, n, k0, k1)
 else:
     raise SystemExit(f"unknown {what}")
 for _ in range(4):
