@@ -485,3 +485,14 @@ def test_bench_module_contract_pieces_importable():
         assert isinstance(dt, str) and "f16" in dt and isinstance(wl.metric, str) and isinstance(wl.workload, str)
     c = b.census_summary()
     assert c["hard2"]["sg_pnp"]["pose_within_bar"] == c["hard2"]["sg_pnp"]["pairs"] and c["hard1"]["sg_pnp"]["inlier_index_sets_identical"] == 64
+
+
+def test_round5_entry_points_reject_bad_arguments_before_touching_a_device():
+    """argument validation of the entry points added in round 5 (no GPU needed: MFR_E_ARG comes back before any launch)"""
+    lib = mfr._lib.load()
+    E_ARG = -1
+    assert lib.mfr_gemm_f16x2_pack_bytes(8, 33) == 0 and lib.mfr_gemm_f16x2_pack_bytes(8, 64) > 0          # K % 32
+    assert lib.mfr_gemm_f16x2_pack_batched(None, 32, 1, 0, 8, 32, 1.0, None, None) == E_ARG                 # null operands
+    assert lib.mfr_gemm_f16x2_batched(None, 32, 0, None, None, None, 8, 0, 1, 8, 8, 32, 0, None) == E_ARG
+    assert lib.mfr_sp_conv1ab_f16x2(None, None, None, None, None, 1, 8, 8, None, None) == E_ARG
+    assert lib.mfr_conv_igemm_f16x2(None, None, None, None, 1, 1, 8, 8, 1, 3, 3, 1, 1, 0, None) == E_ARG
