@@ -247,15 +247,17 @@ class SgPnpWorkload:
 
     @property
     def dtype(self):
-        if split_products() == 3.0:
-            return ("f32 in / f32 accumulate; matrix products of the 3x3 convolutions, attention and the transformer's linear layers on the f16 matrix cores with "
-                    "every fp32 operand carried as TWO f16 terms (xh = rne_f16(x), xl = rne_f16((x - xh) 2^11); weights pre-scaled per output feature; 3 partial "
-                    "products, fp32 accumulate: 2^-24 relative per operand for 2^-12 <= |x| <= 65504, error vs fp64 = the exact-fp32 MFMA's class, "
-                    "profiles/r05_f16x2_probe.jsonl; incl. SuperPoint's 1x1 descriptor head); the score matrix on the fp32 matrix cores, the 1x1 detector "
-                    "head as fp32 FMA chains; f64 solver")
-        return ("f32 in / f32 accumulate; matrix products of the 3x3 convolutions, attention and the transformer's linear layers as 3 x bf16 exact operand splits "
-                "(6 partial products, error = fp32 class; incl. SuperPoint's 1x1 descriptor head); the score matrix on the fp32 matrix cores, the 1x1 detector "
-                "head as fp32 FMA chains; f64 solver")
+        """derived from the routing of THIS run (which objects the networks built), not from a fixed text"""
+        sp, sg = self.pipe.sp, self.pipe.sg
+        f16 = split_products() == 3.0
+        arith = ("on the f16 matrix cores with every fp32 operand carried as TWO f16 terms (xh = rne_f16(x), xl = rne_f16((x - xh) 2^11); weights pre-scaled per "
+                 "output feature; 3 partial products, fp32 accumulate: 2^-24 relative per operand for 2^-12 <= |x| <= 65504 -- range guarded by a device flag, "
+                 "out-of-range batches are re-run in bf16x3 -- error vs fp64 = the exact-fp32 MFMA's class, profiles/r05_f16x2_probe.jsonl)") if f16 else \
+                "as 3 x bf16 exact operand splits (6 partial products, error = fp32 class)"
+        score = "mfr_gemm_f16x2_batched (same two-term arithmetic)" if getattr(sg, "score_gemm", None) is not None else "the library's batched fp32 GEMM"
+        head = "mfr_conv_igemm_f16x2 (same two-term arithmetic)" if getattr(sp, "head_pb", None) is not None else "the library's fp32 convolution"
+        return (f"f32 in / f32 accumulate; matrix products of the 3x3 convolutions, attention, the transformer's linear layers and SuperPoint's 1x1 descriptor head {arith}; "
+                f"SuperGlue's score matrix through {score}; the 1x1 detector head through {head}; softmax / Sinkhorn / NMS in f32; f64 solver")
     metric = "image-pairs/sec @ 540x720 (SuperPoint+SuperGlue + PnP w/ depth)"
     workload = "configs[1]: SuperPoint+SuperGlue matching + PnP w/ depth, 540x720"
 
@@ -312,23 +314,25 @@ class SgPnpWorkload:
         att_exec = split_products() * att_tf if att_tf else None
         nprod = int(split_products())
         kname = ("wino_split_c1_kernel: SuperPoint conv1a (1->64 ch, computed into LDS) + conv1b launch" if self.fused_c1 else "wino_split_p8_kernel conv1b launch")
+        direct_tf = conv_direct / (conv_ms * 1e-3) / 1e12 if conv_ms else None
         return {"kernel": f"{kname} (dominant kernel: fused Winograd F(2x2,3x3) convolution on the 16-bit matrix cores at "
                           f"fp32 accuracy, {'f16x2' if nprod == 3 else 'bf16x3'} operand split, 64->64 ch, pooled output; eight wavefronts per workgroup, two per SIMD)",
-                "bound": "mfma", "achieved": round(achieved, 1) if achieved else None, "peak": BF16_MFMA_PEAK_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4) if achieved else None,
+                "bound": "mfma", "achieved": round(direct_tf, 1) if direct_tf else None, "peak": BF16_MFMA_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(direct_tf / BF16_MFMA_PEAK_TFLOPS, 4) if direct_tf else None,
+                "mfma_pipe_frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4) if achieved else None, "executed_tflops": round(achieved, 1) if achieved else None,
                 "traffic": _traffic("conv1ab" if self.fused_c1 else "conv1b", B), "avg_launch_ms": round(conv_ms, 4) if conv_ms else None,
-                "launches_timed": len(self.conv_timer.events), "flops_per_launch": conv_flops,
-                "note": f"achieved = 16-bit matrix-core flops EXECUTED ({nprod} partial products per fp32 multiply-add of the 16 Winograd GEMMs) / launch time, "
-                        "against the DENSE bf16 / f16 MFMA peak; fp32_equivalent = the same launch priced as fp32 multiply-adds (what the layer delivers); "
-                        "direct_equivalent = priced as the direct 3x3 convolution's multiply-adds (SURVEY 8d's algorithmic work)",
+                "launches_timed": len(self.conv_timer.events), "flops_per_launch": conv_direct, "executed_flops_per_launch": conv_flops,
+                "note": "achieved / frac = ALGORITHMIC work (SURVEY 8d: the direct 3x3 convolution's multiply-adds, 2 x 9 x 64 x 64 x H x W x images) / launch time against the "
+                        f"DENSE f16 / bf16 MFMA peak; mfma_pipe_frac = the 16-bit matrix-core flops the kernel EXECUTES ({nprod} partial products per fp32 multiply-add of the "
+                        "16 Winograd GEMMs: Winograd does 1 / 2.25 of the direct multiply-adds, the operand split 3 x) against the same peak; fp32_equivalent = the Winograd-domain "
+                        "fp32 multiply-adds (what the layer delivers) against the fp32 MFMA peak",
                 "fp32_equivalent": {"tflops": round(eq, 2) if eq else None, "flops_per_launch": conv_fp32,
                                     "vs_fp32_mfma_peak": round(eq / FP32_MFMA_PEAK_TFLOPS, 4) if eq else None,
                                     "round2_exact_fp32_kernel": "8.63 ms / launch, 94.5 TFLOP/s, 0.60 of the fp32 MFMA peak (BENCH_r02)"},
-                "direct_equivalent_tflops": round(conv_direct / (conv_ms * 1e-3) / 1e12, 2) if conv_ms else None,
                 "other_kernels": [self._gemm_line(), {"kernel": ("sg_attention_f16x2_p_kernel (softmax(QK^T/8)V on the f16 matrix cores, two-term operands with main + correction accumulators" if nprod == 3 else "sg_attention_bf16x3_p_kernel (softmax(QK^T/8)V on the bf16 matrix cores, 3-way split operands") + ", 256 queries per workgroup, score product one tile ahead of the softmax)", "bound": "mfma",
-                                   "achieved": round(att_exec, 1) if att_exec else None,
-                                   "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(att_exec / BF16_MFMA_PEAK_TFLOPS, 4) if att_exec else None,
-                                   "fp32_equivalent_tflops": round(att_tf, 2) if att_tf else None,
+                                   "achieved": round(att_tf, 1) if att_tf else None,
+                                   "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(att_tf / BF16_MFMA_PEAK_TFLOPS, 4) if att_tf else None,
+                                   "mfma_pipe_frac": round(att_exec / BF16_MFMA_PEAK_TFLOPS, 4) if att_exec else None, "executed_tflops": round(att_exec, 1) if att_exec else None,
                                    "avg_launch_ms": round(att_ms, 4) if att_ms else None, "launches_timed": len(self.att_timer.events),
                                    "mean_keypoints_per_image": round(nk, 1)},
                                   self._sinkhorn_line(out)]}
@@ -340,9 +344,11 @@ class SgPnpWorkload:
         fp32 = 2.0 * M * 512 * 512
         ex = split_products() * fp32 / (ms * 1e-3) / 1e12 if ms else None
         return {"kernel": f"gemm_split_d_kernel, the 512 -> 512 + ReLU layer of a GNN block (mfr_gemm_{'f16x2' if split_products() == 3.0 else 'bf16x3'}: persistent workgroups, W by LDS-DMA, split operands)",
-                "bound": "mfma", "achieved": round(ex, 1) if ex else None, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ex / BF16_MFMA_PEAK_TFLOPS, 4) if ex else None, "fp32_equivalent_tflops": round(ex / split_products(), 2) if ex else None,
-                "avg_launch_ms": round(ms, 4) if ms else None, "launches_timed": len(self.gemm_timer.events), "flops_per_launch": split_products() * fp32}
+                "bound": "mfma", "achieved": round(ex / split_products(), 1) if ex else None, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(ex / split_products() / BF16_MFMA_PEAK_TFLOPS, 4) if ex else None,
+                "mfma_pipe_frac": round(ex / BF16_MFMA_PEAK_TFLOPS, 4) if ex else None, "executed_tflops": round(ex, 1) if ex else None,
+                "avg_launch_ms": round(ms, 4) if ms else None, "launches_timed": len(self.gemm_timer.events), "flops_per_launch": fp32,
+                "executed_flops_per_launch": split_products() * fp32}
 
     def _sinkhorn_line(self, out):
         """log-Sinkhorn + mutual arg-max stage.  Its binding resource is the transcendental ALU, not HBM: 2 x iters x (n+1)^2
@@ -369,10 +375,16 @@ class LoftrEmatWorkload:
 
     @property
     def dtype(self):
+        """derived from the routing of THIS run (LoFTRHIP.igemm / .sim_gemm / the split of its packed layers)"""
+        lo = self.pipe.loftr
+        f16 = split_products() == 3.0
         arith = ("on the f16 matrix cores with every fp32 operand carried as two f16 terms (3 partial products, fp32 accumulate, error = fp32 class: "
-                 "profiles/r05_f16x2_probe.jsonl)") if split_products() == 3.0 else "as 3 x bf16 exact operand splits (6 partial products, error = fp32 class)"
-        return (f"f32 in / f32 accumulate; 3x3 stride-1 convolutions and the transformer's linear layers {arith}; strided / 7x7 / 1x1 convolutions, similarity "
-                "products and linear attention in fp32 (library / fp32 MFMA kernels); f64 solver")
+                 "profiles/r05_f16x2_probe.jsonl; |x| <= 65504 guarded by a device flag, out-of-range batches are re-run in bf16x3)") if f16 else \
+                "as 3 x bf16 exact operand splits (6 partial products, error = fp32 class)"
+        rest = ("the strided 3x3 / 7x7 / 1x1 convolutions through mfr_conv_igemm_f16x2 and the coarse similarity product through mfr_gemm_f16x2_batched (same two-term arithmetic)"
+                if lo.igemm and lo.sim_gemm is not None else "the strided 3x3 / 7x7 / 1x1 convolutions and the similarity product through the library's fp32 kernels")
+        return (f"f32 in / f32 accumulate; 3x3 stride-1 convolutions, the transformers' linear layers and the fine-stage products {arith}; {rest}; "
+                "linear attention, LayerNorm, dual softmax and the fine expectation in f32 (own kernels); f64 solver")
     metric = "image-pairs/sec @ 540x720 (LoFTR + E-mat RANSAC w/ scale from depth)"
     workload = "configs[2]: LoFTR coarse-to-fine matching + Essential-matrix RANSAC + metric scale, 540x720 (padded to 544)"
 
@@ -412,31 +424,40 @@ class LoftrEmatWorkload:
         cm_tf = cm_flops / (cm_ms * 1e-3) / 1e12 if cm_ms else None
         cm_impl_bytes = (3.0 * L * L * 4 + 2.0 * L * 256 * 4) * B   # as implemented: S written once, swept twice, features in
         cm_impl_gbs = cm_impl_bytes / (cm_ms * 1e-3) / 1e9 if cm_ms else None
-        # the layer runs the bf16x3 Winograd kernel (nets/conv.py: prefer_bf16x3(360, 272)): six bf16 partial products per fp32
-        # multiply-add -> priced against the DENSE bf16 MFMA peak; useful flops count the 196 real channels (the kernel also
-        # multiplies the zero padding: Cin 196 -> 208 = 13 K steps of 16, Cout 196 -> 256 = 4 groups of 64: x1.39 executed)
-        exe = split_products() * achieved if achieved else None
+        # priced three ways: ALGORITHMIC = the direct 3x3 convolution's multiply-adds over the 196 real channels -> achieved / frac;
+        # fp32_equivalent = the 16 Winograd GEMMs' multiply-adds (1 / 2.25 of the direct ones); EXECUTED = split_products() x that, incl. the
+        # zero padding the kernel multiplies (Cin 196 -> 208 = 13 K steps of 16, Cout 196 -> 256 = 4 groups of 64: x 1.39) -> mfma_pipe_frac
+        exe = split_products() * achieved * (208.0 * 256.0) / (196.0 * 196.0) if achieved else None
+        conv_direct = 2.0 * 9 * 196 * 196 * 360 * 272 * 2 * B
+        direct_tf = conv_direct / (conv_ms * 1e-3) / 1e12 if conv_ms else None
+        lo = self.pipe.loftr
+        sim_f16 = lo.sim_gemm is not None
+        cm_peak = BF16_MFMA_PEAK_TFLOPS if sim_f16 else FP32_MFMA_PEAK_TFLOPS
         return {"kernel": "wino_split_p8_kernel layer1_outconv2.0 launch, 196->196 ch at 360x272 (dominant kernel: fused Winograd F(2x2,3x3) convolutions of the "
-                          "ResNet-FPN backbone on the 16-bit matrix cores at fp32 accuracy; a third of the step's GPU time, profiles/r05_bench_loftr_emat_kernel_stats.csv)",
-                "bound": "mfma", "achieved": round(exe, 1) if exe else None, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(exe / BF16_MFMA_PEAK_TFLOPS, 4) if exe else None, "traffic": _traffic("loftr_l1out2", B),
-                "avg_launch_ms": round(conv_ms, 4) if conv_ms else None, "launches_timed": len(self.conv_timer.events), "flops_per_launch": split_products() * conv_flops,
-                "note": f"achieved = useful 16-bit matrix-core flops ({int(split_products())} partial products per fp32 multiply-add of the 16 Winograd GEMMs over the 196 real channels) / launch "
-                        "time against the dense bf16 / f16 peak; executed incl. channel padding = x1.39",
+                          "ResNet-FPN backbone on the 16-bit matrix cores at fp32 accuracy; the family is the largest share of the step's GPU time, profiles/r06_bench_loftr_emat_kernel_stats.csv)",
+                "bound": "mfma", "achieved": round(direct_tf, 1) if direct_tf else None, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(direct_tf / BF16_MFMA_PEAK_TFLOPS, 4) if direct_tf else None,
+                "mfma_pipe_frac": round(exe / BF16_MFMA_PEAK_TFLOPS, 4) if exe else None, "executed_tflops": round(exe, 1) if exe else None,
+                "traffic": _traffic("loftr_l1out2", B),
+                "avg_launch_ms": round(conv_ms, 4) if conv_ms else None, "launches_timed": len(self.conv_timer.events), "flops_per_launch": conv_direct,
+                "note": f"achieved / frac = ALGORITHMIC work (direct 3x3 multiply-adds over the 196 real channels) / launch time against the dense f16 / bf16 MFMA peak; "
+                        f"mfma_pipe_frac = the matrix-core flops EXECUTED ({int(split_products())} partial products per fp32 multiply-add of the 16 Winograd GEMMs, channel padding included)",
                 "fp32_equivalent": {"tflops": round(achieved, 2) if achieved else None, "flops_per_launch": conv_flops,
                                     "vs_fp32_mfma_peak": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4) if achieved else None},
-                "other_kernels": [{"kernel": "dual-softmax coarse matching (similarity + row/col softmax statistics + mutual-NN selection)",
-                                   "bound": "mfma + hbm (fp32 similarity GEMM, then two streaming sweeps over the materialised S)",
-                                   "achieved": round(cm_tf, 2) if cm_tf else None, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                   "frac": round(cm_tf / FP32_MFMA_PEAK_TFLOPS, 4) if cm_tf else None,
+                "other_kernels": [{"kernel": "dual-softmax coarse matching (similarity product + row/col softmax statistics + mutual-NN selection)",
+                                   "bound": ("mfma + hbm (similarity product on the f16 matrix cores, two-term operands: mfr_gemm_f16x2_batched; then streaming sweeps over the materialised S)"
+                                             if sim_f16 else "mfma + hbm (library fp32 similarity GEMM, then streaming sweeps over the materialised S)"),
+                                   "achieved": round(cm_tf, 2) if cm_tf else None, "peak": cm_peak, "unit": "TFLOP/s",
+                                   "frac": round(cm_tf / cm_peak, 4) if cm_tf else None,
+                                   "mfma_pipe_frac": round(split_products() * cm_tf / cm_peak, 4) if (cm_tf and sim_f16) else None,
                                    "avg_launch_ms": round(cm_ms, 4) if cm_ms else None, "flops_per_launch": cm_flops,
                                    "hbm_view": {"implemented_bytes_per_launch": cm_impl_bytes,
                                                 "implemented_gbs": round(cm_impl_gbs, 1) if cm_impl_gbs else None,
                                                 "implemented_frac_of_hbm_peak": round(cm_impl_gbs / HBM_PEAK_GBS, 4) if cm_impl_gbs else None,
                                                 "algorithmic_bytes_per_launch": cm_bytes,
                                                 "algorithmic_frac_of_hbm_peak": round(cm_gbs / HBM_PEAK_GBS, 5) if cm_gbs else None},
-                                   "note": "time = contraction on the fp32 matrix cores + 3 passes over S (150 MB/pair); algorithmic bytes "
-                                           "(features in, 12.5 MB/pair) are not what bounds it -- both fractions are given"}]}
+                                   "note": "time = the contraction + the passes over S (150 MB/pair: written once, swept by the statistics and the selection kernels); algorithmic "
+                                           "bytes (features in, 12.5 MB/pair) are not what bounds it -- both fractions are given; the contraction is priced against the peak of the pipe it runs on"}]}
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -490,12 +511,14 @@ RPR_FAMILIES = (("library convolutions (MIOpen / CK implicit-GEMM: forward of th
 
 
 def rpr_kernel_families():
-    """GPU time of the training step by kernel family, from the committed rocprofv3 kernel trace of THIS command's timed steps
-    (profiles/r04_bench_rpr_train_kernel_stats.csv, tools/kernel_stats_timed.py: warm-up and the library's solution search excluded)"""
+    """GPU time of the training step by kernel family, from the NEWEST committed rocprofv3 kernel trace of THIS command's timed steps
+    (profiles/rNN_bench_rpr_train_kernel_stats.csv, tools/kernel_stats_timed.py: warm-up and the library's solution search excluded)"""
     import csv
-    path = os.path.join(ROOT, "profiles", "r04_bench_rpr_train_kernel_stats.csv")
-    if not os.path.exists(path):
+    import glob
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_bench_rpr_train_kernel_stats.csv")))
+    if not found:
         return None
+    path = found[-1]
     fam = {name: 0.0 for name, _ in RPR_FAMILIES}
     fam["everything else (elementwise, reductions, optimizer, copies)"] = 0.0
     total = 0.0
@@ -507,15 +530,17 @@ def rpr_kernel_families():
                 break
         else:
             fam["everything else (elementwise, reductions, optimizer, copies)"] += ms
-    return {"source": "profiles/r04_bench_rpr_train_kernel_stats.csv", "kernel_ms_per_step": round(total, 3),
+    return {"source": "profiles/" + os.path.basename(path), "kernel_ms_per_step": round(total, 3),
             "ms_per_step": {k: round(v, 3) for k, v in fam.items()}, "share": {k: round(v / total, 4) for k, v in fam.items()}}
 
 
-def rpr_roofline(tr, batch, B, ms_per_step, own):
-    """The family that dominates the step is the LIBRARY's convolutions, so that is what the roofline prices: the model's convolution
-    flops (counted on the modules: 2 Cin Cout k^2 Hout Wout per image and layer; forward + d input + d weight = 3x, minus the
-    decoder forward passes that run the own kernel) over the family's GPU time, against the dense bf16 peak.  The family's time
-    is its share in the committed profile of this command applied to the step time measured now."""
+def rpr_roofline(tr, batch, B, ms_per_step, own, own_fwd_step):
+    """The family that dominates the step is the LIBRARY's convolutions, so that is what the roofline prices: the convolution flops the
+    library runs per step over the family's GPU time, against the dense bf16 peak.  Library flops = 3 x (forward + d input + d weight) the forward
+    flops of every convolution that goes through nn.Conv2d (counted by hooks: 2 Cin Cout k^2 Hout Wout per image and layer; the decoder layers
+    that run the own forward kernel bypass the module call and are NOT in that count) + 2 x the own kernel's forward flops (`own_fwd_step`,
+    counted at its launches: d input and d weight of those layers are library kernels, options RPR_CONV_BWD = 'lib').  The family's time is its
+    share in the committed profile of this command applied to the step time measured now."""
     flops = {"all": 0.0, "own_fwd": 0.0}
 
     def hook(mod, inp, out):
@@ -530,17 +555,18 @@ def rpr_roofline(tr, batch, B, ms_per_step, own):
             h.remove()
     fams = rpr_kernel_families()
     lib_name = RPR_FAMILIES[0][0]
-    own_fwd = sum(k.get("flops_per_launch") or 0 for k in own if "conv_gemm_bf16" in k["kernel"]) * 4      # four decoder layers per step
-    lib_flops = 3.0 * flops["all"] - own_fwd
+    from mapfree_reloc_amd import options as _opt
+    lib_flops = 3.0 * flops["all"] + (2.0 * own_fwd_step if _opt.get("RPR_CONV_BWD") == "lib" else 0.0)
     lib_ms = fams["share"][lib_name] * ms_per_step if fams else None
     ach = lib_flops / (lib_ms * 1e-3) / 1e12 if lib_ms else None
     return {"kernel": lib_name + " -- the family with the largest share of the step's GPU time", "bound": "mfma",
             "achieved": round(ach, 1) if ach else None, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(ach / BF16_MFMA_PEAK_TFLOPS, 4) if ach else None, "traffic": None,
             "family_ms_per_step": round(lib_ms, 3) if lib_ms else None, "flops_per_step": lib_flops,
-            "encoder_conv_flops_forward_per_step": flops["all"],
-            "note": "family time = its share of the kernel time in the committed profile x the step time of this run; flops = 3 x the encoder's forward "
-                    "convolution flops (both views) minus the decoder forward passes the own kernel runs",
+            "library_forward_conv_flops_per_step": flops["all"], "own_kernel_forward_flops_per_step": own_fwd_step,
+            "note": "family time = its share of the kernel time in the committed profile x the step time of this run; flops = 3 x the forward flops of the "
+                    "convolutions the library runs forward (both views) + 2 x the forward flops of the decoder layers whose forward is the own kernel "
+                    "(their d input / d weight are library kernels)",
             "kernel_families": fams, "other_kernels": own}
 
 
@@ -584,7 +610,9 @@ def rpr_train_bench(args, rank, world, dev, use_dist):
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    timed_steps = args.steps
     if tr.graph_step and tr._gstep is not None:
+        timed_steps = 3                                   # the launches below are the ones the timers (and the flop counter) see
         # HIP events cannot be recorded inside a replay: time the correlation-volume kernels over eager steps right after the region
         saved = (tr._gstep, tr._gkeys)
         tr._gstep, tr._gkeys = None, ()
@@ -613,6 +641,7 @@ def rpr_train_bench(args, rank, world, dev, use_dist):
     cgm = cg_t.mean_ms()
     ncg = min(len(cg_flops), len(cg_t.events))
     ach_c = (sum(cg_flops[:ncg]) / max(ncg, 1)) / (cgm * 1e-3) / 1e12 if cgm and ncg else None
+    own_fwd_step = sum(cg_flops) / max(1, timed_steps)       # forward flops of the own decoder-convolution kernel per training step
     own = [{"kernel": "cw_bwd_q_kernel + cw_bwd_kv_kernel (mfr_corr_warp_bwd: fused correlation-volume warping, backward)", "bound": "mfma",
             "achieved": round(ach_b, 2) if ach_b else None, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(ach_b / FP32_MFMA_PEAK_TFLOPS, 4) if ach_b else None, "traffic": _traffic("cw_bwd_kv", B),
@@ -638,7 +667,7 @@ def rpr_train_bench(args, rank, world, dev, use_dist):
                    "precision": cfg.TRAINING.PRECISION, "siamese_batch": bool(cfg.TRAINING.SIAMESE_BATCH), "channels_last": bool(cfg.TRAINING.CHANNELS_LAST), "graph_step": bool(tr.graph_step),
                    "volume_positions": N, "feature_channels": D, "parameters": n_param, "optimizer": "Adam (fused), eps 1e-6",
                    "last_losses": [round(float(x.float().sum()), 5) for x in losses]},
-        "roofline": rpr_roofline(tr, batches[0], B, 1e3 * elapsed / args.steps, own),
+        "roofline": rpr_roofline(tr, batches[0], B, 1e3 * elapsed / args.steps, own, own_fwd_step),
     }
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline_subprocess("rpr_train", args.cpu_pairs, args.cpu_threads, "")
@@ -867,7 +896,6 @@ def main():
             line["secondary"] = [secondary_line("loftr_emat", ["--steps", "8", "--warmup", "2", "--cpu-pairs", "2"], args.secondary_budget),
                                  secondary_line("rpr_train", ["--steps", "20", "--warmup", "3", "--cpu-pairs", "4"], args.secondary_budget)]
             # compact copy at the top level, so that a reader who keeps only scalar keys of the line still sees configs[2] / [4]
-            line["secondary_values"] = {(s_.get("config") or {}).get("workload", "?").split(":")[0].strip() + " " + str(s_.get("unit", "")): s_.get("value") for s_ in line["secondary"]}
             line["secondary_values"] = {"loftr_emat_pairs_per_s": line["secondary"][0].get("value"), "rpr_train_pairs_per_s": line["secondary"][1].get("value")}
         print(json.dumps(line))
     if use_dist:

@@ -297,26 +297,38 @@ class LoFTRHIP:
 
     def coarse_stage(self, images):
         """backbone -> coarse transformer -> dual-softmax matching: everything BEFORE the match count is known.  Fixed shapes and
-        no host synchronisation, so the batch-1 plugin path replays this stage from one captured HIP graph (nets/graph.py)."""
-        B2, _, H, W = images.shape
-        B = B2 // 2
+        no host synchronisation, so the batch-1 plugin path replays this stage from one captured HIP graph (nets/graph.py).
+        Three steps with tensor interfaces (tools/loftr_stage_diff.py substitutes the oracle's tensors between them)."""
         fc, ff = self.backbone(images)
-        hc, wc = fc.shape[2:]
+        xm = self.coarse_tokens(fc)
+        self._transformer(self.coarse, xm, self.linear_attention, images.shape[0] // 2, fc.shape[2] * fc.shape[3])
+        return self.coarse_tail(xm, ff, tuple(fc.shape[2:]), images.shape[2])
+
+    def coarse_tokens(self, fc):
+        """coarse map [2B,256,hc,wc] (+ positional encoding) -> xm [2, B * L0, 512]: NCHW -> token-major, pairs de-interleaved
+        (side-major), one strided copy into the left half"""
+        B2, C, hc, wc = fc.shape
         key = (hc, wc)
         if key not in self._pe:
-            self._pe[key] = position_encoding_sine(256, hc, wc, images.device)
+            self._pe[key] = position_encoding_sine(C, hc, wc, fc.device)
         L0 = hc * wc
-        xm = torch.empty(2, B * L0, 512, dtype=torch.float32, device=images.device)
-        # + positional encoding, NCHW -> token-major, pairs de-interleaved (side-major): one strided copy into the left half
-        _lib.check(_lib.load().mfr_nchw_to_rows(_lib.ptr(fc.contiguous()), _lib.ptr(self._pe[key].contiguous()), B2, 256, L0, 1, _lib.ptr(xm), L0 * 512, 512,
+        xm = torch.empty(2, (B2 // 2) * L0, 2 * C, dtype=torch.float32, device=fc.device)
+        _lib.check(_lib.load().mfr_nchw_to_rows(_lib.ptr(fc.contiguous()), _lib.ptr(self._pe[key].contiguous()), B2, C, L0, 1, _lib.ptr(xm), L0 * 2 * C, 2 * C,
                                                 _lib.stream_ptr()), "mfr_nchw_to_rows")
-        self._transformer(self.coarse, xm, self.linear_attention, B, L0)
+        return xm
+
+    def coarse_tail(self, xm, ff, hw, H):
+        """transformed tokens xm + fine map ff [2B,128,Hf,Wf] -> dual-softmax matches, coarse keypoints, the fine map in NHWC"""
+        hc, wc = hw
+        L0 = hc * wc
+        B = xm.shape[1] // L0
+        B2 = 2 * B
         f0, f1 = xm[0].view(B, L0, 512)[..., :256], xm[1].view(B, L0, 512)[..., :256]     # row-strided views
         i_ids, j_ids, mconf, n = self.coarse_match_features(f0, f1, (hc, wc))
         scale = H // hc
         # coarse keypoints (padded layout)
         ii, jj = i_ids.long(), j_ids.long()
-        valid = torch.arange(L0, device=images.device)[None] < n[:, None]
+        valid = torch.arange(L0, device=xm.device)[None] < n[:, None]
         k0 = torch.stack([ii % wc, ii // wc], -1).float() * scale
         k1 = torch.stack([jj % wc, jj // wc], -1).float() * scale
         Cf, Hf, Wf = ff.shape[1:]
