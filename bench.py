@@ -248,14 +248,16 @@ class SgPnpWorkload:
     @property
     def dtype(self):
         """derived from the routing of THIS run (which objects the networks built), not from a fixed text"""
-        sp, sg = self.pipe.sp, self.pipe.sg
         f16 = split_products() == 3.0
+        pipe = getattr(self, "pipe", None)                  # (no instance: the routing the options select by default)
+        own = lambda obj, name: (getattr(obj, name, None) is not None) if pipe is not None else f16
+        sp, sg = getattr(pipe, "sp", None), getattr(pipe, "sg", None)
         arith = ("on the f16 matrix cores with every fp32 operand carried as TWO f16 terms (xh = rne_f16(x), xl = rne_f16((x - xh) 2^11); weights pre-scaled per "
                  "output feature; 3 partial products, fp32 accumulate: 2^-24 relative per operand for 2^-12 <= |x| <= 65504 -- range guarded by a device flag, "
                  "out-of-range batches are re-run in bf16x3 -- error vs fp64 = the exact-fp32 MFMA's class, profiles/r05_f16x2_probe.jsonl)") if f16 else \
                 "as 3 x bf16 exact operand splits (6 partial products, error = fp32 class)"
-        score = "mfr_gemm_f16x2_batched (same two-term arithmetic)" if getattr(sg, "score_gemm", None) is not None else "the library's batched fp32 GEMM"
-        head = "mfr_conv_igemm_f16x2 (same two-term arithmetic)" if getattr(sp, "head_pb", None) is not None else "the library's fp32 convolution"
+        score = "mfr_gemm_f16x2_batched (same two-term arithmetic)" if own(sg, "score_gemm") else "the library's batched fp32 GEMM"
+        head = "mfr_conv_igemm_f16x2 (same two-term arithmetic)" if own(sp, "head_pb") else "the library's fp32 convolution"
         return (f"f32 in / f32 accumulate; matrix products of the 3x3 convolutions, attention, the transformer's linear layers and SuperPoint's 1x1 descriptor head {arith}; "
                 f"SuperGlue's score matrix through {score}; the 1x1 detector head through {head}; softmax / Sinkhorn / NMS in f32; f64 solver")
     metric = "image-pairs/sec @ 540x720 (SuperPoint+SuperGlue + PnP w/ depth)"
@@ -376,13 +378,14 @@ class LoftrEmatWorkload:
     @property
     def dtype(self):
         """derived from the routing of THIS run (LoFTRHIP.igemm / .sim_gemm / the split of its packed layers)"""
-        lo = self.pipe.loftr
+        pipe = getattr(self, "pipe", None)                  # (no instance: the routing the options select by default)
         f16 = split_products() == 3.0
+        own_rest = (bool(pipe.loftr.igemm) and pipe.loftr.sim_gemm is not None) if pipe is not None else f16
         arith = ("on the f16 matrix cores with every fp32 operand carried as two f16 terms (3 partial products, fp32 accumulate, error = fp32 class: "
                  "profiles/r05_f16x2_probe.jsonl; |x| <= 65504 guarded by a device flag, out-of-range batches are re-run in bf16x3)") if f16 else \
                 "as 3 x bf16 exact operand splits (6 partial products, error = fp32 class)"
         rest = ("the strided 3x3 / 7x7 / 1x1 convolutions through mfr_conv_igemm_f16x2 and the coarse similarity product through mfr_gemm_f16x2_batched (same two-term arithmetic)"
-                if lo.igemm and lo.sim_gemm is not None else "the strided 3x3 / 7x7 / 1x1 convolutions and the similarity product through the library's fp32 kernels")
+                if own_rest else "the strided 3x3 / 7x7 / 1x1 convolutions and the similarity product through the library's fp32 kernels")
         return (f"f32 in / f32 accumulate; 3x3 stride-1 convolutions, the transformers' linear layers and the fine-stage products {arith}; {rest}; "
                 "linear attention, LayerNorm, dual softmax and the fine expectation in f32 (own kernels); f64 solver")
     metric = "image-pairs/sec @ 540x720 (LoFTR + E-mat RANSAC w/ scale from depth)"

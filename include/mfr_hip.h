@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define MFR_ABI_VERSION 4   /* 2: intrinsics as (const void *K, int k_dtype) instead of const float *; 3: mfr_emat_solve_batch takes the
+#define MFR_ABI_VERSION 5   /* 5 (round 6): mfr_f16x2_guard_bind (the f16x2 range guard); 2: intrinsics as (const void *K, int k_dtype) instead of const float *; 3: mfr_emat_solve_batch takes the
                              * model-quality method (MAGSAC++ / count) and its table; 4 (round 5): the f16x2 entry points (mfr_gemm_f16x2*,
                              * mfr_wino_f16x2_*, mfr_conv3x3_wino_f16x2, mfr_conv_igemm_f16x2), mfr_sg_attention_variant renumbered (0 f16x2,
                              * 1 exact fp32, 2 bf16x3), the measurement-only entry points (mfr_conv3x3_wino_bf16x3_variant,
@@ -65,6 +65,17 @@ extern "C" {
 #define MFR_ST_DEGENERATE  4   /* |t| > 1000 (pose_solver.py:223-225)               */
 
 int mfr_abi_version(void);
+
+/* ---- f16x2 range guard (round 6).  The reference's networks are plain fp32 (etc/feature_matching_baselines/matchers.py:50,105 call fp32 PyTorch
+ *      modules: no input-range precondition); the f16x2 kernels (mfr_gemm_f16x2*, mfr_conv_igemm_f16x2, mfr_conv3x3_wino_f16x2, mfr_sp_conv1ab_f16x2,
+ *      mfr_sg_attention variant 0) represent an activation as two f16 terms and need |x| <= 65504 (Winograd: |x| < 16376).  After
+ *      mfr_f16x2_guard_bind(flag) every such launch issued by THIS host thread ORs 1 into *flag (a device int the caller owns and clears) when one of
+ *      its fp32 accumulators is NaN / +-inf before the activation -- which is the case for every output that an out-of-range (or non-finite) input
+ *      element contributes to (csrc/guard.h).  flag = NULL unbinds (the default: no test).  The bound pointer is the ONE piece of state the library
+ *      keeps (thread-local); it is read when a launch is issued, so a captured HIP graph keeps the pointer it was captured with.
+ *      Host side: pipeline.py folds the flag into the per-pair status (MFR_ST_RANGE) and re-runs such a batch in the exact bf16x3 arithmetic. ---- */
+int mfr_f16x2_guard_bind(int *device_flag);
+#define MFR_ST_RANGE 7         /* host-side status (pipeline.py): the f16x2 range guard fired for this batch; no pose unless re-run in bf16x3 */
 /* name of the gfx target the kernels were compiled for ("gfx950") */
 const char *mfr_target_arch(void);
 

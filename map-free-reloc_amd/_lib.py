@@ -18,6 +18,7 @@ _vp, _i, _d, _u64, _sz = C.c_void_p, C.c_int, C.c_double, C.c_uint64, C.c_size_t
 SIGNATURES = {
     "mfr_abi_version": (_i, []),
     "mfr_target_arch": (C.c_char_p, []),
+    "mfr_f16x2_guard_bind": (_i, [_vp]),
     "mfr_test_f64_ops": (_i, [_vp, _vp, _vp, _i, _vp, _vp]),
     "mfr_test_sample": (_i, [_u64, _vp, _i, _i, _i, _i, _vp, _vp]),
     "mfr_pnp_workspace_bytes": (_sz, [_i, _i, _i]),

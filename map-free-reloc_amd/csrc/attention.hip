@@ -26,6 +26,7 @@
 
 #include "../../include/mfr_hip.h"
 #include "split_f16.h"
+#include "guard.h"
 
 #define CHECK_LAUNCH() do { if (hipGetLastError() != hipSuccess) return MFR_E_LAUNCH; } while (0)
 
@@ -476,7 +477,7 @@ __global__ void __launch_bounds__(512, 1) sg_attention_bf16x3_p_kernel(
 #define MFMA_F16(a, b, c) SF_MFMA((a).q, (b).q, (c))
 __global__ void __launch_bounds__(512, 1) sg_attention_f16x2_p_kernel(
     const float *__restrict__ Q, const float *__restrict__ Kp, const float *__restrict__ Vp, int ld,
-    int N, int heads, int B2, const int *__restrict__ n_tok, int cross, float scale_log2e, float *__restrict__ O, int ldo)
+    int N, int heads, int B2, const int *__restrict__ n_tok, int cross, float scale_log2e, float *__restrict__ O, int ldo, int *guard)
 {
     __shared__ __attribute__((aligned(16))) unsigned short Ks[2][2][AT_KT][AB_KS];
     __shared__ __attribute__((aligned(16))) unsigned short Vt[2][2][AT_D][AB_VS];
@@ -671,6 +672,15 @@ __global__ void __launch_bounds__(512, 1) sg_attention_f16x2_p_kernel(
     if (q < N) {
         const float inv = (l_run > 0.f && q < nq) ? 1.f / l_run : 0.f;
         float *op = O + ((size_t)b * N + q) * ldo + h * AT_D + 4 * half;
+        if (guard) {
+            // range guard (guard.h): an out-of-range q / k row turns the row's scores, hence its probabilities and its whole output row, into NaN; an
+            // out-of-range v[n, d] turns column d of every row into NaN -- so every accumulator is tested, before the normalisation (inv = 0 for a NaN sum)
+            float chk = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { MFR_GUARD_ACC(chk, o0[r]); MFR_GUARD_ACC(chk, c0[r]); MFR_GUARD_ACC(chk, o1[r]); MFR_GUARD_ACC(chk, c1[r]); }
+            MFR_GUARD_ACC(chk, l_run);
+            if (chk != chk) atomicOr(guard, 1);            // (rows >= N of the last block do not reach this point: per-lane test)
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) { o0[r] = __builtin_fmaf(c0[r], ILS, o0[r]) * inv; o1[r] = __builtin_fmaf(c1[r], ILS, o1[r]) * inv; }
 #pragma unroll
@@ -701,7 +711,7 @@ int mfr_sg_attention_variant(const float *q, const float *k, const float *v, int
         const int nqb = (N + AT_QW * AB_WAVES - 1) / (AT_QW * AB_WAVES);
         if (variant == 0)
             hipLaunchKernelGGL(sg_attention_f16x2_p_kernel, dim3(nqb * heads * B2), dim3(512), 0, (hipStream_t)stream, q, k, v, ld, N, heads, B2, n_tok, cross,
-                               scale_log2e, out, ldo);
+                               scale_log2e, out, ldo, mfr_guard_current());
         else
             hipLaunchKernelGGL(sg_attention_bf16x3_p_kernel, dim3(nqb * heads * B2), dim3(512), 0, (hipStream_t)stream, q, k, v, ld, N, heads, B2, n_tok, cross,
                                scale_log2e, out, ldo);

@@ -184,7 +184,20 @@ __global__ void __launch_bounds__(256) nchw_to_rows_kernel(const float *__restri
     }
 }
 
+#include "guard.h"
+// the f16x2 range guard's flag pointer (guard.h): per host thread, NULL = no test
+static thread_local int *mfr_guard_tls = nullptr;
+
 extern "C" {
+
+int *mfr_guard_current(void) { return mfr_guard_tls; }
+
+int mfr_f16x2_guard_bind(int *device_flag)
+{
+    mfr_guard_tls = device_flag;
+    return 0;
+}
+
 
 int mfr_conv3x3_c1_relu(const float *x, const float *w, const float *bias, int B, int H, int W, int out_channels,
                         float *y, void *stream)

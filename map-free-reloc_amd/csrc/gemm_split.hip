@@ -32,6 +32,7 @@
 
 #include "../../include/mfr_hip.h"
 #include "split_f16.h"
+#include "guard.h"
 
 #define CHECK_LAUNCH() do { if (hipGetLastError() != hipSuccess) return MFR_E_LAUNCH; } while (0)
 
@@ -159,7 +160,7 @@ __global__ void __launch_bounds__(256) gb_pack_kernel(const float *__restrict__ 
 template <int FLAGS, bool F16>
 __global__ void __launch_bounds__(256, 2) gemm_split_kernel(const float *__restrict__ X, int ldx, const uint4 *__restrict__ Wp, const float *__restrict__ oscale,
                                                             const float *__restrict__ bias, float *__restrict__ Y, int ldy, int M, int N, int K, int nnb,
-                                                            long long xs, long long ws, long long ys)
+                                                            long long xs, long long ws, long long ys, int *guard)
 {
     GB_BATCH_OFFSETS();
     constexpr int XT = GB_XT(F16);
@@ -239,6 +240,14 @@ __global__ void __launch_bounds__(256, 2) gemm_split_kernel(const float *__restr
     }
 #undef GB_GLOAD
 
+    if (F16 && guard) {                                     // range guard (guard.h): one column block covers the tile's rows
+        float chk = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) MFR_GUARD_ACC(chk, acc[i][0][r]);
+        mfr_guard_commit(guard, chk);
+    }
     // epilogue: accumulator register r of tile (i, j): token row 64 wm + 32 i + (r & 3) + 8 (r >> 2) + 4 (lane >> 5), feature 64 wn + 32 j + (lane & 31)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -275,7 +284,7 @@ __global__ void __launch_bounds__(256, 2) gemm_split_kernel(const float *__restr
 template <int FLAGS, bool F16>
 __global__ void __launch_bounds__(256, 2) gemm_split_pk_kernel(const float *__restrict__ X, int ldx, const uint4 *__restrict__ Wp, const float *__restrict__ oscale,
                                                                const float *__restrict__ bias, float *__restrict__ Y, int ldy, int M, int N, int K, int nnb, int nmb,
-                                                               long long xs, long long ws, long long ys)
+                                                               long long xs, long long ws, long long ys, int *guard)
 {
     GB_BATCH_OFFSETS();
     constexpr int XT = GB_XT(F16);
@@ -378,6 +387,14 @@ __global__ void __launch_bounds__(256, 2) gemm_split_pk_kernel(const float *__re
         for (int kb = 0; kb < nkb - 1; ++kb) GB_PSTEP(false);
         GB_PSTEP(true);
 
+        if (F16 && guard) {                                 // range guard (guard.h): one column block covers the tile's rows
+            float chk = 0.f;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) MFR_GUARD_ACC(chk, acc[i][0][r]);
+            mfr_guard_commit(guard, chk);
+        }
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {
             if (n0 + 32 * jj >= N) continue;
@@ -427,7 +444,7 @@ __device__ unsigned long long gd_prof[4][64];
 template <int FLAGS, bool F16>
 __global__ void __launch_bounds__(256, 2) gemm_split_d_kernel(const float *__restrict__ X, int ldx, const uint4 *__restrict__ Wp, unsigned wp_bytes, const float *__restrict__ oscale,
                                                               const float *__restrict__ bias, float *__restrict__ Y, int ldy, int M, int N, int K, int nnb, int nmb,
-                                                              long long xs, long long ws, long long ys)
+                                                              long long xs, long long ws, long long ys, int *guard)
 {
     GB_BATCH_OFFSETS();
     constexpr int XT = GB_XT(F16);
@@ -555,6 +572,16 @@ __global__ void __launch_bounds__(256, 2) gemm_split_d_kernel(const float *__res
         for (int kb = 0; kb < nkb - 2; kb += 2) { GD_STEP(0, xa0, xa1, xb0, xb1, false); GD_STEP(1, xc0, xc1, xd0, xd1, false); }
         GD_STEP(0, xa0, xa1, xb0, xb1, false);
         GD_STEP(1, xc0, xc1, xd0, xd1, true);
+        if (F16 && guard) {
+            // range guard (guard.h): an out-of-range x[m, k] makes EVERY accumulator of output row m non-finite, so one column per row is enough:
+            // column block jj = 0 of every (i, r) covers the tile's 128 rows (lanes / the two wn wavefronts repeat them)
+            float chk = 0.f;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) MFR_GUARD_ACC(chk, acc[i][0][r]);
+            mfr_guard_commit(guard, chk);
+        }
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {
             if (n0 + 32 * jj >= N) continue;
@@ -596,7 +623,7 @@ __global__ void __launch_bounds__(256, 2) gemm_split_d_kernel(const float *__res
 template <int MODE, bool RELU>
 __global__ void __launch_bounds__(256, 2) conv_igemm_f16x2_kernel(const float *__restrict__ X, const uint4 *__restrict__ Wp, const float *__restrict__ oscale,
                                                                   const float *__restrict__ bias, float *__restrict__ Y, int B, int Cin, int H, int W, int Cout,
-                                                                  int Ho, int Wo, int KH, int KW, int stride, int pad, int nkb, int cblocks, int nnb, int npt)
+                                                                  int Ho, int Wo, int KH, int KW, int stride, int pad, int nkb, int cblocks, int nnb, int npt, int *guard)
 {
     constexpr int XT = 2, WT = 2;
     __shared__ uint4 lds[(XT + WT) * GB_TERM_UNITS];
@@ -642,8 +669,10 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_f16x2_kernel(const float *_
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int e = 0; e < 8; ++e)                  // channels >= Cin: the scalar offset is beyond the image's range -> 0
-                    xr[i][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, vo, (unsigned)(c0 + 8 * kg[i] + e) * (unsigned)HW * 4u, 0));
+                for (int e = 0; e < 8; ++e) {                // channels >= Cin (padding of the last 32-channel block): the out-of-range vector offset -> 0
+                    const int ch = c0 + 8 * kg[i] + e;       // (wave-uniform; the scalar offset alone could wrap for Cpad * H * W * 4 >= 2^32)
+                    xr[i][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, ch < Cin ? vo : 0x80000000u, (unsigned)min(ch, Cin - 1) * (unsigned)HW * 4u, 0));
+                }
         } else {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -716,6 +745,13 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_f16x2_kernel(const float *_
         }
     }
 
+    if (guard) {
+        // range guard (guard.h): an out-of-range input makes the accumulators of ALL output channels of the pixels it reaches non-finite:
+        // one channel (i = 0, r = 0) of each of the thread's two pixels covers the tile
+        float chk = 0.f;
+        MFR_GUARD_ACC(chk, acc[0][0][0]); MFR_GUARD_ACC(chk, acc[0][1][0]);
+        mfr_guard_commit(guard, chk);
+    }
     // epilogue: register r of tile (i, j): channel 64 wm + 32 i + (r & 3) + 8 (r >> 2) + 4 (lane >> 5), pixel 64 wn + 32 j + (lane & 31)
     float *yb = Y + (size_t)b * Cout * HoWo;
 #pragma unroll
@@ -767,15 +803,15 @@ static int gb_launch(const float *x, int ldx, const void *packed_w, const float 
     const unsigned grid = 8u * (unsigned)(per_xcd < cap ? per_xcd : cap);
 #define GB_SW(GO) switch (f) { case 0: GO(0); break; case 1: GO(1); break; case 2: GO(2); break; default: GO(3); break; }
     if (one_tile) {
-#define GB_GO(F) hipLaunchKernelGGL((gemm_split_kernel<F, F16>), dim3((unsigned)tiles, (unsigned)nbatch), dim3(256), 0, st, x, ldx, wp, oscale, bias, y, ldy, M, N, K, nnb, xs, ws, ys)
+#define GB_GO(F) hipLaunchKernelGGL((gemm_split_kernel<F, F16>), dim3((unsigned)tiles, (unsigned)nbatch), dim3(256), 0, st, x, ldx, wp, oscale, bias, y, ldy, M, N, K, nnb, xs, ws, ys, F16 ? mfr_guard_current() : (int *)nullptr)
         GB_SW(GB_GO)
 #undef GB_GO
     } else if (pk) {
-#define GB_GO(F) hipLaunchKernelGGL((gemm_split_pk_kernel<F, F16>), dim3(grid, (unsigned)nbatch), dim3(256), 0, st, x, ldx, wp, oscale, bias, y, ldy, M, N, K, nnb, nmb, xs, ws, ys)
+#define GB_GO(F) hipLaunchKernelGGL((gemm_split_pk_kernel<F, F16>), dim3(grid, (unsigned)nbatch), dim3(256), 0, st, x, ldx, wp, oscale, bias, y, ldy, M, N, K, nnb, nmb, xs, ws, ys, F16 ? mfr_guard_current() : (int *)nullptr)
         GB_SW(GB_GO)
 #undef GB_GO
     } else {
-#define GB_GO(F) hipLaunchKernelGGL((gemm_split_d_kernel<F, F16>), dim3(grid, (unsigned)nbatch), dim3(256), 0, st, x, ldx, wp, (unsigned)tb, oscale, bias, y, ldy, M, N, K, nnb, nmb, xs, ws, ys)
+#define GB_GO(F) hipLaunchKernelGGL((gemm_split_d_kernel<F, F16>), dim3(grid, (unsigned)nbatch), dim3(256), 0, st, x, ldx, wp, (unsigned)tb, oscale, bias, y, ldy, M, N, K, nnb, nmb, xs, ws, ys, F16 ? mfr_guard_current() : (int *)nullptr)
         GB_SW(GB_GO)
 #undef GB_GO
     }
@@ -861,7 +897,7 @@ int mfr_conv_igemm_f16x2(const float *x, const void *packed_w, const float *bias
                          int stride, int pad, int relu, void *stream)
 {
     if (!x || !packed_w || !y || B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0 || KH <= 0 || KW <= 0 || stride <= 0 || pad < 0) return MFR_E_ARG;
-    if ((size_t)4 * Cin * H * W >= 0x7fffffffull) return MFR_E_ARG;    // one image must fit a 2 GB buffer descriptor
+    if ((size_t)4 * ((Cin + 31) / 32 * 32) * H * W >= 0x7fffffffull) return MFR_E_ARG;    // one image (padded channel count) must fit a 2 GB buffer descriptor
     const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
     if (Ho <= 0 || Wo <= 0) return MFR_E_ARG;
     const int K = mfr_conv_igemm_k(Cin, KH, KW), nkb = K / GB_BK, cblocks = (Cin + 31) / 32;
@@ -871,7 +907,7 @@ int mfr_conv_igemm_f16x2(const float *x, const void *packed_w, const float *bias
     const size_t tb = gb_tile_bytes(Cout, K, true);
     const float *oscale = (const float *)((const char *)packed_w + tb);
     hipStream_t st = (hipStream_t)stream;
-#define GB_GO(M_, R_) hipLaunchKernelGGL((conv_igemm_f16x2_kernel<M_, R_>), dim3((unsigned)grid), dim3(256), 0, st, x, (const uint4 *)packed_w, oscale, bias, y, B, Cin, H, W, Cout, Ho, Wo, KH, KW, stride, pad, nkb, cblocks, nnb, npt)
+#define GB_GO(M_, R_) hipLaunchKernelGGL((conv_igemm_f16x2_kernel<M_, R_>), dim3((unsigned)grid), dim3(256), 0, st, x, (const uint4 *)packed_w, oscale, bias, y, B, Cin, H, W, Cout, Ho, Wo, KH, KW, stride, pad, nkb, cblocks, nnb, npt, mfr_guard_current())
     if (Cin == 1) { if (relu) GB_GO(1, true); else GB_GO(1, false); }
     else          { if (relu) GB_GO(0, true); else GB_GO(0, false); }
 #undef GB_GO

@@ -38,6 +38,7 @@
 
 #include "../../include/mfr_hip.h"
 #include "split_f16.h"
+#include "guard.h"
 
 #define CHECK_LAUNCH() do { if (hipGetLastError() != hipSuccess) return MFR_E_LAUNCH; } while (0)
 
@@ -155,7 +156,7 @@ __device__ unsigned long long wb_prof[8][32];
 template <bool POOL, bool F16>
 __global__ void __launch_bounds__(512, 2) wino_split_p8_kernel(
     const float *__restrict__ x, const uint4 *__restrict__ upk, const float *__restrict__ oscale, const float *__restrict__ bias, float *__restrict__ y,
-    const float *__restrict__ residual, int Cin, int Cout, int H, int W, int nbx, int nby, int S, int Sx, int ncg, int nks, int act, int chunk)
+    const float *__restrict__ residual, int Cin, int Cout, int H, int W, int nbx, int nby, int S, int Sx, int ncg, int nks, int act, int chunk, int *guard)
 {
     __shared__ __attribute__((aligned(16))) float lds[32768];
     // workgroup -> (spatial block, 64-channel output group): every XCD walks its own contiguous raster range of Sx spatial blocks in
@@ -394,6 +395,7 @@ __global__ void __launch_bounds__(512, 2) wino_split_p8_kernel(
     const int Ho = POOL ? (H >> 1) : H, Wo = POOL ? (W >> 1) : W;
     const size_t cstride = (size_t)Ho * Wo;
     float4 *part = (float4 *)lds;
+    float gchk = 0.f;
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb) {
         __syncthreads();                                    // patch stages (mb = 0) / the previous round's partials (mb = 1) are dead
@@ -440,6 +442,7 @@ __global__ void __launch_bounds__(512, 2) wino_split_p8_kernel(
             const float y0 = (WB_EL(P[0][0]) + WB_EL(P[1][0])) + WB_EL(P[2][0]), y1 = (WB_EL(P[0][1]) + WB_EL(P[1][1])) + WB_EL(P[2][1]);
             const float y2 = (WB_EL(P[1][0]) - WB_EL(P[2][0])) - WB_EL(P[3][0]), y3 = (WB_EL(P[1][1]) - WB_EL(P[2][1])) - WB_EL(P[3][1]);
 #undef WB_EL
+            if (F16 && guard) { MFR_GUARD_ACC(gchk, y0); MFR_GUARD_ACC(gchk, y1); MFR_GUARD_ACC(gchk, y2); MFR_GUARD_ACC(gchk, y3); }   // range guard (guard.h), before bias / residual / activation
             if (F16) { Y[k][0] = __builtin_fmaf(y0, os[k], bv[k]); Y[k][1] = __builtin_fmaf(y1, os[k], bv[k]); Y[k][2] = __builtin_fmaf(y2, os[k], bv[k]); Y[k][3] = __builtin_fmaf(y3, os[k], bv[k]); }
             else     { Y[k][0] = y0 + bv[k]; Y[k][1] = y1 + bv[k]; Y[k][2] = y2 + bv[k]; Y[k][3] = y3 + bv[k]; }
         }
@@ -511,6 +514,7 @@ __global__ void __launch_bounds__(512, 2) wino_split_p8_kernel(
             }
         }
     }
+    if (F16) mfr_guard_commit(guard, gchk);
     WB_STAMP(26);
 }
 
@@ -525,8 +529,9 @@ __global__ void __launch_bounds__(512, 2) wino_split_p8_kernel(
 // wavefronts run free.  Everything from the row combinations to the output transform is the kernel's above (Cin = Cout = 64, pooled, ReLU).
 __global__ void __launch_bounds__(512, 2) wino_split_c1_kernel(
     const float *__restrict__ gray, const float *__restrict__ w1a, const float *__restrict__ b1a, const uint4 *__restrict__ upk, const float *__restrict__ oscale,
-    const float *__restrict__ bias, float *__restrict__ y, int H, int W, int nbx, int nby, int S, int Sx)
+    const float *__restrict__ bias, float *__restrict__ y, int H, int W, int nbx, int nby, int S, int Sx, int *guard)
 {
+    float gchk = 0.f;                                       // range guard (guard.h), over all blocks of this persistent workgroup
     constexpr int GS = 40;                                  // gray window row stride (38 columns used)
     __shared__ __attribute__((aligned(16))) float lds[32768 + 12 * GS];
     float *gwin = lds + 32768;                              // [12][GS] BEHIND the 128 KB the patch stages / output rounds use: it lives across blocks
@@ -781,6 +786,7 @@ __global__ void __launch_bounds__(512, 2) wino_split_c1_kernel(
             const float y0 = (WB_EL(P[0][0]) + WB_EL(P[1][0])) + WB_EL(P[2][0]), y1 = (WB_EL(P[0][1]) + WB_EL(P[1][1])) + WB_EL(P[2][1]);
             const float y2 = (WB_EL(P[1][0]) - WB_EL(P[2][0])) - WB_EL(P[3][0]), y3 = (WB_EL(P[1][1]) - WB_EL(P[2][1])) - WB_EL(P[3][1]);
 #undef WB_EL
+            if (guard) { MFR_GUARD_ACC(gchk, y0); MFR_GUARD_ACC(gchk, y1); MFR_GUARD_ACC(gchk, y2); MFR_GUARD_ACC(gchk, y3); }
             const float Y0 = __builtin_fmaf(y0, os[k], bv[k]), Y1 = __builtin_fmaf(y1, os[k], bv[k]), Y2 = __builtin_fmaf(y2, os[k], bv[k]), Y3 = __builtin_fmaf(y3, os[k], bv[k]);
             m[k] = fmaxf(fmaxf(fmaxf(Y0, Y1), fmaxf(Y2, Y3)), 0.f);
         }
@@ -793,6 +799,7 @@ __global__ void __launch_bounds__(512, 2) wino_split_c1_kernel(
     }
     WB_STAMP(26);
     }   // next block of this workgroup
+    mfr_guard_commit(guard, gchk);
 }
 
 // ---- host ------------------------------------------------------------------------------------------------------------------------------------
@@ -832,8 +839,8 @@ static int wb_conv(const float *x, const void *upk, const float *bias, const flo
     if (grid > 0x7fffffffll || fb >= 0x7fffffffull) return MFR_E_ARG;
     const float *oscale = F16 ? (const float *)((const char *)upk + fb) : nullptr;
     hipStream_t st = (hipStream_t)stream;
-    if (pool) hipLaunchKernelGGL((wino_split_p8_kernel<true, F16>), dim3((unsigned)grid), dim3(512), 0, st, x, (const uint4 *)upk, oscale, bias, y, residual, Cin, Cout, H, W, nbx, nby, (int)S, (int)Sx, ncg, nks, act, chunk);
-    else      hipLaunchKernelGGL((wino_split_p8_kernel<false, F16>), dim3((unsigned)grid), dim3(512), 0, st, x, (const uint4 *)upk, oscale, bias, y, residual, Cin, Cout, H, W, nbx, nby, (int)S, (int)Sx, ncg, nks, act, chunk);
+    if (pool) hipLaunchKernelGGL((wino_split_p8_kernel<true, F16>), dim3((unsigned)grid), dim3(512), 0, st, x, (const uint4 *)upk, oscale, bias, y, residual, Cin, Cout, H, W, nbx, nby, (int)S, (int)Sx, ncg, nks, act, chunk, F16 ? mfr_guard_current() : (int *)nullptr);
+    else      hipLaunchKernelGGL((wino_split_p8_kernel<false, F16>), dim3((unsigned)grid), dim3(512), 0, st, x, (const uint4 *)upk, oscale, bias, y, residual, Cin, Cout, H, W, nbx, nby, (int)S, (int)Sx, ncg, nks, act, chunk, F16 ? mfr_guard_current() : (int *)nullptr);
     CHECK_LAUNCH();
     return 0;
 }
@@ -874,7 +881,7 @@ int mfr_sp_conv1ab_f16x2(const float *gray, const float *w1a, const float *b1a, 
     const long long grid = 8 * (Sx < 32 ? Sx : 32);                    // persistent: one workgroup (128 KB of LDS) per CU, 32 CUs per XCD
     const float *oscale = (const float *)((const char *)upk1b + wb_frag_bytes(64, 64));
     hipLaunchKernelGGL(wino_split_c1_kernel, dim3((unsigned)grid), dim3(512), 0, (hipStream_t)stream, gray, w1a, b1a, (const uint4 *)upk1b, oscale, bias1b, y,
-                       H, W, nbx, nby, (int)S, (int)Sx);
+                       H, W, nbx, nby, (int)S, (int)Sx, mfr_guard_current());
     CHECK_LAUNCH();
     return 0;
 }

@@ -90,12 +90,15 @@ class SuperGlueMatching:
         self.use_graph = bool(cfg.HIP.GRAPH_BATCH1)
         self._graphs = {}
         self._gray = _GrayPairStage()
+        from ..pipeline import RangeGuard
+        self.guard = RangeGuard(self.device, lambda: SuperGlueMatching(cfg))       # f16x2 range guard: flag travels with the result, exact twin on demand
 
     def _forward(self, ims):
-        out = self.sg(self.sp(ims), tuple(ims.shape[-2:]))
-        # one packed result so that the host needs a single D2H copy: [n | pts0 (K x 2) | pts1 (K x 2)]
+        with self.guard:
+            out = self.sg(self.sp(ims), tuple(ims.shape[-2:]))
+        # one packed result so that the host needs a single D2H copy: [n | range flag | pts0 (K x 2) | pts1 (K x 2)]
         import torch
-        return torch.cat([out["n_corr"].to(torch.float32), out["pts0"].reshape(-1), out["pts1"].reshape(-1)])
+        return torch.cat([out["n_corr"].to(torch.float32), self.guard.flag.to(torch.float32), out["pts0"].reshape(-1), out["pts1"].reshape(-1)])
 
     def get_correspondences(self, data):
         import torch
@@ -114,12 +117,17 @@ class SuperGlueMatching:
                 self.use_graph = False
         if flat is None:
             flat = self._forward(ims.to(self.device).contiguous()).cpu().numpy()
+        if flat[1] != 0:                                     # an activation left the f16x2 range: the same pair through the exact (bf16x3) twin
+            from .. import options
+            self.guard.reruns += 1
+            with options.override(SPLIT="bf16x3"):
+                return self.guard.twin().get_correspondences(data)
         n = int(flat[0])
         if n == 0:
             e = np.array([])
             return e, e
-        K = (len(flat) - 1) // 4
-        return flat[1:1 + 2 * K].reshape(K, 2)[:n].copy(), flat[1 + 2 * K:].reshape(K, 2)[:n].copy()
+        K = (len(flat) - 2) // 4
+        return flat[2:2 + 2 * K].reshape(K, 2)[:n].copy(), flat[2 + 2 * K:].reshape(K, 2)[:n].copy()
 
 
 class LoFTRMatching:
@@ -137,11 +145,13 @@ class LoFTRMatching:
         self._gray = _GrayPairStage()
         self.use_graph = bool(cfg.HIP.GRAPH_BATCH1)
         self._graphs = {}
+        from ..pipeline import RangeGuard
+        self.guard = RangeGuard(self.device, lambda: LoFTRMatching(cfg))
 
     def _coarse(self, ims):
         import torch
         H, W = ims.shape[-2:]
-        with torch.no_grad():
+        with torch.no_grad(), self.guard:
             return self.net.coarse_stage(torch.nn.functional.pad(ims, (0, (-W) % 8, 0, (-H) % 8)).contiguous())
 
     def get_correspondences(self, data):
@@ -162,15 +172,21 @@ class LoFTRMatching:
         if c is None:
             c = self._coarse(ims.to(self.device))
         with torch.no_grad():
-            out = self.net.fine_stage(c)                       # reads the graph's static buffers before the next replay
+            with self.guard.keep():
+                out = self.net.fine_stage(c)                   # reads the graph's static buffers before the next replay
             n_t = out["n_corr"][:1].to(torch.float32)
-            flat = torch.cat([n_t, out["pts0"][0].reshape(-1), out["pts1"][0].reshape(-1)]).cpu().numpy()      # one D2H copy
+            flat = torch.cat([n_t, self.guard.flag.to(torch.float32), out["pts0"][0].reshape(-1), out["pts1"][0].reshape(-1)]).cpu().numpy()      # one D2H copy
+        if flat[1] != 0:                                       # f16x2 range guard fired: the exact (bf16x3) twin
+            from .. import options
+            self.guard.reruns += 1
+            with options.override(SPLIT="bf16x3"):
+                return self.guard.twin().get_correspondences(data)
         n = int(flat[0])
         if n == 0:
             e = np.array([])
             return e, e
-        L = (len(flat) - 1) // 4
-        return flat[1:1 + 2 * L].reshape(L, 2)[:n].copy(), flat[1 + 2 * L:].reshape(L, 2)[:n].copy()
+        L = (len(flat) - 2) // 4
+        return flat[2:2 + 2 * L].reshape(L, 2)[:n].copy(), flat[2 + 2 * L:].reshape(L, 2)[:n].copy()
 
 
 def _cv_sift_detector(num_features):

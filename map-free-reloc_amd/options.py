@@ -64,6 +64,26 @@ def set(name, value):           # noqa: A001  (mirrors dict-like usage on purpos
     _EXPLICIT.add(name)
 
 
+class override:
+    """with options.override(SPLIT="bf16x3"): ... -- the named options take the given values inside the block (objects that resolve an option when they
+    are built, or on their first call, must be built AND first called inside it) and get their previous values and explicit-ness back afterwards"""
+
+    def __init__(self, **kv):
+        self.kv = kv
+
+    def __enter__(self):
+        self.saved = {k: (_VALUES[k], k in _EXPLICIT) for k in self.kv}
+        for k, v in self.kv.items():
+            set(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k, (v, ex) in self.saved.items():
+            _VALUES[k] = v
+            (_EXPLICIT.add if ex else _EXPLICIT.discard)(k)
+        return False
+
+
 def reset():
     for k, v in _SPEC.items():
         _VALUES[k] = v[0]

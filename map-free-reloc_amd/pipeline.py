@@ -11,11 +11,74 @@ plugin API stay available (matching/, wire.py) for drop-in use.
 """
 import torch
 
-from . import _lib
+from . import _lib, options
 from .nets.superpoint import SuperPointHIP
 from .nets.superglue import SuperGlueHIP
 from .nets import weights as WT
 from .solver_ops import PnPBatchSolver
+
+
+ST_RANGE = 7            # include/mfr_hip.h MFR_ST_RANGE
+
+
+class RangeGuard:
+    """The f16x2 range guard of ONE pipeline object (include/mfr_hip.h mfr_f16x2_guard_bind, csrc/guard.h).
+
+    The reference's networks are plain fp32 modules (matchers.py:50,105): they have no |x| <= 65504 precondition, the f16x2 kernels do.  Used as a
+    context manager around the matcher stage: the device flag is cleared and bound, every f16x2 launch inside ORs 1 into it when one of its
+    accumulators is non-finite (= an operand outside the range, or a non-finite operand), and `fold` turns a set flag into status ST_RANGE for the
+    batch's pairs -- all on the device, no host synchronisation, graph-capturable (the clear is a kernel, the pointer is a launch argument).
+    Whoever reads the results on the host anyway (submission.predict_fused, the per-pair plugin, the census) calls `rerun_out_of_range`, which runs
+    the batch again through the EXACT twin of the pipeline (options SPLIT = 'bf16x3': three-term bf16 operands, the fp32 exponent range)."""
+
+    def __init__(self, device, make_twin):
+        self.active = options.get("SPLIT") == "f16x2"
+        self.flag = torch.zeros(1, dtype=torch.int32, device=device)
+        self._make_twin, self._twin, self.reruns = make_twin, None, 0
+
+    def __enter__(self):
+        if self.active:
+            self.flag.zero_()
+            _lib.check(_lib.load().mfr_f16x2_guard_bind(self.flag.data_ptr()), "mfr_f16x2_guard_bind")
+        return self
+
+    def __exit__(self, *exc):
+        if self.active:
+            _lib.load().mfr_f16x2_guard_bind(None)
+        return False
+
+    def keep(self):
+        """context manager that binds the flag WITHOUT clearing it: a later stage of the same pair / batch (LoFTR's fine stage after the match count)"""
+        g = self
+
+        class _Keep:
+            def __enter__(self):
+                if g.active:
+                    _lib.check(_lib.load().mfr_f16x2_guard_bind(g.flag.data_ptr()), "mfr_f16x2_guard_bind")
+
+            def __exit__(self, *exc):
+                return g.__exit__()
+        return _Keep()
+
+    def fold(self, status):
+        return torch.where(self.flag > 0, torch.full_like(status, ST_RANGE), status) if self.active else status
+
+    def twin(self):
+        if self._twin is None:
+            with options.override(SPLIT="bf16x3"):
+                self._twin = self._make_twin()
+        return self._twin
+
+
+def rerun_out_of_range(pipe, out, *args, **kw):
+    """out = pipe(*args, **kw) came back: if the range guard marked the batch (status ST_RANGE; reading it synchronises with the device, so call this
+    where the results are read anyway), run the batch again in the exact bf16x3 arithmetic and hand out THAT result"""
+    g = getattr(pipe, "guard", None)
+    if g is None or not g.active or not bool((out["status"] == ST_RANGE).any()):
+        return out
+    g.reruns += 1
+    with options.override(SPLIT="bf16x3"):                  # layers that resolve the option on their first call (nets/loftr.py) do so in here
+        return g.twin()(*args, **kw)
 
 
 class SuperGluePnPPipeline:
@@ -31,6 +94,7 @@ class SuperGluePnPPipeline:
         self.sg = SuperGlueHIP(sg_state or WT.superglue_state_dict(), self.device)
         self.pnp = PnPBatchSolver(pnp_iters, pnp_thr, pnp_conf, seed)
         self.K = max_keypoints
+        self.guard = RangeGuard(self.device, lambda: SuperGluePnPPipeline(device, sp_state, sg_state, max_keypoints, pnp_iters, pnp_thr, pnp_conf, seed, False))
 
     @torch.no_grad()
     def match(self, images):
@@ -58,8 +122,10 @@ class SuperGluePnPPipeline:
 
     @torch.no_grad()
     def _run(self, images, depth0, K0, K1, pair_ids, want_mask=False):
-        m = self.match(images)
+        with self.guard:
+            m = self.match(images)
         out = self.pnp(m["pts0"], m["pts1"], m["n_corr"], depth0, K0, K1, pair_ids, want_mask=want_mask)
+        out["status"] = self.guard.fold(out["status"])
         out["n_corr"] = m["n_corr"]
         out["pts0"], out["pts1"], out["n_kpts"] = m["pts0"], m["pts1"], m["n_kpts"]
         return out
@@ -80,6 +146,7 @@ class LoFTREmatPipeline:
         self.emat = EssentialBatchSolver(pix_thr, conf, seed, score=emat_score)
         self.scale = ScaleFromDepthBatch(scale_thr)
         self.pad_to = pad_to
+        self.guard = RangeGuard(self.device, lambda: LoFTREmatPipeline(device, loftr_state, pix_thr, scale_thr, conf, seed, pad_to, emat_score))
 
     @torch.no_grad()
     def match(self, images):
@@ -92,9 +159,11 @@ class LoFTREmatPipeline:
 
     @torch.no_grad()
     def __call__(self, images, depth0, depth1, K0, K1, pair_ids):
-        m = self.match(images)
+        with self.guard:
+            m = self.match(images)
         e = self.emat(m["pts0"], m["pts1"], m["n_corr"], K0, K1, pair_ids)
         s = self.scale(m["pts0"], m["pts1"], e["mask"], m["n_corr"], depth0, depth1, K0, K1, e["R"], e["t"], e["status"])
+        s["status"] = self.guard.fold(s["status"])
         return dict(R=torch.where((s["status"] == 0)[:, None, None], e["R"], torch.full_like(e["R"], float("nan"))),
                     t=s["t_metric"], n_inliers=s["n_inliers"], status=s["status"], n_corr=m["n_corr"],
                     emat_inliers=e["n_inliers"], pts0=m["pts0"], pts1=m["pts1"], emat_mask=e["mask"])
@@ -185,6 +254,7 @@ class FusedPosePipeline:
         from . import solver_ops as ops
         _lib.load(require_gpu=True)
         self.device = torch.device(device)
+        self.guard = RangeGuard(self.device, lambda: FusedPosePipeline(cfg, device))
         seed = int(cfg.RANSAC.SEED) if "RANSAC" in cfg else 0
         fm = cfg.FEATURE_MATCHING
         if fm == "Precomputed":
@@ -261,8 +331,10 @@ class FusedPosePipeline:
 
     @torch.no_grad()
     def __call__(self, batch):
-        m = self.match(batch)
+        with self.guard:
+            m = self.match(batch)
         out = self.solve(m, batch)
+        out["status"] = self.guard.fold(out["status"])
         ok = (out["status"] == 0)
         nan = float("nan")
         return dict(R=torch.where(ok[:, None, None], out["R"], torch.full_like(out["R"], nan)),

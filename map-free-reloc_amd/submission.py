@@ -127,6 +127,41 @@ def _run_signature(cfg, split):
     return hashlib.sha256(json.dumps({'cfg': plain(cfg), 'split': str(split)}, sort_keys=True).encode()).hexdigest()
 
 
+def _rerun_out_of_range_scenes(pipeline, recs, names, scenes, todo, offsets, B, device, out_dir):
+    """Second pass of predict_fused for the f16x2 range guard (pipeline.RangeGuard, include/mfr_hip.h mfr_f16x2_guard_bind): the hot loop never
+    waits for the guard's flag -- a batch whose activations left the f16x2 range comes back with status ST_RANGE and NaN poses.  Here, after the loop,
+    every scene that holds such a pair is computed AGAIN through the exact (bf16x3) twin of the pipeline, its rows replace the first pass's and its
+    pose file is rewritten.  With in-range networks (every checkpoint seen so far) this function finds nothing and costs one comparison per row."""
+    from . import options, parallel
+    from .pipeline import ST_RANGE
+    guard = getattr(pipeline, 'guard', None)
+    if guard is None or not guard.active or not recs:
+        return recs
+    rows = np.concatenate(recs)
+    hit = rows[:, 9] == ST_RANGE
+    if not hit.any():
+        return recs
+    bad = {names[int(g)][0] for g in rows[hit, 0]}
+    idx = [i for i in todo if scenes[i].scene_id in bad]
+    from .datasets import PairBatchLoader, DevicePrefetcher
+    keep = rows[np.array([names[int(g)][0] not in bad for g in rows[:, 0]], bool)]
+    new_rows = []
+    loader = PairBatchLoader([scenes[i] for i in idx], B, prefetch=1, pin=device.type == 'cuda', global_offsets=[int(offsets[i]) for i in idx], workers=2, decode='thread')
+    try:
+        with options.override(SPLIT='bf16x3'):
+            twin = guard.twin()
+            for batch in DevicePrefetcher(loader, device):
+                out = twin(batch)
+                new_rows.append(parallel.pose_records(batch['global_ids'].to(out['R'].device), out).cpu().numpy())
+                guard.reruns += 1
+    finally:
+        loader.close()
+    new_rows = np.concatenate(new_rows) if new_rows else np.zeros((0, parallel.REC_W))
+    for sid, res in records_to_results(new_rows, names).items():
+        _atomic_write(out_dir / f'pose_{sid}.txt', scene_text(res))
+    return [keep, new_rows]
+
+
 def predict_fused(cfg, split, output_root, pipeline=None, batch_pairs=None, resume=True, scenes=None, prefetch=2):
     """Scene-sharded, batched replacement of the reference's serial loop (submission.py:33-58) -> path of the zip
     (rank 0) or None (other ranks).  Works with or without an initialised torch.distributed process group
@@ -299,6 +334,7 @@ def predict_fused(cfg, split, output_root, pipeline=None, batch_pairs=None, resu
             f.write(json.dumps(line, default=float) + '\n')
     except (OSError, TypeError, ValueError):
         pass
+    recs = _rerun_out_of_range_scenes(pipeline, recs, names, scenes, todo, offsets, B, device, out_dir)
     mine = torch.from_numpy(np.concatenate(recs) if recs else np.zeros((0, parallel.REC_W))).to(device)
     allrec = parallel.gather_records(mine, world).cpu().numpy()
     if rank != 0:
