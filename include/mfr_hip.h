@@ -265,6 +265,12 @@ int mfr_gemm_f16x2_batched(const float *x, int ldx, long long x_batch_stride, co
 int mfr_conv_igemm_k(int Cin, int KH, int KW);
 int mfr_conv_igemm_f16x2(const float *x, const void *packed_w, const float *bias, float *y, int B, int Cin, int H, int W, int Cout, int KH, int KW,
                          int stride, int pad, int relu, void *stream);
+/*   mfr_conv_igemm_f16x2_upadd (round 6): the same convolution (no activation) + the FPN merge of LoFTR's backbone in one pass,
+ *                          y = conv(x) + bias + F.interpolate(lo, scale_factor=2, mode='bilinear', align_corners=True) with lo [B,Cout,Hl,Wl], Ho = 2 Hl,
+ *                          Wo = 2 Wl (upstream ResNetFPN_8_2.forward: x2_out = layer2_outconv(x2) + x3_out_2x, x1_out likewise; call site matchers.py:50);
+ *                          the up-sampling arithmetic is mfr_upsample2x_add's. */
+int mfr_conv_igemm_f16x2_upadd(const float *x, const void *packed_w, const float *bias, const float *lo, int Hl, int Wl, float *y, int B, int Cin, int H, int W,
+                               int Cout, int KH, int KW, int stride, int pad, void *stream);
 size_t mfr_gemm_bf16x3_pack_bytes(int N, int K);
 int mfr_gemm_bf16x3_pack(const float *w, int N, int K, void *packed, void *stream);
 int mfr_gemm_bf16x3(const float *x, int ldx, const void *packed_w, const float *bias, float *y, int ldy, int M, int N, int K, int flags, void *stream);

@@ -620,10 +620,14 @@ __global__ void __launch_bounds__(256, 2) gemm_split_d_kernel(const float *__res
 // first operand is the WEIGHT fragment, so an accumulator holds 32 pixels along the lanes and channels along its registers: NCHW stores of 128
 // bytes.  X staging: a thread owns (pixel, k group of 8) -- eight 4-byte loads whose lanes are consecutive pixels (coalesced along x, half the
 // sectors used at stride 2), split in registers, one 16-byte LDS unit per term; W through registers.  One tile per workgroup, loads one K step ahead.
-template <int MODE, bool RELU>
+// UP (round 6): the epilogue adds the 2x bilinear up-sampling (align_corners = True, the arithmetic of upsample_ac_kernel in loftr_fused.hip) of `lo`
+// [B, Cout, Hl, Wl] -- the FPN merge  layerN_outconv(x_N) + interpolate(x_{N+1}_out)  of LoFTR's backbone in ONE pass: the 1x1 convolution's output is
+// not written, re-read and re-written by a separate up-sample-and-add kernel (4.9 GB of the 360x272 level's traffic per 32 images).
+template <int MODE, bool RELU, bool UP>
 __global__ void __launch_bounds__(256, 2) conv_igemm_f16x2_kernel(const float *__restrict__ X, const uint4 *__restrict__ Wp, const float *__restrict__ oscale,
                                                                   const float *__restrict__ bias, float *__restrict__ Y, int B, int Cin, int H, int W, int Cout,
-                                                                  int Ho, int Wo, int KH, int KW, int stride, int pad, int nkb, int cblocks, int nnb, int npt, int *guard)
+                                                                  int Ho, int Wo, int KH, int KW, int stride, int pad, int nkb, int cblocks, int nnb, int npt, int *guard,
+                                                                  const float *__restrict__ lo, int Hl, int Wl, float rh, float rw)
 {
     constexpr int XT = 2, WT = 2;
     __shared__ uint4 lds[(XT + WT) * GB_TERM_UNITS];
@@ -754,6 +758,21 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_f16x2_kernel(const float *_
     }
     // epilogue: register r of tile (i, j): channel 64 wm + 32 i + (r & 3) + 8 (r >> 2) + 4 (lane >> 5), pixel 64 wn + 32 j + (lane & 31)
     float *yb = Y + (size_t)b * Cout * HoWo;
+    // UP: the four taps and weights of this thread's two pixels (the same for every channel)
+    int uo[2], udw[2], udh[2];
+    float uh0[2], uh1[2], uw0[2], uw1[2];
+    if (UP) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int p = min(pt * 128 + 64 * wn + 32 * j + (lane & 31), HoWo - 1);
+            const int oy = p / Wo, ox = p - oy * Wo;
+            const float h1r = rh * oy, w1r = rw * ox;
+            const int h1 = min((int)h1r, Hl - 1), w1 = min((int)w1r, Wl - 1);
+            uh1[j] = h1r - h1; uh0[j] = 1.f - uh1[j];
+            uw1[j] = w1r - w1; uw0[j] = 1.f - uw1[j];
+            uo[j] = h1 * Wl + w1; udw[j] = (w1 < Wl - 1) ? 1 : 0; udh[j] = (h1 < Hl - 1) ? Wl : 0;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -761,12 +780,17 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_f16x2_kernel(const float *_
             const int co = nb * GB_BN + 64 * wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
             if (co >= Cout) continue;
             const float os = oscale[co], bv = bias ? bias[co] : 0.f;
+            const float *lb = UP ? lo + ((size_t)b * Cout + co) * ((size_t)Hl * Wl) : nullptr;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int p = pt * 128 + 64 * wn + 32 * j + (lane & 31);
                 if (p >= HoWo) continue;
                 float v = __builtin_fmaf(acc[i][j][r], os, bv);
                 if (RELU) v = fmaxf(v, 0.f);
+                if (UP) {
+                    const float *q = lb + uo[j];
+                    v += uh0[j] * (uw0[j] * q[0] + uw1[j] * q[udw[j]]) + uh1[j] * (uw0[j] * q[udh[j]] + uw1[j] * q[udh[j] + udw[j]]);
+                }
                 yb[(size_t)co * HoWo + p] = v;
             }
         }
@@ -893,13 +917,14 @@ int mfr_conv_igemm_k(int Cin, int KH, int KW)
     return Cin == 1 ? (KH * KW + 31) / 32 * 32 : KH * KW * ((Cin + 31) / 32 * 32);
 }
 
-int mfr_conv_igemm_f16x2(const float *x, const void *packed_w, const float *bias, float *y, int B, int Cin, int H, int W, int Cout, int KH, int KW,
-                         int stride, int pad, int relu, void *stream)
+static int gb_conv_igemm(const float *x, const void *packed_w, const float *bias, float *y, int B, int Cin, int H, int W, int Cout, int KH, int KW,
+                         int stride, int pad, int relu, const float *lo, int Hl, int Wl, void *stream)
 {
     if (!x || !packed_w || !y || B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0 || KH <= 0 || KW <= 0 || stride <= 0 || pad < 0) return MFR_E_ARG;
     if ((size_t)4 * ((Cin + 31) / 32 * 32) * H * W >= 0x7fffffffull) return MFR_E_ARG;    // one image (padded channel count) must fit a 2 GB buffer descriptor
     const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
     if (Ho <= 0 || Wo <= 0) return MFR_E_ARG;
+    if (lo && (relu || Cin == 1 || Hl <= 0 || Wl <= 0 || Ho != 2 * Hl || Wo != 2 * Wl)) return MFR_E_ARG;
     const int K = mfr_conv_igemm_k(Cin, KH, KW), nkb = K / GB_BK, cblocks = (Cin + 31) / 32;
     const int nnb = (Cout + GB_BN - 1) / GB_BN, npt = (Ho * Wo + 127) / 128;
     const long long grid = (long long)B * npt * nnb;
@@ -907,12 +932,28 @@ int mfr_conv_igemm_f16x2(const float *x, const void *packed_w, const float *bias
     const size_t tb = gb_tile_bytes(Cout, K, true);
     const float *oscale = (const float *)((const char *)packed_w + tb);
     hipStream_t st = (hipStream_t)stream;
-#define GB_GO(M_, R_) hipLaunchKernelGGL((conv_igemm_f16x2_kernel<M_, R_>), dim3((unsigned)grid), dim3(256), 0, st, x, (const uint4 *)packed_w, oscale, bias, y, B, Cin, H, W, Cout, Ho, Wo, KH, KW, stride, pad, nkb, cblocks, nnb, npt, mfr_guard_current())
-    if (Cin == 1) { if (relu) GB_GO(1, true); else GB_GO(1, false); }
-    else          { if (relu) GB_GO(0, true); else GB_GO(0, false); }
+    // torch's area_pixel_compute_scale for align_corners = True: (in - 1) / (out - 1) in f32, 0 for a single output
+    const float rh = (lo && Ho > 1) ? (float)(Hl - 1) / (float)(Ho - 1) : 0.f, rw = (lo && Wo > 1) ? (float)(Wl - 1) / (float)(Wo - 1) : 0.f;
+#define GB_GO(M_, R_, U_) hipLaunchKernelGGL((conv_igemm_f16x2_kernel<M_, R_, U_>), dim3((unsigned)grid), dim3(256), 0, st, x, (const uint4 *)packed_w, oscale, bias, y, B, Cin, H, W, Cout, Ho, Wo, KH, KW, stride, pad, nkb, cblocks, nnb, npt, mfr_guard_current(), lo, Hl, Wl, rh, rw)
+    if (lo) GB_GO(0, false, true);
+    else if (Cin == 1) { if (relu) GB_GO(1, true, false); else GB_GO(1, false, false); }
+    else               { if (relu) GB_GO(0, true, false); else GB_GO(0, false, false); }
 #undef GB_GO
     CHECK_LAUNCH();
     return 0;
+}
+
+int mfr_conv_igemm_f16x2(const float *x, const void *packed_w, const float *bias, float *y, int B, int Cin, int H, int W, int Cout, int KH, int KW,
+                         int stride, int pad, int relu, void *stream)
+{
+    return gb_conv_igemm(x, packed_w, bias, y, B, Cin, H, W, Cout, KH, KW, stride, pad, relu, nullptr, 0, 0, stream);
+}
+
+int mfr_conv_igemm_f16x2_upadd(const float *x, const void *packed_w, const float *bias, const float *lo, int Hl, int Wl, float *y, int B, int Cin, int H, int W,
+                               int Cout, int KH, int KW, int stride, int pad, void *stream)
+{
+    if (!lo) return MFR_E_ARG;
+    return gb_conv_igemm(x, packed_w, bias, y, B, Cin, H, W, Cout, KH, KW, stride, pad, 0, lo, Hl, Wl, stream);
 }
 
 }  // extern "C"

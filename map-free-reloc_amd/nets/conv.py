@@ -92,13 +92,20 @@ class IgemmConv:
         _lib.check(lib.mfr_gemm_f16x2_pack(_lib.ptr(m.contiguous()), co, K, _lib.ptr(self.packed), _lib.stream_ptr()), "mfr_gemm_f16x2_pack")
         self.b = None if bias is None else bias.contiguous().float()
 
-    def __call__(self, x, relu=False):
+    def __call__(self, x, relu=False, up_add=None):
+        """up_add [B, Cout, Ho / 2, Wo / 2]: y = conv(x) + bias + its 2x bilinear up-sampling (align_corners=True) in the same launch (LoFTR's FPN merge)"""
         lib = _lib.load()
         x = x.contiguous()
         B, C, H, W = x.shape
         assert C == self.ci and x.dtype == torch.float32
         Ho, Wo = (H + 2 * self.pad - self.kh) // self.stride + 1, (W + 2 * self.pad - self.kw) // self.stride + 1
         y = torch.empty(B, self.co, Ho, Wo, dtype=torch.float32, device=x.device)
+        if up_add is not None:
+            lo = up_add.contiguous()
+            assert not relu and lo.shape == (B, self.co, Ho // 2, Wo // 2) and Ho % 2 == 0 and Wo % 2 == 0 and lo.dtype == torch.float32
+            _lib.check(lib.mfr_conv_igemm_f16x2_upadd(_lib.ptr(x), _lib.ptr(self.packed), _lib.ptr(self.b), _lib.ptr(lo), Ho // 2, Wo // 2, _lib.ptr(y), B, C, H, W,
+                                                      self.co, self.kh, self.kw, self.stride, self.pad, _lib.stream_ptr()), "mfr_conv_igemm_f16x2_upadd")
+            return y
         _lib.check(lib.mfr_conv_igemm_f16x2(_lib.ptr(x), _lib.ptr(self.packed), _lib.ptr(self.b), _lib.ptr(y), B, C, H, W, self.co, self.kh, self.kw,
                                             self.stride, self.pad, 1 if relu else 0, _lib.stream_ptr()), "mfr_conv_igemm_f16x2")
         return y

@@ -141,9 +141,16 @@ class LoFTRHIP:
         x2 = self._block(self._block(x1, "layer2.0", 2), "layer2.1", 1)
         x3 = self._block(self._block(x2, "layer3.0", 2), "layer3.1", 1)
         x3_out = self._c(x3, "l3out")
-        x2_out = self._c(self._c(self.upsample2x_add(x3_out, self._c(x2, "l2out")), "l2out2.0", 1, "leaky"), "l2out2.3")
-        x1_out = self._c(self._c(self.upsample2x_add(x2_out, self._c(x1, "l1out")), "l1out2.0", 1, "leaky"), "l1out2.3")
+        x2_out = self._c(self._c(self._lateral_merge(x2, "l2out", x3_out), "l2out2.0", 1, "leaky"), "l2out2.3")
+        x1_out = self._c(self._c(self._lateral_merge(x1, "l1out", x2_out), "l1out2.0", 1, "leaky"), "l1out2.3")
         return x3_out, x1_out
+
+    def _lateral_merge(self, x, name, lo):
+        """FPN merge  layerN_outconv(x) + interpolate(lo, x2, bilinear, align_corners=True):  one launch when the 1x1 convolution runs the own
+        implicit-GEMM kernel (its epilogue samples lo: round 6), else convolution + the in-place up-sample-and-add kernel"""
+        if name in self.igemm and x.shape[2] == 2 * lo.shape[2] and x.shape[3] == 2 * lo.shape[3]:
+            return self.igemm[name](x, up_add=lo)
+        return self.upsample2x_add(lo, self._c(x, name))
 
     # ------------------------------------------------------------------ HIP stage wrappers
     def linear_attention(self, q, kv):

@@ -47,3 +47,22 @@ def test_igemm_conv_error_class_is_fp32():
         rec = (scale, float(e2.abs().max()), float(e1.abs().max()), float(e2.pow(2).mean().sqrt()), float(e1.pow(2).mean().sqrt()))
         assert e2.abs().max() <= 3e-7 and e2.pow(2).mean().sqrt() <= 3e-8, rec
         assert e2.pow(2).mean().sqrt() <= 2.0 * e1.pow(2).mean().sqrt(), rec          # (the maxima are single outliers of 5e6 outputs: 1.8 - 2.3e-7 vs 1.1e-7)
+
+
+@pytest.mark.parametrize("B,ci,co,Hl,Wl", [(2, 128, 196, 45, 34), (1, 196, 256, 23, 17), (2, 40, 70, 5, 7), (1, 32, 128, 1, 1)])
+def test_igemm_conv_with_fpn_upsample_add(B, ci, co, Hl, Wl):
+    """mfr_conv_igemm_f16x2_upadd: layerN_outconv(x) + F.interpolate(lo, scale_factor=2, bilinear, align_corners=True) in one launch (LoFTR's FPN merge,
+    upstream ResNetFPN_8_2.forward) vs float64, and vs the two-launch path it replaces (convolution, then mfr_upsample2x_add)"""
+    from mapfree_reloc_amd import _lib
+    g = torch.Generator().manual_seed(B + ci + Hl)
+    H, W = 2 * Hl, 2 * Wl
+    x = torch.randn(B, ci, H, W, generator=g).to(DEV)
+    lo = torch.randn(B, co, Hl, Wl, generator=g).to(DEV)
+    w = (torch.randn(co, ci, 1, 1, generator=g) / ci ** 0.5).to(DEV)
+    conv = IgemmConv(w, None, 1)
+    y = conv(x, up_add=lo)
+    want = F.conv2d(x.double().cpu(), w.double().cpu()) + F.interpolate(lo.double().cpu(), scale_factor=2.0, mode="bilinear", align_corners=True)
+    assert (y.double().cpu() - want).abs().max().item() < 5e-5          # (the source coordinate is formed in f32, as in torch's kernel: tests/test_gpu_loftr_parity.py)
+    two = conv(x)
+    _lib.check(_lib.load().mfr_upsample2x_add(_lib.ptr(lo), _lib.ptr(two), B * co, Hl, Wl, _lib.stream_ptr()), "mfr_upsample2x_add")
+    assert (y - two).abs().max().item() < 2e-6                           # same taps, same weights; only the compiler's contraction of the 7 operations may differ
