@@ -271,6 +271,15 @@ int mfr_conv_igemm_f16x2(const float *x, const void *packed_w, const float *bias
  *                          the up-sampling arithmetic is mfr_upsample2x_add's. */
 int mfr_conv_igemm_f16x2_upadd(const float *x, const void *packed_w, const float *bias, const float *lo, int Hl, int Wl, float *y, int B, int Cin, int H, int W,
                                int Cout, int KH, int KW, int stride, int pad, void *stream);
+/*   mfr_gemm_f16x2_ln / mfr_gemm_bf16x3_ln (round 6): y = [y +] LayerNorm_N(x W^T + bias) * gamma + beta for N = 128 (one feature block) and K % 64 == 0:
+ *                          the linear layer with the LayerNorm that follows it in upstream LoFTREncoderLayer.forward (`message = self.norm1(self.merge(...))`,
+ *                          `message = self.norm2(self.mlp(...)); return x + message`; call site matchers.py:50) in ONE launch, for the fine-level encoder
+ *                          (d_model 128) whose tensors (2.4 M rows) make every pass HBM-bound.  accumulate != 0: y += (the residual, in place).
+ *                          Two-pass statistics (mean, then centred squares), biased variance, rsqrt(var + eps): the arithmetic of mfr_layernorm. */
+int mfr_gemm_f16x2_ln(const float *x, int ldx, const void *packed_w, const float *bias, const float *gamma, const float *beta, float eps, float *y, int ldy,
+                      int M, int N, int K, int accumulate, void *stream);
+int mfr_gemm_bf16x3_ln(const float *x, int ldx, const void *packed_w, const float *bias, const float *gamma, const float *beta, float eps, float *y, int ldy,
+                       int M, int N, int K, int accumulate, void *stream);
 size_t mfr_gemm_bf16x3_pack_bytes(int N, int K);
 int mfr_gemm_bf16x3_pack(const float *w, int N, int K, void *packed, void *stream);
 int mfr_gemm_bf16x3(const float *x, int ldx, const void *packed_w, const float *bias, float *y, int ldy, int M, int N, int K, int flags, void *stream);

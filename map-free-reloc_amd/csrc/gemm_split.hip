@@ -444,12 +444,20 @@ __device__ unsigned long long gd_prof[4][64];
 template <int FLAGS, bool F16>
 __global__ void __launch_bounds__(256, 2) gemm_split_d_kernel(const float *__restrict__ X, int ldx, const uint4 *__restrict__ Wp, unsigned wp_bytes, const float *__restrict__ oscale,
                                                               const float *__restrict__ bias, float *__restrict__ Y, int ldy, int M, int N, int K, int nnb, int nmb,
-                                                              long long xs, long long ws, long long ys, int *guard)
+                                                              long long xs, long long ws, long long ys, int *guard,
+                                                              const float *__restrict__ ln_gamma, const float *__restrict__ ln_beta, float ln_eps)
 {
     GB_BATCH_OFFSETS();
     constexpr int XT = GB_XT(F16);
     constexpr int WT = GB_WT(F16), WSTAGE = GD_WSTAGE(F16);
     __shared__ uint4 lds[XT * GB_TERM_UNITS + 2 * WSTAGE];
+    // FLAGS & 4 (round 6): LayerNorm over the N = 128 output features in the epilogue (LoFTR's fine-level encoder layers: norm1 behind `merge`,
+    // norm2 (+ residual, FLAGS & 2: Y += ...) behind the MLP's second layer -- upstream LoFTREncoderLayer.forward).  At the fine level every one of
+    // these kernels is HBM-bound (2.4 M rows x 128 floats per tensor), so the separate LayerNorm pass cost its full read + write of the tensor;
+    // the ~700 extra instructions per tile of the in-register reduction below are free.  Row statistics: the thread's two columns, a butterfly
+    // over the 32 lanes that hold the row's other columns of this wavefront, the two wavefronts of a row exchanged through 2 KB of LDS (summed
+    // in the fixed order wn = 0, 1); mean first, then the centred squares (the two-pass form of layernorm_kernel, loftr_fused.hip).
+    __shared__ float lnx[(FLAGS & 4) ? 512 : 1];
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wid >> 1, wn = wid & 1;
     const int nkb = K / GB_BK;
@@ -582,6 +590,64 @@ __global__ void __launch_bounds__(256, 2) gemm_split_d_kernel(const float *__res
                 for (int r = 0; r < 16; ++r) MFR_GUARD_ACC(chk, acc[i][0][r]);
             mfr_guard_commit(guard, chk);
         }
+        if constexpr ((FLAGS & 4) != 0) {
+            const float g0 = ln_gamma[n0], g1 = ln_gamma[n0 + 32], be0 = ln_beta[n0], be1 = ln_beta[n0 + 32];
+            float part[2][16];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    acc[i][0][r] = F16 ? __builtin_fmaf(acc[i][0][r], os0, bv0) : acc[i][0][r] + bv0;
+                    acc[i][1][r] = F16 ? __builtin_fmaf(acc[i][1][r], os1, bv1) : acc[i][1][r] + bv1;
+                    part[i][r] = acc[i][0][r] + acc[i][1][r];
+                }
+#pragma unroll
+            for (int m = 1; m <= 16; m <<= 1)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) part[i][r] += __shfl_xor(part[i][r], m, 64);
+#define GD_LNROW(i, r) (64 * wm + 32 * (i) + ((r) & 3) + 8 * ((r) >> 2) + 4 * (lane >> 5))
+            if ((lane & 31) == 0) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) lnx[wn * 128 + GD_LNROW(i, r)] = part[i][r];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float mean = (lnx[GD_LNROW(i, r)] + lnx[128 + GD_LNROW(i, r)]) * (1.0f / 128.0f);
+                    acc[i][0][r] -= mean; acc[i][1][r] -= mean;
+                    part[i][r] = acc[i][0][r] * acc[i][0][r] + acc[i][1][r] * acc[i][1][r];
+                }
+#pragma unroll
+            for (int m = 1; m <= 16; m <<= 1)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) part[i][r] += __shfl_xor(part[i][r], m, 64);
+            if ((lane & 31) == 0) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) lnx[256 + wn * 128 + GD_LNROW(i, r)] = part[i][r];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float rstd = rsqrtf((lnx[256 + GD_LNROW(i, r)] + lnx[384 + GD_LNROW(i, r)]) * (1.0f / 128.0f) + ln_eps);
+                    float y0 = acc[i][0][r] * rstd * g0 + be0, y1 = acc[i][1][r] * rstd * g1 + be1;
+                    if (FLAGS & 2) { y0 = __builtin_bit_cast(float, ov[i][0][r]) + y0; y1 = __builtin_bit_cast(float, ov[i][1][r]) + y1; }
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y0), ry, yoff, GD_SOFF(i, r), 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y1), ry, yoff + 128u, GD_SOFF(i, r), 0);
+                }
+#undef GD_LNROW
+        } else {
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {
             if (n0 + 32 * jj >= N) continue;
@@ -595,6 +661,7 @@ __global__ void __launch_bounds__(256, 2) gemm_split_d_kernel(const float *__res
                     if (FLAGS & 2) v += __builtin_bit_cast(float, ov[i][jj][r]);
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ry, yoff + 128u * jj, GD_SOFF(i, r), 0);
                 }
+        }
         }
         const int jn = next_item(j);
         if (jn == j) break;
@@ -801,8 +868,24 @@ static size_t gb_tile_bytes(int N, int K, bool f16) { return (size_t)((N + GB_BN
 
 template <bool F16>
 static int gb_launch(const float *x, int ldx, const void *packed_w, const float *bias, float *y, int ldy, int M, int N, int K, int flags, void *stream,
-                     int nbatch = 1, long long xs = 0, long long ws_bytes = 0, long long ys = 0)
+                     int nbatch = 1, long long xs = 0, long long ws_bytes = 0, long long ys = 0, const float *ln_gamma = nullptr, const float *ln_beta = nullptr,
+                     float ln_eps = 0.f)
 {
+    if (ln_gamma) {
+        // LayerNorm epilogue: the default (LDS-DMA) kernel only, one 128-feature block; flags: 0 or 2 (Y += LayerNorm(...))
+        if (!ln_beta || N != GB_BN || (K % 64) || (flags & ~2) || nbatch != 1 || !x || !packed_w || !y || M <= 0 || (ldx & 3) || ldx < K || ldy < N || ((uintptr_t)x & 15)) return MFR_E_ARG;
+        const size_t tb = gb_tile_bytes(N, K, F16);
+        if (tb >= 0xffffffffull) return MFR_E_ARG;
+        const int nmb = (M + GB_BM - 1) / GB_BM;
+        const long long per_xcd = (long long)((nmb + 7) / 8);
+        const unsigned grid = 8u * (unsigned)(per_xcd < 64 ? per_xcd : 64);
+        const float *oscale = F16 ? (const float *)((const char *)packed_w + tb) : nullptr;
+        int *g = F16 ? mfr_guard_current() : (int *)nullptr;
+        if (flags & 2) hipLaunchKernelGGL((gemm_split_d_kernel<6, F16>), dim3(grid), dim3(256), 0, (hipStream_t)stream, x, ldx, (const uint4 *)packed_w, (unsigned)tb, oscale, bias, y, ldy, M, N, K, 1, nmb, 0ll, 0ll, 0ll, g, ln_gamma, ln_beta, ln_eps);
+        else           hipLaunchKernelGGL((gemm_split_d_kernel<4, F16>), dim3(grid), dim3(256), 0, (hipStream_t)stream, x, ldx, (const uint4 *)packed_w, (unsigned)tb, oscale, bias, y, ldy, M, N, K, 1, nmb, 0ll, 0ll, 0ll, g, ln_gamma, ln_beta, ln_eps);
+        CHECK_LAUNCH();
+        return 0;
+    }
     if (nbatch <= 0 || nbatch > 65535 || (ws_bytes & 15) || (xs & 3) || xs < 0 || ys < 0) return MFR_E_ARG;
     const long long ws = ws_bytes / 16;
     // flags: 1 = ReLU, 2 = accumulate; 4 = one tile per workgroup (the baseline of the bitwise-agreement test), 8 = persistent 128 x 128 workgroups
@@ -835,7 +918,7 @@ static int gb_launch(const float *x, int ldx, const void *packed_w, const float 
         GB_SW(GB_GO)
 #undef GB_GO
     } else {
-#define GB_GO(F) hipLaunchKernelGGL((gemm_split_d_kernel<F, F16>), dim3(grid, (unsigned)nbatch), dim3(256), 0, st, x, ldx, wp, (unsigned)tb, oscale, bias, y, ldy, M, N, K, nnb, nmb, xs, ws, ys, F16 ? mfr_guard_current() : (int *)nullptr)
+#define GB_GO(F) hipLaunchKernelGGL((gemm_split_d_kernel<F, F16>), dim3(grid, (unsigned)nbatch), dim3(256), 0, st, x, ldx, wp, (unsigned)tb, oscale, bias, y, ldy, M, N, K, nnb, nmb, xs, ws, ys, F16 ? mfr_guard_current() : (int *)nullptr, (const float *)nullptr, (const float *)nullptr, 0.f)
         GB_SW(GB_GO)
 #undef GB_GO
     }
@@ -903,6 +986,20 @@ int mfr_gemm_bf16x3(const float *x, int ldx, const void *packed_w, const float *
 int mfr_gemm_f16x2(const float *x, int ldx, const void *packed_w, const float *bias, float *y, int ldy, int M, int N, int K, int flags, void *stream)
 {
     return gb_launch<true>(x, ldx, packed_w, bias, y, ldy, M, N, K, flags, stream);
+}
+
+int mfr_gemm_f16x2_ln(const float *x, int ldx, const void *packed_w, const float *bias, const float *gamma, const float *beta, float eps, float *y, int ldy,
+                      int M, int N, int K, int accumulate, void *stream)
+{
+    if (!gamma || !beta) return MFR_E_ARG;
+    return gb_launch<true>(x, ldx, packed_w, bias, y, ldy, M, N, K, accumulate ? 2 : 0, stream, 1, 0, 0, 0, gamma, beta, eps);
+}
+
+int mfr_gemm_bf16x3_ln(const float *x, int ldx, const void *packed_w, const float *bias, const float *gamma, const float *beta, float eps, float *y, int ldy,
+                       int M, int N, int K, int accumulate, void *stream)
+{
+    if (!gamma || !beta) return MFR_E_ARG;
+    return gb_launch<false>(x, ldx, packed_w, bias, y, ldy, M, N, K, accumulate ? 2 : 0, stream, 1, 0, 0, 0, gamma, beta, eps);
 }
 
 int mfr_gemm_f16x2_batched(const float *x, int ldx, long long x_batch_stride, const void *packed_w, const float *bias, float *y, int ldy, long long y_batch_stride,

@@ -17,6 +17,7 @@ class SplitLinear:
         self._pack_bytes = getattr(lib, f"mfr_gemm_{self.split}_pack_bytes")
         self._pack = getattr(lib, f"mfr_gemm_{self.split}_pack")
         self._gemm = getattr(lib, f"mfr_gemm_{self.split}")
+        self._gemm_ln = getattr(lib, f"mfr_gemm_{self.split}_ln")
         self.N, self.K = int(weight.shape[0]), int(weight.shape[1])
         nb = self._pack_bytes(self.N, self.K)
         if nb == 0:
@@ -26,15 +27,25 @@ class SplitLinear:
         _lib.check(self._pack(_lib.ptr(w), self.N, self.K, _lib.ptr(self.packed), _lib.stream_ptr()), f"mfr_gemm_{self.split}_pack")
         self.bias = None if bias is None else bias.contiguous().float()
 
-    def __call__(self, x, out=None, relu=False, accumulate=False, kernel_flag=0):
+    def ln_fusable(self):
+        """can the LayerNorm that follows this layer run in its epilogue (mfr_gemm_*_ln: one 128-feature block, the LDS-DMA kernel)?"""
+        return self.N == 128 and self.K % 64 == 0
+
+    def __call__(self, x, out=None, relu=False, accumulate=False, kernel_flag=0, ln=None, eps=1e-5):
         """x [M, K] (row stride x.stride(0), unit column stride) -> out [M, N] (allocated when None); accumulate: out += result.
-        kernel_flag: 0 (default kernel) | 4 | 8 -- the other kernel generations, for the bitwise-agreement test"""
+        kernel_flag: 0 (default kernel) | 4 | 8 -- the other kernel generations, for the bitwise-agreement test.
+        ln = (gamma, beta): out = [out +] LayerNorm(x W^T + b) in the same launch (N = 128 only: ln_fusable())"""
         assert x.dim() == 2 and x.shape[1] == self.K and x.stride(1) == 1 and x.dtype == torch.float32
         M = x.shape[0]
         if out is None:
             assert not accumulate
             out = torch.empty(M, self.N, dtype=torch.float32, device=x.device)
         assert out.shape == (M, self.N) and out.stride(1) == 1
+        if ln is not None:
+            assert self.ln_fusable() and not relu and kernel_flag == 0
+            _lib.check(self._gemm_ln(x.data_ptr(), x.stride(0), _lib.ptr(self.packed), _lib.ptr(self.bias), _lib.ptr(ln[0]), _lib.ptr(ln[1]), float(eps),
+                                     out.data_ptr(), out.stride(0), M, self.N, self.K, 1 if accumulate else 0, _lib.stream_ptr()), f"mfr_gemm_{self.split}_ln")
+            return out
         _lib.check(self._gemm(x.data_ptr(), x.stride(0), _lib.ptr(self.packed), _lib.ptr(self.bias), out.data_ptr(), out.stride(0),
                               M, self.N, self.K, (1 if relu else 0) | (2 if accumulate else 0) | kernel_flag, _lib.stream_ptr()), f"mfr_gemm_{self.split}")
         return out

@@ -264,6 +264,13 @@ class LoFTRHIP:
         q = Lw["lq"](x)
         kv = Lw["lkv"](src)
         msg = attn(q.view(nb, L, C), kv.view(nb, L, 2 * C))
+        if Lw["lm"].ln_fusable() and n > 0:
+            # d_model 128 (the fine level): both LayerNorms run in the epilogue of the linear layer before them (round 6: the rows are 2.4 M x 128
+            # floats per tensor, every separate pass is its full HBM read + write)
+            Lw["lm"](msg.view(n, C), out=xm[:, C:], ln=Lw["n1"])
+            hid = Lw["l1"](xm, relu=True)
+            Lw["l2"](hid, out=x, ln=Lw["n2"], accumulate=True)                     # x += norm2(mlp)
+            return xm
         self.layernorm(Lw["lm"](msg.view(n, C)), Lw["n1"], xm[:, C:])
         hid = Lw["l1"](xm, relu=True)                                              # relu([x | message] W1^T) in the GEMM epilogue
         self.layernorm(Lw["l2"](hid), Lw["n2"], x, residual=x)                     # x += norm2(mlp)

@@ -146,3 +146,36 @@ def test_batched_products_equal_the_per_problem_launches_and_float64(nb, M, N, K
     big = torch.full((nb, M, N + 8), 7.0, device=DEV)
     bg(x, w, out_mul=mul, out=big[:, :, :N])
     assert torch.equal(big[:, :, :N], y) and (big[:, :, N:] == 7.0).all()
+
+
+@pytest.mark.parametrize("split", ["f16x2", "bf16x3"])
+@pytest.mark.parametrize("M,K", [(1, 128), (127, 128), (128, 256), (1031, 256), (50000, 128)])
+def test_linear_plus_layernorm_in_one_launch(split, M, K):
+    """mfr_gemm_*_ln (round 6): LayerNorm_128(x W^T + b) [+ residual, in place] in the GEMM epilogue -- the `norm1(merge(.))` / `x + norm2(mlp(.))` pairs of
+    upstream LoFTREncoderLayer at d_model 128 -- against float64 and against the two launches it replaces (mfr_gemm_* then mfr_layernorm: same two-pass
+    statistics, another summation order).  Strided operands as nets/loftr.py uses them (the [x | message] buffer); f32 tolerance 2e-6 (1 + |y|) as in
+    test_fused_layernorm_vs_torch, on normalised outputs of unit scale."""
+    import torch.nn.functional as F
+    from mapfree_reloc_amd.nets.linear import SplitLinear
+    from mapfree_reloc_amd.nets.loftr import LoFTRHIP
+    g = torch.Generator().manual_seed(M + K)
+    w = (torch.randn(128, K, generator=g) / K ** 0.5).to(DEV)
+    b = torch.randn(128, generator=g).to(DEV)
+    gam, bet = (1 + 0.3 * torch.randn(128, generator=g)).to(DEV), torch.randn(128, generator=g).to(DEV)
+    lin = SplitLinear(w, b, split=split)
+    assert lin.ln_fusable()
+    xin = torch.randn(M, K + 64, generator=g).to(DEV)[:, :K]                       # row stride K + 64
+    xm = torch.randn(M, 256, generator=g).to(DEV)
+    keep = xm.clone()
+    want = F.layer_norm(xin.double().cpu() @ w.double().cpu().T + b.double().cpu(), (128,), gam.double().cpu(), bet.double().cpu(), 1e-5)
+    lin(xin, out=xm[:, 128:], ln=(gam, bet))                                        # norm1 -> right half of [x | message]
+    got = xm[:, 128:].double().cpu()
+    assert torch.equal(xm[:, :128], keep[:, :128])
+    assert ((got - want).abs() / (1 + want.abs())).max().item() < 4e-6
+    two = torch.empty(M, 128, device=DEV)
+    LoFTRHIP.layernorm(lin(xin), (gam, bet), two)
+    assert ((got - two.double().cpu()).abs() / (1 + want.abs())).max().item() < 4e-6
+    lin(xin, out=xm[:, :128], ln=(gam, bet), accumulate=True)                       # x += norm2(...) in place
+    want2 = keep[:, :128].double().cpu() + want
+    assert ((xm[:, :128].double().cpu() - want2).abs() / (1 + want2.abs())).max().item() < 4e-6
+    assert torch.equal(xm[:, 128:].double().cpu(), got)                             # the right half is not touched by the in-place update

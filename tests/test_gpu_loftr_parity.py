@@ -142,13 +142,16 @@ def test_loftr_end_to_end_vs_oracle(pair, hw):
     n = int(out["n_corr"][0])
     got = torch.cat([out["pts0"][0, :n], out["pts1"][0, :n]], 1).cpu().numpy()
     assert len(want) > 100 and not np.isnan(want).any()
-    # same coarse matches (key = the two coarse cells); fine offsets within 1e-2 px
+    # same coarse matches (key = the two coarse cells); fine coordinates: the measured state of the shipped arithmetic with one unit of slack
+    # (profiles/r06_loftr_stage_diff_hard2.json, 16 pairs: every coarse match common, 99th percentile <= 7.4e-4 px, maximum <= 9.3e-3 px, ~220 of ~5000
+    # coordinates differ at all -- the SAME figures with the exact bf16x3 products: it is the backbone's fp32 summation order against oneDNN's, not the
+    # f16x2 split).  This is the regression detector of the matcher: the pose-level census cannot be one (tests/test_gpu_parity_census.py).
     kw = {(int(r[0]), int(r[1])): r for r in want}
     kg = {(int(r[0]), int(r[1])): r for r in got}
     common = set(kw) & set(kg)
-    assert len(common) >= 0.97 * max(len(kw), len(kg)), (len(kw), len(kg), len(common))
+    assert len(common) >= 0.998 * max(len(kw), len(kg)), (len(kw), len(kg), len(common))
     d = np.array([np.abs(kw[k] - kg[k]).max() for k in common])
-    assert np.quantile(d, 0.99) < 2e-2, np.quantile(d, [0.5, 0.9, 0.99, 1.0])
+    assert np.quantile(d, 0.99) < 1e-3 and d.max() < 2e-2 and (d > 0).mean() < 0.15, (np.quantile(d, [0.5, 0.9, 0.99, 1.0]), (d > 0).mean())
 
 
 @pytest.mark.parametrize("rows,C", [(1, 256), (1031, 256), (777, 128), (6120 * 3, 256)])

@@ -26,52 +26,53 @@ def _check(recs, min_identical, min_common):
     return s
 
 
+# Round 6: the bars below are the MEASURED state of the shipped code (profiles/r06_parity_census_{easy,hard,hard2}.json) with one unit of slack, so
+# that a regression of the kind VERDICT r5 found (a pair drifting across the 1e-4 m bar unnoticed) fails the suite.  What the pose-level numbers of
+# the LoFTR rows can and cannot show is measured in profiles/r06_loftr_sensitivity_*.json (tools/loftr_sensitivity.py): the ORACLE's own pose moves
+# by centimetres when 186 of its 5000 fine coordinates move by one float32 ulp on 19 % of the hard = 2 draws (the exhaustive scale RANSAC and the E-mat
+# RANSAC switch between discrete solutions), so the coordinate-level bars (tests/test_gpu_loftr_parity.py) are the regression detector for the matcher
+# and the pose-level bars here hold the whole path to what it reaches today.
 def test_census_superglue_pnp_32_pairs():
-    s = _check(census("sg_pnp", [5000 + i for i in range(32)]), SG_MIN_IDENTICAL, 0.97)
-    assert s["identical_as_sets"] >= 28 and s["inlier_count_equal"] >= 28 and s["pose_within_bar"] >= 30, s     # measured: 32 / 32 / 32
-    # fp32 near-tie decisions (keypoint order at equal scores, Sinkhorn scores next to the 0.2 threshold) may flip a match in
-    # some pairs; the pose must still be the oracle's far below the benchmark's resolution (0.25 m / 5 deg)
-    assert s["max_rot_rad"] < 5e-3 and s["max_trans_m"] < 5e-3, s
+    s = _check(census("sg_pnp", [5000 + i for i in range(32)]), 0.70, 1.0)                          # measured: 24 / 32 in the same ORDER ...
+    assert s["identical_as_sets"] == 32 and s["inlier_index_sets_identical"] == 32, s              # ... and 32 / 32 the same SET (equal-score keypoints in another order)
+    assert s["inlier_count_equal"] == 32 and s["pose_within_bar"] == 32 and s["pose_bit_equal"] >= 28, s   # measured 29 bit-equal
+    assert s["max_rot_rad"] < 1e-6 and s["max_trans_m"] < 1e-9, s                                 # measured 3.0e-8 rad, 1.3e-11 m
 
 
 def test_census_loftr_emat_8_pairs():
-    s = _check(census("loftr_emat", [5000 + i for i in range(8)], chunk=4), LOFTR_MIN_IDENTICAL, 0.99)
-    assert s["pose_within_bar"] >= 7 and s["inlier_count_equal"] >= 6, s                                        # measured: 8 / 8
-    assert s["max_rot_rad"] < 2e-2 and s["max_trans_m"] < 2e-2, s
+    s = _check(census("loftr_emat", [5000 + i for i in range(8)], chunk=4), 0.0, 0.997)            # measured: common fraction 0.99898
+    assert s["pose_within_bar"] == 8 and s["inlier_count_equal"] == 8, s
+    assert s["max_rot_rad"] < 2e-6 and s["max_trans_m"] < 1e-5 and s["min_inlier_set_jaccard_q64"] > 0.99, s     # measured 1.6e-7 rad, 9.4e-7 m, 0.9955
 
 
 def test_census_hard_scenes_inlier_index_sets():
-    """hard scenes (moving objects + occluder, and for PnP 35-55 % of the depth map wrong): 30-60 % outliers, the RANSACs run hundreds of hypotheses.
-    Wherever the matcher reproduces the oracle's match set, the inlier INDEX SET (canonical order) is the oracle's, bit for bit."""
+    """hard scenes (moving objects + occluder, and 35-55 % of the depth map wrong): 30-75 % outliers, the RANSACs run hundreds of hypotheses"""
     recs = census("sg_pnp", [5000 + i for i in range(16)], hard=2)
     s = PR.summarize(recs)
     print(json.dumps(s))
-    assert s["status_agree"] == s["pairs"]
-    assert s["inlier_index_sets_compared"] >= 14 and s["median_inlier_fraction"] < 0.8, s           # 35-55 % of the lifted points carry a wrong depth
-    for r in recs:
-        if r["identical_set"] and "inlier_set_identical" in r:
-            assert r["inlier_set_identical"] and r["rot_rad"] <= 1e-4 and r["trans_m"] <= 1e-4, r
-    assert s["pose_within_bar"] >= 13, s
-    recs = census("loftr_emat", [5000 + i for i in range(4)], chunk=4, hard=True)
+    assert s["status_agree"] == s["pairs"] == 16 and s["median_inlier_fraction"] < 0.8, s           # 35-55 % of the lifted points carry a wrong depth
+    assert s["identical_match_sets"] == 16 and s["inlier_index_sets_identical"] == 16 and s["pose_bit_equal"] == 16, s     # measured: 32 / 32 of each
+    # LoFTR, hard = 1 (epipolar outliers only): every pair within the bar
+    recs = census("loftr_emat", [5000 + i for i in range(8)], chunk=4, hard=1)
     s = PR.summarize(recs)
     print(json.dumps(s))
-    assert s["status_agree"] == s["pairs"] and s["median_inlier_fraction"] < 0.8, s                    # 30-60 % outliers for the E-mat RANSAC
-    assert s["min_inlier_set_jaccard_q64"] > 0.97 and s["pose_within_bar"] == s["pairs"], s
+    assert s["status_agree"] == s["pairs"] == 8 and s["median_inlier_fraction"] < 0.8, s
+    assert s["pose_within_bar"] == 8 and s["inlier_count_equal"] == 8 and s["min_inlier_set_jaccard_q64"] > 0.99, s          # measured (16 pairs): 16, 16, 0.9938
+    assert s["max_rot_rad"] < 1e-5 and s["max_trans_m"] < 1e-4, s                                  # measured 3.4e-6 rad, 1.2e-5 m
+    # LoFTR, hard = 2 (+ wrong depths for the scale RANSAC), incl. seed 5007 -- the pair of VERDICT r5 (inlier fraction 0.26, 1.43e-4 m)
+    recs = census("loftr_emat", [5000 + i for i in range(8)], chunk=4, hard=2)
+    s = PR.summarize(recs)
+    print(json.dumps(s), json.dumps([r for r in recs if r["seed"] == 5007]))
+    assert s["status_agree"] == s["pairs"] == 8 and s["inlier_count_equal"] == 8 and s["min_inlier_set_jaccard_q64"] > 0.99, s
+    assert s["max_rot_rad"] < 1e-5 and s["max_trans_m"] < 2e-4 and s["pose_within_bar"] >= 7, s    # measured 3.4e-6 rad, 1.43e-4 m, 7 of these 8 (15 / 16)
 
 
 def test_census_procrustes_and_sift_leg():
     """f-1 (SuperGlue -> Procrustes RANSAC) and configs[0] (descriptor leg -> E-mat RANSAC): whole HIP path vs whole oracle path"""
     s = PR.summarize(census("sg_procrustes", [5000 + i for i in range(8)], hard=2))
     print(json.dumps(s))
-    assert s["status_agree"] == s["pairs"] and s["pose_within_bar"] >= 6 and s["inlier_count_equal"] >= 6, s
+    assert s["status_agree"] == s["pairs"] and s["pose_within_bar"] == 8 and s["inlier_count_equal"] == 8 and s["pose_bit_equal"] == 8, s
     recs = census("sift_emat", list(range(8)))
     s = PR.summarize(recs)
     print(json.dumps(s))
     assert s["identical_match_sets"] == 8 and s["inlier_index_sets_identical"] == 8 and s["pose_bit_equal"] == 8, s
-
-
-# lower bounds on the fraction of pairs whose whole match set is bit-identical to the oracle's (measured:
-# profiles/r02_parity_census.json); LoFTR's fine stage is a sub-pixel fp32 expectation, so exact equality of every
-# coordinate is not expected there and the common-fraction (1/64 px quantised) carries the check
-SG_MIN_IDENTICAL = 0.4        # measured 0.66: the other pairs hold the same SET in another keypoint order (equal-score ties)
-LOFTR_MIN_IDENTICAL = 0.0
