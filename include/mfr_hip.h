@@ -280,6 +280,16 @@ int mfr_gemm_f16x2_ln(const float *x, int ldx, const void *packed_w, const float
                       int M, int N, int K, int accumulate, void *stream);
 int mfr_gemm_bf16x3_ln(const float *x, int ldx, const void *packed_w, const float *bias, const float *gamma, const float *beta, float eps, float *y, int ldy,
                        int M, int N, int K, int accumulate, void *stream);
+/*   mfr_gemm_f16x2_windows / mfr_gemm_bf16x3_windows (round 6): upstream FinePreprocess.forward (F.unfold(feat_f, 5x5, stride 4, padding 2) -> rows at the
+ *                          matches -> merge_feat; call site matchers.py:50) as ONE product: y [nwin win^2, N] = window tokens W^T (+ bias) (+ window_bias
+ *                          [nwin, N] broadcast over a window's tokens), the tokens read from the NHWC fine map feat [Bimg,Hf,Wf,C] in place: window w =
+ *                          the win x win pixels around cell cell_ids[w] (centre ((cell / wc) stride, (cell % wc) stride)) of image img_ids[w], zero
+ *                          outside the map (zero_row: C zeros the caller provides).  C = K a multiple of 64.  Replaces mfr_loftr_gather_windows + the
+ *                          window tensor + mfr_gemm_* + a broadcast add. */
+int mfr_gemm_f16x2_windows(const float *feat, int Bimg, int Hf, int Wf, int C, const int32_t *img_ids, const int32_t *cell_ids, int nwin, int wc, int stride, int win,
+                           const float *zero_row, const void *packed_w, const float *bias, const float *window_bias, float *y, int ldy, int N, void *stream);
+int mfr_gemm_bf16x3_windows(const float *feat, int Bimg, int Hf, int Wf, int C, const int32_t *img_ids, const int32_t *cell_ids, int nwin, int wc, int stride, int win,
+                            const float *zero_row, const void *packed_w, const float *bias, const float *window_bias, float *y, int ldy, int N, void *stream);
 size_t mfr_gemm_bf16x3_pack_bytes(int N, int K);
 int mfr_gemm_bf16x3_pack(const float *w, int N, int K, void *packed, void *stream);
 int mfr_gemm_bf16x3(const float *x, int ldx, const void *packed_w, const float *bias, float *y, int ldy, int M, int N, int K, int flags, void *stream);

@@ -441,11 +441,22 @@ __device__ unsigned long long gd_prof[4][64];
 #else
 #define GD_STAMP(k) do { } while (0)
 #endif
+// FLAGS & 8 (round 6): the X rows are the tokens of LoFTR's fine-level 5x5 WINDOWS, read straight from the NHWC fine map (row g = window g / W^2,
+// token g % W^2 -> pixel (cell centre - W / 2 + token offset) of image img_ids[window]; outside the map: the zero row = F.unfold's padding), and the
+// epilogue adds one bias row PER WINDOW (the coarse half of merge_feat, constant over a window's tokens).  Replaces fine_gather_kernel + the
+// [2 M, 25, 128] window tensor + the broadcast add behind the GEMM (upstream FinePreprocess.forward: unfold -> gather at the matches -> merge_feat).
+struct GdWindows {
+    const int *img_ids, *cell_ids;       // [nwin]
+    const float *zero;                   // K zeros
+    const float *rgb;                    // [nwin, N] per-window bias, or NULL
+    int wc, stride, Hf, Wf, win;
+};
+
 template <int FLAGS, bool F16>
 __global__ void __launch_bounds__(256, 2) gemm_split_d_kernel(const float *__restrict__ X, int ldx, const uint4 *__restrict__ Wp, unsigned wp_bytes, const float *__restrict__ oscale,
                                                               const float *__restrict__ bias, float *__restrict__ Y, int ldy, int M, int N, int K, int nnb, int nmb,
                                                               long long xs, long long ws, long long ys, int *guard,
-                                                              const float *__restrict__ ln_gamma, const float *__restrict__ ln_beta, float ln_eps)
+                                                              const float *__restrict__ ln_gamma, const float *__restrict__ ln_beta, float ln_eps, GdWindows wnd)
 {
     GB_BATCH_OFFSETS();
     constexpr int XT = GB_XT(F16);
@@ -507,10 +518,21 @@ __global__ void __launch_bounds__(256, 2) gemm_split_d_kernel(const float *__res
     // X stream (registers, two steps ahead)
     const float *lx0, *lx1;
     int lk = 0, lj = j;
+    auto window_row = [&](int g) -> const float * {
+        const int ww = wnd.win * wnd.win, m = g / ww, t = g - m * ww, ky = t / wnd.win;
+        const int img = wnd.img_ids[m], cell = wnd.cell_ids[m];
+        const int y = (cell / wnd.wc) * wnd.stride - wnd.win / 2 + ky, x = (cell % wnd.wc) * wnd.stride - wnd.win / 2 + (t - ky * wnd.win);
+        return (y >= 0 && y < wnd.Hf && x >= 0 && x < wnd.Wf) ? X + (((size_t)img * wnd.Hf + y) * wnd.Wf + x) * (size_t)ldx : wnd.zero;
+    };
     auto x_tile_start = [&](int jj) {
         GD_TILE(jj, mb, nb); (void)nb;
-        lx0 = X + (size_t)min(mb * GB_BM + xr[0], M - 1) * ldx + xk[0];
-        lx1 = X + (size_t)min(mb * GB_BM + xr[1], M - 1) * ldx + xk[1];
+        if constexpr ((FLAGS & 8) != 0) {
+            lx0 = window_row(min(mb * GB_BM + xr[0], M - 1)) + xk[0];
+            lx1 = window_row(min(mb * GB_BM + xr[1], M - 1)) + xk[1];
+        } else {
+            lx0 = X + (size_t)min(mb * GB_BM + xr[0], M - 1) * ldx + xk[0];
+            lx1 = X + (size_t)min(mb * GB_BM + xr[1], M - 1) * ldx + xk[1];
+        }
     };
     float4 xa0, xa1, xb0, xb1, xc0, xc1, xd0, xd1;         // set 0: xa (rows u >> 2), xb (+ 64 rows); set 1: xc, xd
 #define GD_XLOAD(p0, p1, q0, q1) do { \
@@ -659,6 +681,12 @@ __global__ void __launch_bounds__(256, 2) gemm_split_d_kernel(const float *__res
                     float v = F16 ? __builtin_fmaf(acc[i][jj][r], os, bv) : acc[i][jj][r] + bv;
                     if (FLAGS & 1) v = fmaxf(v, 0.f);
                     if (FLAGS & 2) v += __builtin_bit_cast(float, ov[i][jj][r]);
+                    if constexpr ((FLAGS & 8) != 0) {
+                        if (wnd.rgb) {
+                            const int g = min(m0 + 64 * wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), M - 1);
+                            v += wnd.rgb[(size_t)(g / (wnd.win * wnd.win)) * N + n0 + 32 * jj];
+                        }
+                    }
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ry, yoff + 128u * jj, GD_SOFF(i, r), 0);
                 }
         }
@@ -881,8 +909,8 @@ static int gb_launch(const float *x, int ldx, const void *packed_w, const float 
         const unsigned grid = 8u * (unsigned)(per_xcd < 64 ? per_xcd : 64);
         const float *oscale = F16 ? (const float *)((const char *)packed_w + tb) : nullptr;
         int *g = F16 ? mfr_guard_current() : (int *)nullptr;
-        if (flags & 2) hipLaunchKernelGGL((gemm_split_d_kernel<6, F16>), dim3(grid), dim3(256), 0, (hipStream_t)stream, x, ldx, (const uint4 *)packed_w, (unsigned)tb, oscale, bias, y, ldy, M, N, K, 1, nmb, 0ll, 0ll, 0ll, g, ln_gamma, ln_beta, ln_eps);
-        else           hipLaunchKernelGGL((gemm_split_d_kernel<4, F16>), dim3(grid), dim3(256), 0, (hipStream_t)stream, x, ldx, (const uint4 *)packed_w, (unsigned)tb, oscale, bias, y, ldy, M, N, K, 1, nmb, 0ll, 0ll, 0ll, g, ln_gamma, ln_beta, ln_eps);
+        if (flags & 2) hipLaunchKernelGGL((gemm_split_d_kernel<6, F16>), dim3(grid), dim3(256), 0, (hipStream_t)stream, x, ldx, (const uint4 *)packed_w, (unsigned)tb, oscale, bias, y, ldy, M, N, K, 1, nmb, 0ll, 0ll, 0ll, g, ln_gamma, ln_beta, ln_eps, GdWindows{});
+        else           hipLaunchKernelGGL((gemm_split_d_kernel<4, F16>), dim3(grid), dim3(256), 0, (hipStream_t)stream, x, ldx, (const uint4 *)packed_w, (unsigned)tb, oscale, bias, y, ldy, M, N, K, 1, nmb, 0ll, 0ll, 0ll, g, ln_gamma, ln_beta, ln_eps, GdWindows{});
         CHECK_LAUNCH();
         return 0;
     }
@@ -918,11 +946,34 @@ static int gb_launch(const float *x, int ldx, const void *packed_w, const float 
         GB_SW(GB_GO)
 #undef GB_GO
     } else {
-#define GB_GO(F) hipLaunchKernelGGL((gemm_split_d_kernel<F, F16>), dim3(grid, (unsigned)nbatch), dim3(256), 0, st, x, ldx, wp, (unsigned)tb, oscale, bias, y, ldy, M, N, K, nnb, nmb, xs, ws, ys, F16 ? mfr_guard_current() : (int *)nullptr, (const float *)nullptr, (const float *)nullptr, 0.f)
+#define GB_GO(F) hipLaunchKernelGGL((gemm_split_d_kernel<F, F16>), dim3(grid, (unsigned)nbatch), dim3(256), 0, st, x, ldx, wp, (unsigned)tb, oscale, bias, y, ldy, M, N, K, nnb, nmb, xs, ws, ys, F16 ? mfr_guard_current() : (int *)nullptr, (const float *)nullptr, (const float *)nullptr, 0.f, GdWindows{})
         GB_SW(GB_GO)
 #undef GB_GO
     }
 #undef GB_SW
+    CHECK_LAUNCH();
+    return 0;
+}
+
+template <bool F16>
+static int gb_windows(const float *feat, int Bimg, int Hf, int Wf, int C, const int32_t *img_ids, const int32_t *cell_ids, int nwin, int wc, int stride, int win,
+                      const float *zero_row, const void *packed_w, const float *bias, const float *window_bias, float *y, int ldy, int N, void *stream)
+{
+    if (!feat || !img_ids || !cell_ids || !zero_row || !packed_w || !y || Bimg <= 0 || Hf <= 0 || Wf <= 0 || C <= 0 || (C % 64) || nwin < 0 || wc <= 0 || stride <= 0 ||
+        win <= 0 || N <= 0 || ldy < N || (((uintptr_t)feat | (uintptr_t)zero_row) & 15)) return MFR_E_ARG;
+    if (nwin == 0) return 0;
+    const long long Mll = (long long)nwin * win * win;
+    if (Mll > 0x7fffffffll) return MFR_E_ARG;
+    const int M = (int)Mll, K = C;
+    const size_t tb = gb_tile_bytes(N, K, F16);
+    if (tb >= 0xffffffffull) return MFR_E_ARG;
+    const int nnb = (N + GB_BN - 1) / GB_BN, nmb = (M + GB_BM - 1) / GB_BM;
+    const long long per_xcd = (long long)((nmb + 7) / 8) * nnb;
+    const unsigned grid = 8u * (unsigned)(per_xcd < 64 ? per_xcd : 64);
+    const float *oscale = F16 ? (const float *)((const char *)packed_w + tb) : nullptr;
+    GdWindows w{img_ids, cell_ids, zero_row, window_bias, wc, stride, Hf, Wf, win};
+    hipLaunchKernelGGL((gemm_split_d_kernel<8, F16>), dim3(grid), dim3(256), 0, (hipStream_t)stream, feat, C, (const uint4 *)packed_w, (unsigned)tb, oscale, bias, y, ldy, M, N, K,
+                       nnb, nmb, 0ll, 0ll, 0ll, F16 ? mfr_guard_current() : (int *)nullptr, (const float *)nullptr, (const float *)nullptr, 0.f, w);
     CHECK_LAUNCH();
     return 0;
 }
@@ -986,6 +1037,18 @@ int mfr_gemm_bf16x3(const float *x, int ldx, const void *packed_w, const float *
 int mfr_gemm_f16x2(const float *x, int ldx, const void *packed_w, const float *bias, float *y, int ldy, int M, int N, int K, int flags, void *stream)
 {
     return gb_launch<true>(x, ldx, packed_w, bias, y, ldy, M, N, K, flags, stream);
+}
+
+int mfr_gemm_f16x2_windows(const float *feat, int Bimg, int Hf, int Wf, int C, const int32_t *img_ids, const int32_t *cell_ids, int nwin, int wc, int stride, int win,
+                           const float *zero_row, const void *packed_w, const float *bias, const float *window_bias, float *y, int ldy, int N, void *stream)
+{
+    return gb_windows<true>(feat, Bimg, Hf, Wf, C, img_ids, cell_ids, nwin, wc, stride, win, zero_row, packed_w, bias, window_bias, y, ldy, N, stream);
+}
+
+int mfr_gemm_bf16x3_windows(const float *feat, int Bimg, int Hf, int Wf, int C, const int32_t *img_ids, const int32_t *cell_ids, int nwin, int wc, int stride, int win,
+                            const float *zero_row, const void *packed_w, const float *bias, const float *window_bias, float *y, int ldy, int N, void *stream)
+{
+    return gb_windows<false>(feat, Bimg, Hf, Wf, C, img_ids, cell_ids, nwin, wc, stride, win, zero_row, packed_w, bias, window_bias, y, ldy, N, stream);
 }
 
 int mfr_gemm_f16x2_ln(const float *x, int ldx, const void *packed_w, const float *bias, const float *gamma, const float *beta, float eps, float *y, int ldy,

@@ -27,6 +27,22 @@ class SplitLinear:
         _lib.check(self._pack(_lib.ptr(w), self.N, self.K, _lib.ptr(self.packed), _lib.stream_ptr()), f"mfr_gemm_{self.split}_pack")
         self.bias = None if bias is None else bias.contiguous().float()
 
+    def windows(self, feat_nhwc, img_ids, cell_ids, wc, stride, win, out, window_bias=None):
+        """out [nwin * win^2, N] (row-strided view) = tokens of the win x win windows of the NHWC map (zero padded) @ W^T (+ bias) (+ window_bias [nwin, N]
+        per window): mfr_gemm_*_windows -- the fine-level gather, the merge_feat product and the broadcast add in one launch"""
+        Bimg, Hf, Wf, C = feat_nhwc.shape
+        nwin = img_ids.numel()
+        assert C == self.K and feat_nhwc.is_contiguous() and out.shape == (nwin * win * win, self.N) and out.stride(1) == 1
+        assert img_ids.dtype == torch.int32 and cell_ids.dtype == torch.int32 and img_ids.is_contiguous() and cell_ids.is_contiguous()
+        assert window_bias is None or (window_bias.shape == (nwin, self.N) and window_bias.is_contiguous())
+        if getattr(self, "_zero_row", None) is None:
+            self._zero_row = torch.zeros(self.K, dtype=torch.float32, device=feat_nhwc.device)
+        lib = _lib.load()
+        _lib.check(getattr(lib, f"mfr_gemm_{self.split}_windows")(_lib.ptr(feat_nhwc), Bimg, Hf, Wf, C, _lib.ptr(img_ids), _lib.ptr(cell_ids), nwin, wc, stride, win,
+                                                                   _lib.ptr(self._zero_row), _lib.ptr(self.packed), _lib.ptr(self.bias), _lib.ptr(window_bias),
+                                                                   out.data_ptr(), out.stride(0), self.N, _lib.stream_ptr()), f"mfr_gemm_{self.split}_windows")
+        return out
+
     def ln_fusable(self):
         """can the LayerNorm that follows this layer run in its epilogue (mfr_gemm_*_ln: one 128-feature block, the LDS-DMA kernel)?"""
         return self.N == 128 and self.K % 64 == 0

@@ -369,9 +369,6 @@ class LoFTRHIP:
             Hf = ff_nhwc.shape[1]
             stride = Hf // hc
             WW = self.W * self.W
-            win = torch.empty(2 * M, WW, 128, dtype=torch.float32, device=dev)
-            self.gather_windows(ff_nhwc, (2 * b_ids).int(), mi.int(), wc, stride, out=win[:M])
-            self.gather_windows(ff_nhwc, (2 * b_ids + 1).int(), mj.int(), wc, stride, out=win[M:])
             # down_proj on the matched coarse features, merge_feat(cat[window, coarse]) = window Wa^T + (coarse Wb^T + b): the coarse half is
             # constant over the 25 taps.  All three products through csrc/gemm_split.hip (rounds 1-4: library GEMMs); the window product lands
             # in the left half of the fine transformer's [x | message] operand, the per-window constant is added in place.
@@ -383,9 +380,10 @@ class LoFTRHIP:
             lin_down, lin_coarse, lin_win = self._fine_lin
             cw = lin_coarse(lin_down(torch.cat([f0[b_ids, mi], f1[b_ids, mj]], 0)))
             xf = torch.empty(2, M * WW, 256, dtype=torch.float32, device=dev)
-            lin_win(win.view(2 * M * WW, 128), out=xf.view(2 * M * WW, 256)[:, :128])
-            xw = xf.view(2 * M, WW, 256)[..., :128]
-            xw += cw[:, None, :]
+            # round 6: the windows' tokens are read from the NHWC fine map inside the product and cw is added per window in its epilogue -- no gather
+            # kernel, no [2 M, 25, 128] window tensor, no broadcast add (upstream FinePreprocess: unfold -> gather -> merge_feat)
+            lin_win.windows(ff_nhwc, torch.cat([2 * b_ids, 2 * b_ids + 1]).int(), torch.cat([mi, mj]).int(), wc, stride, self.W,
+                            out=xf.view(2 * M * WW, 256)[:, :128], window_bias=cw)
             self._transformer(self.fine, xf, self.fine_attention if self.W == 5 else self._torch_linear_attention(8), M, WW)
             # FineMatching: centre-feature correlation, softmax, spatial expectation and the sub-pixel update in one kernel
             self.fine_match(xf, M, (b_ids * L0 + slot).int(), k1, pts1, float((self.W // 2) * (H // Hf)))

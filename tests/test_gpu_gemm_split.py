@@ -179,3 +179,32 @@ def test_linear_plus_layernorm_in_one_launch(split, M, K):
     want2 = keep[:, :128].double().cpu() + want
     assert ((xm[:, :128].double().cpu() - want2).abs() / (1 + want2.abs())).max().item() < 4e-6
     assert torch.equal(xm[:, 128:].double().cpu(), got)                             # the right half is not touched by the in-place update
+
+
+@pytest.mark.parametrize("split", ["f16x2", "bf16x3"])
+@pytest.mark.parametrize("nwin,with_bias", [(1, True), (7, False), (500, True), (2049, True)])
+def test_windowed_product_equals_gather_then_gemm_then_add(split, nwin, with_bias):
+    """mfr_gemm_*_windows (round 6, upstream FinePreprocess: unfold -> gather at the matches -> merge_feat): the 5x5 windows' tokens read from the NHWC
+    fine map inside the product + the per-window bias in the epilogue == mfr_loftr_gather_windows -> mfr_gemm_* -> broadcast add, bit for bit (same
+    operands, same K order, the same two roundings); windows at the map's border exercise the zero padding, 2049 windows a partial last row block"""
+    from mapfree_reloc_amd import _lib
+    from mapfree_reloc_amd.nets.linear import SplitLinear
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(nwin)
+    Bimg, Hf, Wf, C, wc, hc, stride, W = 4, 60, 44, 128, 11, 15, 4, 5
+    feat = torch.randn(Bimg, Hf, Wf, C, generator=g).to(DEV)
+    img = torch.randint(0, Bimg, (nwin,), generator=g).int().to(DEV)
+    cell = torch.randint(0, wc * hc, (nwin,), generator=g).int()
+    cell[0] = 0; cell[-1] = wc * hc - 1                                            # corners: two rows / columns of padding
+    cell = cell.to(DEV)
+    lin = SplitLinear((torch.randn(128, C, generator=g) / C ** 0.5).to(DEV), split=split)
+    cw = torch.randn(nwin, 128, generator=g).to(DEV) if with_bias else None
+    xf = torch.full((nwin * W * W, 256), 7.0, device=DEV)
+    lin.windows(feat, img, cell, wc, stride, W, out=xf[:, :128], window_bias=cw)
+    win = torch.empty(nwin, W * W, C, device=DEV)
+    _lib.check(lib.mfr_loftr_gather_windows(_lib.ptr(feat), Bimg, Hf, Wf, C, _lib.ptr(img), _lib.ptr(cell), nwin, wc, stride, W, _lib.ptr(win), _lib.stream_ptr()), "gather")
+    want = lin(win.view(nwin * W * W, C)).view(nwin, W * W, 128)
+    if cw is not None:
+        want = want + cw[:, None, :]
+    assert torch.equal(xf[:, :128], want.reshape(nwin * W * W, 128))
+    assert (xf[:, 128:] == 7.0).all()
