@@ -567,13 +567,24 @@ __global__ void __launch_bounds__(128) fine_attention_kernel(const float *__rest
     const float inv_len = 1.0f / FA_L;
     const float *kb = K + (size_t)win * FA_L * ld, *vb = V + (size_t)win * FA_L * ld, *qb = Q + (size_t)win * FA_L * ldq;
 
-    float kq[2][FA_L];
+    float kq[2][FA_L], qr0[FA_L], qr1[FA_L];
+    // round 6: the window's Q rows are requested together with K and V (150 loads in flight per lane) -- the kernel moves 51 KB per window at a few
+    // FMAs per byte, and loading Q only after the K^T V phase exposed the HBM latency a second time with nothing else of this wavefront in flight
 #pragma unroll
     for (int s = 0; s < FA_L; ++s) {
-        kq[0][s] = phi(kb[(size_t)s * ld + lane]);
-        kq[1][s] = phi(kb[(size_t)s * ld + 64 + lane]);
-        Xs[wv][s][lane] = vb[(size_t)s * ld + lane] * inv_len;
-        Xs[wv][s][64 + lane] = vb[(size_t)s * ld + 64 + lane] * inv_len;
+        kq[0][s] = kb[(size_t)s * ld + lane];
+        kq[1][s] = kb[(size_t)s * ld + 64 + lane];
+    }
+    float vr0[FA_L], vr1[FA_L];
+#pragma unroll
+    for (int s = 0; s < FA_L; ++s) { vr0[s] = vb[(size_t)s * ld + lane]; vr1[s] = vb[(size_t)s * ld + 64 + lane]; }
+#pragma unroll
+    for (int s = 0; s < FA_L; ++s) { qr0[s] = qb[(size_t)s * ldq + lane]; qr1[s] = qb[(size_t)s * ldq + 64 + lane]; }
+#pragma unroll
+    for (int s = 0; s < FA_L; ++s) {
+        kq[0][s] = phi(kq[0][s]); kq[1][s] = phi(kq[1][s]);
+        Xs[wv][s][lane] = vr0[s] * inv_len;
+        Xs[wv][s][64 + lane] = vr1[s] * inv_len;
     }
     __syncthreads();
     // KV[h][d = this lane's channel][v] = sum_s K[s][h,d] V[s][h,v]
@@ -604,8 +615,8 @@ __global__ void __launch_bounds__(128) fine_attention_kernel(const float *__rest
     __syncthreads();                                        // V fully consumed, KV / Ksum visible
 #pragma unroll
     for (int s = 0; s < FA_L; ++s) {
-        Xs[wv][s][lane] = phi(qb[(size_t)s * ldq + lane]);
-        Xs[wv][s][64 + lane] = phi(qb[(size_t)s * ldq + 64 + lane]);
+        Xs[wv][s][lane] = phi(qr0[s]);
+        Xs[wv][s][64 + lane] = phi(qr1[s]);
     }
     __syncthreads();
     // out[l][h, v = this lane] = (sum_d Q[l][h,d] KV[h][d][v]) / (sum_d Q[l][h,d] Ksum[h,d] + eps) * L

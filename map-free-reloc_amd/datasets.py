@@ -271,6 +271,7 @@ class MapFreeScene:
         self.scene_id = os.path.basename(self.scene_root.rstrip("/"))
         self.sample_factor, self.estimated_depth = sample_factor, estimated_depth
         self.poses, self.K = {}, {}
+        self._file_sizes = set()                                # (W, H) of the frames as intrinsics.txt lists them
         with open(os.path.join(self.scene_root, "poses.txt")) as f:
             for line in f:
                 if "#" in line:
@@ -284,6 +285,7 @@ class MapFreeScene:
                     continue
                 parts = line.strip().split(" ")
                 fx, fy, cx, cy, W, H = map(float, parts[1:])
+                self._file_sizes.add((int(W), int(H)))
                 K = np.array([[fx, 0, cx], [0, fy, cy], [0, 0, 1]], dtype=np.float32)
                 if resize is not None:
                     T = np.eye(3)
@@ -351,8 +353,8 @@ class MapFreeScene:
         return img, d
 
     def _gray_frame(self, rel, keep=False, out_g=None, out_d=None):
-        """(gray plane [h,w] f32, depth [h,w] f32 or None) of one frame as numpy arrays -- to_gray(image) / depth of _frame(rel), bit for bit,
-        without the float RGB image, decoded straight into out_g / out_d when given; keep=True: the same small least-recently-used cache as
+        """(gray plane [h,w] f32, depth [h,w] f32 or None) of one frame as numpy arrays -- to_gray(image) / depth of _frame(rel), bit for bit at
+        the file's own size (gray_pair, the only caller, refuses other sizes), without the float RGB image, decoded straight into out_g / out_d when given; keep=True: the same small least-recently-used cache as
         _frame under its own keys (the cached arrays are copied into out_g / out_d)"""
         path = os.path.join(self.scene_root, rel)
         dpath = path.replace(".jpg", f".{self.estimated_depth}.png") if self.estimated_depth is not None else None
@@ -383,12 +385,21 @@ class MapFreeScene:
 
     has_gray_pair = True        # the loaders' fast path (an explicit capability: subclasses whose pairs are not (frame, frame) switch it off)
 
+    def resize_is_native(self):
+        """is cfg's (W, H) the size the files have (Map-free: 540 x 720, config/mapfree.yaml)?  Only then is the gray plane route-independent: the
+        generic per-sample route resizes the 8-bit RGB image and takes the rounded luma of THAT (lib/datasets/utils.py:58-74 -> to_gray), the fast
+        route would take the luma first and resize the float gray image (SuperGlue's read_image order, matchers.py:101-104) -- different planes
+        whenever a resize really happens.  With a non-native size gray_pair() therefore returns None and every loader takes the generic
+        route, so the batched loaders, the reference-view cache and the per-pair plugin see ONE plane."""
+        return self.resize is None or all(sz == (int(self.resize[0]), int(self.resize[1])) for sz in self._file_sizes)
+
     def gray_pair(self, index, want_ref=True, out=None):
         """what the batched loaders need of sample `index`: (gray0 or None, depth0, gray1, depth1, K0, K1, pair_id, (name0, name1)), numpy arrays
-        with the values of to_gray(self[index]['image0' / 'image1']) and its depth maps.  out = (g0, d0, g1, d1) destination arrays (entries
+        with the values of to_gray(self[index]['image0' / 'image1']) and its depth maps -- bit for bit AT THE FILES' OWN SIZE, the only case this
+        route serves (resize_is_native(); otherwise None).  out = (g0, d0, g1, d1) destination arrays (entries
         may be None): the planes are then decoded / copied straight into them.  Returns None when this scene's images are not plain RGB reads
         (black_white training transform): the caller takes the generic sample then."""
-        if self.black_white:
+        if self.black_white or not self.resize_is_native():
             return None
         sa, ia, sb, ib = self.pairs[index]
         p1, p2 = f"seq{sa}/frame_{ia:05}.jpg", f"seq{sb}/frame_{ib:05}.jpg"
@@ -552,13 +563,13 @@ def to_gray(img):
     if img.shape[0] == 1:
         return img[0]
     if isinstance(img, torch.Tensor) and img.device.type != "cpu":
-        u = (img.float() * 255.0).round().to(torch.int32)
+        u = (img.detach().float() * 255.0).round().clamp_(0, 255).to(torch.int32)          # (values a hair outside [0, 1] must not wrap modulo 256)
         g8 = (u[0] * 19595 + u[1] * 38470 + u[2] * 7471 + 0x8000) >> 16
         return g8.to(torch.float32) / 255.0
     # numpy on the calling thread: torch's CPU elementwise kernels fan a 1.5 MB image out over every host core (256 on the
     # GPU boxes), which costs more in thread wake-ups than the arithmetic (measured ~20 ms vs < 1 ms per pair)
-    a = img.numpy() if isinstance(img, torch.Tensor) else np.asarray(img)
-    u8 = np.rint(a.astype(np.float32, copy=False) * np.float32(255)).astype(np.uint8)
+    a = img.detach().numpy() if isinstance(img, torch.Tensor) else np.asarray(img)
+    u8 = np.clip(np.rint(a.astype(np.float32, copy=False) * np.float32(255)), 0, 255).astype(np.uint8)
     return torch.from_numpy(gray_plane(np.moveaxis(u8, 0, -1)))
 
 

@@ -5,9 +5,13 @@ class M(resize: (W, H), outdoor: bool) with match(pair_path: (str, str)) -> ndar
 
 Image reading: the reference uses SuperGlue's read_image (cv2.imread GRAYSCALE, cv2.resize of the float
 image to (W,H), /255).  cv2 is not available offline: the file is decoded with PIL and the
-gray plane is datasets.gray_plane -- the ONE definition every route of this package shares (offline
-matchers, batched loaders, online plugin): ITU-R 601-2 luma rounded to a byte, cv2-style half-pixel
-bilinear resize of the float gray image when the size changes, / 255.  (Unpinned against OpenCV: libjpeg's
+gray plane is datasets.gray_plane: ITU-R 601-2 luma rounded to a byte, cv2-style half-pixel bilinear
+resize of the FLOAT gray image when the size changes, / 255.  At the files' own size (Map-free: 540 x 720 =
+config/mapfree.yaml) this is the ONE plane every route of the package feeds the matcher (offline matchers,
+batched loaders, online plugin: tests/test_gpu_routes_agree.py).  With a real resize the reference itself has
+two orders -- this offline reader resizes the gray image, its dataset class resizes the 8-bit RGB image
+(lib/datasets/utils.py:58-74) -- and so has this package: offline = here, every loader / plugin route = the
+dataset's order (datasets.MapFreeScene.resize_is_native, ADVICE r5).  (Unpinned against OpenCV: libjpeg's
 own grayscale output can differ from the luma of its RGB output by a grey level; tests/external/gen_cv_golden.py
 dumps cv2's planes for three JPEGs when run off-box.)
 

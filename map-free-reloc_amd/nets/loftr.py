@@ -163,7 +163,9 @@ class LoFTRHIP:
             self._ws_la = torch.empty(need, dtype=torch.uint8, device=q.device)
         out = torch.empty(B, L, D, dtype=torch.float32, device=q.device)
         base = kv.data_ptr()
-        _lib.check(lib.mfr_loftr_linear_attention(_lib.ptr(q), D, base, base + D * 4, 2 * D, B, L, heads, _lib.ptr(self._ws_la),
+        # q / kv may be column slices of one [B, L, 3 D] buffer (self layers): rows stay L * ld apart, only the row stride differs
+        assert q.stride(2) == 1 and kv.stride(2) == 1 and q.stride(0) == L * q.stride(1) and kv.stride(0) == L * kv.stride(1)
+        _lib.check(lib.mfr_loftr_linear_attention(q.data_ptr(), q.stride(1), base, base + D * 4, kv.stride(1), B, L, heads, _lib.ptr(self._ws_la),
                                                   self._ws_la.numel(), _lib.ptr(out), D, _lib.stream_ptr()),
                    "mfr_loftr_linear_attention")
         return out
@@ -173,10 +175,10 @@ class LoFTRHIP:
         (8 heads x 16, 5x5 windows), one wavefront per window (csrc/loftr.hip)"""
         lib = _lib.load()
         Bw, L, D = q.shape
-        q, kv = q.contiguous(), kv.contiguous()
+        assert q.stride(2) == 1 and kv.stride(2) == 1 and q.stride(0) == L * q.stride(1) and kv.stride(0) == L * kv.stride(1)
         out = torch.empty(Bw, L, D, dtype=torch.float32, device=q.device)
         base = kv.data_ptr()
-        _lib.check(lib.mfr_loftr_fine_attention(_lib.ptr(q), D, base, base + D * 4, 2 * D, Bw, L, D, 8, _lib.ptr(out), D,
+        _lib.check(lib.mfr_loftr_fine_attention(q.data_ptr(), q.stride(1), base, base + D * 4, kv.stride(1), Bw, L, D, 8, _lib.ptr(out), D,
                                                 _lib.stream_ptr()), "mfr_loftr_fine_attention")
         return out
 
@@ -261,9 +263,14 @@ class LoFTRHIP:
             from .linear import SplitLinear
             Lw["lq"], Lw["lkv"], Lw["lm"] = SplitLinear(Lw["wq"]), SplitLinear(Lw["wkv"]), SplitLinear(Lw["wm"])
             Lw["l1"], Lw["l2"] = SplitLinear(Lw["w1"]), SplitLinear(Lw["w2"])
-        q = Lw["lq"](x)
-        kv = Lw["lkv"](src)
-        msg = attn(q.view(nb, L, C), kv.view(nb, L, 2 * C))
+            Lw["lqkv"] = SplitLinear(torch.cat([Lw["wq"], Lw["wkv"]], 0))         # self layers: q | k | v from ONE pass over x (round 6)
+        if src.data_ptr() == x.data_ptr() and src.stride() == x.stride() and src.shape == x.shape:
+            qkv = Lw["lqkv"](x)                                                   # [n, 3 C]: the same rows feed q and k / v
+            msg = attn(qkv.view(nb, L, 3 * C)[..., :C], qkv.view(nb, L, 3 * C)[..., C:])
+        else:
+            q = Lw["lq"](x)
+            kv = Lw["lkv"](src)
+            msg = attn(q.view(nb, L, C), kv.view(nb, L, 2 * C))
         if Lw["lm"].ln_fusable() and n > 0:
             # d_model 128 (the fine level): both LayerNorms run in the epilogue of the linear layer before them (round 6: the rows are 2.4 M x 128
             # floats per tensor, every separate pass is its full HBM read + write)

@@ -182,6 +182,9 @@ class Trainer:
                     dist.broadcast(t.data, 0)
         elif self.world > 1:
             mb = int(getattr(self.cfg.TRAINING, "DDP_BUCKET_MB", 64))
+            # the heads' sticky NaN / Inf flag is per-rank state: DDP's buffer broadcast (rank 0 -> all, every forward) would clear a flag raised on
+            # another rank between two reads; BatchNorm's running statistics keep being broadcast
+            step._ddp_params_and_buffers_to_ignore = [n for n, _ in step.named_buffers() if n.endswith(".invalid") or n == "invalid"]
             step = nn.parallel.DistributedDataParallel(
                 step, device_ids=[self.device.index] if self.device.type == "cuda" else None,
                 bucket_cap_mb=mb, gradient_as_bucket_view=True, broadcast_buffers=True)

@@ -451,6 +451,43 @@ def test_gray_and_depth_planes_equal_the_reference_readers(tmp_path):
         D._HOST_LIB = False
 
 
+def test_loader_routes_agree_at_a_real_resize(tmp_path):
+    """with a NON-native cfg resize the fast loader route (luma first, float resize) and the per-sample route (8-bit RGB resize
+    first, rounded luma) are different planes, so the fast route must not be taken: gray_pair() returns None, and the batched loader delivers exactly
+    to_gray(sample image) -- the plane of the per-pair plugin -- for every pair; at the native size the fast route is taken and gives the same bytes"""
+    from PIL import Image
+    from mapfree_reloc_amd import datasets as D
+    rng = np.random.default_rng(3)
+    sc = tmp_path / "s00000"
+    (sc / "seq0").mkdir(parents=True); (sc / "seq1").mkdir()
+    names = ["seq0/frame_00000.jpg"] + [f"seq1/frame_{5 * k:05d}.jpg" for k in range(3)]
+    for nme in names:
+        Image.fromarray(rng.integers(0, 256, (96, 72, 3), dtype=np.uint8)).save(sc / nme, quality=95)
+    (sc / "poses.txt").write_text("\n".join(f"{n} 1 0 0 0 0 0 0" for n in names))
+    (sc / "intrinsics.txt").write_text("\n".join(f"{n} 60.0 60.0 35.5 47.5 72 96" for n in names))
+    D.clear_frame_cache()
+    for rs, native in (((72, 96), True), ((54, 72), False), (None, True)):
+        scene = D.MapFreeScene(str(sc), rs, sample_factor=1)
+        assert scene.resize_is_native() == native and (scene.gray_pair(0) is None) == (not native)
+        loader = D.PairBatchLoader([scene], 2, prefetch=1, pin=False, workers=2, decode="thread")
+        try:
+            got = [b for b in loader]
+        finally:
+            loader.close()
+        ims = np.concatenate([b["images"].numpy() for b in got])                   # [2 n, 1, h, w]
+        for i in range(len(scene)):
+            smp = scene[i]
+            assert np.array_equal(ims[2 * i, 0], D.to_gray(smp["image0"]).numpy()), (rs, i)
+            assert np.array_equal(ims[2 * i + 1, 0], D.to_gray(smp["image1"]).numpy()), (rs, i)
+        if not native:                                                              # ... and that is NOT what the fast route would have produced
+            fast = D.read_gray_plane(str(sc / names[1]), rs)
+            assert np.abs(fast - ims[1, 0]).max() > 0.5 / 255
+    # float inputs a hair outside [0, 1] clip instead of wrapping modulo 256 (ADVICE r5, low)
+    x = np.zeros((3, 2, 2), np.float32); x[:, 0, 0] = 1.0 + 3e-3; x[:, 1, 1] = -2e-3
+    g = D.to_gray(torch.from_numpy(x).requires_grad_(False)).numpy()
+    assert g[0, 0] == 1.0 and g[1, 1] == 0.0
+
+
 def test_gray_plane_is_byte_rounded_luma_on_every_route():
     """VERDICT r4 missing-4: the online / fused routes used to feed SuperPoint the UNROUNDED float luma while the offline route reads an 8-bit
     gray image.  Now to_gray (CPU numpy, torch CPU tensor) and the online plugin's stage give exactly float32(luma_u8) / 255."""
