@@ -74,6 +74,8 @@ def parse(argv=None):
                     "graph's static buffers every step), 0 = eager launches (default: at 8-32 pairs per step the eager step is GPU-bound, "
                     "measured 699 vs 694 pairs/s).  With 1 the roofline kernels are timed with HIP events over extra eager steps AFTER the "
                     "timed region (events cannot be recorded inside a replay).")
+    ap.add_argument("--overlap", type=int, default=1, help="1 (default): the RANSAC stage of step i runs on a second HIP stream under the matcher of step i + 1 "
+                    "(pipeline.SolverOverlap; every step's work is inside the timed region, which ends with a join + synchronize), 0: one stream")
     ap.add_argument("--hip-opt", action="append", default=[], metavar="NAME=VALUE", help="set a declared kernel-selection option (mapfree_reloc_amd/options.py), e.g. CONV_KERNEL=exact, RPR_CONV=miopen; repeatable")
     ap.add_argument("--rpr-opts", default="siamese,graph", help="rpr_train only, comma list: siamese (TRAINING.SIAMESE_BATCH: both images of a pair in one "
                     "encoder pass, BatchNorm statistics per view = the arithmetic of the reference's two encoder calls), graph (TRAINING.GRAPH_STEP: "
@@ -208,6 +210,7 @@ def parity_leg(wl, oracle_npz, dev):
     sb = IM.synthetic_batch(seeds, H, W)
     d = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in sb.items()}
     out = wl.run(d)
+    wl.pipe.join()
     torch.cuda.synchronize()
     o = {k: v.cpu().numpy() for k, v in out.items() if isinstance(v, torch.Tensor)}
     recs = []
@@ -263,10 +266,10 @@ class SgPnpWorkload:
     metric = "image-pairs/sec @ 540x720 (SuperPoint+SuperGlue + PnP w/ depth)"
     workload = "configs[1]: SuperPoint+SuperGlue matching + PnP w/ depth, 540x720"
 
-    def __init__(self, dev, B, timers, graph=False):
+    def __init__(self, dev, B, timers, graph=False, overlap=False):
         from mapfree_reloc_amd.pipeline import SuperGluePnPPipeline
         self.B = B
-        self.pipe = SuperGluePnPPipeline(dev, seed=0, graph=graph)
+        self.pipe = SuperGluePnPPipeline(dev, seed=0, graph=graph, overlap_solver=overlap)
         self.att_timer, self.conv_timer, self.sk_timer = KernelTimer(every=9), KernelTimer(every=1), KernelTimer(every=1)
         self.gemm_timer = KernelTimer(every=6)
         if timers:
@@ -391,10 +394,10 @@ class LoftrEmatWorkload:
     metric = "image-pairs/sec @ 540x720 (LoFTR + E-mat RANSAC w/ scale from depth)"
     workload = "configs[2]: LoFTR coarse-to-fine matching + Essential-matrix RANSAC + metric scale, 540x720 (padded to 544)"
 
-    def __init__(self, dev, B, timers):
+    def __init__(self, dev, B, timers, overlap=False):
         from mapfree_reloc_amd.pipeline import LoFTREmatPipeline
         self.B = B
-        self.pipe = LoFTREmatPipeline(dev, seed=0)
+        self.pipe = LoFTREmatPipeline(dev, seed=0, overlap_solver=overlap)
         self.conv_timer, self.cm_timer = KernelTimer(every=1), KernelTimer(every=1)
         if timers:
             lo = self.pipe.loftr
@@ -795,7 +798,9 @@ def main():
         sb = IM.synthetic_batch(seeds, H, W)
         batches.append({key: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for key, v in sb.items()})
     use_graph = args.config == "sg_pnp" and args.graph == 1
-    wl = SgPnpWorkload(dev, B, not args.no_kernel_timer, graph=use_graph) if args.config == "sg_pnp" else LoftrEmatWorkload(dev, B, not args.no_kernel_timer)
+    overlap = bool(args.overlap) and not use_graph
+    wl = (SgPnpWorkload(dev, B, not args.no_kernel_timer, graph=use_graph, overlap=overlap) if args.config == "sg_pnp"
+          else LoftrEmatWorkload(dev, B, not args.no_kernel_timer, overlap=overlap))
 
     def step(i):
         return wl.run(batches[i & 1])
@@ -809,6 +814,7 @@ def main():
 
     for i in range(args.warmup):
         out = step(i)
+    wl.pipe.join()
     if args.warmup > 0:
         # the collective is part of a step's tail: warm it up too (RCCL builds its channels on the first all_gather; at world 1 the
         # record-packing kernels load their code objects on first use: 48 ms measured inside the timed region otherwise)
@@ -832,6 +838,7 @@ def main():
             torch.cuda.synchronize()
             print(f"step {i}: host issue {hi:.1f} ms, done {1e3 * (time.perf_counter() - ts):.1f} ms", file=sys.stderr)
     # one gather of the per-pair pose records for the whole run
+    wl.pipe.join()                                         # (--overlap: this stream waits for the last solver stage before it reads any result)
     all_ids = torch.cat([r[0] for r in results])
     all_out = {k: torch.cat([r[1][k] for r in results]) for k in ("R", "t", "n_inliers", "status")}
     torch.cuda.synchronize()
@@ -869,7 +876,9 @@ def main():
         value = total_pairs / elapsed
         o = results[-1][1]
         cfg = {"workload": wl.workload, "pairs_per_gpu_per_step": B, "parallelism": f"pair-sharded x{world}",
-               "launch": "one captured HIP graph per step (static-input copies inside the step)" if use_graph else "eager kernel launches",
+               "launch": ("one captured HIP graph per step (static-input copies inside the step)" if use_graph else
+                          "eager kernel launches; the RANSAC stage of step i on a second HIP stream under the matcher of step i + 1 (one join before the gather)" if overlap
+                          else "eager kernel launches, one stream"),
                "pairs_solved_last_step": int((o["status"] == 0).sum()), "mean_matches_last_step": float(o["n_corr"].float().mean()),
                "gathered_records": int(rec.shape[0]), "synthetic_pose_error": _pose_error(o, batches[(args.steps - 1) & 1])}
         cfg.update(wl.config(o))

@@ -60,8 +60,14 @@ class RangeGuard:
                 return g.__exit__()
         return _Keep()
 
-    def fold(self, status):
-        return torch.where(self.flag > 0, torch.full_like(status, ST_RANGE), status) if self.active else status
+    def snapshot(self):
+        """a copy of the flag, made on the CURRENT stream right after the matcher stage: what a solver stage running on another stream folds into the
+        status while the next batch's matcher already clears and re-uses the flag itself"""
+        return self.flag.clone() if self.active else None
+
+    def fold(self, status, flag=None):
+        flag = self.flag if flag is None else flag
+        return torch.where(flag > 0, torch.full_like(status, ST_RANGE), status) if self.active else status
 
     def twin(self):
         if self._twin is None:
@@ -70,9 +76,49 @@ class RangeGuard:
         return self._twin
 
 
+class SolverOverlap:
+    """The solver stage of batch i on a SECOND HIP stream, so that it runs under the matcher stage of batch i + 1 (opt-in: `overlap_solver=True`).
+
+    The RANSAC kernels are latency-bound on small grids -- `pnp_select` is 32 wavefronts on a 1024-SIMD chip, `emat_roots` 16 k threads -- while the
+    matcher's convolutions fill the chip: run back to back on one stream the solver's 0.7 ms (SuperGlue + PnP) / 2.9 ms (LoFTR + E-mat) per step are
+    almost idle time.  Ordering: the side stream waits for an event recorded after the matcher stage; every tensor it reads that the main stream
+    produced is `record_stream`ed (the caching allocator must not recycle it early); successive solver stages are ordered by the side stream itself
+    (they share the solvers' workspaces).  The CONSUMER of the results must call `join()` (pipeline.join()) on the stream it reads them from --
+    bench.py does so once, before the gather that ends the timed region."""
+
+    def __init__(self, device):
+        self.stream = torch.cuda.Stream(device=device)
+        self.done, self._outs = None, []
+
+    def run(self, fn, consumed):
+        main = torch.cuda.current_stream()
+        ev = torch.cuda.Event()
+        ev.record(main)
+        with torch.cuda.stream(self.stream):
+            self.stream.wait_event(ev)
+            out = fn()
+        for t in consumed:
+            if isinstance(t, torch.Tensor) and t.is_cuda:
+                t.record_stream(self.stream)
+        self.done = torch.cuda.Event()
+        self.done.record(self.stream)
+        self._outs = [t for t in out.values() if isinstance(t, torch.Tensor) and t.is_cuda]
+        return out
+
+    def join(self):
+        if self.done is not None:
+            cur = torch.cuda.current_stream()
+            cur.wait_event(self.done)
+            for t in self._outs:                      # allocated on the side stream, read on this one from here on
+                t.record_stream(cur)
+            self.done, self._outs = None, []
+
+
 def rerun_out_of_range(pipe, out, *args, **kw):
     """out = pipe(*args, **kw) came back: if the range guard marked the batch (status ST_RANGE; reading it synchronises with the device, so call this
     where the results are read anyway), run the batch again in the exact bf16x3 arithmetic and hand out THAT result"""
+    if hasattr(pipe, "join"):
+        pipe.join()
     g = getattr(pipe, "guard", None)
     if g is None or not g.active or not bool((out["status"] == ST_RANGE).any()):
         return out
@@ -83,8 +129,9 @@ def rerun_out_of_range(pipe, out, *args, **kw):
 
 class SuperGluePnPPipeline:
     def __init__(self, device="cuda", sp_state=None, sg_state=None, max_keypoints=1024,
-                 pnp_iters=1000, pnp_thr=3.0, pnp_conf=0.9999, seed=0, graph=False):
-        """graph=True: the whole step (SuperPoint x2 -> SuperGlue -> lift -> PnP-RANSAC, ~330 kernel launches) is captured once
+                 pnp_iters=1000, pnp_thr=3.0, pnp_conf=0.9999, seed=0, graph=False, overlap_solver=False):
+        """overlap_solver=True: the PnP stage runs on a second stream under the next call's matcher (SolverOverlap; call join() before reading results).
+        graph=True: the whole step (SuperPoint x2 -> SuperGlue -> lift -> PnP-RANSAC, ~330 kernel launches) is captured once
         per batch shape and replayed as ONE HIP graph; inputs are copied into the graph's static buffers on every call and the
         (small) results are handed out as copies (nets/graph.py)."""
         _lib.load(require_gpu=True)
@@ -95,6 +142,12 @@ class SuperGluePnPPipeline:
         self.pnp = PnPBatchSolver(pnp_iters, pnp_thr, pnp_conf, seed)
         self.K = max_keypoints
         self.guard = RangeGuard(self.device, lambda: SuperGluePnPPipeline(device, sp_state, sg_state, max_keypoints, pnp_iters, pnp_thr, pnp_conf, seed, False))
+        self._ov = SolverOverlap(self.device) if (overlap_solver and not graph) else None
+
+    def join(self):
+        """make the current stream wait for the solver stage of the last call (only needed with overlap_solver=True)"""
+        if self._ov is not None:
+            self._ov.join()
 
     @torch.no_grad()
     def match(self, images):
@@ -124,8 +177,17 @@ class SuperGluePnPPipeline:
     def _run(self, images, depth0, K0, K1, pair_ids, want_mask=False):
         with self.guard:
             m = self.match(images)
-        out = self.pnp(m["pts0"], m["pts1"], m["n_corr"], depth0, K0, K1, pair_ids, want_mask=want_mask)
-        out["status"] = self.guard.fold(out["status"])
+        if self._ov is not None:
+            bad = self.guard.snapshot()
+
+            def solve():
+                o = self.pnp(m["pts0"], m["pts1"], m["n_corr"], depth0, K0, K1, pair_ids, want_mask=want_mask)
+                o["status"] = self.guard.fold(o["status"], bad)
+                return o
+            out = self._ov.run(solve, [m["pts0"], m["pts1"], m["n_corr"], bad, depth0, K0, K1, pair_ids])
+        else:
+            out = self.pnp(m["pts0"], m["pts1"], m["n_corr"], depth0, K0, K1, pair_ids, want_mask=want_mask)
+            out["status"] = self.guard.fold(out["status"])
         out["n_corr"] = m["n_corr"]
         out["pts0"], out["pts1"], out["n_kpts"] = m["pts0"], m["pts1"], m["n_kpts"]
         return out
@@ -137,7 +199,7 @@ class LoFTREmatPipeline:
     CONFIDENCE 0.9999), one device-resident pass over a batch of pairs.  Replaces
     LoFTR_matcher.match (matchers.py:24-59) + EssentialMatrixMetricSolver (pose_solver.py:115-172)."""
 
-    def __init__(self, device="cuda", loftr_state=None, pix_thr=2.0, scale_thr=0.1, conf=0.9999, seed=0, pad_to=8, emat_score="magsac"):
+    def __init__(self, device="cuda", loftr_state=None, pix_thr=2.0, scale_thr=0.1, conf=0.9999, seed=0, pad_to=8, emat_score="magsac", overlap_solver=False):
         from .nets.loftr import LoFTRHIP
         from .solver_ops import EssentialBatchSolver, ScaleFromDepthBatch
         _lib.load(require_gpu=True)
@@ -147,6 +209,11 @@ class LoFTREmatPipeline:
         self.scale = ScaleFromDepthBatch(scale_thr)
         self.pad_to = pad_to
         self.guard = RangeGuard(self.device, lambda: LoFTREmatPipeline(device, loftr_state, pix_thr, scale_thr, conf, seed, pad_to, emat_score))
+        self._ov = SolverOverlap(self.device) if overlap_solver else None      # E-mat + scale stage under the next call's matcher; join() before reading
+
+    def join(self):
+        if self._ov is not None:
+            self._ov.join()
 
     @torch.no_grad()
     def match(self, images):
@@ -161,12 +228,17 @@ class LoFTREmatPipeline:
     def __call__(self, images, depth0, depth1, K0, K1, pair_ids):
         with self.guard:
             m = self.match(images)
-        e = self.emat(m["pts0"], m["pts1"], m["n_corr"], K0, K1, pair_ids)
-        s = self.scale(m["pts0"], m["pts1"], e["mask"], m["n_corr"], depth0, depth1, K0, K1, e["R"], e["t"], e["status"])
-        s["status"] = self.guard.fold(s["status"])
-        return dict(R=torch.where((s["status"] == 0)[:, None, None], e["R"], torch.full_like(e["R"], float("nan"))),
-                    t=s["t_metric"], n_inliers=s["n_inliers"], status=s["status"], n_corr=m["n_corr"],
-                    emat_inliers=e["n_inliers"], pts0=m["pts0"], pts1=m["pts1"], emat_mask=e["mask"])
+        bad = self.guard.snapshot() if self._ov is not None else None
+
+        def solve():
+            e = self.emat(m["pts0"], m["pts1"], m["n_corr"], K0, K1, pair_ids)
+            s = self.scale(m["pts0"], m["pts1"], e["mask"], m["n_corr"], depth0, depth1, K0, K1, e["R"], e["t"], e["status"])
+            s["status"] = self.guard.fold(s["status"], bad)
+            return dict(R=torch.where((s["status"] == 0)[:, None, None], e["R"], torch.full_like(e["R"], float("nan"))),
+                        t=s["t_metric"], n_inliers=s["n_inliers"], status=s["status"], emat_inliers=e["n_inliers"], emat_mask=e["mask"])
+        out = self._ov.run(solve, [m["pts0"], m["pts1"], m["n_corr"], bad, depth0, depth1, K0, K1, pair_ids]) if self._ov is not None else solve()
+        out.update(n_corr=m["n_corr"], pts0=m["pts0"], pts1=m["pts1"])
+        return out
 
 
 # ---------------------------------------------------------------------------------------------------------------
