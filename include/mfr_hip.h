@@ -290,6 +290,14 @@ int mfr_gemm_f16x2_windows(const float *feat, int Bimg, int Hf, int Wf, int C, c
                            const float *zero_row, const void *packed_w, const float *bias, const float *window_bias, float *y, int ldy, int N, void *stream);
 int mfr_gemm_bf16x3_windows(const float *feat, int Bimg, int Hf, int Wf, int C, const int32_t *img_ids, const int32_t *cell_ids, int nwin, int wc, int stride, int win,
                             const float *zero_row, const void *packed_w, const float *bias, const float *window_bias, float *y, int ldy, int N, void *stream);
+/*   mfr_mlp_ln_f16x2 / mfr_mlp_ln_bf16x3 (round 6): y = [y +] LayerNorm_128( relu(x W1^T + b1) W2^T + b2 ) * gamma + beta in ONE launch: the MLP + norm2 +
+ *                          residual of upstream LoFTREncoderLayer.forward at d_model 128 (`message = self.mlp(cat[x, message])`, `self.norm2`, `x + message`;
+ *                          call site matchers.py:50).  x [M, K1] (K1 % 64 == 0; the fine level: 256 = [x | message]); W1 [256, K1] and W2 [128, 256] packed by
+ *                          mfr_gemm_*_pack; the 256 hidden activations of a 128-row tile never leave the chip.  accumulate != 0: y += (in place residual). */
+int mfr_mlp_ln_f16x2(const float *x, int ldx, int K1, const void *packed_w1, const float *b1, const void *packed_w2, const float *b2, const float *gamma, const float *beta,
+                     float eps, float *y, int ldy, int M, int accumulate, void *stream);
+int mfr_mlp_ln_bf16x3(const float *x, int ldx, int K1, const void *packed_w1, const float *b1, const void *packed_w2, const float *b2, const float *gamma, const float *beta,
+                      float eps, float *y, int ldy, int M, int accumulate, void *stream);
 size_t mfr_gemm_bf16x3_pack_bytes(int N, int K);
 int mfr_gemm_bf16x3_pack(const float *w, int N, int K, void *packed, void *stream);
 int mfr_gemm_bf16x3(const float *x, int ldx, const void *packed_w, const float *bias, float *y, int ldy, int M, int N, int K, int flags, void *stream);

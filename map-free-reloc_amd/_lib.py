@@ -51,6 +51,8 @@ SIGNATURES = {
     "mfr_conv_igemm_f16x2_upadd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "mfr_gemm_f16x2_windows": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "mfr_gemm_bf16x3_windows": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "mfr_mlp_ln_f16x2": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, C.c_float, _vp, _i, _i, _i, _vp]),
+    "mfr_mlp_ln_bf16x3": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, C.c_float, _vp, _i, _i, _i, _vp]),
     "mfr_gemm_f16x2_ln": (_i, [_vp, _i, _vp, _vp, _vp, _vp, C.c_float, _vp, _i, _i, _i, _i, _i, _vp]),
     "mfr_gemm_bf16x3_ln": (_i, [_vp, _i, _vp, _vp, _vp, _vp, C.c_float, _vp, _i, _i, _i, _i, _i, _vp]),
     "mfr_gemm_bf16x3_pack_bytes": (_sz, [_i, _i]),

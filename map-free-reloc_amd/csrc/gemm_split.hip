@@ -702,6 +702,305 @@ __global__ void __launch_bounds__(256, 2) gemm_split_d_kernel(const float *__res
 #undef GD_TILE
 }
 
+// ---- round 6: the MLP of a fine-level LoFTR encoder layer in ONE kernel ------------------------------------------------------------------------
+// Upstream LoFTREncoderLayer.forward (un-vendored; call site matchers.py:50):  message = mlp(cat[x, message]); message = norm2(message);
+// return x + message  with  mlp = Linear(2 C, 2 C, no bias) -> ReLU -> Linear(2 C, C, no bias),  C = 128 at the fine level.  As separate launches the
+// hidden activations (2.4 M rows x 256 floats per 16 pairs) are written and read back once, and the input is read by one kernel and the residual by the
+// next: 8 row-tensor passes where the arithmetic needs 3 (input, residual = its left half, output).  Here a workgroup keeps a 128-row tile on chip:
+//   for each 128-feature half h of the hidden layer:
+//     phase 1  hid_h^T = W1[h] X^T            K1 / 32 steps of gemm_split_d_kernel's pipeline (X through registers two steps ahead, W by LDS-DMA one
+//                                             step ahead) with the MFMA operands SWAPPED: the accumulators hold hidden FEATURES along the registers and
+//                                             rows along the lanes -- the layout in which a thread owns runs of 4 consecutive features of one row;
+//     scale / bias / ReLU in registers; v_permlane32_swap pairs the two half-wavefronts' runs into 8 consecutive features per lane;
+//     phase 2  out += hid_h W2[:, h]^T        4 steps: the wavefronts that own the step's 32 hidden features split them (split_f16.h) into the X stage
+//                                             of LDS -- exactly the image gb_xsplit_store makes of 8 consecutive K elements of a row -- and all four
+//                                             wavefronts multiply it with the W2 tile the DMA stream delivered (standard operand roles);
+//   epilogue: LayerNorm over the 128 outputs (+ residual) as in gemm_split_d_kernel<FLAGS & 4>.
+// The W stream is the same 2 (K1 / 32 + 4) tile images for every row tile (W1 half 0, W2 first half, W1 half 1, W2 second half): 384 KB per tile from L2.
+// Every output element is the same sum of the same products in the same order as the two-launch path, so the result agrees with it to the rounding of
+// the MFMA's internal adder under operand exchange (tests/test_gpu_gemm_split.py holds both to the float64 bars).
+template <bool F16>
+__device__ __forceinline__ void gb_products_t(f32x16 (&acc)[2][2], const GbFrag (&a)[2][3], const GbFrag (&b)[2][3])
+{
+    // acc[fi][rj] (features x rows) += W-fragment fi (first operand) x X-fragment rj (second operand); same term order as gb_products
+#define GB_T4(ta, tb) do { \
+        if (F16) { acc[0][0] = SF_MFMA(b[0][tb].q, a[0][ta].q, acc[0][0]); acc[0][1] = SF_MFMA(b[0][tb].q, a[1][ta].q, acc[0][1]); \
+                   acc[1][0] = SF_MFMA(b[1][tb].q, a[0][ta].q, acc[1][0]); acc[1][1] = SF_MFMA(b[1][tb].q, a[1][ta].q, acc[1][1]); } \
+        else     { acc[0][0] = GB_MFMA_BF(b[0][tb].v, a[0][ta].v, acc[0][0]); acc[0][1] = GB_MFMA_BF(b[0][tb].v, a[1][ta].v, acc[0][1]); \
+                   acc[1][0] = GB_MFMA_BF(b[1][tb].v, a[0][ta].v, acc[1][0]); acc[1][1] = GB_MFMA_BF(b[1][tb].v, a[1][ta].v, acc[1][1]); } } while (0)
+    if (F16) { GB_T4(1, 2); GB_T4(0, 1); GB_T4(0, 0); }
+    else     { GB_T4(1, 1); GB_T4(0, 2); GB_T4(2, 0); GB_T4(0, 1); GB_T4(1, 0); GB_T4(0, 0); }
+#undef GB_T4
+}
+
+static __device__ __forceinline__ void gb_swap32(float &a, float &b) { asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+
+template <bool F16, bool ACC>
+__global__ void __launch_bounds__(256, 2) mlp_ln_kernel(const float *__restrict__ X, int ldx, int K1,
+                                                        const uint4 *__restrict__ W1p, unsigned w1_bytes, const float *__restrict__ os1, const float *__restrict__ b1,
+                                                        const uint4 *__restrict__ W2p, unsigned w2_bytes, const float *__restrict__ os2, const float *__restrict__ b2,
+                                                        const float *__restrict__ ln_gamma, const float *__restrict__ ln_beta, float ln_eps,
+                                                        float *__restrict__ Y, int ldy, int M, int nmb, int *guard)
+{
+    constexpr int XT = GB_XT(F16);
+    constexpr int WT = GB_WT(F16), WSTAGE = GD_WSTAGE(F16);
+    __shared__ uint4 lds[XT * GB_TERM_UNITS + 2 * WSTAGE];
+    __shared__ float lnx[512];
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid >> 1, wn = wid & 1;
+    const int nkb1 = K1 / GB_BK;                           // even (K1 % 64 == 0)
+    const int half_steps = nkb1 + 4, steps = 2 * half_steps;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
+    const int items = (nmb + 7) >> 3;
+    int j = slot;
+    if (j >= items || j * 8 + xcd >= nmb) return;
+    auto next_item = [&](int jj) { const int jn = jj + per_xcd; return (jn < items && jn * 8 + xcd < nmb) ? jn : jj; };
+
+    int xdst[2], xr[2], xk[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int u = tid + 256 * i;
+        xr[i] = u >> 2; xk[i] = 8 * (u & 3);
+        xdst[i] = (u & 3) * GB_KG_STRIDE + xr[i];
+    }
+    const int arow = (lane >> 5) * GB_KG_STRIDE + 64 * wm + (lane & 31);
+    const int brow = XT * GB_TERM_UNITS + (lane >> 5) * 128 + 64 * wn + (lane & 31);
+    const unsigned rowb = (unsigned)ldy * 4u;
+
+    // W stream: the same `steps` tile images for every row tile
+    typedef unsigned gd_u32x4 __attribute__((ext_vector_type(4)));
+    gd_u32x4 wdesc1, wdesc2;
+    wdesc1.x = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)W1p);
+    wdesc1.y = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)W1p >> 32) & 0xffffu);
+    wdesc1.z = w1_bytes; wdesc1.w = GB_RSRC_FLAGS;
+    wdesc2.x = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)W2p);
+    wdesc2.y = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)W2p >> 32) & 0xffffu);
+    wdesc2.z = w2_bytes; wdesc2.w = GB_RSRC_FLAGS;
+    const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) uint4 *)lds;
+    const unsigned lane16 = 16u * (unsigned)lane;
+    int wstep = 0;
+    auto wdma = [&](int stage) {
+        const int half = wstep >= half_steps ? 1 : 0, r = wstep - half * half_steps;
+        const bool first = r < nkb1;
+        const unsigned img = (unsigned)(first ? half * nkb1 + r : 4 * half + (r - nkb1)) * (unsigned)(WSTAGE * 16);
+#pragma unroll
+        for (int q = 0; q < 2 * WT; ++q) {
+            const unsigned so = __builtin_amdgcn_readfirstlane(img + (unsigned)(64 * (wid + 4 * q)) * 16u);
+            const unsigned m0v = __builtin_amdgcn_readfirstlane(lds0 + 16u * (unsigned)(XT * GB_TERM_UNITS + stage * WSTAGE + 64 * (wid + 4 * q)));
+            if (first) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" :: "s"(m0v), "v"(lane16), "s"(wdesc1), "s"(so) : "memory");
+            else       asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" :: "s"(m0v), "v"(lane16), "s"(wdesc2), "s"(so) : "memory");
+        }
+        if (++wstep == steps) wstep = 0;
+    };
+    // X stream (registers, two steps ahead): the tile's K1 / 32 steps twice (once per hidden half), then the next tile
+    const float *lx0, *lx1;
+    int xstep = 0, lj = j;
+    auto x_tile_start = [&](int jj) {
+        const int mb = jj * 8 + xcd;
+        lx0 = X + (size_t)min(mb * GB_BM + xr[0], M - 1) * ldx + xk[0];
+        lx1 = X + (size_t)min(mb * GB_BM + xr[1], M - 1) * ldx + xk[1];
+    };
+    float4 xa0, xa1, xb0, xb1, xc0, xc1, xd0, xd1;
+#define ML_XLOAD(p0, p1, q0, q1) do { \
+        p0 = *(const float4 *)lx0; p1 = *(const float4 *)(lx0 + 4); q0 = *(const float4 *)lx1; q1 = *(const float4 *)(lx1 + 4); \
+        lx0 += GB_BK; lx1 += GB_BK; ++xstep; \
+        if (xstep == nkb1) { lx0 -= K1; lx1 -= K1; } \
+        else if (xstep == 2 * nkb1) { xstep = 0; lj = next_item(lj); x_tile_start(lj); } } while (0)
+
+    f32x16 acc1[2][2], acc2[2][2];
+#define ML_SOFF(i, r) ((unsigned)(32 * (i) + ((r) & 3) + 8 * ((r) >> 2)) * rowb)
+    // phase-1 step of parity P (X register set P, W stage P); FIRST: no X loads of a previous phase-1 step are in flight behind this step's DMA
+#define ML_STEP1(P, p0, p1, q0, q1, FIRST) do { \
+        __syncthreads(); \
+        gb_xsplit_store<F16>(lds, p0, p1, xdst[0]); gb_xsplit_store<F16>(lds, q0, q1, xdst[1]); \
+        wdma((P) ^ 1); ML_XLOAD(p0, p1, q0, q1); \
+        if (FIRST) GD_VMCNT(4 + 2 * WT); else GD_VMCNT(8 + 2 * WT); \
+        __syncthreads(); \
+        __builtin_amdgcn_sched_barrier(0); \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) { \
+            GbFrag a[2][3], b[2][3]; \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i) { \
+                _Pragma("unroll") for (int t = 0; t < XT; ++t) a[i][t].q = lds[t * GB_TERM_UNITS + 2 * ks * GB_KG_STRIDE + arow + 32 * i]; \
+                _Pragma("unroll") for (int t = 0; t < WT; ++t) b[i][t].q = lds[(P) * WSTAGE + t * 512 + 2 * ks * 128 + brow + 32 * i]; \
+                if (F16) b[i][2].q = gb_wq(b[i][0].q); } \
+            gb_products_t<F16>(acc1, a, b); } } while (0)
+
+    x_tile_start(j);
+    wdma(0);
+    ML_XLOAD(xa0, xa1, xb0, xb1);
+    ML_XLOAD(xc0, xc1, xd0, xd1);
+    const float g0 = ln_gamma[64 * wn + (lane & 31)], g1 = ln_gamma[64 * wn + 32 + (lane & 31)];
+    const float be0 = ln_beta[64 * wn + (lane & 31)], be1 = ln_beta[64 * wn + 32 + (lane & 31)];
+    for (;;) {
+        const int mb = j * 8 + xcd, m0 = mb * GB_BM;
+        const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void *)(Y + (size_t)m0 * ldy), 0, (int)((unsigned)min(GB_BM, M - m0) * rowb), GB_RSRC_FLAGS);
+        const int n0 = 64 * wn + (lane & 31);
+        const unsigned yoff = (unsigned)(64 * wm + 4 * (lane >> 5)) * rowb + 4u * (unsigned)n0;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc2[i][jj][r] = 0.f;
+        float chk = 0.f;
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc1[i][jj][r] = 0.f;
+            ML_STEP1(0, xa0, xa1, xb0, xb1, true);
+            ML_STEP1(1, xc0, xc1, xd0, xd1, false);
+            for (int kb = 2; kb < nkb1; kb += 2) { ML_STEP1(0, xa0, xa1, xb0, xb1, false); ML_STEP1(1, xc0, xc1, xd0, xd1, false); }
+            // range guard (guard.h): an out-of-range x poisons every hidden feature of its row: one register per (feature block 0, row block)
+            if (F16 && guard) { MFR_GUARD_ACC(chk, acc1[0][0][0]); MFR_GUARD_ACC(chk, acc1[0][1][0]); }
+            // scale / bias / ReLU: register r of acc1[fi][rj] is hidden feature 128 h + 64 wn + 32 fi + (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+#pragma unroll
+            for (int fi = 0; fi < 2; ++fi)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int f = 128 * h + 64 * wn + 32 * fi + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    const float bv = b1 ? b1[f] : 0.f;
+                    const float os = F16 ? os1[f] : 1.0f;
+#pragma unroll
+                    for (int rj = 0; rj < 2; ++rj) {
+                        const float v = F16 ? __builtin_fmaf(acc1[fi][rj][r], os, bv) : acc1[fi][rj][r] + bv;
+                        acc1[fi][rj][r] = fmaxf(v, 0.f);
+                    }
+                }
+            // pair the half-wavefronts' runs: afterwards a lane of half hl holds, for g' = 0, 1, the 8 consecutive features of k group g' + 2 hl in
+            // registers 4 g' .. 4 g' + 3 (features 8 kg .. + 3) and 8 + 4 g' .. 8 + 4 g' + 3 (features 8 kg + 4 .. + 7)
+#pragma unroll
+            for (int fi = 0; fi < 2; ++fi)
+#pragma unroll
+                for (int rj = 0; rj < 2; ++rj)
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) {
+                        float a_ = acc1[fi][rj][r], b_ = acc1[fi][rj][r + 8];
+                        gb_swap32(a_, b_);
+                        acc1[fi][rj][r] = a_; acc1[fi][rj][r + 8] = b_;
+                    }
+            // phase 2: out += hid_h W2[:, 128 h + 32 c .. + 32)^T, c = 0 .. 3 (W stage = c & 1)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                __syncthreads();
+                if (wn == (c >> 1)) {
+                    const int fi = c & 1;
+#pragma unroll
+                    for (int rj = 0; rj < 2; ++rj)
+#pragma unroll
+                        for (int gq = 0; gq < 2; ++gq) {
+                            const float4 p = make_float4(acc1[fi][rj][4 * gq], acc1[fi][rj][4 * gq + 1], acc1[fi][rj][4 * gq + 2], acc1[fi][rj][4 * gq + 3]);
+                            const float4 q = make_float4(acc1[fi][rj][8 + 4 * gq], acc1[fi][rj][9 + 4 * gq], acc1[fi][rj][10 + 4 * gq], acc1[fi][rj][11 + 4 * gq]);
+                            gb_xsplit_store<F16>(lds, p, q, (gq + 2 * (lane >> 5)) * GB_KG_STRIDE + 64 * wm + 32 * rj + (lane & 31));
+                        }
+                }
+                wdma((c & 1) ^ 1);
+                GD_VMCNT(2 * WT);
+                __syncthreads();
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    GbFrag a[2][3], b[2][3];
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+                        for (int t = 0; t < XT; ++t) a[i][t].q = lds[t * GB_TERM_UNITS + 2 * ks * GB_KG_STRIDE + arow + 32 * i];
+#pragma unroll
+                        for (int t = 0; t < WT; ++t) b[i][t].q = lds[(c & 1) * WSTAGE + t * 512 + 2 * ks * 128 + brow + 32 * i];
+                        if (F16) b[i][2].q = gb_wq(b[i][0].q);
+                    }
+                    gb_products<F16>(acc2, a, b);
+                }
+            }
+        }
+        // ---- epilogue: out = acc2 / scale + bias -> LayerNorm (+ residual) -> Y
+        unsigned ov[2][2][16];
+        if (ACC) {
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) ov[i][jj][r] = __builtin_amdgcn_raw_buffer_load_b32(ry, yoff + 128u * jj, ML_SOFF(i, r), 0);
+        }
+        if (F16 && guard) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) MFR_GUARD_ACC(chk, acc2[i][0][r]);
+            mfr_guard_commit(guard, chk);
+        }
+        {
+            const float bv0 = b2 ? b2[n0] : 0.f, bv1 = b2 ? b2[n0 + 32] : 0.f;
+            const float os0 = F16 ? os2[n0] : 1.f, os1v = F16 ? os2[n0 + 32] : 1.f;
+            float part[2][16];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    acc2[i][0][r] = F16 ? __builtin_fmaf(acc2[i][0][r], os0, bv0) : acc2[i][0][r] + bv0;
+                    acc2[i][1][r] = F16 ? __builtin_fmaf(acc2[i][1][r], os1v, bv1) : acc2[i][1][r] + bv1;
+                    part[i][r] = acc2[i][0][r] + acc2[i][1][r];
+                }
+#pragma unroll
+            for (int m = 1; m <= 16; m <<= 1)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) part[i][r] += __shfl_xor(part[i][r], m, 64);
+#define ML_LNROW(i, r) (64 * wm + 32 * (i) + ((r) & 3) + 8 * ((r) >> 2) + 4 * (lane >> 5))
+            if ((lane & 31) == 0) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) lnx[wn * 128 + ML_LNROW(i, r)] = part[i][r];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float mean = (lnx[ML_LNROW(i, r)] + lnx[128 + ML_LNROW(i, r)]) * (1.0f / 128.0f);
+                    acc2[i][0][r] -= mean; acc2[i][1][r] -= mean;
+                    part[i][r] = acc2[i][0][r] * acc2[i][0][r] + acc2[i][1][r] * acc2[i][1][r];
+                }
+#pragma unroll
+            for (int m = 1; m <= 16; m <<= 1)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) part[i][r] += __shfl_xor(part[i][r], m, 64);
+            if ((lane & 31) == 0) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) lnx[256 + wn * 128 + ML_LNROW(i, r)] = part[i][r];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float rstd = rsqrtf((lnx[256 + ML_LNROW(i, r)] + lnx[384 + ML_LNROW(i, r)]) * (1.0f / 128.0f) + ln_eps);
+                    float y0 = acc2[i][0][r] * rstd * g0 + be0, y1 = acc2[i][1][r] * rstd * g1 + be1;
+                    if (ACC) { y0 = __builtin_bit_cast(float, ov[i][0][r]) + y0; y1 = __builtin_bit_cast(float, ov[i][1][r]) + y1; }
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y0), ry, yoff, ML_SOFF(i, r), 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y1), ry, yoff + 128u, ML_SOFF(i, r), 0);
+                }
+#undef ML_LNROW
+        }
+        const int jn = next_item(j);
+        if (jn == j) break;
+        j = jn;
+    }
+    GD_VMCNT(0);                                           // the streams' last (unused) DMA must not land in the LDS of the next workgroup
+#undef ML_STEP1
+#undef ML_SOFF
+#undef ML_XLOAD
+}
+
 // ---- implicit-GEMM convolution on NCHW images (round 5): what the matcher backbones' strided / 1x1 / 7x7 convolutions run ----------------------
 // Reference call site: LoFTR_matcher (etc/feature_matching_baselines/matchers.py:16-19,50) -> the un-vendored ResNet-FPN backbone: conv1 (7x7, stride 2,
 // 1 -> 128), the first 3x3 convolution and the 1x1 downsample of layer2.0 / layer3.0 (stride 2), the 1x1 lateral / output convolutions of the FPN
@@ -956,6 +1255,27 @@ static int gb_launch(const float *x, int ldx, const void *packed_w, const float 
 }
 
 template <bool F16>
+static int gb_mlp_ln(const float *x, int ldx, int K1, const void *packed_w1, const float *b1, const void *packed_w2, const float *b2, const float *gamma, const float *beta,
+                     float eps, float *y, int ldy, int M, int accumulate, void *stream)
+{
+    // hidden width 256 (two 128-feature blocks), output width 128: the fine-level LoFTR encoder layer (d_model 128)
+    if (!x || !packed_w1 || !packed_w2 || !gamma || !beta || !y || M <= 0 || K1 <= 0 || (K1 % 64) || (ldx & 3) || ldx < K1 || ldy < GB_BN || ((uintptr_t)x & 15)) return MFR_E_ARG;
+    const size_t tb1 = gb_tile_bytes(2 * GB_BN, K1, F16), tb2 = gb_tile_bytes(GB_BN, 2 * GB_BN, F16);
+    if (tb1 >= 0xffffffffull) return MFR_E_ARG;
+    const int nmb = (M + GB_BM - 1) / GB_BM;
+    const long long per_xcd = (long long)((nmb + 7) / 8);
+    const unsigned grid = 8u * (unsigned)(per_xcd < 64 ? per_xcd : 64);
+    const float *os1 = F16 ? (const float *)((const char *)packed_w1 + tb1) : nullptr, *os2 = F16 ? (const float *)((const char *)packed_w2 + tb2) : nullptr;
+    int *g = F16 ? mfr_guard_current() : (int *)nullptr;
+    if (accumulate) hipLaunchKernelGGL((mlp_ln_kernel<F16, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, x, ldx, K1, (const uint4 *)packed_w1, (unsigned)tb1, os1, b1,
+                                       (const uint4 *)packed_w2, (unsigned)tb2, os2, b2, gamma, beta, eps, y, ldy, M, nmb, g);
+    else            hipLaunchKernelGGL((mlp_ln_kernel<F16, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, x, ldx, K1, (const uint4 *)packed_w1, (unsigned)tb1, os1, b1,
+                                       (const uint4 *)packed_w2, (unsigned)tb2, os2, b2, gamma, beta, eps, y, ldy, M, nmb, g);
+    CHECK_LAUNCH();
+    return 0;
+}
+
+template <bool F16>
 static int gb_windows(const float *feat, int Bimg, int Hf, int Wf, int C, const int32_t *img_ids, const int32_t *cell_ids, int nwin, int wc, int stride, int win,
                       const float *zero_row, const void *packed_w, const float *bias, const float *window_bias, float *y, int ldy, int N, void *stream)
 {
@@ -1037,6 +1357,18 @@ int mfr_gemm_bf16x3(const float *x, int ldx, const void *packed_w, const float *
 int mfr_gemm_f16x2(const float *x, int ldx, const void *packed_w, const float *bias, float *y, int ldy, int M, int N, int K, int flags, void *stream)
 {
     return gb_launch<true>(x, ldx, packed_w, bias, y, ldy, M, N, K, flags, stream);
+}
+
+int mfr_mlp_ln_f16x2(const float *x, int ldx, int K1, const void *packed_w1, const float *b1, const void *packed_w2, const float *b2, const float *gamma, const float *beta,
+                     float eps, float *y, int ldy, int M, int accumulate, void *stream)
+{
+    return gb_mlp_ln<true>(x, ldx, K1, packed_w1, b1, packed_w2, b2, gamma, beta, eps, y, ldy, M, accumulate, stream);
+}
+
+int mfr_mlp_ln_bf16x3(const float *x, int ldx, int K1, const void *packed_w1, const float *b1, const void *packed_w2, const float *b2, const float *gamma, const float *beta,
+                      float eps, float *y, int ldy, int M, int accumulate, void *stream)
+{
+    return gb_mlp_ln<false>(x, ldx, K1, packed_w1, b1, packed_w2, b2, gamma, beta, eps, y, ldy, M, accumulate, stream);
 }
 
 int mfr_gemm_f16x2_windows(const float *feat, int Bimg, int Hf, int Wf, int C, const int32_t *img_ids, const int32_t *cell_ids, int nwin, int wc, int stride, int win,

@@ -95,3 +95,22 @@ class SplitBatchedNT:
         _lib.check(self.lib.mfr_gemm_f16x2_batched(x.data_ptr(), x.stride(1), x.stride(0), _lib.ptr(pk), None, out.data_ptr(), out.stride(1), out.stride(0),
                                                    nb, M, N, K, 0, st), "mfr_gemm_f16x2_batched")
         return out
+
+
+class FusedMlpLn:
+    """out = [out +] LayerNorm_128(relu(x W1^T + b1) W2^T + b2) in one launch (mfr_mlp_ln_*, csrc/gemm_split.hip mlp_ln_kernel): the MLP + norm2 (+ residual) of
+    a LoFTR encoder layer at d_model 128.  Built from the two SplitLinear objects of the layer (their packed weights are used as they are)."""
+
+    def __init__(self, lin1, lin2):
+        assert lin1.split == lin2.split and lin1.N == 256 and lin2.N == 128 and lin2.K == 256 and lin1.K % 64 == 0
+        self.l1, self.l2 = lin1, lin2
+        self._fn = getattr(_lib.load(require_gpu=True), f"mfr_mlp_ln_{lin1.split}")
+
+    def __call__(self, x, out, ln, accumulate=False, eps=1e-5):
+        assert x.dim() == 2 and x.shape[1] == self.l1.K and x.stride(1) == 1 and x.dtype == torch.float32
+        M = x.shape[0]
+        assert out.shape == (M, 128) and out.stride(1) == 1
+        _lib.check(self._fn(x.data_ptr(), x.stride(0), self.l1.K, _lib.ptr(self.l1.packed), _lib.ptr(self.l1.bias), _lib.ptr(self.l2.packed), _lib.ptr(self.l2.bias),
+                            _lib.ptr(ln[0]), _lib.ptr(ln[1]), float(eps), out.data_ptr(), out.stride(0), M, 1 if accumulate else 0, _lib.stream_ptr()),
+                   f"mfr_mlp_ln_{self.l1.split}")
+        return out

@@ -275,8 +275,10 @@ class LoFTRHIP:
             # d_model 128 (the fine level): both LayerNorms run in the epilogue of the linear layer before them (round 6: the rows are 2.4 M x 128
             # floats per tensor, every separate pass is its full HBM read + write)
             Lw["lm"](msg.view(n, C), out=xm[:, C:], ln=Lw["n1"])
-            hid = Lw["l1"](xm, relu=True)
-            Lw["l2"](hid, out=x, ln=Lw["n2"], accumulate=True)                     # x += norm2(mlp)
+            if "mlp" not in Lw:
+                from .linear import FusedMlpLn
+                Lw["mlp"] = FusedMlpLn(Lw["l1"], Lw["l2"])
+            Lw["mlp"](xm, out=x, ln=Lw["n2"], accumulate=True)                     # x += norm2(mlp([x | message])): hidden activations stay on chip
             return xm
         self.layernorm(Lw["lm"](msg.view(n, C)), Lw["n1"], xm[:, C:])
         hid = Lw["l1"](xm, relu=True)                                              # relu([x | message] W1^T) in the GEMM epilogue

@@ -208,3 +208,35 @@ def test_windowed_product_equals_gather_then_gemm_then_add(split, nwin, with_bia
         want = want + cw[:, None, :]
     assert torch.equal(xf[:, :128], want.reshape(nwin * W * W, 128))
     assert (xf[:, 128:] == 7.0).all()
+
+
+@pytest.mark.parametrize("split", ["f16x2", "bf16x3"])
+@pytest.mark.parametrize("M", [1, 127, 128, 1031, 40000])
+def test_fused_mlp_layernorm_residual(split, M):
+    """mfr_mlp_ln_* (round 6): x += LayerNorm_128(relu([x | msg] W1^T) W2^T) in ONE launch (upstream LoFTREncoderLayer: mlp -> norm2 -> residual, d_model
+    128) against float64 and against the two launches it replaces (mfr_gemm_* with ReLU, then mfr_gemm_*_ln): in place on the left half of the [x | message]
+    buffer as nets/loftr.py runs it; partial last row tile, single row, many tiles per workgroup (40000 rows = 313 tiles on a 512-workgroup grid)."""
+    import torch.nn.functional as F
+    from mapfree_reloc_amd.nets.linear import FusedMlpLn, SplitLinear
+    g = torch.Generator().manual_seed(M)
+    w1 = (torch.randn(256, 256, generator=g) / 16.0).to(DEV)
+    w2 = (torch.randn(128, 256, generator=g) / 16.0).to(DEV)
+    gam, bet = (1 + 0.3 * torch.randn(128, generator=g)).to(DEV), torch.randn(128, generator=g).to(DEV)
+    l1, l2 = SplitLinear(w1, split=split), SplitLinear(w2, split=split)
+    mlp = FusedMlpLn(l1, l2)
+    xm = torch.randn(M, 256, generator=g).to(DEV)
+    keep = xm.clone()
+    hid64 = (keep.double().cpu() @ w1.double().cpu().T).relu()
+    want = keep[:, :128].double().cpu() + F.layer_norm(hid64 @ w2.double().cpu().T, (128,), gam.double().cpu(), bet.double().cpu(), 1e-5)
+    two = keep.clone()
+    l2(l1(two, relu=True), out=two[:, :128], ln=(gam, bet), accumulate=True)
+    mlp(xm, out=xm[:, :128], ln=(gam, bet), accumulate=True)
+    assert torch.equal(xm[:, 128:], keep[:, 128:])
+    got = xm[:, :128].double().cpu()
+    assert ((got - want).abs() / (1 + want.abs())).max().item() < 6e-6, ((got - want).abs() / (1 + want.abs())).max().item()
+    assert ((got - two[:, :128].double().cpu()).abs() / (1 + want.abs())).max().item() < 6e-6
+    # without the residual, into a separate buffer
+    out = torch.full((M, 128), 3.0, device=DEV)
+    mlp(keep, out=out, ln=(gam, bet))
+    want0 = want - keep[:, :128].double().cpu()
+    assert ((out.double().cpu() - want0).abs() / (1 + want0.abs())).max().item() < 6e-6
