@@ -433,21 +433,34 @@ class LoftrEmatWorkload:
         # priced three ways: ALGORITHMIC = the direct 3x3 convolution's multiply-adds over the 196 real channels -> achieved / frac;
         # fp32_equivalent = the 16 Winograd GEMMs' multiply-adds (1 / 2.25 of the direct ones); EXECUTED = split_products() x that, incl. the
         # zero padding the kernel multiplies (Cin 196 -> 208 = 13 K steps of 16, Cout 196 -> 256 = 4 groups of 64: x 1.39) -> mfma_pipe_frac
-        exe = split_products() * achieved * (208.0 * 256.0) / (196.0 * 196.0) if achieved else None
         conv_direct = 2.0 * 9 * 196 * 196 * 360 * 272 * 2 * B
         direct_tf = conv_direct / (conv_ms * 1e-3) / 1e12 if conv_ms else None
+        from mapfree_reloc_amd import options as _opt
+        is_direct = _opt.get("CONV_KERNEL") in ("auto", "direct") and _opt.get("SPLIT") == "f16x2"     # nets/conv.py: which kernel ran the layer
+        if is_direct:
+            # round 6: the direct halo-staged kernel (csrc/conv_direct.hip): EXECUTED = 3 partial products x the direct multiply-adds, incl. the padding it
+            # multiplies (Cin 196 -> 208, Cout 196 -> 256 = 2 groups of 128, 360 columns -> 12 tiles of 32 = 384)
+            exe = 3.0 * direct_tf * (208.0 * 256.0) / (196.0 * 196.0) * (384.0 / 360.0) if direct_tf else None
+            kname = ("conv_direct_f16x2_kernel<2, 4, false> layer1_outconv2.0 launch, 196->196 ch at 360x272 (dominant kernel: the 3x3 / stride-1 convolutions of the ResNet-FPN "
+                     "backbone as direct implicit GEMMs with an LDS-staged halo tile on the f16 matrix cores at fp32 accuracy; the family is the largest share of the step's GPU "
+                     "time, profiles/r06_bench_loftr_emat_kernel_stats.csv)")
+            knote = ("mfma_pipe_frac = the matrix-core flops EXECUTED (3 partial products per fp32 multiply-add of the direct convolution, channel / tile padding included) at the "
+                     "NOMINAL 2.4 GHz peak; under this kernel the chip runs at its power limit, ~1.25 GHz with the matrix pipe 62-74 % busy (profiles/r06_pmc_dconv_*.json)")
+        else:
+            exe = split_products() * achieved * (208.0 * 256.0) / (196.0 * 196.0) if achieved else None
+            kname = ("wino_split_p8_kernel layer1_outconv2.0 launch, 196->196 ch at 360x272 (dominant kernel: fused Winograd F(2x2,3x3) convolutions of the "
+                     "ResNet-FPN backbone on the 16-bit matrix cores at fp32 accuracy; the family is the largest share of the step's GPU time, profiles/r06_bench_loftr_emat_kernel_stats.csv)")
+            knote = f"mfma_pipe_frac = the matrix-core flops EXECUTED ({int(split_products())} partial products per fp32 multiply-add of the 16 Winograd GEMMs, channel padding included)"
         lo = self.pipe.loftr
         sim_f16 = lo.sim_gemm is not None
         cm_peak = BF16_MFMA_PEAK_TFLOPS if sim_f16 else FP32_MFMA_PEAK_TFLOPS
-        return {"kernel": "wino_split_p8_kernel layer1_outconv2.0 launch, 196->196 ch at 360x272 (dominant kernel: fused Winograd F(2x2,3x3) convolutions of the "
-                          "ResNet-FPN backbone on the 16-bit matrix cores at fp32 accuracy; the family is the largest share of the step's GPU time, profiles/r06_bench_loftr_emat_kernel_stats.csv)",
+        return {"kernel": kname,
                 "bound": "mfma", "achieved": round(direct_tf, 1) if direct_tf else None, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(direct_tf / BF16_MFMA_PEAK_TFLOPS, 4) if direct_tf else None,
                 "mfma_pipe_frac": round(exe / BF16_MFMA_PEAK_TFLOPS, 4) if exe else None, "executed_tflops": round(exe, 1) if exe else None,
                 "traffic": _traffic("loftr_l1out2", B),
                 "avg_launch_ms": round(conv_ms, 4) if conv_ms else None, "launches_timed": len(self.conv_timer.events), "flops_per_launch": conv_direct,
-                "note": f"achieved / frac = ALGORITHMIC work (direct 3x3 multiply-adds over the 196 real channels) / launch time against the dense f16 / bf16 MFMA peak; "
-                        f"mfma_pipe_frac = the matrix-core flops EXECUTED ({int(split_products())} partial products per fp32 multiply-add of the 16 Winograd GEMMs, channel padding included)",
+                "note": "achieved / frac = ALGORITHMIC work (direct 3x3 multiply-adds over the 196 real channels) / launch time against the dense f16 / bf16 MFMA peak; " + knote,
                 "fp32_equivalent": {"tflops": round(achieved, 2) if achieved else None, "flops_per_launch": conv_flops,
                                     "vs_fp32_mfma_peak": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4) if achieved else None},
                 "other_kernels": [{"kernel": "dual-softmax coarse matching (similarity product + row/col softmax statistics + mutual-NN selection)",

@@ -499,6 +499,17 @@ size_t mfr_wino_f16x2_filter_bytes(int Cin, int Cout);
 int mfr_wino_f16x2_filter_transform(const float *w, int Cin, int Cout, void *upk, void *stream);
 int mfr_conv3x3_wino_f16x2(const float *x, const void *upk, const float *bias, const float *residual, int B, int Cin, int Cout,
                            int H, int W, int act, int pool, float *y, void *stream);
+/* The same layer once more (same arguments, same epilogue, f16x2 arithmetic) as a DIRECT implicit GEMM (round 6, csrc/conv_direct.hip): the halo tile
+ * of 16 input channels is split ONCE into LDS in operand form and the nine taps are shifted reads of it; a workgroup computes 32 x 32 pixels x 64
+ * channels (Cout <= 64) or 16 x 32 pixels x 128 channels.  2.25x Winograd's matrix instructions at ~1 other instruction per MFMA instead of 10-18;
+ * nets/conv.py picks per layer shape (profiles/r06_ab_direct_conv_halo.json).  Precondition |activation| <= 65504 (guarded: mfr_f16x2_guard_bind).
+ *   mfr_conv3x3_direct_f16x2_filter_bytes   size of the packed filter: ceil(Cout/64) * ceil(Cin/16) * 54 KiB + the channel scales
+ *   mfr_conv3x3_direct_f16x2_filter_pack    w [Cout,Cin,3,3] f32 -> packed; once per weight set
+ *   mfr_conv3x3_direct_f16x2                as mfr_conv3x3_wino */
+size_t mfr_conv3x3_direct_f16x2_filter_bytes(int Cin, int Cout);
+int mfr_conv3x3_direct_f16x2_filter_pack(const float *w, int Cin, int Cout, void *packed, void *stream);
+int mfr_conv3x3_direct_f16x2(const float *x, const void *packed, const float *bias, const float *residual, int B, int Cin, int Cout,
+                             int H, int W, int act, int pool, float *y, void *stream);
 /*   mfr_sp_conv1ab_f16x2         SuperPoint's first two layers in ONE kernel (round 5): y [B,64,H/2,W/2] = max_pool2(relu(conv1b(relu(conv1a(gray))))) for
  *                                gray [B,1,H,W]; w1a [64,1,3,3] / b1a [64] as they are, upk1b = mfr_wino_f16x2_filter_transform of conv1b's [64,64,3,3].
  *                                Bit-identical to mfr_conv3x3_c1_relu followed by mfr_conv3x3_wino_f16x2(..., act 1, pool 1): the 64-channel

@@ -1,6 +1,9 @@
-"""3x3 / stride 1 / pad 1 convolution layers of the matcher backbones: packed Winograd filters + kernel choice.
+"""3x3 / stride 1 / pad 1 convolution layers of the matcher backbones: packed filters + kernel choice.
 
-Two hand-written kernels compute the same layer (include/mfr_hip.h):
+Three hand-written kernels compute the same layer (include/mfr_hip.h):
+  * mfr_conv3x3_direct_f16x2 (csrc/conv_direct.hip, round 6)  direct implicit GEMM, halo tile split once into LDS in operand form, f16x2 arithmetic: the
+                             default for SPLIT = 'f16x2' -- 1.0-1.3x the Winograd kernel on every layer shape of the two backbones at the bench batches
+                             (profiles/r06_ab_direct_conv_halo.json; matrix pipe 62-74 % busy, the chip at its power limit: profiles/r06_pmc_dconv_*.json);
   * mfr_conv3x3_wino_f16x2 / _bf16x3  (csrc/winograd_split.hip)  Winograd F(2x2,3x3) on the 16-bit matrix cores at fp32 accuracy by operand
                              splitting; the arithmetic is `HIP.SPLIT` ('f16x2', the default: three partial products; 'bf16x3': six),
                              resolved when the layer's filters are packed;
@@ -20,7 +23,7 @@ WASTE_LIMIT = {"bf16x3": 0.2, "f16x2": 0.5}
 def prefer_split(H, W, split=None):
     """tile-block waste of the split kernel along x: ceil(tiles / 16) * 16 / tiles - 1; above the limit the exact kernel wins"""
     mode = options.get("CONV_KERNEL")                        # "split" / "exact" force one kernel (A/B runs, tests; options.py)
-    if mode == "split":
+    if mode in ("split", "direct"):
         return True
     if mode == "exact":
         return False
@@ -29,7 +32,7 @@ def prefer_split(H, W, split=None):
 
 
 class WinoConv3x3:
-    """one 3x3 layer: both packed filter forms (built once per weight set) and the launch"""
+    """one 3x3 layer: the packed filter forms (built once per weight set) and the launch"""
 
     def __init__(self, weight, bias, split=None):
         lib = _lib.load(require_gpu=True)
@@ -50,10 +53,21 @@ class WinoConv3x3:
         _lib.check(getattr(lib, f"mfr_wino_{self.split}_filter_transform")(_lib.ptr(self.w), self.ci, self.co, _lib.ptr(self.u_split), _lib.stream_ptr()),
                    f"mfr_wino_{self.split}_filter_transform")
         self._conv_split = getattr(lib, f"mfr_conv3x3_wino_{self.split}")
+        self.direct = None                                       # built on first use (CONV_KERNEL 'auto' / 'direct', f16x2)
+
+    def _direct(self):
+        if self.direct is None:
+            if self.split != "f16x2":
+                raise ValueError("CONV_KERNEL = 'direct' exists in the f16x2 arithmetic only")
+            self.direct = DirectConv3x3(self.w, self.b)
+        return self.direct
 
     def __call__(self, x, act=0, pool=False, residual=None):
         """act: 0 none, 1 ReLU, 2 LeakyReLU(0.01); pool: fused 2x2 max-pool; residual [B,Cout,H,W] added before the activation"""
         lib = _lib.load()
+        mode = options.get("CONV_KERNEL")
+        if mode == "direct" or (mode == "auto" and self.split == "f16x2"):
+            return self._direct()(x, act=act, pool=pool, residual=residual)
         x = x.contiguous()
         B, C, H, W = x.shape
         y = torch.empty((B, self.co, H // 2, W // 2) if pool else (B, self.co, H, W), dtype=torch.float32, device=x.device)
@@ -64,6 +78,31 @@ class WinoConv3x3:
         else:
             _lib.check(lib.mfr_conv3x3_wino(_lib.ptr(x), _lib.ptr(self.u_exact), _lib.ptr(self.b), res, B, C, self.co, H, W, int(act), int(pool),
                                             _lib.ptr(y), _lib.stream_ptr()), "mfr_conv3x3_wino")
+        return y
+
+
+class DirectConv3x3:
+    """the same 3x3 / stride 1 / pad 1 layer as a direct implicit GEMM with an LDS-staged halo tile (csrc/conv_direct.hip, mfr_conv3x3_direct_f16x2;
+    f16x2 arithmetic only).  Same call signature as WinoConv3x3."""
+
+    def __init__(self, weight, bias):
+        lib = _lib.load(require_gpu=True)
+        self.w, self.b = weight.contiguous().float(), bias
+        self.co, self.ci = int(weight.shape[0]), int(weight.shape[1])
+        self.split = "f16x2"
+        self.packed = torch.empty(lib.mfr_conv3x3_direct_f16x2_filter_bytes(self.ci, self.co), dtype=torch.uint8, device=weight.device)
+        _lib.check(lib.mfr_conv3x3_direct_f16x2_filter_pack(_lib.ptr(self.w), self.ci, self.co, _lib.ptr(self.packed), _lib.stream_ptr()),
+                   "mfr_conv3x3_direct_f16x2_filter_pack")
+
+    def __call__(self, x, act=0, pool=False, residual=None):
+        lib = _lib.load()
+        x = x.contiguous()
+        B, C, H, W = x.shape
+        assert C == self.ci and x.dtype == torch.float32
+        y = torch.empty((B, self.co, H // 2, W // 2) if pool else (B, self.co, H, W), dtype=torch.float32, device=x.device)
+        res = _lib.ptr(residual.contiguous()) if residual is not None else None
+        _lib.check(lib.mfr_conv3x3_direct_f16x2(_lib.ptr(x), _lib.ptr(self.packed), _lib.ptr(self.b), res, B, C, self.co, H, W, int(act), int(pool),
+                                                _lib.ptr(y), _lib.stream_ptr()), "mfr_conv3x3_direct_f16x2")
         return y
 
 

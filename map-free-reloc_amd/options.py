@@ -7,7 +7,8 @@ merge) through `apply_cfg(cfg)`, or directly by a tool / test (`options.set("CON
                     (rounds 3-4: exact 3-way bf16 split of both operands): the arithmetic of the matrix-core kernels (linear layers,
                     3x3 convolutions); resolved when a weight is packed
   CONV              'wino' (own Winograd kernels) | 'miopen' (library convolution + own epilogue kernels): 3x3 layers of the matchers
-  CONV_KERNEL       'auto' (per layer shape, nets/conv.py) | 'split' (the operand-splitting kernel, arithmetic = SPLIT) | 'exact': which own Winograd kernel
+  CONV_KERNEL       'auto' (nets/conv.py: f16x2 -> the direct halo-staged kernel, round 6; bf16x3 -> split / exact Winograd per layer shape) | 'direct'
+                    (csrc/conv_direct.hip, f16x2 only) | 'split' (the operand-splitting Winograd kernel, arithmetic = SPLIT) | 'exact' (fp32 Winograd): which own 3x3 kernel
   FUSED_CONV1       SuperPoint conv1a + conv1b (+ ReLUs, max-pool) as ONE kernel that builds conv1b's input patches in LDS (True, f16x2 only) or as
                     two launches through the 6.4 GB intermediate (False); the same bits either way
   FUSED_CONV_RELU   SuperPoint conv1a through the fused first-layer kernel with ReLU folded (True / False)
@@ -21,7 +22,7 @@ merge) through `apply_cfg(cfg)`, or directly by a tool / test (`options.set("CON
 _SPEC = {
     "SPLIT": ("f16x2", ("f16x2", "bf16x3")),
     "CONV": ("wino", ("wino", "miopen")),
-    "CONV_KERNEL": ("auto", ("auto", "split", "exact")),
+    "CONV_KERNEL": ("auto", ("auto", "split", "exact", "direct")),
     "FUSED_CONV1": (True, (False, True)),
     "FUSED_CONV_RELU": (False, (False, True)),
     "RPR_CONV": ("hip", ("hip", "miopen")),

@@ -51,7 +51,9 @@ def test_census_hard_scenes_inlier_index_sets():
     s = PR.summarize(recs)
     print(json.dumps(s))
     assert s["status_agree"] == s["pairs"] == 16 and s["median_inlier_fraction"] < 0.8, s           # 35-55 % of the lifted points carry a wrong depth
-    assert s["identical_match_sets"] == 16 and s["inlier_index_sets_identical"] == 16 and s["pose_bit_equal"] == 16, s     # measured: 32 / 32 of each
+    # measured (32 pairs, profiles/r06_parity_census_hard2.json): the same match SET, the same inlier index set and a bit-equal pose on 32 / 32; in the same
+    # ORDER on 31 / 32 with the direct convolution kernel (32 / 32 with the Winograd one: keypoints of equal score whose order hangs on the last bit)
+    assert s["identical_as_sets"] == 16 and s["identical_match_sets"] >= 14 and s["inlier_index_sets_identical"] == 16 and s["pose_bit_equal"] == 16, s
     # LoFTR, hard = 1 (epipolar outliers only): every pair within the bar
     recs = census("loftr_emat", [5000 + i for i in range(8)], chunk=4, hard=1)
     s = PR.summarize(recs)

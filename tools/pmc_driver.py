@@ -25,6 +25,13 @@ elif what in ("conv1b", "loftr_l1out2"):
     options.set("CONV_KERNEL", "split")
     cv = WinoConv3x3(w, b)
     fn = lambda: cv(x, act=act, pool=pool)
+elif what in ("dconv_l1", "dconv_conv2a", "dconv_l1out2"):      # the direct halo-staged kernel (csrc/conv_direct.hip) on LoFTR layer1 (128 -> 128, residual), SuperPoint conv2a, LoFTR l1out2.0
+    from mapfree_reloc_amd.nets.conv import DirectConv3x3
+    B, ci, co, H, W, act, res = {"dconv_l1": (32, 128, 128, 272, 360, 1, True), "dconv_conv2a": (64, 64, 64, 270, 360, 1, False), "dconv_l1out2": (32, 196, 196, 272, 360, 2, False)}[what]
+    x = torch.randn(B, ci, H, W, device=dev); w = torch.randn(co, ci, 3, 3, device=dev) / (3.0 * ci ** 0.5); b = torch.randn(co, device=dev)
+    r = torch.randn(B, co, H, W, device=dev) if res else None
+    cv = DirectConv3x3(w, b)
+    fn = lambda: cv(x, act=act, residual=r)
 elif what == "conv1ab":
     from mapfree_reloc_amd.nets.superpoint import SuperPointHIP
     from mapfree_reloc_amd.nets import weights as WT
