@@ -715,7 +715,7 @@ def _traffic(tag, B):
     """HBM traffic of the dominant kernel: PMC counters cannot be read inside this process, so the per-launch figure
     comes from the committed rocprofv3 --pmc passes of this same command (2 x FETCH_SIZE + WRITE_SIZE, the guide's
     gfx950 correction), profiles/r02_pmc_<tag>.json"""
-    for rnd in ("r05", "r04", "r03", "r02", "r01"):
+    for rnd in ("r06", "r05", "r04", "r03", "r02", "r01"):
         try:
             name = {"conv1b": "wino"}.get(tag, tag) if rnd == "r01" else tag
             pj = json.load(open(os.path.join(ROOT, "profiles", f"{rnd}_pmc_{name}.json")))

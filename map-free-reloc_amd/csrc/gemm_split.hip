@@ -1150,44 +1150,77 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_f16x2_kernel(const float *_
         MFR_GUARD_ACC(chk, acc[0][0][0]); MFR_GUARD_ACC(chk, acc[0][1][0]);
         mfr_guard_commit(guard, chk);
     }
-    // epilogue: register r of tile (i, j): channel 64 wm + 32 i + (r & 3) + 8 (r >> 2) + 4 (lane >> 5), pixel 64 wn + 32 j + (lane & 31)
-    float *yb = Y + (size_t)b * Cout * HoWo;
-    // UP: the four taps and weights of this thread's two pixels (the same for every channel)
-    int uo[2], udw[2], udh[2];
-    float uh0[2], uh1[2], uw0[2], uw1[2];
-    if (UP) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int p = min(pt * 128 + 64 * wn + 32 * j + (lane & 31), HoWo - 1);
-            const int oy = p / Wo, ox = p - oy * Wo;
-            const float h1r = rh * oy, w1r = rw * ox;
-            const int h1 = min((int)h1r, Hl - 1), w1 = min((int)w1r, Wl - 1);
-            uh1[j] = h1r - h1; uh0[j] = 1.f - uh1[j];
-            uw1[j] = w1r - w1; uw0[j] = 1.f - uw1[j];
-            uo[j] = h1 * Wl + w1; udw[j] = (w1 < Wl - 1) ? 1 : 0; udh[j] = (h1 < Hl - 1) ? Wl : 0;
-        }
-    }
+    // epilogue: register r of tile (i, j): channel 64 wm + 32 i + (r & 3) + 8 (r >> 2) + 4 (lane >> 5), pixel 64 wn + 32 j + (lane & 31).
+    // Round 6 (what conv_direct.hip's store tail measured, profiles/r06_dconv_timeline_*.json): gfx950 returns loads and stores through ONE in-order
+    // counter, so a load that is waited for behind a store waits for the store's acknowledgement (~1 k cycles), and a predicated plain store costs
+    // a compare, two exec-mask updates and a branch.  The first form of this epilogue -- 32 x [load scale, bias (, eight up-sampling taps); wait; two
+    // predicated stores] -- cost more than the whole K loop of a 1x1 / 7x7 layer.  Now: scale / bias of all 32 registers are fetched before the
+    // first store, the up-sampling taps two iterations ahead of their use, and every store is an unconditional buffer store whose offset lies
+    // beyond the buffer where nothing must be written (invalid channel part 0x40000000, invalid pixel part 0x80000000: host check Cout Ho Wo 4 < 2^30).
+    const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc((void *)(Y + (size_t)b * Cout * HoWo), 0, Cout * HoWo * 4, GB_RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t rsL = __builtin_amdgcn_make_buffer_rsrc((void *)(UP ? lo + (size_t)b * Cout * ((size_t)Hl * Wl) : nullptr), 0, UP ? Cout * Hl * Wl * 4 : 0, GB_RSRC_FLAGS);
+    float osv[2][16], bvv[2][16];
+    unsigned cho[2][16];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int co = nb * GB_BN + 64 * wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            if (co >= Cout) continue;
-            const float os = oscale[co], bv = bias ? bias[co] : 0.f;
-            const float *lb = UP ? lo + ((size_t)b * Cout + co) * ((size_t)Hl * Wl) : nullptr;
+            osv[i][r] = oscale[co];                                              // (padded to nnb * 128 entries)
+            bvv[i][r] = bias ? bias[min(co, Cout - 1)] : 0.f;
+            cho[i][r] = co < Cout ? (unsigned)co : 0x10000000u;                  // in ELEMENTS of a plane (x plane size x 4 below)
+        }
+    unsigned pixoff[2];
+    // UP: the four taps and weights of this thread's two pixels (the same for every channel)
+    unsigned uo[2], udw[2], udh[2];
+    float uh0[2], uh1[2], uw0[2], uw1[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int p = pt * 128 + 64 * wn + 32 * j + (lane & 31);
+        pixoff[j] = p < HoWo ? (unsigned)p * 4u : 0x80000000u;
+        if (UP) {
+            const int pc = min(p, HoWo - 1);
+            const int oy = pc / Wo, ox = pc - oy * Wo;
+            const float h1r = rh * oy, w1r = rw * ox;
+            const int h1 = min((int)h1r, Hl - 1), w1 = min((int)w1r, Wl - 1);
+            uh1[j] = h1r - h1; uh0[j] = 1.f - uh1[j];
+            uw1[j] = w1r - w1; uw0[j] = 1.f - uw1[j];
+            uo[j] = (unsigned)(h1 * Wl + w1) * 4u; udw[j] = (w1 < Wl - 1) ? 4u : 0u; udh[j] = (h1 < Hl - 1) ? (unsigned)Wl * 4u : 0u;
+        }
+    }
+    const unsigned HlWl4 = (unsigned)(Hl * Wl) * 4u, HoWo4 = (unsigned)HoWo * 4u;
+    constexpr int UD = 2;                                                        // iterations of up-sampling taps in flight ahead of the stores
+    float ut[UP ? 32 : 1][2][4];
+    auto uload = [&](int it) {
+        if (UP) {
+            const int i = it >> 4, r = it & 15;
+            const unsigned cb = cho[i][r] < 0x10000000u ? cho[i][r] * HlWl4 : 0x80000000u;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const int p = pt * 128 + 64 * wn + 32 * j + (lane & 31);
-                if (p >= HoWo) continue;
-                float v = __builtin_fmaf(acc[i][j][r], os, bv);
-                if (RELU) v = fmaxf(v, 0.f);
-                if (UP) {
-                    const float *q = lb + uo[j];
-                    v += uh0[j] * (uw0[j] * q[0] + uw1[j] * q[udw[j]]) + uh1[j] * (uw0[j] * q[udh[j]] + uw1[j] * q[udh[j] + udw[j]]);
-                }
-                yb[(size_t)co * HoWo + p] = v;
+                ut[it][j][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsL, cb + uo[j], 0, 0));
+                ut[it][j][1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsL, cb + uo[j] + udw[j], 0, 0));
+                ut[it][j][2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsL, cb + uo[j] + udh[j], 0, 0));
+                ut[it][j][3] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsL, cb + uo[j] + udh[j] + udw[j], 0, 0));
             }
         }
+    };
+    if (UP) {
+#pragma unroll
+        for (int it = 0; it < UD; ++it) uload(it);
+    }
+#pragma unroll
+    for (int it = 0; it < 32; ++it) {
+        const int i = it >> 4, r = it & 15;
+        if (UP && it + UD < 32) uload(it + UD);
+        const unsigned cb = cho[i][r] < 0x10000000u ? cho[i][r] * HoWo4 : 0x40000000u;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float v = __builtin_fmaf(acc[i][j][r], osv[i][r], bvv[i][r]);
+            if (RELU) v = fmaxf(v, 0.f);
+            if (UP) v += uh0[j] * (uw0[j] * ut[it][j][0] + uw1[j] * ut[it][j][1]) + uh1[j] * (uw0[j] * ut[it][j][2] + uw1[j] * ut[it][j][3]);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsY, cb + pixoff[j], 0, 0);
+        }
+    }
 }
 
 // ---- host ------------------------------------------------------------------------------------------------------------------------------------
@@ -1416,6 +1449,7 @@ static int gb_conv_igemm(const float *x, const void *packed_w, const float *bias
     if ((size_t)4 * ((Cin + 31) / 32 * 32) * H * W >= 0x7fffffffull) return MFR_E_ARG;    // one image (padded channel count) must fit a 2 GB buffer descriptor
     const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
     if (Ho <= 0 || Wo <= 0) return MFR_E_ARG;
+    if ((size_t)4 * Cout * Ho * Wo >= 0x40000000ull) return MFR_E_ARG;                   // one output image < 1 GB: the epilogue's out-of-buffer offsets must not wrap
     if (lo && (relu || Cin == 1 || Hl <= 0 || Wl <= 0 || Ho != 2 * Hl || Wo != 2 * Wl)) return MFR_E_ARG;
     const int K = mfr_conv_igemm_k(Cin, KH, KW), nkb = K / GB_BK, cblocks = (Cin + 31) / 32;
     const int nnb = (Cout + GB_BN - 1) / GB_BN, npt = (Ho * Wo + 127) / 128;

@@ -26,7 +26,10 @@ for f in glob.glob(D + "/p1/*kernel_trace.csv"):
             dur.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
 d = {c: sum(v) / len(v) for c, v in acc.items()}
 o = {"what": what, "kernel": (name or "")[:100], "launch_ms_under_pmc": sum(dur) / max(len(dur), 1), "counters": d}
-if "FETCH_SIZE" in d: o["hbm_read_GB_corrected(2x)"] = 2 * d["FETCH_SIZE"] * 1024 / 1e9
+# FETCH_SIZE: gfx950 reports 1/2 of the bytes of WIDE (16 B / lane) coalesced reads (MI355X_MICROARCH.md, HBM): doubled for the kernels that stream that way.  The direct
+# convolution (dconv_*) fetches its patches 4 bytes per lane: calibrated on the layer's known byte count (input x halo 1.33 + residual: 3.7 GB for dconv_l1, counter 3.97 GB) -> as reported.
+fscale = 1 if what.startswith("dconv") else 2
+if "FETCH_SIZE" in d: o["hbm_read_GB_corrected(%dx)" % fscale] = fscale * d["FETCH_SIZE"] * 1024 / 1e9
 if "WRITE_SIZE" in d: o["hbm_write_GB"] = d["WRITE_SIZE"] * 1024 / 1e9
 if "TCC_HIT_sum" in d: o["l2_hit_rate"] = d["TCC_HIT_sum"] / max(d["TCC_HIT_sum"] + d["TCC_MISS_sum"], 1)
 if "SQ_WAVE_CYCLES" in d:
@@ -37,11 +40,14 @@ if "SQ_INSTS_MFMA" in d and d["SQ_INSTS_MFMA"]:
     o["per_mfma"] = {"valu": d.get("SQ_INSTS_VALU", 0) / d["SQ_INSTS_MFMA"], "lds": d.get("SQ_INSTS_LDS", 0) / d["SQ_INSTS_MFMA"], "vmem_rd": d.get("SQ_INSTS_VMEM_RD", 0) / d["SQ_INSTS_MFMA"]}
 if "SQ_VALU_MFMA_BUSY_CYCLES" in d and "SQ_BUSY_CYCLES" in d and d["SQ_BUSY_CYCLES"]:
     o["mfma_pipe_busy_over_sq_busy_x4simd"] = d["SQ_VALU_MFMA_BUSY_CYCLES"] / (4 * d["SQ_BUSY_CYCLES"])
-ALG = {"conv1b": (64 * 64 * 720 * 540 * 4 + 64 * 64 * 360 * 270 * 4, 32), "conv1ab": (64 * 1 * 720 * 540 * 4 + 64 * 64 * 360 * 270 * 4, 32), "loftr_l1out2": (32 * 196 * 360 * 272 * 4 * 2, 16)}
+ALG = {"dconv_l1out2": (32 * 196 * 360 * 272 * 4 * 2, 16), "conv1b": (64 * 64 * 720 * 540 * 4 + 64 * 64 * 360 * 270 * 4, 32), "conv1ab": (64 * 1 * 720 * 540 * 4 + 64 * 64 * 360 * 270 * 4, 32), "loftr_l1out2": (32 * 196 * 360 * 272 * 4 * 2, 16)}
 if what in ALG and "FETCH_SIZE" in d and "WRITE_SIZE" in d:       # the per-launch record bench.py quotes as roofline.traffic
-    o["hbm_bytes_per_launch"] = 2 * d["FETCH_SIZE"] * 1024 + d["WRITE_SIZE"] * 1024
+    o["hbm_bytes_per_launch"] = fscale * d["FETCH_SIZE"] * 1024 + d["WRITE_SIZE"] * 1024
     o["algorithmic_bytes_per_launch"], o["pairs_per_step"] = ALG[what]
-o["correction"] = "FETCH_SIZE doubled (gfx950 reports 1/2 of wide coalesced reads, MI355X_MICROARCH.md HBM section); WRITE_SIZE as reported; separate --pmc passes"
+o["correction"] = ("FETCH_SIZE doubled (gfx950 reports 1/2 of wide coalesced reads, MI355X_MICROARCH.md HBM section)" if fscale == 2 else "FETCH_SIZE as reported (4-byte-per-lane reads, calibrated on the layer's known byte count)") + "; WRITE_SIZE as reported; separate --pmc passes"
+if "GRBM_GUI_ACTIVE" in d and o["launch_ms_under_pmc"]:
+    o["effective_clock_GHz"] = d["GRBM_GUI_ACTIVE"] / 8 / (o["launch_ms_under_pmc"] * 1e6)        # (summed over the 8 XCDs)
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in d: o["mfma_pipe_busy"] = d["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024 / (d["GRBM_GUI_ACTIVE"] / 8)
 json.dump(o, open(out, "w"), indent=1)
 print(json.dumps(o)[:1500])
 PY
