@@ -63,6 +63,7 @@ extern "C" int *mfr_guard_current(void) { return nullptr; }
 #define DC_STAMP(k) do { } while (0)
 #endif
 
+#define DC_IC(k) std::integral_constant<int, k>{}
 template <int MG, int NW> struct DcGeom {
     static constexpr int NT = 64 * NW;                 // threads per workgroup
     static constexpr int NGW = NW / MG;                // row groups (4 rows each) per workgroup
@@ -124,14 +125,17 @@ __global__ void __launch_bounds__(64 * NW, 8 / NW) conv_direct_f16x2_kernel(
     __shared__ __attribute__((aligned(16))) uint4 lds[2 * G::STAGE];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int mg = w % MG, ng = w / MG;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int cgi = slot % ncgw, s = (slot / ncgw) * 8 + xcd;
     if (s >= S) return;
     const int bx = s % nbx, by = (s / nbx) % nby, b = s / (nbx * nby);
     const int x0 = 32 * bx, y0 = G::TR * by;
     const int HW = H * W;
-    const int cg64 = cgi * MG + mg;                      // this wavefront's 64-channel group
+    // Wavefront blocking: MB channel blocks x NB pixel rows.  Standard (2 x 4): channel pair mg = w % MG, row group ng = w / MG of four rows.  TAIL (3 x 2;
+    // LoFTR's 196-channel layers): the layer's last 128-channel group has only three blocks with real channels (128 .. 223 of 196): all four wavefronts
+    // take the same three blocks and two rows each -- 6 accumulator blocks instead of 8, 12.5 % fewer MFMAs per such layer at equal work per wavefront
+    // (a wavefront that merely skipped its dead block would idle at the step barriers while its SIMD's other workgroup may be in the same state).
+    const bool tail = !POOL && NW == 4 && MG == 2 && cgi == ncgw - 1 && (Cout - cgi * 128 + 31) / 32 == 3;
 
     // ---- staging plan (K-loop invariant): round r, item i = NT r + tid -> channel half hh = i / PPAD (wave-uniform: PPAD % 64 == 0), patch pixel p
     const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void *)(x + (size_t)b * Cin * HW), 0, Cin * HW * 4, DC_RSRC_FLAGS);
@@ -167,11 +171,16 @@ __global__ void __launch_bounds__(64 * NW, 8 / NW) conv_direct_f16x2_kernel(
     // ---- weight fragments: [m][term] of the current tap; fragment index wave-uniform (scalar offset), vector address = lane * 16
     const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void *)wp, 0, (int)wp_bytes, DC_RSRC_FLAGS);
     const unsigned lane16 = (unsigned)lane * 16u;
-    const unsigned abase = (unsigned)cg64 * (unsigned)nks * (9u * DC_FRAGS_PER_TAP * 1024u);
-    auto aload = [&](int c, int tap, int m, int term) -> uint4 {        // tap may be 9 (= tap 0 of step c + 1)
-        return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsW, lane16, abase + (unsigned)(((c * 9 + tap) * 2 + m) * 3 + term) * 1024u, 0));
+    auto body = [&](auto mbc, auto nbc) {
+    constexpr int MB = decltype(mbc)::value, NB = decltype(nbc)::value;
+    const int mg = MB == 2 ? w % MG : 0, ng = MB == 2 ? w / MG : w;
+    const int mb0 = (cgi * MG + mg) * 2;                 // this wavefront's first 32-channel block (global index)
+    const unsigned kstride = (unsigned)nks * (9u * DC_FRAGS_PER_TAP * 1024u);       // bytes per 64-channel group
+    auto aload = [&](int c, int tap, int m, int term) -> uint4 {        // tap may be 9, 10 (= taps 0, 1 of step c + 1)
+        const int mbg = mb0 + m;
+        return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsW, lane16, (unsigned)(mbg >> 1) * kstride + (unsigned)(((c * 9 + tap) * 2 + (mbg & 1)) * 3 + term) * 1024u, 0));
     };
-    const int rdb = (lane >> 5) * G::PPAD + (4 * ng) * DC_PC + (lane & 31);
+    const int rdb = (lane >> 5) * G::PPAD + (NB * ng) * DC_PC + (lane & 31);
 
     DC_STAMP(0);
     // ---- prologue: stage 0 (all rounds' loads in flight together: the accumulators are not live yet), the first two taps' weights
@@ -191,14 +200,14 @@ __global__ void __launch_bounds__(64 * NW, 8 / NW) conv_direct_f16x2_kernel(
     // for the tap TWO ahead one phase after their last use: five phases (40 MFMAs, ~1300 cycles) between a fragment's request and its use.  gfx950
     // returns vector-memory loads in order, so a wait for a weight fragment also waits for every OLDER load -- the staging loads below are HBM
     // misses (~1 k cycles): with a one-tap lead every staging round would stall the matrix stream.
-    uint4 AE[2][3], AO[2][3], Bh[4], Bl[4];
+    uint4 AE[MB][3], AO[MB][3], Bh[NB], Bl[NB];
 #pragma unroll
-    for (int m = 0; m < 2; ++m) { AE[m][0] = aload(0, 0, m, 0); AE[m][1] = aload(0, 0, m, 1); AE[m][2] = aload(0, 0, m, 2); AO[m][1] = aload(0, 1, m, 1); AO[m][2] = aload(0, 1, m, 2); AO[m][0] = AE[m][0]; }
-    dc_f32x16 acc[2][4];
+    for (int m = 0; m < MB; ++m) { AE[m][0] = aload(0, 0, m, 0); AE[m][1] = aload(0, 0, m, 1); AE[m][2] = aload(0, 0, m, 2); AO[m][1] = aload(0, 1, m, 1); AO[m][2] = aload(0, 1, m, 2); AO[m][0] = AE[m][0]; }
+    dc_f32x16 acc[MB][NB];
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < MB; ++m)
 #pragma unroll
-        for (int n = 0; n < 4; ++n)
+        for (int n = 0; n < NB; ++n)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
@@ -213,7 +222,7 @@ __global__ void __launch_bounds__(64 * NW, 8 / NW) conv_direct_f16x2_kernel(
         const uint4 *st = lds + (c & 1) * G::STAGE + rdb;
         const int nbuf = (c + 1) & 1;
 #pragma unroll
-        for (int n = 0; n < 4; ++n) Bl[n] = st[2 * G::PPAD + n * DC_PC];
+        for (int n = 0; n < NB; ++n) Bl[n] = st[2 * G::PPAD + n * DC_PC];
         DC_STAMP(3 + 4 * (c & 7));
         auto stage_event = [&](int phi) {
 #pragma unroll
@@ -222,52 +231,50 @@ __global__ void __launch_bounds__(64 * NW, 8 / NW) conv_direct_f16x2_kernel(
                 if (phi == DC_SL(r)) sload(r, c + 1);
             }
         };
-        auto do_tap = [&](auto tapc, uint4 (&A)[2][3], uint4 (&Ao)[2][3]) {
+        auto do_tap = [&](auto tapc, uint4 (&A)[MB][3], uint4 (&Ao)[MB][3]) {
             constexpr int tap = decltype(tapc)::value;
             constexpr int dy = tap / 3, dx = tap - 3 * dy;
             constexpr int dyn = (tap + 1) / 3, dxn = (tap + 1) - 3 * dyn;
             // phase 1: wq . xl  |  requests: this tap's xh, the OTHER set's wh (tap + 1)
 #pragma unroll
-            for (int n = 0; n < 4; ++n) Bh[n] = st[(n + dy) * DC_PC + dx];
+            for (int n = 0; n < NB; ++n) Bh[n] = st[(n + dy) * DC_PC + dx];
             __builtin_amdgcn_sched_barrier(0);           // the reads first: phase 2 needs them 8 MFMAs from here
 #pragma unroll
-            for (int m = 0; m < 2; ++m) Ao[m][0] = aload(c, tap + 1, m, 0);
+            for (int m = 0; m < MB; ++m) Ao[m][0] = aload(c, tap + 1, m, 0);
             stage_event(3 * tap);
 #pragma unroll
-            for (int m = 0; m < 2; ++m)
+            for (int m = 0; m < MB; ++m)
 #pragma unroll
-                for (int n = 0; n < 4; ++n) acc[m][n] = SF_MFMA(A[m][2], Bl[n], acc[m][n]);
+                for (int n = 0; n < NB; ++n) acc[m][n] = SF_MFMA(A[m][2], Bl[n], acc[m][n]);
             __builtin_amdgcn_sched_barrier(0);
             // phase 2: wl . xh  |  requests: wq of tap + 2, the next tap's xl
 #pragma unroll
-            for (int m = 0; m < 2; ++m) A[m][2] = aload(c, tap + 2, m, 2);
+            for (int m = 0; m < MB; ++m) A[m][2] = aload(c, tap + 2, m, 2);
             if (tap < 8) {
 #pragma unroll
-                for (int n = 0; n < 4; ++n) Bl[n] = st[2 * G::PPAD + (n + dyn) * DC_PC + dxn];
+                for (int n = 0; n < NB; ++n) Bl[n] = st[2 * G::PPAD + (n + dyn) * DC_PC + dxn];
             }
             stage_event(3 * tap + 1);
 #pragma unroll
-            for (int m = 0; m < 2; ++m)
+            for (int m = 0; m < MB; ++m)
 #pragma unroll
-                for (int n = 0; n < 4; ++n) acc[m][n] = SF_MFMA(A[m][1], Bh[n], acc[m][n]);
+                for (int n = 0; n < NB; ++n) acc[m][n] = SF_MFMA(A[m][1], Bh[n], acc[m][n]);
             __builtin_amdgcn_sched_barrier(0);
             // phase 3: wh . xh  |  requests: wl of tap + 2
 #pragma unroll
-            for (int m = 0; m < 2; ++m) A[m][1] = aload(c, tap + 2, m, 1);
+            for (int m = 0; m < MB; ++m) A[m][1] = aload(c, tap + 2, m, 1);
             stage_event(3 * tap + 2);
 #pragma unroll
-            for (int m = 0; m < 2; ++m)
+            for (int m = 0; m < MB; ++m)
 #pragma unroll
-                for (int n = 0; n < 4; ++n) acc[m][n] = SF_MFMA(A[m][0], Bh[n], acc[m][n]);
+                for (int n = 0; n < NB; ++n) acc[m][n] = SF_MFMA(A[m][0], Bh[n], acc[m][n]);
             __builtin_amdgcn_sched_barrier(0);
         };
-#define DC_IC(k) std::integral_constant<int, k>{}
         do_tap(DC_IC(0), AE, AO); do_tap(DC_IC(1), AO, AE); do_tap(DC_IC(2), AE, AO); DC_STAMP(4 + 4 * (c & 7)); do_tap(DC_IC(3), AO, AE); do_tap(DC_IC(4), AE, AO);
         do_tap(DC_IC(5), AO, AE); DC_STAMP(5 + 4 * (c & 7)); do_tap(DC_IC(6), AE, AO); do_tap(DC_IC(7), AO, AE); do_tap(DC_IC(8), AE, AO);
-#undef DC_IC
         // nine taps: the sets change roles (O holds tap 0 of the next step, E's wl / wq its tap 1)
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+        for (int m = 0; m < MB; ++m)
 #pragma unroll
             for (int t = 0; t < 3; ++t) { const uint4 tmp = AE[m][t]; AE[m][t] = AO[m][t]; AO[m][t] = tmp; }
     }
@@ -279,9 +286,9 @@ __global__ void __launch_bounds__(64 * NW, 8 / NW) conv_direct_f16x2_kernel(
     float gchk = 0.f;
     if (guard) {
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+        for (int m = 0; m < MB; ++m)
 #pragma unroll
-            for (int n = 0; n < 4; ++n)
+            for (int n = 0; n < NB; ++n)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) MFR_GUARD_ACC(gchk, acc[m][n][r]);      // before bias / residual / activation (guard.h)
         mfr_guard_commit(guard, gchk);
@@ -304,21 +311,21 @@ __global__ void __launch_bounds__(64 * NW, 8 / NW) conv_direct_f16x2_kernel(
     const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc((void *)(residual + (size_t)b * Cout * HW), 0, residual ? Cout * HW * 4 : 0, DC_RSRC_FLAGS);   // (one image)
     if (!(W & 3)) {
         const int L8 = lane >> 3, L7 = lane & 7;
-        float os[2][4], bv[2][4];
-        unsigned cho[2][4];
+        float os[MB][4], bv[MB][4];
+        unsigned cho[MB][4];
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+        for (int m = 0; m < MB; ++m)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int co = cg64 * 64 + 32 * m + 8 * j + L8;                       // this lane's channel of read-back j
+                const int co = (mb0 + m) * 32 + 8 * j + L8;                       // this lane's channel of read-back j
                 os[m][j] = oscale[min(co, cpad1)];                                    // (padded to ncg * 64 entries)
                 bv[m][j] = bias ? bias[min(co, Cout - 1)] : 0.f;
                 cho[m][j] = co < Cout ? (unsigned)co * (unsigned)cstride * 4u : 0x40000000u;
             }
-        unsigned pix[4];
+        unsigned pix[NB];
 #pragma unroll
-        for (int n = 0; n < 4; ++n) {
-            const int oy = y0 + 4 * ng + n, xg = x0 + 4 * L7;
+        for (int n = 0; n < NB; ++n) {
+            const int oy = y0 + NB * ng + n, xg = x0 + 4 * L7;
             if (POOL) pix[n] = ((oy >> 1) < Ho && (xg >> 1) < Wo) ? (unsigned)((oy >> 1) * Wo + (xg >> 1)) * 4u : DC_OOB;      // (n even; W % 4 == 0: a pair is in or out as a whole)
             else      pix[n] = (oy < H && xg < W) ? (unsigned)(oy * W + xg) * 4u : DC_OOB;
         }
@@ -327,18 +334,18 @@ __global__ void __launch_bounds__(64 * NW, 8 / NW) conv_direct_f16x2_kernel(
         float *tb = (float *)lds + 1024 * w;             // wave-private 32 channels x 32 pixels
         constexpr int NSTEP = POOL ? 2 : 1;
         constexpr int DC_RD = 6;                         // residual requests in flight ahead of the stores
-        float4 rv[POOL ? 1 : 32];
-        auto rload = [&](int it) {                       // it = (m * 4 + n) * 4 + j
-            if (!POOL) rv[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsR, cho[it >> 4][it & 3] + pix[(it >> 2) & 3], 0, 0));
+        float4 rv[POOL ? 1 : MB * NB * 4];
+        auto rload = [&](int it) {                       // it = (m * NB + n) * 4 + j
+            if (!POOL) rv[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsR, cho[it / (4 * NB)][it & 3] + pix[(it >> 2) % NB], 0, 0));
         };
         if (!POOL && residual) {
 #pragma unroll
             for (int it = 0; it < DC_RD; ++it) rload(it);
         }
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+        for (int m = 0; m < MB; ++m)
 #pragma unroll
-            for (int n = 0; n < 4; n += NSTEP) {
+            for (int n = 0; n < NB; n += NSTEP) {
                 if (m == 1 && n == 0) DC_STAMP(37);
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
@@ -351,11 +358,11 @@ __global__ void __launch_bounds__(64 * NW, 8 / NW) conv_direct_f16x2_kernel(
                         typedef unsigned dc_u32x2 __attribute__((ext_vector_type(2)));
                         __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(dc_u32x2, make_float2(v0, v1)), rsY, cho[m][j] + pix[n], 0, 0);
                     } else {
-                        const int it = (m * 4 + n) * 4 + j;
+                        const int it = (m * NB + n) * 4 + j;
                         float4 v = make_float4(__builtin_fmaf(t.x, os[m][j], bv[m][j]), __builtin_fmaf(t.y, os[m][j], bv[m][j]),
                                                __builtin_fmaf(t.z, os[m][j], bv[m][j]), __builtin_fmaf(t.w, os[m][j], bv[m][j]));
                         if (residual) {
-                            if (it + DC_RD < 32) rload(it + DC_RD);
+                            if (it + DC_RD < MB * NB * 4) rload(it + DC_RD);
                             v.x += rv[it].x; v.y += rv[it].y; v.z += rv[it].z; v.w += rv[it].w;
                         }
                         v = make_float4(activate(v.x), activate(v.y), activate(v.z), activate(v.w));
@@ -366,35 +373,35 @@ __global__ void __launch_bounds__(64 * NW, 8 / NW) conv_direct_f16x2_kernel(
             }
     } else {
         // any width: lane = pixel, register = channel, 4-byte stores (128-byte runs along x per channel)
-        float osv[2][16], bvv[2][16];
+        float osv[MB][16], bvv[MB][16];
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+        for (int m = 0; m < MB; ++m)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int co = cg64 * 64 + 32 * m + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int co = (mb0 + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                 osv[m][r] = oscale[min(co, cpad1)];
                 bvv[m][r] = bias ? bias[min(co, Cout - 1)] : 0.f;
             }
-        unsigned pixoff[4];
+        unsigned pixoff[NB];
 #pragma unroll
-        for (int n = 0; n < 4; ++n) {
-            const int oy = y0 + 4 * ng + n;
+        for (int n = 0; n < NB; ++n) {
+            const int oy = y0 + NB * ng + n;
             if (POOL) pixoff[n] = (!(lane & 1) && (oy >> 1) < Ho && (px >> 1) < Wo) ? (unsigned)((oy >> 1) * Wo + (px >> 1)) * 4u : DC_OOB;      // (n even)
             else      pixoff[n] = (oy < H && px < W) ? (unsigned)(oy * W + px) * 4u : DC_OOB;
         }
         auto choff = [&](int m, int r) -> unsigned {
-            const int co = cg64 * 64 + 32 * m + (r & 3) + 8 * (r >> 2) + 4 * half;
+            const int co = (mb0 + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
             return co < Cout ? (unsigned)co * (unsigned)cstride * 4u : 0x40000000u;
         };
         DC_STAMP(36);
         if (POOL) {
 #pragma unroll
-            for (int m = 0; m < 2; ++m)
+            for (int m = 0; m < MB; ++m)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const unsigned co4 = choff(m, r);
 #pragma unroll
-                    for (int n = 0; n < 4; n += 2) {
+                    for (int n = 0; n < NB; n += 2) {
                         float v = fmaxf(__builtin_fmaf(acc[m][n][r], osv[m][r], bvv[m][r]), __builtin_fmaf(acc[m][n + 1][r], osv[m][r], bvv[m][r]));
                         v = activate(fmaxf(v, __shfl_xor(v, 1)));                       // the activations are monotone: act(max) = max(act)
                         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsY, co4 + pixoff[n], 0, 0);
@@ -402,23 +409,23 @@ __global__ void __launch_bounds__(64 * NW, 8 / NW) conv_direct_f16x2_kernel(
                 }
         } else {
             constexpr int DC_RD = 4;                                                     // iterations (of four loads) in flight ahead of the stores
-            float rv[32][4];
+            float rv[MB * 16][NB];
             auto rload = [&](int it) {
                 const unsigned co4 = choff(it >> 4, it & 15);
 #pragma unroll
-                for (int n = 0; n < 4; ++n) rv[it][n] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsR, co4 + pixoff[n], 0, 0));
+                for (int n = 0; n < NB; ++n) rv[it][n] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsR, co4 + pixoff[n], 0, 0));
             };
             if (residual) {
 #pragma unroll
                 for (int it = 0; it < DC_RD; ++it) rload(it);
             }
 #pragma unroll
-            for (int it = 0; it < 32; ++it) {
+            for (int it = 0; it < MB * 16; ++it) {
                 const int m = it >> 4, r = it & 15;
                 const unsigned co4 = choff(m, r);
-                if (residual && it + DC_RD < 32) rload(it + DC_RD);
+                if (residual && it + DC_RD < MB * 16) rload(it + DC_RD);
 #pragma unroll
-                for (int n = 0; n < 4; ++n) {
+                for (int n = 0; n < NB; ++n) {
                     float v = __builtin_fmaf(acc[m][n][r], osv[m][r], bvv[m][r]);
                     if (residual) v += rv[it][n];
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, activate(v)), rsY, co4 + pixoff[n], 0, 0);
@@ -426,6 +433,9 @@ __global__ void __launch_bounds__(64 * NW, 8 / NW) conv_direct_f16x2_kernel(
             }
         }
     }
+    };
+    if (tail) body(DC_IC(3), DC_IC(2));
+    else body(DC_IC(2), DC_IC(4));
     DC_STAMP(35);
 }
 
