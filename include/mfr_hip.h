@@ -500,9 +500,9 @@ int mfr_wino_f16x2_filter_transform(const float *w, int Cin, int Cout, void *upk
 int mfr_conv3x3_wino_f16x2(const float *x, const void *upk, const float *bias, const float *residual, int B, int Cin, int Cout,
                            int H, int W, int act, int pool, float *y, void *stream);
 /* The same layer once more (same arguments, same epilogue, f16x2 arithmetic) as a DIRECT implicit GEMM (round 6, csrc/conv_direct.hip): the halo tile
- * of 16 input channels is split ONCE into LDS in operand form and the nine taps are shifted reads of it; a workgroup computes 32 x 32 pixels x 64
- * channels (Cout <= 64) or 16 x 32 pixels x 128 channels.  2.25x Winograd's matrix instructions at ~1 other instruction per MFMA instead of 10-18;
- * nets/conv.py picks per layer shape (profiles/r06_ab_direct_conv_halo.json).  Precondition |activation| <= 65504 (guarded: mfr_f16x2_guard_bind).
+ * of 16 input channels is split ONCE into LDS in operand form and the nine taps are shifted reads of it; a 4-wavefront workgroup (two per CU) computes 16 x 32 pixels x 64
+ * channels (Cout <= 64) or 8 x 32 pixels x 128 channels.  2.25x Winograd's matrix instructions at ~2 other instructions per MFMA instead of 10-18: 1.0-1.3x
+ * the Winograd kernel on every layer of the two backbones (profiles/r06_ab_direct_conv_halo.json), the default of nets/conv.py for SPLIT = f16x2.  Precondition |activation| <= 65504 (guarded: mfr_f16x2_guard_bind).
  *   mfr_conv3x3_direct_f16x2_filter_bytes   size of the packed filter: ceil(Cout/64) * ceil(Cin/16) * 54 KiB + the channel scales
  *   mfr_conv3x3_direct_f16x2_filter_pack    w [Cout,Cin,3,3] f32 -> packed; once per weight set
  *   mfr_conv3x3_direct_f16x2                as mfr_conv3x3_wino */

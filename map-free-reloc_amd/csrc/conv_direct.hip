@@ -14,22 +14,26 @@
 // 32 cycles).  2.25x the MFMAs at 2.5-3x the pipe utilisation.
 //
 // Mapping to CDNA4.
-//   * workgroup = 8 wavefronts (two per SIMD) = a tile of TR rows x 32 columns of output pixels x 64 MG output channels, MG in {1, 2}: TR = 32 / 16.
-//     Wavefront w: channel pair-block mg = w % MG (2 x 32 channels), row group ng = w / MG (4 rows = 4 pixel blocks of 32): 2 x 4 accumulator
-//     blocks of 32 x 32 = 128 registers.  A = weights (32 channels x 16 input channels), B = pixels (16 input channels x 32 pixels of one row).
+//   * workgroup = DC_NW = 4 wavefronts, TWO workgroups per CU (one wavefront of each per SIMD): a tile of TR rows x 32 columns of output pixels x 64 MG
+//     output channels, MG in {1 (Cout <= 64), 2}: TR = 16 / 8.  Wavefront w: channel pair mg = w % MG (2 x 32 channels), row group ng = w / MG (4 rows = 4
+//     pixel blocks of 32): 2 x 4 accumulator blocks of 32 x 32 = 128 registers (the last group of a 196-channel layer: 3 x 2, see `tail`).  A = weights
+//     (32 channels x 16 input channels), B = pixels (16 input channels x 32 pixels of one row).
 //   * K step = 16 input channels.  The (TR + 2) x 34 halo patch of the step is staged as [term (xh | xl)][channel half][pixel] x 16 bytes (eight
 //     f16 channels of one pixel): a wavefront's B operand of tap (dy, dx) is ONE ds_read_b128 per lane at pixel (row + dy, column + dx), 32
-//     consecutive 16-byte units per channel half -- conflict-free for every tap, no padding.  Two stages (155,648 / 81,920 B of LDS): the patch
-//     of step c + 1 is fetched (buffer loads, zeros outside the image and beyond Cin), split and written while step c multiplies, spread over
-//     the nine taps so that no phase carries more than ~20 extra instructions; ONE barrier per K step (216 MFMAs per wavefront).
+//     consecutive 16-byte units per channel half -- conflict-free for every tap (SQ_LDS_BANK_CONFLICT = 0), no padding.  Two stages (81,920 / 49,152 B
+//     of LDS per workgroup): the patch of step c + 1 is fetched (buffer loads, zeros outside the image and beyond Cin), split and written while step c
+//     multiplies, spread over the 27 phases of the step; the K loop is ONE basic block with ONE barrier per K step (216 MFMAs per wavefront).
 //   * weights: pre-scaled per output channel, split into (wh, wl, wq = wh 2^-11) and packed in operand order [64-channel group][K step][tap]
-//     [block][term] x 1 KB; every wavefront streams its own 6 fragments per tap from L2 straight into registers one phase ahead -- no operand of the
+//     [block][term] x 1 KB; every wavefront streams its own 6 fragments per tap from L2 straight into registers TWO taps ahead (gfx950 returns
+//     vector-memory loads in order: a shorter lead would make every weight wait a wait for the staging loads' HBM latency) -- no operand of the
 //     weight side crosses LDS, nothing waits on a barrier.
-//   * a tap = three phases of 8 independent MFMAs (wq.xl, wl.xh, wh.xh -- small terms first, one accumulator); the operands a phase frees are
-//     reloaded for the NEXT tap right behind it (16 MFMAs = 512 cycles ahead of their use).
-//   * epilogue from the accumulators: lane = pixel, register = channel: 128-byte runs along x per channel.  Pooling: rows pair inside the wavefront
-//     (blocks n, n + 1), columns pair across lanes l, l ^ 1.
+//   * a tap = three phases of 8 independent MFMAs (wq.xl, wl.xh, wh.xh -- small terms first, one accumulator); the operand registers a phase frees
+//     are reloaded in the next phase for the tap after (xl, xh from LDS) or the tap after that (weights).
+//   * epilogue: every 32 x 32 accumulator block goes through 4 KB of wave-private LDS (lane = pixel -> lane = four consecutive pixels of one
+//     channel) and leaves as four unconditional 16-byte buffer stores of eight full 128-byte lines; scale / bias / residual are fetched ahead of the
+//     stores (one in-order counter for loads and stores).  Pooling: rows pair in registers before the exchange, columns pair inside a lane after it.
 //   * grid: 1-D, XCD-aware: workgroup id & 7 = XCD; the channel groups of one spatial tile run back to back on the same XCD (its L2 holds the halo).
+// What bounds it: the matrix pipe at the chip's power limit (62-74 % busy at 1.25-1.29 GHz, profiles/r06_pmc_dconv_*.json).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <type_traits>
@@ -308,7 +312,7 @@ __global__ void __launch_bounds__(64 * NW, 8 / NW) conv_direct_f16x2_kernel(
     auto activate = [&](float v) { return act == 1 ? fmaxf(v, 0.f) : act == 2 ? (v > 0.f ? v : 0.01f * v) : v; };
     // invalid channel part 0x40000000, invalid pixel part 0x80000000: any sum of the two lies beyond a buffer of < 2^30 bytes (host check), none wraps
     const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc((void *)(y + (size_t)b * Cout * cstride), 0, (int)(Cout * cstride * 4), DC_RSRC_FLAGS);
-    const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc((void *)(residual + (size_t)b * Cout * HW), 0, residual ? Cout * HW * 4 : 0, DC_RSRC_FLAGS);   // (one image)
+    const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc((void *)(residual ? residual + (size_t)b * Cout * HW : nullptr), 0, residual ? Cout * HW * 4 : 0, DC_RSRC_FLAGS);   // (one image)
     if (!(W & 3)) {
         const int L8 = lane >> 3, L7 = lane & 7;
         float os[MB][4], bv[MB][4];
