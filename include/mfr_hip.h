@@ -510,6 +510,11 @@ size_t mfr_conv3x3_direct_f16x2_filter_bytes(int Cin, int Cout);
 int mfr_conv3x3_direct_f16x2_filter_pack(const float *w, int Cin, int Cout, void *packed, void *stream);
 int mfr_conv3x3_direct_f16x2(const float *x, const void *packed, const float *bias, const float *residual, int B, int Cin, int Cout,
                              int H, int W, int act, int pool, float *y, void *stream);
+/*   mfr_conv3x3s2_direct_f16x2              the STRIDE-2 3x3 / pad 1 layer (LoFTR's layer2.0 / layer3.0 conv1, `nn.Conv2d(k=3, s=2, p=1)` + folded BatchNorm + ReLU;
+ *                                           un-vendored loftr/backbone/resnet_fpn.py, call site matchers.py:50) through the same kernel: the (2 TR + 1) x 65 patch is staged
+ *                                           with its columns de-interleaved by parity, so every tap is again 32 consecutive LDS units; same packed filter as the
+ *                                           stride-1 entry.  y [B,Cout,(H-1)/2+1,(W-1)/2+1]; act as above; no residual, no pool.  Rounds 1-5: mfr_conv_igemm_f16x2. */
+int mfr_conv3x3s2_direct_f16x2(const float *x, const void *packed, const float *bias, int B, int Cin, int Cout, int H, int W, int act, float *y, void *stream);
 /*   mfr_sp_conv1ab_f16x2         SuperPoint's first two layers in ONE kernel (round 5): y [B,64,H/2,W/2] = max_pool2(relu(conv1b(relu(conv1a(gray))))) for
  *                                gray [B,1,H,W]; w1a [64,1,3,3] / b1a [64] as they are, upk1b = mfr_wino_f16x2_filter_transform of conv1b's [64,64,3,3].
  *                                Bit-identical to mfr_conv3x3_c1_relu followed by mfr_conv3x3_wino_f16x2(..., act 1, pool 1): the 64-channel

@@ -68,12 +68,17 @@ extern "C" int *mfr_guard_current(void) { return nullptr; }
 #endif
 
 #define DC_IC(k) std::integral_constant<int, k>{}
-template <int MG, int NW> struct DcGeom {
+// STR = 2 (round 6; LoFTR's strided 3x3 layers): the patch of a TR x 32 output tile is (2 TR + 1) x 65 input pixels, staged with its COLUMNS de-interleaved by
+// parity -- row = [33 even columns | 33 odd columns] -- so that tap (dy, dx) of a row of 32 outputs is again 32 consecutive 16-byte units (row 2 r + dy,
+// half dx & 1, column c + (dx >> 1)).  Four times the patch per output: MG = 4 (all four wavefronts share 4 rows, 256 channels per workgroup) keeps
+// two stages within 80 KB.
+template <int MG, int NW, int STR> struct DcGeom {
     static constexpr int NT = 64 * NW;                 // threads per workgroup
     static constexpr int NGW = NW / MG;                // row groups (4 rows each) per workgroup
     static constexpr int TR = 4 * NGW;                 // output rows per tile
-    static constexpr int PR = TR + 2;                  // patch rows
-    static constexpr int P = PR * DC_PC;               // patch pixels
+    static constexpr int PR = STR == 1 ? TR + 2 : 2 * TR + 1;      // patch rows
+    static constexpr int PCW = STR == 1 ? DC_PC : 66;  // staged row width (pixels)
+    static constexpr int P = PR * PCW;                 // patch pixels
     static constexpr int PPAD = (P + 63) / 64 * 64;    // plane stride (16-byte units)
     static constexpr int STAGE = 4 * PPAD;             // [term][channel half][pixel]
     static constexpr int R = (2 * PPAD + NT - 1) / NT; // staging rounds: item = (channel half, pixel), NT per round
@@ -120,12 +125,13 @@ __global__ void __launch_bounds__(256) dc_pack_kernel(const float *__restrict__ 
 }
 
 // ---- the convolution ----------------------------------------------------------------------------------------------------------------------------
-template <int MG, int NW, bool POOL>
+template <int MG, int NW, bool POOL, int STR>
 __global__ void __launch_bounds__(64 * NW, 8 / NW) conv_direct_f16x2_kernel(
     const float *__restrict__ x, const uint4 *__restrict__ wp, unsigned wp_bytes, const float *__restrict__ oscale, const float *__restrict__ bias,
     const float *__restrict__ residual, float *__restrict__ y, int Cin, int Cout, int H, int W, int nbx, int nby, int S, int ncgw, int nks, int act, int *guard)
 {
-    using G = DcGeom<MG, NW>;
+    static_assert(STR == 1 || (STR == 2 && !POOL), "stride 1 or 2; no pooled strided variant");
+    using G = DcGeom<MG, NW, STR>;
     __shared__ __attribute__((aligned(16))) uint4 lds[2 * G::STAGE];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -133,8 +139,9 @@ __global__ void __launch_bounds__(64 * NW, 8 / NW) conv_direct_f16x2_kernel(
     const int cgi = slot % ncgw, s = (slot / ncgw) * 8 + xcd;
     if (s >= S) return;
     const int bx = s % nbx, by = (s / nbx) % nby, b = s / (nbx * nby);
-    const int x0 = 32 * bx, y0 = G::TR * by;
+    const int x0 = 32 * bx, y0 = G::TR * by;            // (output coordinates)
     const int HW = H * W;
+    const int Hout = STR == 1 ? H : (H - 1) / 2 + 1, Wout = STR == 1 ? W : (W - 1) / 2 + 1;
     // Wavefront blocking: MB channel blocks x NB pixel rows.  Standard (2 x 4): channel pair mg = w % MG, row group ng = w / MG of four rows.  TAIL (3 x 2;
     // LoFTR's 196-channel layers): the layer's last 128-channel group has only three blocks with real channels (128 .. 223 of 196): all four wavefronts
     // take the same three blocks and two rows each -- 6 accumulator blocks instead of 8, 12.5 % fewer MFMAs per such layer at equal work per wavefront
@@ -149,9 +156,10 @@ __global__ void __launch_bounds__(64 * NW, 8 / NW) conv_direct_f16x2_kernel(
     for (int r = 0; r < G::R; ++r) {
         const int h = (G::NT * r + 64 * w) / G::PPAD;     // >= 2: this wavefront has no item in the (last, partial) round -- it stages zeros into the planes' padding
         const int p = G::NT * r + tid - h * G::PPAD;     // (no branch: the K loop stays ONE basic block and the scheduler spreads the staging over the MFMAs)
-        const int pr = p / DC_PC, pc = p - pr * DC_PC;
-        const int gy = y0 - 1 + pr, gx = x0 - 1 + pc;
-        const bool ok = h < 2 && p < G::P && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        const int pr = p / G::PCW, q = p - pr * G::PCW;
+        const int pc = STR == 1 ? q : 2 * (q % 33) + q / 33;                        // patch column of the staged unit (STR 2: [even | odd] halves)
+        const int gy = STR * y0 - 1 + pr, gx = STR * x0 - 1 + pc;
+        const bool ok = h < 2 && p < G::P && pc < STR * 32 + 3 - STR && gy >= 0 && gy < H && gx >= 0 && gx < W;
         voff[r] = ok ? (unsigned)(gy * W + gx) * 4u : DC_OOB;
         hh[r] = h < 2 ? h : 0;
         wdst[r] = h < 2 ? h * G::PPAD + p : G::P + (lane & 15);
@@ -184,7 +192,8 @@ __global__ void __launch_bounds__(64 * NW, 8 / NW) conv_direct_f16x2_kernel(
         const int mbg = mb0 + m;
         return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsW, lane16, (unsigned)(mbg >> 1) * kstride + (unsigned)(((c * 9 + tap) * 2 + (mbg & 1)) * 3 + term) * 1024u, 0));
     };
-    const int rdb = (lane >> 5) * G::PPAD + (NB * ng) * DC_PC + (lane & 31);
+    const int rdb = (lane >> 5) * G::PPAD + (STR * NB * ng) * G::PCW + (lane & 31);
+    auto tapoff = [](int n, int dy, int dx) { return STR == 1 ? (n + dy) * G::PCW + dx : (2 * n + dy) * G::PCW + (dx & 1) * 33 + (dx >> 1); };
 
     DC_STAMP(0);
     // ---- prologue: stage 0 (all rounds' loads in flight together: the accumulators are not live yet), the first two taps' weights
@@ -226,7 +235,7 @@ __global__ void __launch_bounds__(64 * NW, 8 / NW) conv_direct_f16x2_kernel(
         const uint4 *st = lds + (c & 1) * G::STAGE + rdb;
         const int nbuf = (c + 1) & 1;
 #pragma unroll
-        for (int n = 0; n < NB; ++n) Bl[n] = st[2 * G::PPAD + n * DC_PC];
+        for (int n = 0; n < NB; ++n) Bl[n] = st[2 * G::PPAD + tapoff(n, 0, 0)];
         DC_STAMP(3 + 4 * (c & 7));
         auto stage_event = [&](int phi) {
 #pragma unroll
@@ -241,7 +250,7 @@ __global__ void __launch_bounds__(64 * NW, 8 / NW) conv_direct_f16x2_kernel(
             constexpr int dyn = (tap + 1) / 3, dxn = (tap + 1) - 3 * dyn;
             // phase 1: wq . xl  |  requests: this tap's xh, the OTHER set's wh (tap + 1)
 #pragma unroll
-            for (int n = 0; n < NB; ++n) Bh[n] = st[(n + dy) * DC_PC + dx];
+            for (int n = 0; n < NB; ++n) Bh[n] = st[tapoff(n, dy, dx)];
             __builtin_amdgcn_sched_barrier(0);           // the reads first: phase 2 needs them 8 MFMAs from here
 #pragma unroll
             for (int m = 0; m < MB; ++m) Ao[m][0] = aload(c, tap + 1, m, 0);
@@ -256,7 +265,7 @@ __global__ void __launch_bounds__(64 * NW, 8 / NW) conv_direct_f16x2_kernel(
             for (int m = 0; m < MB; ++m) A[m][2] = aload(c, tap + 2, m, 2);
             if (tap < 8) {
 #pragma unroll
-                for (int n = 0; n < NB; ++n) Bl[n] = st[2 * G::PPAD + (n + dyn) * DC_PC + dxn];
+                for (int n = 0; n < NB; ++n) Bl[n] = st[2 * G::PPAD + tapoff(n, dyn, dxn)];
             }
             stage_event(3 * tap + 1);
 #pragma unroll
@@ -285,6 +294,7 @@ __global__ void __launch_bounds__(64 * NW, 8 / NW) conv_direct_f16x2_kernel(
 #undef DC_SL
 #undef DC_SW
 
+    const int H = Hout, W = Wout, HW = Hout * Wout;      // from here on: the OUTPUT image (they shadow the input's; the staging lambdas above keep the input's)
     // ---- epilogue: lane = pixel (row y0 + 4 ng + n, column x0 + (lane & 31)), register r of block m = channel cg64 * 64 + 32 m + (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
     DC_STAMP(34);
     float gchk = 0.f;
@@ -456,10 +466,10 @@ extern "C" {
 int mfr_dconv_occupancy(int mg, int pool)                /* workgroups per CU the runtime grants the instantiation */
 {
     int n = -1;
-    if (mg == 1 && !pool) hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_direct_f16x2_kernel<1, DC_NW, false>, 64 * DC_NW, 0);
-    if (mg == 1 && pool)  hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_direct_f16x2_kernel<1, DC_NW, true>, 64 * DC_NW, 0);
-    if (mg == 2 && !pool) hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_direct_f16x2_kernel<2, DC_NW, false>, 64 * DC_NW, 0);
-    if (mg == 2 && pool)  hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_direct_f16x2_kernel<2, DC_NW, true>, 64 * DC_NW, 0);
+    if (mg == 1 && !pool) hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_direct_f16x2_kernel<1, DC_NW, false, 1>, 64 * DC_NW, 0);
+    if (mg == 1 && pool)  hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_direct_f16x2_kernel<1, DC_NW, true, 1>, 64 * DC_NW, 0);
+    if (mg == 2 && !pool) hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_direct_f16x2_kernel<2, DC_NW, false, 1>, 64 * DC_NW, 0);
+    if (mg == 2 && pool)  hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_direct_f16x2_kernel<2, DC_NW, true, 1>, 64 * DC_NW, 0);
     return n;
 }
 int mfr_dconv_profile(unsigned long long *out_host)      /* the stamps of the last launch: 8 wavefronts x 64 */
@@ -501,11 +511,30 @@ int mfr_conv3x3_direct_f16x2(const float *x, const void *packed, const float *bi
     if (grid > 0x7fffffffll) return MFR_E_ARG;
     hipStream_t st = (hipStream_t)stream;
     int *guard = mfr_guard_current();
-#define DC_LAUNCH(MGV, POOLV) hipLaunchKernelGGL((conv_direct_f16x2_kernel<MGV, DC_NW, POOLV>), dim3((unsigned)grid), dim3(64 * DC_NW), 0, st, x, (const uint4 *)packed, (unsigned)fb, oscale, bias, \
+#define DC_LAUNCH(MGV, POOLV) hipLaunchKernelGGL((conv_direct_f16x2_kernel<MGV, DC_NW, POOLV, 1>), dim3((unsigned)grid), dim3(64 * DC_NW), 0, st, x, (const uint4 *)packed, (unsigned)fb, oscale, bias, \
                                                   residual, y, Cin, Cout, H, W, nbx, nby, (int)S, ncgw, nks, act, guard)
     if (mg == 1) { if (pool) DC_LAUNCH(1, true); else DC_LAUNCH(1, false); }
     else         { if (pool) DC_LAUNCH(2, true); else DC_LAUNCH(2, false); }
 #undef DC_LAUNCH
+    CHECK_LAUNCH();
+    return 0;
+}
+
+int mfr_conv3x3s2_direct_f16x2(const float *x, const void *packed, const float *bias, int B, int Cin, int Cout, int H, int W, int act, float *y, void *stream)
+{
+    if (!x || !packed || !y || B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || act < 0 || act > 2) return MFR_E_ARG;
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    if ((size_t)4 * (Cin + 15) * H * W >= 0x7fffffffull || (size_t)4 * Cout * Ho * Wo >= 0x40000000ull) return MFR_E_ARG;
+    const size_t fb = dc_frag_bytes(Cin, Cout);
+    if (fb >= 0x7fffffffull) return MFR_E_ARG;
+    const int nks = (Cin + 15) / 16;
+    const float *oscale = (const float *)((const char *)packed + fb);
+    const int nbx = (Wo + 31) / 32, nby = (Ho + 3) / 4, ncgw = (Cout + 255) / 256;
+    const long long S = (long long)nbx * nby * B;
+    const long long grid = ((S + 7) / 8) * 8 * ncgw;
+    if (grid > 0x7fffffffll) return MFR_E_ARG;
+    hipLaunchKernelGGL((conv_direct_f16x2_kernel<4, 4, false, 2>), dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, x, (const uint4 *)packed, (unsigned)fb, oscale, bias,
+                       (const float *)nullptr, y, Cin, Cout, H, W, nbx, nby, (int)S, ncgw, nks, act, mfr_guard_current());
     CHECK_LAUNCH();
     return 0;
 }

@@ -94,6 +94,17 @@ class DirectConv3x3:
         _lib.check(lib.mfr_conv3x3_direct_f16x2_filter_pack(_lib.ptr(self.w), self.ci, self.co, _lib.ptr(self.packed), _lib.stream_ptr()),
                    "mfr_conv3x3_direct_f16x2_filter_pack")
 
+    def strided(self, x, act=0):
+        """the same filter at stride 2 (pad 1): y [B, Cout, (H - 1) // 2 + 1, (W - 1) // 2 + 1] (mfr_conv3x3s2_direct_f16x2)"""
+        lib = _lib.load()
+        x = x.contiguous()
+        B, C, H, W = x.shape
+        assert C == self.ci and x.dtype == torch.float32
+        y = torch.empty(B, self.co, (H - 1) // 2 + 1, (W - 1) // 2 + 1, dtype=torch.float32, device=x.device)
+        _lib.check(lib.mfr_conv3x3s2_direct_f16x2(_lib.ptr(x), _lib.ptr(self.packed), _lib.ptr(self.b), B, C, self.co, H, W, int(act), _lib.ptr(y), _lib.stream_ptr()),
+                   "mfr_conv3x3s2_direct_f16x2")
+        return y
+
     def __call__(self, x, act=0, pool=False, residual=None):
         lib = _lib.load()
         x = x.contiguous()
@@ -130,8 +141,12 @@ class IgemmConv:
         self.packed = torch.empty(nb, dtype=torch.uint8, device=w.device)
         _lib.check(lib.mfr_gemm_f16x2_pack(_lib.ptr(m.contiguous()), co, K, _lib.ptr(self.packed), _lib.stream_ptr()), "mfr_gemm_f16x2_pack")
         self.b = None if bias is None else bias.contiguous().float()
+        # round 6: the strided 3x3 layers through the direct halo-staged kernel (CONV_KERNEL 'auto' / 'direct'); the implicit-GEMM form stays for the A/B
+        self.direct_s2 = DirectConv3x3(w, self.b) if (kh, kw, self.stride, self.pad) == (3, 3, 2, 1) and ci > 1 else None
 
     def __call__(self, x, relu=False, up_add=None):
+        if self.direct_s2 is not None and up_add is None and options.get("CONV_KERNEL") in ("auto", "direct"):
+            return self.direct_s2.strided(x, act=1 if relu else 0)
         """up_add [B, Cout, Ho / 2, Wo / 2]: y = conv(x) + bias + its 2x bilinear up-sampling (align_corners=True) in the same launch (LoFTR's FPN merge)"""
         lib = _lib.load()
         x = x.contiguous()

@@ -143,3 +143,25 @@ def test_direct_conv_range_guard():
         finally:
             _lib.check(lib.mfr_f16x2_guard_bind(None), "unbind")
         assert int(flag.item()) == (0 if bad is None else 1), (bad, where)
+
+
+@pytest.mark.parametrize("B,ci,co,H,W,act,bias", [
+    (1, 16, 64, 8, 64, 0, 0), (2, 8, 32, 11, 38, 1, 1), (1, 64, 64, 17, 45, 1, 1), (3, 12, 96, 9, 33, 0, 1), (1, 4, 32, 2, 2, 1, 1), (1, 4, 32, 1, 1, 0, 1),
+    (2, 20, 300, 40, 130, 1, 1), (1, 128, 196, 272, 360, 1, 1), (2, 196, 256, 136, 180, 1, 1), (1, 128, 256, 67, 91, 2, 1), (2, 48, 196, 135, 181, 1, 0)])
+def test_strided_direct_conv_vs_float64(B, ci, co, H, W, act, bias):
+    """mfr_conv3x3s2_direct_f16x2 (stride 2, pad 1; LoFTR's layer2.0 / layer3.0 conv1 shapes among them) against a float64 convolution, 2e-5 like the
+    stride-1 kernel; odd and even sizes (the last patch column / row is present or not), several tiles, more than 256 output channels"""
+    lib = _lib.load(require_gpu=True)
+    g = torch.Generator().manual_seed(B * 1000 + ci + H)
+    x = torch.randn(B, ci, H, W, generator=g).to(DEV)
+    w = (torch.randn(co, ci, 3, 3, generator=g) / (3.0 * ci ** 0.5)).to(DEV)
+    b = torch.randn(co, generator=g).to(DEV) if bias else None
+    u = torch.empty(lib.mfr_conv3x3_direct_f16x2_filter_bytes(ci, co), dtype=torch.uint8, device=DEV)
+    _lib.check(lib.mfr_conv3x3_direct_f16x2_filter_pack(_lib.ptr(w), ci, co, _lib.ptr(u), _lib.stream_ptr()), "pack")
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    y = torch.full((B, co, Ho, Wo), float("nan"), dtype=torch.float32, device=DEV)
+    _lib.check(lib.mfr_conv3x3s2_direct_f16x2(_lib.ptr(x), _lib.ptr(u), _lib.ptr(b) if b is not None else None, B, ci, co, H, W, act, _lib.ptr(y), _lib.stream_ptr()), "conv")
+    want = F.conv2d(x.double().cpu(), w.double().cpu(), None if b is None else b.double().cpu(), stride=2, padding=1)
+    want = want.relu() if act == 1 else F.leaky_relu(want, 0.01) if act == 2 else want
+    assert y.shape == want.shape and torch.isfinite(y).all()
+    assert (y.double().cpu() - want).abs().max().item() < 2e-5
