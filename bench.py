@@ -330,7 +330,9 @@ class SgPnpWorkload:
                 "note": "achieved / frac = ALGORITHMIC work (SURVEY 8d: the direct 3x3 convolution's multiply-adds, 2 x 9 x 64 x 64 x H x W x images) / launch time against the "
                         f"DENSE f16 / bf16 MFMA peak; mfma_pipe_frac = the 16-bit matrix-core flops the kernel EXECUTES ({nprod} partial products per fp32 multiply-add of the "
                         "16 Winograd GEMMs: Winograd does 1 / 2.25 of the direct multiply-adds, the operand split 3 x) against the same peak; fp32_equivalent = the Winograd-domain "
-                        "fp32 multiply-adds (what the layer delivers) against the fp32 MFMA peak",
+                        "fp32 multiply-adds (what the layer delivers) against the fp32 MFMA peak.  Both fractions are against the NOMINAL 2.5 PFLOP/s (2.4 GHz): measured in round 6, a "
+                        "dense f16 MFMA stream on random data is power-limited at ~0.92 busy x GHz ~ 960 TFLOP/s executed (the direct-convolution and linear-layer launches of this "
+                        "step sit on that line; DESIGN.md 4.4, profiles/r06_pmc_dconv_*.json)",
                 "fp32_equivalent": {"tflops": round(eq, 2) if eq else None, "flops_per_launch": conv_fp32,
                                     "vs_fp32_mfma_peak": round(eq / FP32_MFMA_PEAK_TFLOPS, 4) if eq else None,
                                     "round2_exact_fp32_kernel": "8.63 ms / launch, 94.5 TFLOP/s, 0.60 of the fp32 MFMA peak (BENCH_r02)"},
