@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define MFR_ABI_VERSION 5   /* 5 (round 6): mfr_f16x2_guard_bind (the f16x2 range guard); 2: intrinsics as (const void *K, int k_dtype) instead of const float *; 3: mfr_emat_solve_batch takes the
+#define MFR_ABI_VERSION 6   /* 6 (round 6): mfr_conv3x3_direct_f16x2*, mfr_conv3x3s2_direct_f16x2, mfr_mlp_ln_*; 5 (round 6): mfr_f16x2_guard_bind (the f16x2 range guard); 2: intrinsics as (const void *K, int k_dtype) instead of const float *; 3: mfr_emat_solve_batch takes the
                              * model-quality method (MAGSAC++ / count) and its table; 4 (round 5): the f16x2 entry points (mfr_gemm_f16x2*,
                              * mfr_wino_f16x2_*, mfr_conv3x3_wino_f16x2, mfr_conv_igemm_f16x2), mfr_sg_attention_variant renumbered (0 f16x2,
                              * 1 exact fp32, 2 bf16x3), the measurement-only entry points (mfr_conv3x3_wino_bf16x3_variant,

@@ -116,7 +116,7 @@ def test_cabi_library_exports_every_declared_symbol():
     assert set(mfr._lib.SIGNATURES) == declared
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.mfr_abi_version() == 5 and lib.mfr_target_arch() == b"gfx950"
+    assert lib.mfr_abi_version() == 6 and lib.mfr_target_arch() == b"gfx950"
     assert lib.mfr_pnp_workspace_bytes(16, 1024, 1000) > 0
     # ... and INTEGRATION.md's table names every one of them beside the reference interface it replaces (workspace-size queries as a family)
     doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
