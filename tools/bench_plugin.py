@@ -32,7 +32,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--pairs", type=int, default=40)
     ap.add_argument("--out", default="gpurun_out/bench_plugin.json")
+    ap.add_argument("--hip-opt", action="append", default=[], metavar="NAME=VALUE", help="declared kernel-selection option (options.py), e.g. CONV_KERNEL=split")
     a = ap.parse_args()
+    from mapfree_reloc_amd import options
+    for kv in a.hip_opt:
+        k, v = kv.split("=", 1)
+        options.set(k, v)
     res = {}
     # solver plugins alone on synthetic correspondences (1024 per pair, 30 % outliers)
     prs = [synth.make_pair(100 + i, 1024, outlier_frac=0.3) for i in range(a.pairs)]
