@@ -510,6 +510,10 @@ size_t mfr_conv3x3_direct_f16x2_filter_bytes(int Cin, int Cout);
 int mfr_conv3x3_direct_f16x2_filter_pack(const float *w, int Cin, int Cout, void *packed, void *stream);
 int mfr_conv3x3_direct_f16x2(const float *x, const void *packed, const float *bias, const float *residual, int B, int Cin, int Cout,
                              int H, int W, int act, int pool, float *y, void *stream);
+/*   mfr_conv3x3_direct_f16x2_rows           the same layer with TOKEN-MAJOR output: yrows [B H W, ldy], channel c of pixel p at yrows[p ldy + c] (ldy >= Cout, both multiples
+ *                                           of 4) -- what the 1x1 / linear layer behind the convolution reads (SuperPoint convDa -> convDb, models/superpoint.py; LoFTR
+ *                                           layer1_outconv2 -> FinePreprocess' unfold, matchers.py:50): replaces the NCHW store + mfr_nchw_to_rows.  No residual, no pool. */
+int mfr_conv3x3_direct_f16x2_rows(const float *x, const void *packed, const float *bias, int B, int Cin, int Cout, int H, int W, int act, float *yrows, int ldy, void *stream);
 /*   mfr_conv3x3s2_direct_f16x2              the STRIDE-2 3x3 / pad 1 layer (LoFTR's layer2.0 / layer3.0 conv1, `nn.Conv2d(k=3, s=2, p=1)` + folded BatchNorm + ReLU;
  *                                           un-vendored loftr/backbone/resnet_fpn.py, call site matchers.py:50) through the same kernel: the (2 TR + 1) x 65 patch is staged
  *                                           with its columns de-interleaved by parity, so every tap is again 32 consecutive LDS units; same packed filter as the

@@ -89,6 +89,7 @@ SIGNATURES = {
     "mfr_conv3x3_direct_f16x2_filter_pack": (_i, [_vp, _i, _i, _vp, _vp]),
     "mfr_conv3x3_direct_f16x2": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "mfr_conv3x3s2_direct_f16x2": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "mfr_conv3x3_direct_f16x2_rows": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp]),
     "mfr_wino_filter_bytes": (_sz, [_i, _i]),
     "mfr_wino_filter_transform": (_i, [_vp, _i, _i, _vp, _vp]),
     "mfr_conv3x3_wino": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),

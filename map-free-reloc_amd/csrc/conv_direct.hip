@@ -128,7 +128,7 @@ __global__ void __launch_bounds__(256) dc_pack_kernel(const float *__restrict__ 
 template <int MG, int NW, bool POOL, int STR>
 __global__ void __launch_bounds__(64 * NW, 8 / NW) conv_direct_f16x2_kernel(
     const float *__restrict__ x, const uint4 *__restrict__ wp, unsigned wp_bytes, const float *__restrict__ oscale, const float *__restrict__ bias,
-    const float *__restrict__ residual, float *__restrict__ y, int Cin, int Cout, int H, int W, int nbx, int nby, int S, int ncgw, int nks, int act, int *guard)
+    const float *__restrict__ residual, float *__restrict__ y, int Cin, int Cout, int H, int W, int nbx, int nby, int S, int ncgw, int nks, int act, int *guard, int ldrows)
 {
     static_assert(STR == 1 || (STR == 2 && !POOL), "stride 1 or 2; no pooled strided variant");
     using G = DcGeom<MG, NW, STR>;
@@ -323,7 +323,36 @@ __global__ void __launch_bounds__(64 * NW, 8 / NW) conv_direct_f16x2_kernel(
     // invalid channel part 0x40000000, invalid pixel part 0x80000000: any sum of the two lies beyond a buffer of < 2^30 bytes (host check), none wraps
     const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc((void *)(y + (size_t)b * Cout * cstride), 0, (int)(Cout * cstride * 4), DC_RSRC_FLAGS);
     const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc((void *)(residual ? residual + (size_t)b * Cout * HW : nullptr), 0, residual ? Cout * HW * 4 : 0, DC_RSRC_FLAGS);   // (one image)
-    if (!(W & 3)) {
+    if (ldrows > 0) {
+        // ROWS output (round 6): y [B H W, ldrows] token-major, channel c of pixel p at y[p * ldrows + c] -- what the linear layer behind the convolution
+        // reads (SuperPoint's descriptor head, LoFTR's fine map): the accumulators already hold four consecutive channels of a pixel per register
+        // group, so each group leaves as one 16-byte store and the NCHW -> rows transposition pass (mfr_nchw_to_rows) disappears.
+        const __amdgpu_buffer_rsrc_t rsQ = __builtin_amdgcn_make_buffer_rsrc((void *)(y + (size_t)b * HW * ldrows), 0, HW * ldrows * 4, DC_RSRC_FLAGS);
+        unsigned pixrow[NB];
+#pragma unroll
+        for (int n = 0; n < NB; ++n) {
+            const int oy = y0 + NB * ng + n;
+            pixrow[n] = (oy < H && px < W) ? (unsigned)(oy * W + px) * (unsigned)ldrows * 4u : DC_OOB;
+        }
+        DC_STAMP(36);
+#pragma unroll
+        for (int m = 0; m < MB; ++m)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c0 = (mb0 + m) * 32 + 8 * q + 4 * half;                     // four consecutive channels (Cout % 4 == 0: all in or all out)
+                float o4[4], b4[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { o4[k] = oscale[min(c0 + k, cpad1)]; b4[k] = bias ? bias[min(c0 + k, Cout - 1)] : 0.f; }
+                const unsigned cpart = c0 < Cout ? (unsigned)c0 * 4u : 0x40000000u;
+#pragma unroll
+                for (int n = 0; n < NB; ++n) {
+                    typedef unsigned dc_u32x4 __attribute__((ext_vector_type(4)));
+                    const float4 v = make_float4(activate(__builtin_fmaf(acc[m][n][4 * q], o4[0], b4[0])), activate(__builtin_fmaf(acc[m][n][4 * q + 1], o4[1], b4[1])),
+                                                 activate(__builtin_fmaf(acc[m][n][4 * q + 2], o4[2], b4[2])), activate(__builtin_fmaf(acc[m][n][4 * q + 3], o4[3], b4[3])));
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(dc_u32x4, v), rsQ, cpart + pixrow[n], 0, 0);
+                }
+            }
+    } else if (!(W & 3)) {
         const int L8 = lane >> 3, L7 = lane & 7;
         float os[MB][4], bv[MB][4];
         unsigned cho[MB][4];
@@ -493,8 +522,8 @@ int mfr_conv3x3_direct_f16x2_filter_pack(const float *w, int Cin, int Cout, void
     return 0;
 }
 
-int mfr_conv3x3_direct_f16x2(const float *x, const void *packed, const float *bias, const float *residual, int B, int Cin, int Cout, int H, int W,
-                             int act, int pool, float *y, void *stream)
+static int dc_conv(const float *x, const void *packed, const float *bias, const float *residual, int B, int Cin, int Cout, int H, int W,
+                   int act, int pool, float *y, int ldrows, void *stream)
 {
     if (!x || !packed || !y || B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || act < 0 || act > 2) return MFR_E_ARG;
     if (pool && (H < 2 || W < 2 || residual)) return MFR_E_ARG;
@@ -512,12 +541,24 @@ int mfr_conv3x3_direct_f16x2(const float *x, const void *packed, const float *bi
     hipStream_t st = (hipStream_t)stream;
     int *guard = mfr_guard_current();
 #define DC_LAUNCH(MGV, POOLV) hipLaunchKernelGGL((conv_direct_f16x2_kernel<MGV, DC_NW, POOLV, 1>), dim3((unsigned)grid), dim3(64 * DC_NW), 0, st, x, (const uint4 *)packed, (unsigned)fb, oscale, bias, \
-                                                  residual, y, Cin, Cout, H, W, nbx, nby, (int)S, ncgw, nks, act, guard)
+                                                  residual, y, Cin, Cout, H, W, nbx, nby, (int)S, ncgw, nks, act, guard, ldrows)
     if (mg == 1) { if (pool) DC_LAUNCH(1, true); else DC_LAUNCH(1, false); }
     else         { if (pool) DC_LAUNCH(2, true); else DC_LAUNCH(2, false); }
 #undef DC_LAUNCH
     CHECK_LAUNCH();
     return 0;
+}
+
+int mfr_conv3x3_direct_f16x2(const float *x, const void *packed, const float *bias, const float *residual, int B, int Cin, int Cout, int H, int W,
+                             int act, int pool, float *y, void *stream)
+{
+    return dc_conv(x, packed, bias, residual, B, Cin, Cout, H, W, act, pool, y, 0, stream);
+}
+
+int mfr_conv3x3_direct_f16x2_rows(const float *x, const void *packed, const float *bias, int B, int Cin, int Cout, int H, int W, int act, float *yrows, int ldy, void *stream)
+{
+    if (ldy < Cout || (ldy & 3) || (Cout & 3) || H <= 0 || W <= 0 || (size_t)4 * ldy * H * W >= 0x40000000ull) return MFR_E_ARG;
+    return dc_conv(x, packed, bias, nullptr, B, Cin, Cout, H, W, act, 0, yrows, ldy, stream);
 }
 
 int mfr_conv3x3s2_direct_f16x2(const float *x, const void *packed, const float *bias, int B, int Cin, int Cout, int H, int W, int act, float *y, void *stream)
@@ -534,7 +575,7 @@ int mfr_conv3x3s2_direct_f16x2(const float *x, const void *packed, const float *
     const long long grid = ((S + 7) / 8) * 8 * ncgw;
     if (grid > 0x7fffffffll) return MFR_E_ARG;
     hipLaunchKernelGGL((conv_direct_f16x2_kernel<4, 4, false, 2>), dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, x, (const uint4 *)packed, (unsigned)fb, oscale, bias,
-                       (const float *)nullptr, y, Cin, Cout, H, W, nbx, nby, (int)S, ncgw, nks, act, mfr_guard_current());
+                       (const float *)nullptr, y, Cin, Cout, H, W, nbx, nby, (int)S, ncgw, nks, act, mfr_guard_current(), 0);
     CHECK_LAUNCH();
     return 0;
 }

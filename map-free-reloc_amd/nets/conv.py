@@ -55,6 +55,13 @@ class WinoConv3x3:
         self._conv_split = getattr(lib, f"mfr_conv3x3_wino_{self.split}")
         self.direct = None                                       # built on first use (CONV_KERNEL 'auto' / 'direct', f16x2)
 
+    def rows(self, x, act=0):
+        """[B, H, W, Cout] token-major output when the direct kernel runs this layer (CONV_KERNEL 'auto' / 'direct', f16x2, Cout % 4 == 0), else None"""
+        mode = options.get("CONV_KERNEL")
+        if self.co % 4 or not (mode == "direct" or (mode == "auto" and self.split == "f16x2")):
+            return None
+        return self._direct().rows(x, act=act)
+
     def _direct(self):
         if self.direct is None:
             if self.split != "f16x2":
@@ -93,6 +100,17 @@ class DirectConv3x3:
         self.packed = torch.empty(lib.mfr_conv3x3_direct_f16x2_filter_bytes(self.ci, self.co), dtype=torch.uint8, device=weight.device)
         _lib.check(lib.mfr_conv3x3_direct_f16x2_filter_pack(_lib.ptr(self.w), self.ci, self.co, _lib.ptr(self.packed), _lib.stream_ptr()),
                    "mfr_conv3x3_direct_f16x2_filter_pack")
+
+    def rows(self, x, act=0):
+        """token-major output [B, H, W, Cout] (mfr_conv3x3_direct_f16x2_rows): for the layer in front of a 1x1 / linear layer"""
+        lib = _lib.load()
+        x = x.contiguous()
+        B, C, H, W = x.shape
+        assert C == self.ci and x.dtype == torch.float32 and self.co % 4 == 0
+        y = torch.empty(B, H, W, self.co, dtype=torch.float32, device=x.device)
+        _lib.check(lib.mfr_conv3x3_direct_f16x2_rows(_lib.ptr(x), _lib.ptr(self.packed), _lib.ptr(self.b), B, C, self.co, H, W, int(act), _lib.ptr(y), self.co,
+                                                     _lib.stream_ptr()), "mfr_conv3x3_direct_f16x2_rows")
+        return y
 
     def strided(self, x, act=0):
         """the same filter at stride 2 (pad 1): y [B, Cout, (H - 1) // 2 + 1, (W - 1) // 2 + 1] (mfr_conv3x3s2_direct_f16x2)"""

@@ -142,7 +142,11 @@ class LoFTRHIP:
         x3 = self._block(self._block(x2, "layer3.0", 2), "layer3.1", 1)
         x3_out = self._c(x3, "l3out")
         x2_out = self._c(self._c(self._lateral_merge(x2, "l2out", x3_out), "l2out2.0", 1, "leaky"), "l2out2.3")
-        x1_out = self._c(self._c(self._lateral_merge(x1, "l1out", x2_out), "l1out2.0", 1, "leaky"), "l1out2.3")
+        h1 = self._c(self._lateral_merge(x1, "l1out", x2_out), "l1out2.0", 1, "leaky")
+        # round 6: the fine map leaves its last convolution token-major (NHWC memory, returned as an NCHW VIEW) when the direct kernel runs it: coarse_tail's
+        # NCHW -> NHWC transposition pass disappears
+        fine = self.upk["l1out2.3"].rows(h1) if "l1out2.3" in self.upk else None
+        x1_out = fine.permute(0, 3, 1, 2) if fine is not None else self._c(h1, "l1out2.3")
         return x3_out, x1_out
 
     def _lateral_merge(self, x, name, lo):
@@ -355,9 +359,12 @@ class LoFTRHIP:
         k0 = torch.stack([ii % wc, ii // wc], -1).float() * scale
         k1 = torch.stack([jj % wc, jj // wc], -1).float() * scale
         Cf, Hf, Wf = ff.shape[1:]
-        ff_nhwc = torch.empty(B2, Hf, Wf, Cf, dtype=torch.float32, device=ff.device)    # [2B, Hf, Wf, 128]: LDS-tiled transpose (csrc/elementwise.hip)
-        _lib.check(_lib.load().mfr_nchw_to_rows(_lib.ptr(ff.contiguous()), None, B2, Cf, Hf * Wf, 0, _lib.ptr(ff_nhwc), Hf * Wf * Cf, Cf, _lib.stream_ptr()),
-                   "mfr_nchw_to_rows")
+        if ff.permute(0, 2, 3, 1).is_contiguous() and not ff.is_contiguous():             # already NHWC memory (backbone, round 6)
+            ff_nhwc = ff.permute(0, 2, 3, 1)
+        else:
+            ff_nhwc = torch.empty(B2, Hf, Wf, Cf, dtype=torch.float32, device=ff.device)    # [2B, Hf, Wf, 128]: LDS-tiled transpose (csrc/elementwise.hip)
+            _lib.check(_lib.load().mfr_nchw_to_rows(_lib.ptr(ff.contiguous()), None, B2, Cf, Hf * Wf, 0, _lib.ptr(ff_nhwc), Hf * Wf * Cf, Cf, _lib.stream_ptr()),
+                       "mfr_nchw_to_rows")
         return dict(xm=xm, ff_nhwc=ff_nhwc, i_ids=i_ids, j_ids=j_ids, ii=ii, jj=jj, mconf=mconf, n=n, valid=valid, k0=k0, k1=k1,
                     hc=hc, wc=wc, H=H)
 

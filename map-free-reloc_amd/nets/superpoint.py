@@ -168,12 +168,18 @@ class SuperPointHIP:
         scores = self.score_map(logits)
         cand, cnt, _ = self.nms_candidates(scores)
         kpts, sc, n = self.select(cand, cnt, scores.shape[2])
-        cDa = self._conv(x, "convDa")
-        B, C, Hc, Wc = cDa.shape
-        # 1x1 descriptor head (convDb) through the own GEMM: every row's K loop runs in the same order whatever the number of rows
-        rows = torch.empty(B * Hc * Wc, C, dtype=torch.float32, device=cDa.device)        # NCHW -> token-major rows (csrc/elementwise.hip)
-        _lib.check(_lib.load().mfr_nchw_to_rows(_lib.ptr(cDa.contiguous()), None, B, C, Hc * Wc, 0, _lib.ptr(rows), Hc * Wc * C, C, _lib.stream_ptr()),
-                   "mfr_nchw_to_rows")
+        # 1x1 descriptor head (convDb) through the own GEMM: every row's K loop runs in the same order whatever the number of rows.  Round 6: convDa writes its
+        # output token-major itself when the direct kernel runs it (mfr_conv3x3_direct_f16x2_rows); else NCHW -> rows by csrc/elementwise.hip
+        cDa_rows = self.upk["convDa"].rows(x, act=1) if (self.use_wino and "convDa" in self.upk) else None
+        if cDa_rows is not None:
+            B, Hc, Wc, C = cDa_rows.shape
+            rows = cDa_rows.view(B * Hc * Wc, C)
+        else:
+            cDa = self._conv(x, "convDa")
+            B, C, Hc, Wc = cDa.shape
+            rows = torch.empty(B * Hc * Wc, C, dtype=torch.float32, device=cDa.device)
+            _lib.check(_lib.load().mfr_nchw_to_rows(_lib.ptr(cDa.contiguous()), None, B, C, Hc * Wc, 0, _lib.ptr(rows), Hc * Wc * C, C, _lib.stream_ptr()),
+                       "mfr_nchw_to_rows")
         dense = self.convDb(rows)
         desc = self.sample(dense.view(B, Hc, Wc, 256), kpts, n)
         return dict(kpts=kpts, scores=sc, desc=desc, n=n)

@@ -165,3 +165,22 @@ def test_strided_direct_conv_vs_float64(B, ci, co, H, W, act, bias):
     want = want.relu() if act == 1 else F.leaky_relu(want, 0.01) if act == 2 else want
     assert y.shape == want.shape and torch.isfinite(y).all()
     assert (y.double().cpu() - want).abs().max().item() < 2e-5
+
+
+@pytest.mark.parametrize("B,ci,co,H,W,act,ld", [(1, 16, 64, 8, 64, 0, 64), (2, 128, 256, 67, 90, 1, 256), (1, 196, 128, 41, 52, 0, 128), (2, 8, 36, 11, 38, 2, 48), (1, 64, 196, 20, 33, 1, 196)])
+def test_direct_conv_rows_output_equals_nchw_output_bitwise(B, ci, co, H, W, act, ld):
+    """mfr_conv3x3_direct_f16x2_rows: the token-major output is the NCHW output permuted, bit for bit (same accumulators, same epilogue arithmetic), incl. a row
+    stride larger than Cout (columns beyond Cout untouched) and a 196-channel layer (3 x 2 blocking of the last group)"""
+    lib = _lib.load(require_gpu=True)
+    g = torch.Generator().manual_seed(ci + H)
+    x = torch.randn(B, ci, H, W, generator=g).to(DEV)
+    w = (torch.randn(co, ci, 3, 3, generator=g) / (3.0 * ci ** 0.5)).to(DEV)
+    b = torch.randn(co, generator=g).to(DEV)
+    want = _conv(x, w, b, act, 0)
+    u = torch.empty(lib.mfr_conv3x3_direct_f16x2_filter_bytes(ci, co), dtype=torch.uint8, device=DEV)
+    _lib.check(lib.mfr_conv3x3_direct_f16x2_filter_pack(_lib.ptr(w), ci, co, _lib.ptr(u), _lib.stream_ptr()), "pack")
+    y = torch.full((B, H, W, ld), 7.0, dtype=torch.float32, device=DEV)
+    _lib.check(lib.mfr_conv3x3_direct_f16x2_rows(_lib.ptr(x), _lib.ptr(u), _lib.ptr(b), B, ci, co, H, W, act, _lib.ptr(y), ld, _lib.stream_ptr()), "rows")
+    assert torch.equal(y[..., :co].permute(0, 3, 1, 2), want)
+    assert (y[..., co:] == 7.0).all()
+    assert lib.mfr_conv3x3_direct_f16x2_rows(_lib.ptr(x), _lib.ptr(u), _lib.ptr(b), B, ci, co, H, W, act, _lib.ptr(y), co - 4, None) != 0      # ldy < Cout
