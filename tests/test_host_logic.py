@@ -533,3 +533,26 @@ def test_round5_entry_points_reject_bad_arguments_before_touching_a_device():
     assert lib.mfr_gemm_f16x2_batched(None, 32, 0, None, None, None, 8, 0, 1, 8, 8, 32, 0, None) == E_ARG
     assert lib.mfr_sp_conv1ab_f16x2(None, None, None, None, None, 1, 8, 8, None, None) == E_ARG
     assert lib.mfr_conv_igemm_f16x2(None, None, None, None, 1, 1, 8, 8, 1, 3, 3, 1, 1, 0, None) == E_ARG
+
+
+def test_round6_entry_points_reject_bad_arguments_before_touching_a_device():
+    """argument validation of the entry points added in round 6 (no GPU needed: MFR_E_ARG comes back before any launch)"""
+    import ctypes as C
+    lib = mfr._lib.load()
+    E_ARG = -1
+    dummy = C.create_string_buffer(64)
+    p = C.cast(dummy, C.c_void_p)
+    assert lib.mfr_conv3x3_direct_f16x2_filter_bytes(64, 64) == 4 * 54 * 1024 + 256 and lib.mfr_conv3x3_direct_f16x2_filter_bytes(0, 64) == 0
+    assert lib.mfr_conv3x3_direct_f16x2_filter_bytes(196, 196) == 4 * 13 * 54 * 1024 + 4 * 256           # channels padded to 16 / 64 inside the packed filter
+    assert lib.mfr_conv3x3_direct_f16x2_filter_pack(None, 4, 4, None, None) == E_ARG
+    assert lib.mfr_conv3x3_direct_f16x2(None, None, None, None, 1, 4, 4, 8, 8, 0, 0, None, None) == E_ARG                 # null operands
+    assert lib.mfr_conv3x3_direct_f16x2(p, p, None, None, 1, 4, 4, 8, 8, 3, 0, p, None) == E_ARG                          # unknown activation
+    assert lib.mfr_conv3x3_direct_f16x2(p, p, None, p, 1, 4, 4, 8, 8, 0, 1, p, None) == E_ARG                             # residual with pooling
+    assert lib.mfr_conv3x3_direct_f16x2(p, p, None, None, 1, 4, 4, 1, 8, 0, 1, p, None) == E_ARG                          # pooling needs H, W >= 2
+    assert lib.mfr_conv3x3_direct_f16x2(p, p, None, None, 1, 64, 64, 40000, 40000, 0, 0, p, None) == E_ARG                # an image beyond a 2 GB buffer descriptor
+    assert lib.mfr_conv3x3s2_direct_f16x2(None, None, None, 1, 4, 4, 8, 8, 0, None, None) == E_ARG
+    assert lib.mfr_conv3x3s2_direct_f16x2(p, p, None, 1, 4, 4, 8, 8, 5, p, None) == E_ARG
+    assert lib.mfr_conv3x3_direct_f16x2_rows(p, p, None, 1, 4, 6, 8, 8, 0, p, 8, None) == E_ARG                           # Cout % 4
+    assert lib.mfr_conv3x3_direct_f16x2_rows(p, p, None, 1, 4, 8, 8, 8, 0, p, 4, None) == E_ARG                           # row stride < Cout
+    assert lib.mfr_conv3x3_direct_f16x2_rows(p, p, None, 1, 4, 8, 8, 8, 0, p, 10, None) == E_ARG                          # row stride % 4
+    assert lib.mfr_mlp_ln_f16x2(None, 256, 256, None, None, None, None, None, None, 1e-5, None, 128, 16, 0, None) == E_ARG
