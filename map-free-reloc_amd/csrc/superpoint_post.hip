@@ -86,7 +86,17 @@ static __device__ __forceinline__ void strip_max9(const float v[16], float o[8])
 // m_in: margin (from the LDS tile's edge) inside which `src` is valid, m_out = m_in + R: margin inside which `dst` is needed.  Round 5: every
 // pool works on ITS region only -- the k-th of the five pools is needed R k inside the tile edge and reads what the (k - 1)-th left valid --
 // instead of on the whole 104 x 72 tile: 5 768 instead of 9 360 strips per tile, the same values wherever a value is used.
-static __device__ __forceinline__ void pool9(const float *src, float *tmp, float *dst, int m_in, int m_out)
+// MASKED (round 6): the pool's input is supp_scores = where(supp_mask, 0, scores) formed ON THE FLY from the scores and the suppression mask's bit rows
+// (sup[2 y], sup[2 y + 1] = bits 0-63 / 64-103 of tile row y) -- the masked scores are never materialised.
+struct NmsBits { unsigned long long lo, hi; };
+static __device__ __forceinline__ unsigned nms_window16(const unsigned long long *rows, int y, int x)       // bits x .. x + 15 of tile row y (x >= 0)
+{
+    const unsigned long long lo = rows[2 * y], hi = rows[2 * y + 1];
+    const unsigned long long v = x >= 64 ? (hi >> (x - 64)) : x == 0 ? lo : ((lo >> x) | (hi << (64 - x)));
+    return (unsigned)v & 0xffffu;
+}
+template <bool MASKED>
+static __device__ __forceinline__ void pool9(const float *src, float *tmp, float *dst, int m_in, int m_out, const unsigned long long *sup = nullptr)
 {
     // row pass: strip = 8 outputs x0..x0+7 of row y, inputs x0-4..x0+11; rows m_in .. LH - m_in (what the column pass reads)
     // (consecutive lanes -> consecutive rows: stride 105 floats = conflict-free)
@@ -95,10 +105,12 @@ static __device__ __forceinline__ void pool9(const float *src, float *tmp, float
         for (int t = threadIdx.x; t < nrows * nst; t += NMS_THREADS) {
             const int st = t / nrows, y = m_in + (t - st * nrows), x0 = (st0 + st) * 8;
             float v[16], o[8];
+            const unsigned sb = MASKED ? nms_window16(sup, y, max(x0 - NMS_R, 0)) << (x0 < NMS_R ? NMS_R - x0 : 0) : 0u;      // bit i = suppressed(x0 - 4 + i)
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int xx = x0 - NMS_R + i;
                 v[i] = (xx >= 0 && xx < NMS_LW) ? src[y * NMS_LS + xx] : -INFINITY;
+                if (MASKED && ((sb >> i) & 1u) && v[i] != -INFINITY) v[i] = 0.f;      // out-of-image stays -inf (max_pool2d's padding)
             }
             strip_max9(v, o);
 #pragma unroll
@@ -106,37 +118,44 @@ static __device__ __forceinline__ void pool9(const float *src, float *tmp, float
         }
     }
     __syncthreads();
-    // column pass: strip = 8 outputs y0..y0+7 of column x (consecutive threads -> consecutive x); columns m_out .. LW - m_out
+    // column pass IN PLACE (dst == tmp; round 6: one work tile instead of two, 64 KB of LDS per workgroup, TWO workgroups per CU): every strip is read into
+    // registers, a barrier, then written -- the strips of a pass are at most NMS_THREADS, one per thread
     {
         const int ys0 = m_out / 8, nys = (NMS_LH - m_out + 7) / 8 - ys0, ncols = NMS_LW - 2 * m_out;
-        for (int t = threadIdx.x; t < nys * ncols; t += NMS_THREADS) {
-            const int ys = t / ncols, x = m_out + (t - ys * ncols), y0 = (ys0 + ys) * 8;
-            float v[16], o[8];
+        const int t = threadIdx.x;
+        const bool live = t < nys * ncols;                  // (host-side static check: nys * ncols <= NMS_THREADS for every pool)
+        const int ys = live ? t / ncols : 0, x = m_out + (live ? t - ys * ncols : 0), y0 = (ys0 + ys) * 8;
+        float v[16], o[8];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int yy = y0 - NMS_R + i;
-                // rows outside [m_in, LH - m_in) were not produced by the row pass: they only reach outputs outside the needed region
-                v[i] = (yy >= m_in && yy < NMS_LH - m_in) ? tmp[yy * NMS_LS + x] : -INFINITY;
-            }
-            strip_max9(v, o);
+        for (int i = 0; i < 16; ++i) {
+            const int yy = y0 - NMS_R + i;
+            v[i] = (live && yy >= m_in && yy < NMS_LH - m_in) ? tmp[yy * NMS_LS + x] : -INFINITY;
+        }
+        strip_max9(v, o);
+        __syncthreads();
+        if (live) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) dst[(y0 + i) * NMS_LS + x] = o[i];
+            for (int i = 0; i < 8; ++i)
+                if (y0 + i < NMS_LH) dst[(y0 + i) * NMS_LS + x] = o[i];
         }
     }
     __syncthreads();
 }
 
-__global__ void __launch_bounds__(NMS_THREADS) sp_nms_kernel(const float *__restrict__ scores, int H, int W, float thr,
+__global__ void __launch_bounds__(NMS_THREADS, 8) sp_nms_kernel(const float *__restrict__ scores, int H, int W, float thr,
                                                      int border, float *__restrict__ nms_out /*may be NULL*/,
                                                      unsigned long long *__restrict__ cand, int cand_cap,
                                                      int *__restrict__ cand_count)
 {
+    // Round 6: the two MASK pools of simple_nms (max_pool(max_mask) > 0 = a 9 x 9 dilation) run on BIT rows -- 72 rows x 104 bits, a thread per
+    // row, a few shifts and ORs -- and the suppressed scores are formed on the fly inside the next pool's row pass: 9 passes over the 104 x 72
+    // float tile instead of 15, three float buffers instead of five (rounds 1-5: masks as 0 / 1 floats through the same separable max-pool as the scores).
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *s = (float *)smem;            // scores (-inf outside the image: max_pool2d padding)
-    float *a = s + NMS_N;                // work buffers
-    float *t = a + NMS_N;
-    float *mk = t + NMS_N;               // max_mask as 0/1
-    float *p5 = mk + NMS_N;              // pooled suppressed scores
+    float *a = s + NMS_N;                // the work tile: row-pass output, then (in place) the pool result
+    unsigned long long *mk = (unsigned long long *)(a + NMS_N);      // max_mask bit rows [72][2]
+    unsigned long long *hz = mk + 2 * NMS_LH;                        // horizontally dilated rows
+    unsigned long long *sup = hz + 2 * NMS_LH;                       // supp_mask bit rows
     const int b = blockIdx.z;
     const int x0 = blockIdx.x * NMS_TW - NMS_HALO, y0 = blockIdx.y * NMS_TH - NMS_HALO;
     const float *img = scores + (size_t)b * H * W;
@@ -146,30 +165,52 @@ __global__ void __launch_bounds__(NMS_THREADS) sp_nms_kernel(const float *__rest
         s[i] = (lx < NMS_LW && gx >= 0 && gx < W && gy >= 0 && gy < H) ? img[(size_t)gy * W + gx] : -INFINITY;
     }
     __syncthreads();
-    pool9(s, t, a, 0, NMS_R);                                   // a = max_pool(scores)
-    for (int i = threadIdx.x; i < NMS_N; i += NMS_THREADS)                  // max_mask (in-image cells only)
-        mk[i] = (s[i] != -INFINITY && s[i] == a[i]) ? 1.f : 0.f;
-    __syncthreads();
-    for (int round = 0; round < 2; ++round) {
-        pool9(mk, t, a, (2 * round + 1) * NMS_R, (2 * round + 2) * NMS_R);      // a = max_pool(max_mask) (>0 = supp_mask)
-        // a <- supp_scores = supp ? 0 : scores   (keep supp flag in t? t is pool scratch -> recompute)
-        for (int i = threadIdx.x; i < NMS_N; i += NMS_THREADS) {
-            const bool supp = a[i] > 0.f;
-            // out-of-image stays -inf so that it never wins a max (padding semantics)
-            a[i] = (s[i] == -INFINITY) ? -INFINITY : (supp ? 0.f : s[i]);
-            // stash supp in the sign of mk: mk in {0,1} -> encode as mk + 2*supp
-            mk[i] = mk[i] + (supp ? 2.f : 0.f);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    constexpr unsigned long long HI_MASK = (1ull << (NMS_LW - 64)) - 1ull;
+    // a row of 104 mask bits from a per-pixel predicate: unit = (row, 64-column chunk), one ballot each, wavefront wv takes units wv, wv + 16, ...
+    auto dilate = [&]() {                                            // sup = 9 x 9 dilation of mk (bits outside the tile: 0)
+        if (threadIdx.x < NMS_LH) {
+            const unsigned long long lo = mk[2 * threadIdx.x], hi = mk[2 * threadIdx.x + 1];
+            unsigned long long dl = lo, dh = hi;
+#pragma unroll
+            for (int k = 1; k <= NMS_R; ++k) {
+                dl |= (lo << k) | (lo >> k) | (hi << (64 - k));
+                dh |= (hi << k) | (hi >> k) | (lo >> (64 - k));
+            }
+            hz[2 * threadIdx.x] = dl; hz[2 * threadIdx.x + 1] = dh & HI_MASK;
         }
         __syncthreads();
-        pool9(a, t, p5, (2 * round + 2) * NMS_R, (2 * round + 3) * NMS_R);      // p5 = max_pool(supp_scores)
-        for (int i = threadIdx.x; i < NMS_N; i += NMS_THREADS) {
-            const float m = p5[i];
-            // new_max_mask = supp_scores == max_pool(supp_scores); max_mask |= new & ~supp
-            const float code = mk[i];
-            const bool supp = code >= 2.f;
-            const bool old = (code == 1.f) || (code == 3.f);
-            const bool nw = (a[i] == m);
-            mk[i] = (old || (nw && !supp)) ? 1.f : 0.f;
+        if (threadIdx.x < NMS_LH) {
+            unsigned long long dl = 0ull, dh = 0ull;
+#pragma unroll
+            for (int k = -NMS_R; k <= NMS_R; ++k) {
+                const int yy = (int)threadIdx.x + k;
+                if (yy >= 0 && yy < NMS_LH) { dl |= hz[2 * yy]; dh |= hz[2 * yy + 1]; }
+            }
+            sup[2 * threadIdx.x] = dl; sup[2 * threadIdx.x + 1] = dh;
+        }
+        __syncthreads();
+    };
+    pool9<false>(s, a, a, 0, NMS_R);                                 // a = max_pool(scores)
+    for (int u = wv; u < 2 * NMS_LH; u += NMS_THREADS / 64) {        // max_mask = scores == max_pool(scores) (in-image cells only)
+        const int y = u >> 1, x = 64 * (u & 1) + lane;
+        const float sv = x < NMS_LW ? s[y * NMS_LS + x] : -INFINITY;
+        const bool bit = x < NMS_LW && sv != -INFINITY && sv == a[y * NMS_LS + x];
+        const unsigned long long m = __ballot(bit);
+        if (lane == 0) mk[u] = m;
+    }
+    __syncthreads();
+    for (int round = 0; round < 2; ++round) {
+        dilate();                                                    // supp_mask = max_pool(max_mask) > 0
+        pool9<true>(s, a, a, (2 * round + 2) * NMS_R, (2 * round + 3) * NMS_R, sup);      // a = max_pool(supp_scores), supp_scores = where(supp_mask, 0, scores)
+        for (int u = wv; u < 2 * NMS_LH; u += NMS_THREADS / 64) {    // max_mask |= (supp_scores == max_pool(supp_scores)) & ~supp_mask
+            const int y = u >> 1, x = 64 * (u & 1) + lane;
+            const unsigned long long sm = sup[u];
+            const float sv = x < NMS_LW ? s[y * NMS_LS + x] : -INFINITY;
+            const float ss = (sv != -INFINITY && ((sm >> lane) & 1ull)) ? 0.f : sv;
+            const bool nw = x < NMS_LW && ss == a[y * NMS_LS + x];
+            const unsigned long long m = __ballot(nw);
+            if (lane == 0) mk[u] |= m & ~sm;
         }
         __syncthreads();
     }
@@ -178,7 +219,7 @@ __global__ void __launch_bounds__(NMS_THREADS) sp_nms_kernel(const float *__rest
     // reserves its range of the per-image list with ONE global atomic: per-candidate atomics on the
     // 32 adjacent per-image counters (one cache line) serialised the whole launch (1.7 ms -> ...).
     unsigned long long *lkeys = (unsigned long long *)a;          // <= NMS_TW*NMS_TH keys = 16 KB
-    int *lcount = (int *)p5, *lbase = lcount + 1;
+    int *lcount = (int *)hz, *lbase = lcount + 1;
     if (threadIdx.x == 0) *lcount = 0;
     __syncthreads();
     for (int i = threadIdx.x; i < NMS_TW * NMS_TH; i += NMS_THREADS) {
@@ -186,7 +227,8 @@ __global__ void __launch_bounds__(NMS_THREADS) sp_nms_kernel(const float *__rest
         const int gx = blockIdx.x * NMS_TW + tx, gy = blockIdx.y * NMS_TH + ty;
         if (gx >= W || gy >= H) continue;
         const int li = (ty + NMS_HALO) * NMS_LS + tx + NMS_HALO;
-        const float v = (mk[li] == 1.f) ? s[li] : 0.f;
+        const int mx = tx + NMS_HALO;
+        const float v = ((mk[2 * (ty + NMS_HALO) + (mx >> 6)] >> (mx & 63)) & 1ull) ? s[li] : 0.f;
         if (nms_out) nms_out[(size_t)b * H * W + (size_t)gy * W + gx] = v;
         if (v > thr && gx >= border && gx < W - border && gy >= border && gy < H - border) {
             const int slot = atomicAdd(lcount, 1);
@@ -356,10 +398,10 @@ int mfr_sp_nms_candidates(const float *scores, int B, int H, int W, int nms_radi
     hipStream_t s = (hipStream_t)stream;
     if (mfr_zero_async(cand_count, sizeof(int32_t) * (size_t)B, s) != hipSuccess) return MFR_E_LAUNCH;
     dim3 grid((W + NMS_TW - 1) / NMS_TW, (H + NMS_TH - 1) / NMS_TH, B);
-    // 148 KiB of the CU's 160 KiB LDS: above the 64 KiB default dynamic limit
-    if (hipFuncSetAttribute((const void *)sp_nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            5 * NMS_N * sizeof(float)) != hipSuccess) return MFR_E_LAUNCH;
-    hipLaunchKernelGGL(sp_nms_kernel, grid, dim3(NMS_THREADS), 5 * NMS_N * sizeof(float), s, scores, H, W, threshold, border,
+    // 62.5 KiB of LDS (two float tiles + three sets of bit rows): two workgroups per CU
+    const size_t smem = 2 * NMS_N * sizeof(float) + 3 * 2 * NMS_LH * sizeof(unsigned long long);
+    if (hipFuncSetAttribute((const void *)sp_nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return MFR_E_LAUNCH;
+    hipLaunchKernelGGL(sp_nms_kernel, grid, dim3(NMS_THREADS), smem, s, scores, H, W, threshold, border,
                        nms_out, (unsigned long long *)cand, cand_cap, cand_count);
     CHECK_LAUNCH();
     return 0;
